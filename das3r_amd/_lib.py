@@ -1,0 +1,128 @@
+"""ctypes binding of das3r_amd/libdas3r_hip.so (C-ABI: include/das3r_raster.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, a RuntimeError is raised.
+PyTorch is used only for device memory (allocations handed to the library through the allocator callbacks)
+and for the current HIP stream.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdas3r_hip.so")
+ABI_VERSION = 1
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class RasterArgs(C.Structure):
+    _fields_ = [("P", C.c_int32), ("sh_degree", C.c_int32), ("M", C.c_int32), ("image_width", C.c_int32),
+                ("image_height", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
+                ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
+                ("prefiltered", C.c_int32), ("debug", C.c_int32)]
+
+
+class RasterIn(C.Structure):
+    _fields_ = [("means3D", C.c_void_p), ("opacities", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
+                ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p)]
+
+
+class RasterOut(C.Structure):
+    _fields_ = [("out_color", C.c_void_p), ("radii", C.c_void_p)]
+
+
+class RasterSaved(C.Structure):
+    _fields_ = [("geom", C.c_void_p), ("binning", C.c_void_p), ("img", C.c_void_p), ("num_rendered", C.c_int64)]
+
+
+class RasterGrads(C.Structure):
+    _fields_ = [("dL_dmeans2D", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dmeans3D", C.c_void_p),
+                ("dL_dshs", C.c_void_p), ("dL_dcolors_precomp", C.c_void_p), ("dL_dscales", C.c_void_p),
+                ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p), ("scratch", C.c_void_p)]
+
+
+class RasterLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in
+                ("geom_bytes", "binning_bytes", "img_bytes", "depth_key", "xy", "conic_opacity", "rgbd", "clamped",
+                 "tiles_touched", "sorted_idx", "offsets", "point_list", "final_T", "n_contrib", "ranges")]
+
+
+# every symbol include/das3r_raster.h declares
+EXPORTS = ("das3r_raster_forward", "das3r_raster_backward", "das3r_mark_visible", "das3r_knn3_workspace_bytes",
+           "das3r_knn3_mean_dist2", "das3r_raster_get_layout", "das3r_abi_version", "das3r_last_error",
+           "das3r_profile_enable", "das3r_profile_report")
+
+_lib = None
+
+
+def load():
+    """Load libdas3r_hip.so (once).  Raises RuntimeError — never falls back — when it is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"das3r_amd: HIP library not found at {LIB_PATH}. Build it with `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` or `make -C das3r_amd/csrc`. There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(L, name):
+            raise RuntimeError(f"das3r_amd: {LIB_PATH} does not export {name}; rebuild it")
+    L.das3r_abi_version.restype = C.c_int
+    if L.das3r_abi_version() != ABI_VERSION:
+        raise RuntimeError("das3r_amd: ABI version mismatch between the Python host layer and libdas3r_hip.so; rebuild")
+    L.das3r_last_error.restype = C.c_char_p
+    L.das3r_raster_forward.restype = C.c_int64
+    L.das3r_raster_forward.argtypes = [C.POINTER(RasterArgs), C.POINTER(RasterIn), C.POINTER(RasterOut), ALLOC_FN, ALLOC_FN,
+                                       ALLOC_FN, C.c_void_p, C.POINTER(RasterSaved), C.c_void_p]
+    L.das3r_raster_backward.restype = C.c_int
+    L.das3r_raster_backward.argtypes = [C.POINTER(RasterArgs), C.POINTER(RasterIn), C.POINTER(RasterSaved), C.c_void_p,
+                                        C.POINTER(RasterGrads), C.c_void_p]
+    L.das3r_mark_visible.restype = C.c_int
+    L.das3r_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.das3r_knn3_workspace_bytes.restype = C.c_size_t
+    L.das3r_knn3_workspace_bytes.argtypes = [C.c_int32]
+    L.das3r_knn3_mean_dist2.restype = C.c_int
+    L.das3r_knn3_mean_dist2.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.das3r_raster_get_layout.restype = C.c_int
+    L.das3r_raster_get_layout.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(RasterLayout)]
+    _lib = L
+    return L
+
+
+def profile_enable(on):
+    L = load()
+    L.das3r_profile_enable.restype = None
+    L.das3r_profile_enable.argtypes = [C.c_int]
+    L.das3r_profile_enable(int(bool(on)))
+
+
+def profile_report():
+    """-> {kernel name: (launches, total_ms)}; clears the records.  Template arguments are stripped from names."""
+    L = load()
+    L.das3r_profile_report.restype = C.c_int
+    L.das3r_profile_report.argtypes = [C.c_char_p, C.c_size_t]
+    buf = C.create_string_buffer(1 << 16)
+    check(L.das3r_profile_report(buf, len(buf)), "das3r_profile_report")
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, n, ms = line.rsplit(" ", 2)
+        name = name.strip("() ").split("<")[0]
+        c, t = out.get(name, (0, 0.0))
+        out[name] = (c + int(n), t + float(ms))
+    return out
+
+
+def last_error():
+    return load().das3r_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what):
+    if rc < 0:
+        raise RuntimeError(f"{what} failed (status {rc}): {last_error()}")
+    return rc
+
+
+def layout(P, num_rendered, W, H):
+    out = RasterLayout()
+    check(load().das3r_raster_get_layout(int(P), int(num_rendered), int(W), int(H), C.byref(out)), "das3r_raster_get_layout")
+    return {n: getattr(out, n) for n, _ in RasterLayout._fields_}

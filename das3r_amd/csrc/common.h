@@ -1,0 +1,135 @@
+// common.h — shared device/host helpers for libdas3r_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/das3r_raster.h"
+
+#define TILE_X 16
+#define TILE_Y 16
+#define TILE_PIX 256
+#define WAVE 64
+#define NEAR_PLANE 0.001f  // /root/reference/README.md:41-44
+
+namespace das3r {
+
+void set_error(const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            das3r::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return DAS3R_ERR_HIP;                                                              \
+        }                                                                                      \
+    } while (0)
+
+// After a kernel launch: always check the launch; in debug mode also synchronise so that a faulting kernel is
+// reported at the call that caused it (upstream CHECK_CUDA(..., debug) behaviour).
+#define KERNEL_CHECK(stream, debug, name)                                                      \
+    do {                                                                                       \
+        hipError_t _e = hipGetLastError();                                                     \
+        if (_e == hipSuccess && (debug)) _e = hipStreamSynchronize(stream);                    \
+        if (_e != hipSuccess) {                                                                \
+            das3r::set_error("kernel %s failed: %s", name, hipGetErrorString(_e));             \
+            return DAS3R_ERR_HIP;                                                              \
+        }                                                                                      \
+    } while (0)
+
+// Optional per-kernel timing with HIP events recorded on the launch stream (das3r_profile_* in the C-ABI).
+// Declare one right before a launch; when profiling is off it costs one branch.
+bool profile_enabled();
+void profile_begin(const char *name, hipStream_t s);
+void profile_end(hipStream_t s);
+struct ProfTimer {
+    hipStream_t s;
+    bool on;
+    ProfTimer(const char *name, hipStream_t stream) : s(stream), on(profile_enabled()) {
+        if (on) profile_begin(name, s);
+    }
+    ~ProfTimer() {
+        if (on) profile_end(s);
+    }
+};
+
+// every kernel launch goes through this macro so that the optional profiler sees it (name = kernel symbol)
+#define DAS3R_LAUNCH(kernel, grid, block, shmem, stream, ...)                \
+    do {                                                                     \
+        das3r::ProfTimer _pt(#kernel, stream);                               \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__); \
+    } while (0)
+
+static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+static inline int div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- radix-sort geometry (sort.hip) ----
+constexpr int RADIX_BITS = 8;
+constexpr int RADIX_SIZE = 1 << RADIX_BITS;
+constexpr int SORT_WAVES_PER_BLOCK = 4;
+// keys handled by one wave ("chunk"); chosen per problem size so that small sorts still fill the chip
+static inline int sort_items_per_lane(int64_t n) { return n >= (int64_t)(1 << 21) ? 32 : (n >= (1 << 18) ? 16 : 4); }
+static inline int sort_num_chunks(int64_t n) { return n == 0 ? 0 : div_up(n, (int64_t)WAVE * sort_items_per_lane(n)); }
+static inline int tile_bits(int ntiles) {
+    int b = 0;
+    while ((1 << b) < ntiles) b++;
+    return b < 1 ? 1 : b;
+}
+
+struct Layout {
+    das3r_raster_layout pub;
+    // private scratch offsets
+    size_t g_keyA, g_keyB, g_valA, g_valB, g_hist, g_totals, g_blocksums, g_count;
+    size_t b_keyA, b_keyB, b_valA, b_valB, b_hist, b_totals;
+    int tiles_x, tiles_y, ntiles, tbits, tile_passes;
+    int chunksP, chunksI;
+};
+void compute_layout(int P, int64_t I, int W, int H, Layout *L);
+
+// ---- launchers implemented in the individual .hip files ----
+int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int32_t *radii, char *geom, const Layout &L,
+                      hipStream_t s);
+int launch_mark_visible(int P, const float *means3D, const float *viewmatrix, uint8_t *present, hipStream_t s);
+int launch_depth_sort_and_scan(int P, char *geom, const Layout &L, bool debug, hipStream_t s);
+int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *geom, char *binning, char *img, const Layout &L,
+                   bool debug, hipStream_t s);
+int launch_render_forward(const das3r_raster_args *a, const float *colors_precomp, float *out_color, char *geom, char *binning,
+                          char *img, const Layout &L, hipStream_t s);
+// dL_dconic has row stride 8 floats (the [P,8] scratch); dL_dcolor has row stride `color_stride` (8 inside the
+// scratch, 3 when it is the caller's dL_dcolors_precomp)
+int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
+                           float *dL_dmean2D, float *dL_dconic, float *dL_dopacity, float *dL_dcolor, int color_stride,
+                           hipStream_t s);
+int launch_preprocess_backward(const das3r_raster_args *a, const das3r_raster_in *in, char *geom, const Layout &L,
+                               const das3r_raster_grads *g, const float *dL_dconic, const float *dL_dcolor, int color_stride,
+                               hipStream_t s);
+
+// ---- device helpers ----
+#ifdef __HIPCC__
+__device__ __forceinline__ int lane_id() { return __lane_id(); }
+
+// Wave64 sum reduction on the DPP network (no LDS traffic).  Result valid in lane 63.
+// GFX9/CDNA dpp_ctrl encodings: row_shr:n = 0x110+n, row_bcast15 = 0x142, row_bcast31 = 0x143.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_step(float v) {
+    int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
+    return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v = dpp_step<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_step<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_step<0x114, 0xf>(v);  // row_shr:4  (lanes 4.. of each row; partial sums still correct at lane 15)
+    v = dpp_step<0x118, 0xf>(v);  // row_shr:8
+    v = dpp_step<0x142, 0xa>(v);  // row_bcast15 into rows 1,3
+    v = dpp_step<0x143, 0xc>(v);  // row_bcast31 into rows 2,3
+    return v;
+}
+// Portable (ds_bpermute based) full-wave sum; every lane gets the result.  Reference for the DPP path.
+__device__ __forceinline__ float wave_sum_shfl(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+#endif
+
+}  // namespace das3r

@@ -1,0 +1,142 @@
+// preprocess.hip — K1: per-Gaussian cull, projection, 3D->2D covariance (EWA), conic, 3-sigma extent, tile
+// rect, SH -> RGB.  Replaces upstream:cuda_rasterizer/forward.cu preprocessCUDA for the call
+// at /root/reference/gaussian_renderer/__init__.py:131-140.
+//
+// Pure streaming map, HBM-bound: 44 + 12(D+1)^2 input bytes and 53 output bytes per Gaussian.  One lane per
+// Gaussian, 256-lane blocks; the (P,M,3) SH rows are 16-byte aligned (M = 16 -> 192 B) and are read as float4;
+// outputs are SoA so every store instruction of a wave writes one contiguous run.
+// Compiled with -ffp-contract=off: all arithmetic is plain IEEE fp32 (+,-,*,/,sqrt correctly rounded), which
+// makes radii / tile rects / conics reproducible bit-for-bit by the CPU oracle.
+#include "common.h"
+#include "splat_math.h"
+
+namespace das3r {
+
+template <bool HAS_SH, bool HAS_COV>
+__global__ void __launch_bounds__(256) preprocess_kernel(
+    int P, int D, int M, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
+    const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ shs,
+    const float *__restrict__ cov3D_precomp, const float *__restrict__ colors_precomp, const float *__restrict__ viewmatrix,
+    const float *__restrict__ projmatrix, const float *__restrict__ campos, int W, int H, float tanfovx, float tanfovy,
+    int tiles_x, int tiles_y, int32_t *__restrict__ radii, uint32_t *__restrict__ depth_key, float2 *__restrict__ xy,
+    float4 *__restrict__ conic_opacity, float4 *__restrict__ rgbd, uint8_t *__restrict__ clamped,
+    uint32_t *__restrict__ tiles_touched) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+
+    float V[16], PM[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        V[i] = viewmatrix[i];   // uniform -> scalar loads
+        PM[i] = projmatrix[i];
+    }
+    const float focal_x = W / (2.0f * tanfovx), focal_y = H / (2.0f * tanfovy);
+
+    int radius_out = 0;
+    uint32_t key_out = 0xFFFFFFFFu, tiles_out = 0;
+    uint8_t clamp_out = 0;
+    float2 xy_out = make_float2(0.f, 0.f);
+    float4 co_out = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 rgbd_out = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+    const float3 p_view = xform43(p, V);
+    if (p_view.z > NEAR_PLANE) {
+        const float4 p_hom = xform44(p, PM);
+        const float p_w = 1.0f / (p_hom.w + 0.0000001f);
+        const float ndc_x = p_hom.x * p_w, ndc_y = p_hom.y * p_w;
+
+        float c3[6];
+        if (HAS_COV) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) c3[i] = cov3D_precomp[6 * idx + i];
+        } else {
+            const float3 s = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
+            const float4 q = reinterpret_cast<const float4 *>(rotations)[idx];
+            cov3d_from_scale_rot(s, scale_modifier, q, c3);
+        }
+        float T[2][3];
+        float3 t;
+        bool cx, cy;
+        ewa_T(p_view, V, focal_x, focal_y, tanfovx, tanfovy, T, t, cx, cy);
+        float a, b, c;
+        cov2d_from_T(T, c3, a, b, c);
+        const float det = a * c - b * b;
+        if (det != 0.0f) {
+            const float det_inv = 1.f / det;
+            const float conA = c * det_inv, conB = -b * det_inv, conC = a * det_inv;
+            const float mid = 0.5f * (a + c);
+            const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+            const float px = ((ndc_x + 1.0f) * W - 1.0f) * 0.5f;
+            const float py = ((ndc_y + 1.0f) * H - 1.0f) * 0.5f;
+            const int r = (int)my_radius;
+            int rminx, rminy, rmaxx, rmaxy;
+            tile_rect(px, py, r, tiles_x, tiles_y, rminx, rminy, rmaxx, rmaxy);
+            const int area = (rmaxx - rminx) * (rmaxy - rminy);
+            if (area != 0) {
+                float3 col;
+                if (HAS_SH) {
+                    col = sh_to_rgb(D, M, shs + (size_t)idx * M * 3, p, campos, clamp_out);
+                } else {
+                    col = make_float3(colors_precomp[3 * idx], colors_precomp[3 * idx + 1], colors_precomp[3 * idx + 2]);
+                }
+                radius_out = r;
+                key_out = __float_as_uint(p_view.z);
+                tiles_out = (uint32_t)area;
+                xy_out = make_float2(px, py);
+                co_out = make_float4(conA, conB, conC, opacities[idx]);
+                rgbd_out = make_float4(col.x, col.y, col.z, p_view.z);
+            }
+        }
+    }
+    radii[idx] = radius_out;
+    depth_key[idx] = key_out;
+    tiles_touched[idx] = tiles_out;
+    xy[idx] = xy_out;
+    conic_opacity[idx] = co_out;
+    rgbd[idx] = rgbd_out;
+    clamped[idx] = clamp_out;
+}
+
+__global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float *__restrict__ means3D,
+                                                           const float *__restrict__ viewmatrix, uint8_t *__restrict__ present) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    float V[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) V[i] = viewmatrix[i];
+    const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+    present[idx] = xform43(p, V).z > NEAR_PLANE ? 1 : 0;
+}
+
+int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int32_t *radii, char *geom, const Layout &L,
+                      hipStream_t s) {
+    const int P = a->P;
+    if (P == 0) return DAS3R_OK;
+    dim3 grid(div_up(P, 256)), block(256);
+    const bool has_sh = in->shs != nullptr, has_cov = in->cov3D_precomp != nullptr;
+#define ARGS                                                                                                              \
+    P, a->sh_degree, a->M, in->means3D, in->scales, a->scale_modifier, in->rotations, in->opacities, in->shs,             \
+        in->cov3D_precomp, in->colors_precomp, a->viewmatrix, a->projmatrix, a->campos, a->image_width, a->image_height,  \
+        a->tanfovx, a->tanfovy, L.tiles_x, L.tiles_y, radii, (uint32_t *)(geom + L.g_keyA), (float2 *)(geom + L.pub.xy),  \
+        (float4 *)(geom + L.pub.conic_opacity), (float4 *)(geom + L.pub.rgbd), (uint8_t *)(geom + L.pub.clamped),         \
+        (uint32_t *)(geom + L.pub.tiles_touched)
+    if (has_sh && !has_cov) DAS3R_LAUNCH((preprocess_kernel<true, false>), grid, block, 0, s, ARGS);
+    else if (has_sh && has_cov) DAS3R_LAUNCH((preprocess_kernel<true, true>), grid, block, 0, s, ARGS);
+    else if (!has_sh && !has_cov) DAS3R_LAUNCH((preprocess_kernel<false, false>), grid, block, 0, s, ARGS);
+    else DAS3R_LAUNCH((preprocess_kernel<false, true>), grid, block, 0, s, ARGS);
+#undef ARGS
+    KERNEL_CHECK(s, a->debug, "preprocess");
+    return DAS3R_OK;
+}
+
+int launch_mark_visible(int P, const float *means3D, const float *viewmatrix, uint8_t *present, hipStream_t s) {
+    if (P == 0) return DAS3R_OK;
+    DAS3R_LAUNCH(mark_visible_kernel, dim3(div_up(P, 256)), dim3(256), 0, s, P, means3D, viewmatrix, present);
+    KERNEL_CHECK(s, false, "mark_visible");
+    return DAS3R_OK;
+}
+
+}  // namespace das3r

@@ -1,0 +1,277 @@
+"""Host-side mirror of the `diff_gaussian_rasterization` Python surface on top of the
+MI355X C-ABI library.
+
+Same names, argument meaning, return values and error behaviour as the module DAS3R imports at
+/root/reference/gaussian_renderer/__init__.py:14-17 and calls at :62-80,131-140
+(upstream:diff_gaussian_rasterization/__init__.py): `GaussianRasterizationSettings` (12-field NamedTuple),
+`GaussianRasterizer(nn.Module)` with `forward(...) -> (color[3,H,W], radii[P])` and `markVisible`.
+"""
+import ctypes as C
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def cpu_deep_copy_tuple(input_tuple):
+    return tuple(item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple)
+
+
+def _ptr(t):
+    return None if t is None or t.numel() == 0 else C.c_void_p(t.data_ptr())
+
+
+def _prep(t, device, name):
+    """contiguous fp32 tensor on `device` (empty tensors mean 'not provided', as upstream)."""
+    if t is None or t.numel() == 0:
+        return torch.empty(0, device=device)
+    if t.numel() and t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32 (got {t.dtype})")
+    if t.device != device:
+        raise RuntimeError(f"{name} is on {t.device}, expected {device}")
+    return t.contiguous()
+
+
+def _small(t, device, n, name):
+    t = torch.as_tensor(t, dtype=torch.float32, device=device).contiguous()
+    if t.numel() != n:
+        raise ValueError(f"{name} must have {n} elements")
+    return t
+
+
+class _Alloc:
+    """Allocator callbacks handed to the library (upstream's resizeFunctional): torch owns the bytes."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs = {}
+        self.fns = {k: _lib.ALLOC_FN(self._make(k)) for k in ("geom", "binning", "img")}
+
+    def _make(self, key):
+        def fn(_user, nbytes):
+            try:
+                t = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=self.device)
+                self.bufs[key] = t
+                return t.data_ptr()
+            except Exception:  # noqa: BLE001 - reported by the library as DAS3R_ERR_ALLOC
+                return 0
+        return fn
+
+
+def _fill_args(rs, P, M, device, keep):
+    a = _lib.RasterArgs()
+    a.P, a.sh_degree, a.M = P, int(rs.sh_degree), M
+    a.image_width, a.image_height = int(rs.image_width), int(rs.image_height)
+    a.tanfovx, a.tanfovy, a.scale_modifier = float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier)
+    bg = _small(rs.bg, device, 3, "bg")
+    vm = _small(rs.viewmatrix, device, 16, "viewmatrix")
+    pm = _small(rs.projmatrix, device, 16, "projmatrix")
+    cp = _small(rs.campos, device, 3, "campos")
+    keep.extend([bg, vm, pm, cp])
+    a.bg, a.viewmatrix, a.projmatrix, a.campos = bg.data_ptr(), vm.data_ptr(), pm.data_ptr(), cp.data_ptr()
+    a.prefiltered, a.debug = int(bool(rs.prefiltered)), int(bool(rs.debug))
+    return a
+
+
+def _fill_in(means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp):
+    i = _lib.RasterIn()
+    i.means3D, i.opacities = _ptr(means3D), _ptr(opacities)
+    i.shs, i.colors_precomp = _ptr(sh), _ptr(colors_precomp)
+    i.scales, i.rotations, i.cov3D_precomp = _ptr(scales), _ptr(rotations), _ptr(cov3Ds_precomp)
+    return i
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _forward_impl(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp):
+    lib = _lib.load()
+    device = means3D.device
+    if device.type != "cuda":
+        raise RuntimeError("das3r_amd rasterizer: tensors must live on a HIP device (torch device 'cuda'); "
+                           "there is no CPU path")
+    if means3D.dim() != 2 or means3D.shape[1] != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    P = means3D.shape[0]
+    H, W = int(rs.image_height), int(rs.image_width)
+    M = 0
+    if sh.numel():
+        if sh.dim() != 3 or sh.shape[0] != P or sh.shape[2] != 3:
+            raise RuntimeError("shs must have dimensions (num_points, M, 3)")
+        M = sh.shape[1]
+    color = torch.zeros(3, H, W, dtype=torch.float32, device=device)
+    radii = torch.zeros(P, dtype=torch.int32, device=device)
+    alloc = _Alloc(device)
+    if P == 0:
+        e = torch.empty(0, dtype=torch.uint8, device=device)
+        return 0, color, radii, e, e, e
+    keep = []
+    a = _fill_args(rs, P, M, device, keep)
+    i = _fill_in(means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp)
+    o = _lib.RasterOut()
+    o.out_color, o.radii = color.data_ptr(), radii.data_ptr()
+    saved = _lib.RasterSaved()
+    with torch.cuda.device(device):
+        rc = lib.das3r_raster_forward(C.byref(a), C.byref(i), C.byref(o), alloc.fns["geom"], alloc.fns["binning"],
+                                      alloc.fns["img"], None, C.byref(saved), _stream(device))
+    _lib.check(rc, "das3r_raster_forward")
+    empty = torch.empty(0, dtype=torch.uint8, device=device)
+    return int(rc), color, radii, alloc.bufs.get("geom", empty), alloc.bufs.get("binning", empty), alloc.bufs.get("img", empty)
+
+
+def _backward_impl(rs, num_rendered, grad_out_color, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                   geom, binning, img):
+    lib = _lib.load()
+    device = means3D.device
+    P = means3D.shape[0]
+    M = sh.shape[1] if sh.numel() else 0
+    z = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)  # fully written by the library
+    g_means2D, g_opac, g_means3D = z(P, 3), z(P, 1), z(P, 3)
+    g_sh = z(P, M, 3) if M else torch.zeros(P, 0, 3, device=device)
+    g_colors = z(P, 3)
+    g_scales, g_rot, g_cov = z(P, 3), z(P, 4), z(P, 6)
+    if P == 0:
+        return g_means2D, g_colors, g_opac, g_means3D, g_cov, g_sh, g_scales, g_rot
+    has_sh, has_cov = sh.numel() > 0, cov3Ds_precomp.numel() > 0
+    scratch = z(P, 8)
+    keep = []
+    a = _fill_args(rs, P, M, device, keep)
+    i = _fill_in(means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp)
+    saved = _lib.RasterSaved()
+    saved.geom, saved.binning, saved.img = _ptr(geom), _ptr(binning), _ptr(img)
+    saved.num_rendered = int(num_rendered)
+    g = _lib.RasterGrads()
+    g.dL_dmeans2D, g.dL_dopacities, g.dL_dmeans3D = g_means2D.data_ptr(), g_opac.data_ptr(), g_means3D.data_ptr()
+    g.dL_dshs = _ptr(g_sh) if has_sh else None
+    g.dL_dcolors_precomp = None if has_sh else g_colors.data_ptr()
+    g.dL_dscales = None if has_cov else g_scales.data_ptr()
+    g.dL_drotations = None if has_cov else g_rot.data_ptr()
+    g.dL_dcov3D = g_cov.data_ptr() if has_cov else None
+    g.scratch = scratch.data_ptr()
+    dL = grad_out_color.contiguous()
+    if dL.dtype != torch.float32:
+        dL = dL.float()
+    with torch.cuda.device(device):
+        rc = lib.das3r_raster_backward(C.byref(a), C.byref(i), C.byref(saved), C.c_void_p(dL.data_ptr()), C.byref(g),
+                                       _stream(device))
+    _lib.check(rc, "das3r_raster_backward")
+    return g_means2D, g_colors, g_opac, g_means3D, g_cov, g_sh, g_scales, g_rot
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                     raster_settings)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        device = means3D.device
+        means3D = _prep(means3D, device, "means3D")
+        sh = _prep(sh, device, "shs")
+        colors_precomp = _prep(colors_precomp, device, "colors_precomp")
+        opacities = _prep(opacities, device, "opacities")
+        scales = _prep(scales, device, "scales")
+        rotations = _prep(rotations, device, "rotations")
+        cov3Ds_precomp = _prep(cov3Ds_precomp, device, "cov3D_precomp")
+        args = (raster_settings, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
+        if raster_settings.debug:
+            cpu_args = cpu_deep_copy_tuple(args)  # copy them before they can be corrupted
+            try:
+                num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _forward_impl(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise ex
+        else:
+            num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _forward_impl(*args)
+        ctx.raster_settings = raster_settings
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities, geomBuffer,
+                              binningBuffer, imgBuffer)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii):
+        rs = ctx.raster_settings
+        (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities, geomBuffer, binningBuffer,
+         imgBuffer) = ctx.saved_tensors
+        args = (rs, ctx.num_rendered, grad_out_color, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                geomBuffer, binningBuffer, imgBuffer)
+        if rs.debug:
+            cpu_args = cpu_deep_copy_tuple(args)
+            try:
+                out = _backward_impl(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_bw.dump")
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise ex
+        else:
+            out = _backward_impl(*args)
+        g_means2D, g_colors, g_opac, g_means3D, g_cov, g_sh, g_scales, g_rot = out
+        return (g_means3D, g_means2D, g_sh if sh.numel() else None, g_colors if colors_precomp.numel() else None, g_opac,
+                g_scales if scales.numel() else None, g_rot if rotations.numel() else None,
+                g_cov if cov3Ds_precomp.numel() else None, None)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        with torch.no_grad():
+            rs = self.raster_settings
+            device = positions.device
+            if device.type != "cuda":
+                raise RuntimeError("das3r_amd rasterizer: positions must live on a HIP device; there is no CPU path")
+            pos = _prep(positions, device, "positions")
+            P = pos.shape[0]
+            present = torch.zeros(P, dtype=torch.uint8, device=device)
+            if P:
+                vm = _small(rs.viewmatrix, device, 16, "viewmatrix")
+                pm = _small(rs.projmatrix, device, 16, "projmatrix")
+                with torch.cuda.device(device):
+                    rc = _lib.load().das3r_mark_visible(P, _ptr(pos), _ptr(vm), _ptr(pm), _ptr(present), _stream(device))
+                _lib.check(rc, "das3r_mark_visible")
+            return present.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        raster_settings = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        if shs is None:
+            shs = torch.Tensor([])
+        if colors_precomp is None:
+            colors_precomp = torch.Tensor([])
+        if scales is None:
+            scales = torch.Tensor([])
+        if rotations is None:
+            rotations = torch.Tensor([])
+        if cov3D_precomp is None:
+            cov3D_precomp = torch.Tensor([])
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   raster_settings)

@@ -1,0 +1,165 @@
+/*
+ * das3r_raster.h — C-ABI of libdas3r_hip.so: the MI355X (gfx950) differentiable Gaussian-splat
+ * rasterizer + distCUDA2 that sit behind DAS3R's gaussian_renderer.render().
+ *
+ * Each entry point replaces one function of the reference's native extension modules (both are
+ * un-vendored submodules of /root/reference — .gitmodules:1-6 — so the interfaces are cited by their
+ * reference CALL SITES plus the upstream symbol they stand for):
+ *
+ *   das3r_raster_forward    <- diff_gaussian_rasterization._C.rasterize_gaussians
+ *                              (upstream:rasterize_points.cu RasterizeGaussiansCUDA), reached from
+ *                              /root/reference/gaussian_renderer/__init__.py:131-140 through
+ *                              GaussianRasterizer.forward / _RasterizeGaussians.forward
+ *   das3r_raster_backward   <- diff_gaussian_rasterization._C.rasterize_gaussians_backward
+ *                              (upstream:rasterize_points.cu RasterizeGaussiansBackwardCUDA), reached from
+ *                              loss.backward() at /root/reference/train_gui.py:579
+ *   das3r_mark_visible      <- diff_gaussian_rasterization._C.mark_visible (GaussianRasterizer.markVisible)
+ *   das3r_knn3_mean_dist2   <- simple_knn._C.distCUDA2, /root/reference/scene/gaussian_model.py:213,641
+ *
+ * Conventions: every data pointer is a DEVICE pointer to contiguous row-major fp32 unless
+ * stated; matrices are in the reference's row-vector layout (p_row @ M, i.e. what
+ * scene/cameras.py:90-93 stores); no exceptions cross the ABI — functions return >= 0 on success and a
+ * negative das3r_status on failure, with a message available from das3r_last_error().  The library owns no
+ * memory across calls: scratch comes from caller-supplied allocators (mirroring upstream's
+ * std::function<char*(size_t)> resize callbacks) and stays alive in the caller's autograd context until
+ * backward.  All work is enqueued on the caller's HIP stream.
+ */
+#ifndef DAS3R_RASTER_H
+#define DAS3R_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DAS3R_ABI_VERSION 1
+
+typedef enum {
+    DAS3R_OK = 0,
+    DAS3R_ERR_INVALID_ARG = -1,
+    DAS3R_ERR_HIP = -2,
+    DAS3R_ERR_ALLOC = -3,
+    DAS3R_ERR_OVERFLOW = -4
+} das3r_status;
+
+/* hipStream_t passed as an opaque pointer so that this header needs no HIP include. */
+typedef void *das3r_stream_t;
+
+/* Scratch allocator: must return a device pointer to at least `bytes` bytes, 256-byte aligned, valid until
+ * the caller drops it (the caller keeps geom/binning/img alive for backward).  NULL = failure. */
+typedef char *(*das3r_alloc_fn)(void *user, size_t bytes);
+
+/* The 12 fields of GaussianRasterizationSettings (/root/reference/gaussian_renderer/__init__.py:62-78)
+ * plus the tensor extents. */
+typedef struct {
+    int32_t P;              /* number of Gaussians */
+    int32_t sh_degree;      /* active SH degree D (0..3) */
+    int32_t M;              /* stored SH coefficients per channel (max_degree+1)^2; 0 if shs == NULL */
+    int32_t image_width;
+    int32_t image_height;
+    float tanfovx;
+    float tanfovy;
+    float scale_modifier;
+    const float *bg;         /* [3]    device */
+    const float *viewmatrix; /* [4,4]  device, row-vector layout */
+    const float *projmatrix; /* [4,4]  device, row-vector layout */
+    const float *campos;     /* [3]    device */
+    int32_t prefiltered;
+    int32_t debug;           /* !=0: synchronise + check after every kernel */
+} das3r_raster_args;
+
+/* Inputs of GaussianRasterizer.forward.  Exactly one of shs/colors_precomp and exactly one of
+ * (scales,rotations)/cov3D_precomp is non-NULL. */
+typedef struct {
+    const float *means3D;        /* [P,3] */
+    const float *opacities;      /* [P,1] */
+    const float *shs;            /* [P,M,3] or NULL */
+    const float *colors_precomp; /* [P,3]   or NULL */
+    const float *scales;         /* [P,3]   or NULL (already activated) */
+    const float *rotations;      /* [P,4]   or NULL (w,x,y,z), NOT normalised */
+    const float *cov3D_precomp;  /* [P,6]   or NULL */
+} das3r_raster_in;
+
+typedef struct {
+    float *out_color; /* [3,H,W] planar */
+    int32_t *radii;   /* [P] */
+} das3r_raster_out;
+
+/* What forward leaves behind for backward (upstream: geomBuffer, binningBuffer, imgBuffer, num_rendered). */
+typedef struct {
+    char *geom;
+    char *binning;
+    char *img;
+    int64_t num_rendered;
+} das3r_raster_saved;
+
+/* Gradient outputs of backward.  Every buffer is fully written by the call (no pre-zeroing needed). */
+typedef struct {
+    float *dL_dmeans2D;        /* [P,3]  (x,y) = pixel-space grad * (W/2, H/2); z = 0 */
+    float *dL_dopacities;      /* [P,1] */
+    float *dL_dmeans3D;        /* [P,3] */
+    float *dL_dshs;            /* [P,M,3] dense; NULL when colors_precomp was used */
+    float *dL_dcolors_precomp; /* [P,3]; may be NULL when shs was used (internal scratch is used then) */
+    float *dL_dscales;         /* [P,3]; NULL when cov3D_precomp was used */
+    float *dL_drotations;      /* [P,4]; NULL when cov3D_precomp was used */
+    float *dL_dcov3D;          /* [P,6]; NULL unless cov3D_precomp was used */
+    float *scratch;            /* [P,8] caller-provided scratch (dL_dconic[3] + dL_dcolor[3] + pad) */
+} das3r_raster_grads;
+
+/* Returns num_rendered (>= 0) or a negative das3r_status.  Fills *saved. */
+int64_t das3r_raster_forward(const das3r_raster_args *args, const das3r_raster_in *in, const das3r_raster_out *out,
+                             das3r_alloc_fn alloc_geom, das3r_alloc_fn alloc_binning, das3r_alloc_fn alloc_img,
+                             void *alloc_user, das3r_raster_saved *saved, das3r_stream_t stream);
+
+int das3r_raster_backward(const das3r_raster_args *args, const das3r_raster_in *in, const das3r_raster_saved *saved,
+                          const float *dL_dpix /* [3,H,W] */, const das3r_raster_grads *grads, das3r_stream_t stream);
+
+/* present[i] = (view-space z of means3D[i]) > near plane (0.001, /root/reference/README.md:41-44). */
+int das3r_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,
+                       uint8_t *present, das3r_stream_t stream);
+
+/* distCUDA2: out[i] = mean of squared distances to the 3 nearest other points.  `workspace` must hold
+ * das3r_knn3_workspace_bytes(P) bytes of device memory. */
+size_t das3r_knn3_workspace_bytes(int32_t P);
+int das3r_knn3_mean_dist2(int32_t P, const float *points /* [P,3] */, float *out /* [P] */, char *workspace,
+                          das3r_stream_t stream);
+
+/* ---- introspection (used by the parity tests and the roofline accounting) ---- */
+
+/* Byte offsets of the saved intermediates inside geom / binning / img for given extents. */
+typedef struct {
+    size_t geom_bytes, binning_bytes, img_bytes;
+    /* geom */
+    size_t depth_key;      /* u32[P]  fp32 depth bits, 0xFFFFFFFF = culled */
+    size_t xy;             /* f32[P,2] */
+    size_t conic_opacity;  /* f32[P,4] */
+    size_t rgbd;           /* f32[P,4] (r,g,b,depth) */
+    size_t clamped;        /* u8[P]    bit c set = channel c clamped */
+    size_t tiles_touched;  /* u32[P] */
+    size_t sorted_idx;     /* u32[P]   depth rank -> gaussian index */
+    size_t offsets;        /* u32[P]   exclusive instance offset per depth rank */
+    /* binning */
+    size_t point_list;     /* u32[I]   gaussian index per instance, ordered (tile, depth, index) */
+    /* img */
+    size_t final_T;        /* f32[H*W] */
+    size_t n_contrib;      /* u32[H*W] */
+    size_t ranges;         /* u32[tiles,2] */
+} das3r_raster_layout;
+
+int das3r_raster_get_layout(int32_t P, int64_t num_rendered, int32_t W, int32_t H, das3r_raster_layout *out);
+
+/* Optional per-kernel timing: when enabled, every kernel launch of the library is bracketed by HIP events recorded on
+ * the launch stream.  das3r_profile_report synchronises and writes one line per kernel, "<kernel> <launches> <total_ms>\n",
+ * into buf, then clears the records; returns bytes written or a negative status.  Single-threaded use (bench.py). */
+void das3r_profile_enable(int on);
+int das3r_profile_report(char *buf, size_t cap);
+
+int das3r_abi_version(void);
+const char *das3r_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DAS3R_RASTER_H */

@@ -1,0 +1,190 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI, via the drop-in GaussianRasterizer surface) against the CPU
+oracle on the same seeded inputs.  Integer / index work (radii, tile counts, per-tile splat order, ranges) must be
+bit-exact; floating point within the tolerances stated in tests/util.py."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _view(buf, off, dtype, count):
+    item = torch.tensor([], dtype=dtype).element_size()
+    return buf[off:off + count * item].view(dtype)
+
+
+def _run_hip(sc, mode, backward=True):
+    from das3r_amd import GaussianRasterizationSettings, GaussianRasterizer
+    dev = _dev()
+    kw = {k: v.to(dev).clone().requires_grad_(backward) for k, v in util.raster_inputs(sc, mode).items()}
+    skw = util.settings_kwargs(sc, mode)
+    skw = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in skw.items()}
+    rs = GaussianRasterizationSettings(**skw)
+    means2D = torch.zeros(sc.P, 3, device=dev, requires_grad=backward)
+    color, radii = GaussianRasterizer(rs)(means2D=means2D, **kw)
+    grads = None
+    if backward:
+        color.backward(sc.dL_dpix.to(dev))
+        grads = {k: v.grad for k, v in kw.items()}
+        grads["means2D"] = means2D.grad
+    torch.cuda.synchronize()
+    return color.detach(), radii, grads, color.grad_fn
+
+
+@pytest.mark.parametrize("name", util.VARIANTS)
+def test_forward_backward_vs_oracle(name):
+    sc, mode = util.scene_variant(name)
+    ref_color, ref_radii, ref_g, S = util.run_oracle(sc, mode)
+    color, radii, g, fn = _run_hip(sc, mode)
+    assert np.array_equal(radii.cpu().numpy(), ref_radii), "radii must match the oracle exactly"
+    assert fn.num_rendered == S["num_rendered"], "num_rendered must match the oracle exactly"
+    util.assert_color_close(color.cpu().numpy(), ref_color, f"{name} colour")
+    gmap = {"means3D": "means3D", "opacities": "opacities", "shs": "shs", "scales": "scales", "rotations": "rotations",
+            "means2D": "means2D", "colors_precomp": "colors", "cov3D_precomp": "cov3D"}
+    for k, t in g.items():
+        assert t is not None, f"no gradient for {k}"
+        util.assert_grad_close(t.cpu().numpy(), ref_g[gmap[k]], f"{name} dL/d{k}")
+    # viewspace gradient convention: z component stays zero
+    assert float(g["means2D"][:, 2].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("name", ["basic_deg3", "ragged_image", "long_lists", "culled", "depth_ties", "world_camera"])
+def test_binning_bit_exact(name):
+    """Per-Gaussian geometry, depth order, per-tile splat lists and tile ranges are integer / exactly-rounded fp32 work:
+    they must equal the oracle's bit for bit."""
+    from das3r_amd import _lib
+    sc, mode = util.scene_variant(name)
+    _, ref_radii, _, S = util.run_oracle(sc, mode, backward=False)
+    color, radii, _, fn = _run_hip(sc, mode, backward=True)  # backward=True so that grad_fn keeps the buffers
+    (_, _, _, _, _, _, _, _, geom, binning, img) = fn.saved_tensors
+    P, I, npix = sc.P, fn.num_rendered, sc.W * sc.H
+    L = _lib.layout(P, I, sc.W, sc.H)
+    vis = ref_radii > 0
+    tt = _view(geom, L["tiles_touched"], torch.int32, P).cpu().numpy().astype(np.uint32)
+    assert np.array_equal(tt, S["tiles_touched"])
+    xy = _view(geom, L["xy"], torch.float32, 2 * P).cpu().numpy().reshape(P, 2)
+    co = _view(geom, L["conic_opacity"], torch.float32, 4 * P).cpu().numpy().reshape(P, 4)
+    rgbd = _view(geom, L["rgbd"], torch.float32, 4 * P).cpu().numpy().reshape(P, 4)
+    assert np.array_equal(xy[vis], S["xy"][vis]), "pixel centres must be bit-exact (no FMA contraction in K1)"
+    assert np.array_equal(co[vis], S["conic_opacity"][vis]), "conics must be bit-exact"
+    assert np.array_equal(rgbd[vis, 3], S["depths"][vis])
+    if not mode["colors_precomp"]:
+        assert np.array_equal(rgbd[vis, :3], S["rgb"][vis]), "SH colours must be bit-exact"
+    assert I == S["num_rendered"]
+    if I:
+        pl = _view(binning, L["point_list"], torch.int32, I).cpu().numpy().astype(np.uint32)
+        assert np.array_equal(pl, S["point_list"]), "per-tile (depth, index) order must match exactly"
+    tiles = S["ranges"].shape[0]
+    rg = _view(img, L["ranges"], torch.int32, 2 * tiles).cpu().numpy().reshape(tiles, 2).astype(np.uint32)
+    assert np.array_equal(rg, S["ranges"])
+    nc = _view(img, L["n_contrib"], torch.int32, npix).cpu().numpy().reshape(sc.H, sc.W).astype(np.uint32)
+    assert (nc != S["n_contrib"]).mean() <= util.FLIP_FRACTION
+
+
+def test_empty_scene_returns_zero_image():
+    """P == 0: zero image, background NOT applied, empty radii (upstream:rasterize_points.cu behaviour)."""
+    from das3r_amd import GaussianRasterizationSettings, GaussianRasterizer
+    dev = _dev()
+    sc, mode = util.scene_variant("deg0")
+    skw = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in sc.settings_kwargs().items()}
+    skw["bg"] = torch.tensor([0.3, 0.4, 0.5], device=dev)
+    rast = GaussianRasterizer(GaussianRasterizationSettings(**skw))
+    z = lambda *s: torch.zeros(*s, device=dev)
+    color, radii = rast(means3D=z(0, 3), means2D=z(0, 3), opacities=z(0, 1), shs=z(0, 16, 3), scales=z(0, 3), rotations=z(0, 4))
+    assert color.shape == (3, sc.H, sc.W) and float(color.abs().max()) == 0.0 and radii.numel() == 0
+
+
+def test_all_culled_gives_background():
+    from das3r_amd import GaussianRasterizationSettings, GaussianRasterizer
+    dev = _dev()
+    sc, mode = util.scene_variant("deg0")
+    sc.means3D[:, 2] = -1.0
+    ref_color, ref_radii, _, S = util.run_oracle(sc, mode, backward=False)
+    assert S["num_rendered"] == 0
+    color, radii, g, fn = _run_hip(sc, mode)
+    assert fn.num_rendered == 0 and int(radii.abs().max()) == 0
+    assert np.array_equal(color.cpu().numpy(), ref_color)
+    for k, t in g.items():
+        assert float(t.abs().max()) == 0.0, k
+
+
+def test_retain_graph_double_backward_call():
+    """DAS3R calls loss.backward(retain_graph=True) (/root/reference/train_gui.py:579): the saved buffers must survive."""
+    from das3r_amd import GaussianRasterizationSettings, GaussianRasterizer
+    dev = _dev()
+    sc, mode = util.scene_variant("basic_deg3")
+    scd = sc.to(dev)
+    rs = GaussianRasterizationSettings(**scd.settings_kwargs())
+    m3 = scd.means3D.clone().requires_grad_()
+    m2 = torch.zeros(sc.P, 3, device=dev, requires_grad=True)
+    color, _ = GaussianRasterizer(rs)(means3D=m3, means2D=m2, opacities=scd.opacities, shs=scd.shs, scales=scd.scales,
+                                      rotations=scd.rotations)
+    loss = (color * scd.dL_dpix).sum()
+    loss.backward(retain_graph=True)
+    g1 = m3.grad.clone()
+    m3.grad = None
+    loss.backward()
+    assert torch.allclose(g1, m3.grad, rtol=1e-4, atol=1e-9)
+
+
+def test_mark_visible():
+    from das3r_amd import GaussianRasterizationSettings, GaussianRasterizer
+    from oracle import c_oracle
+    dev = _dev()
+    sc, _ = util.scene_variant("culled")
+    scd = sc.to(dev)
+    rast = GaussianRasterizer(GaussianRasterizationSettings(**scd.settings_kwargs()))
+    got = rast.markVisible(scd.means3D).cpu().numpy()
+    ref = c_oracle.mark_visible(sc.means3D.numpy(), sc.viewmatrix.numpy(), sc.projmatrix.numpy())
+    assert got.dtype == bool and np.array_equal(got, ref)
+
+
+def test_reduction_modes_agree(monkeypatch):
+    """The DPP wave reduction of the backward kernel against its ds_bpermute reference reduction."""
+    sc, mode = util.scene_variant("long_lists")
+    monkeypatch.setenv("DAS3R_BWD_REDUCE", "shfl")
+    _, _, g_ref, _ = _run_hip(sc, mode)
+    monkeypatch.setenv("DAS3R_BWD_REDUCE", "dpp")
+    _, _, g, _ = _run_hip(sc, mode)
+    for k in g:
+        util.assert_grad_close(g[k].cpu().numpy(), g_ref[k].cpu().numpy(), f"dpp vs shfl {k}", tol=1e-4)
+
+
+def test_finite_difference_directional():
+    """Directional derivative of the HIP forward (central differences in fp32, smooth scene: low opacity, no splat near a
+    threshold dominates) against the HIP backward."""
+    from das3r_amd import GaussianRasterizationSettings, GaussianRasterizer
+    dev = _dev()
+    from das3r_amd.synth import make_scene
+    sc = make_scene(P=400, W=64, H=48, focal=60.0, sh_degree=2, seed=77, s_px=(2.0, 6.0), opacity=0.3).to(dev)
+    rs = GaussianRasterizationSettings(**sc.settings_kwargs())
+    rast = GaussianRasterizer(rs)
+    w = torch.randn(3, sc.H, sc.W, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    names = ["means3D", "opacities", "shs", "scales", "rotations"]
+    base = {k: getattr(sc, k).double() for k in names}
+
+    def f(vals):
+        kw = {k: v.float().contiguous() for k, v in vals.items()}
+        c, _ = rast(means2D=torch.zeros(sc.P, 3, device=dev), **kw)
+        return float((c.double() * w.double()).sum())
+
+    leaves = {k: v.float().clone().requires_grad_() for k, v in base.items()}
+    c, _ = rast(means2D=torch.zeros(sc.P, 3, device=dev, requires_grad=True), **leaves)
+    (c * w).sum().backward()
+    g = torch.Generator(device=dev).manual_seed(5)
+    for k in names:
+        d = torch.randn(base[k].shape, device=dev, generator=g, dtype=torch.float64)
+        d = d / d.norm() * base[k].norm() * 1e-3
+        plus, minus = dict(base), dict(base)
+        plus[k] = base[k] + d
+        minus[k] = base[k] - d
+        fd = (f(plus) - f(minus)) / 2.0
+        an = float((leaves[k].grad.double() * d).sum())
+        assert abs(fd - an) <= 5e-2 * max(abs(fd), abs(an)) + 1e-6, f"{k}: finite difference {fd:.6e} vs analytic {an:.6e}"

@@ -1,0 +1,146 @@
+"""Shared helpers for the parity tests: scene variants that hit every branch of SURVEY.md A.9, oracle runners and the
+stated tolerances."""
+import math
+
+import numpy as np
+import torch
+
+from das3r_amd.camera import projection_matrix
+from das3r_amd.synth import Scene, make_scene
+
+# ---- stated fp32 tolerances (north_star: "within a stated fp32 tolerance") ----
+COLOR_TOL = 1e-4          # max |delta| on colours in [0,1] ...
+FLIP_FRACTION = 1e-3      # ... except at most this fraction of pixels, explained by a threshold flip
+FLIP_MAX = 2.5e-2         # (alpha<1/255 or T<1e-4 decided differently by a 1-ulp exp difference), each bounded by this
+GRAD_REL_TOL = 2e-3       # gradients: max |delta| relative to the tensor's max |grad| (atomics reorder + exp ulp)
+
+
+def look_at_view(eye, target, up=(0.0, 1.0, 0.0)):
+    """World->camera 4x4 (column convention) for a camera at `eye` looking at `target`, +z forward, +y down-ish."""
+    eye, target, up = (np.asarray(v, dtype=np.float64) for v in (eye, target, up))
+    f = target - eye
+    f /= np.linalg.norm(f)
+    r = np.cross(up, f)
+    r /= np.linalg.norm(r)
+    u = np.cross(f, r)
+    R = np.stack([r, u, f], 0)
+    M = np.eye(4)
+    M[:3, :3] = R
+    M[:3, 3] = -R @ eye
+    return torch.tensor(M, dtype=torch.float32)
+
+
+def scene_variant(name):
+    """Returns (Scene, mode dict).  mode: colors_precomp / cov3D_precomp flags, scale_modifier."""
+    mode = dict(colors_precomp=False, cov3D_precomp=False, scale_modifier=1.0)
+    if name == "basic_deg3":
+        sc = make_scene(P=1500, W=128, H=80, focal=100.0, sh_degree=3, seed=21, bg=(0.2, 0.1, 0.3))
+    elif name == "deg0":
+        sc = make_scene(P=1200, W=96, H=96, focal=90.0, sh_degree=0, seed=22)
+    elif name == "deg1":
+        sc = make_scene(P=900, W=112, H=64, focal=80.0, sh_degree=1, seed=23, bg=(1.0, 1.0, 1.0))
+    elif name == "deg2":
+        sc = make_scene(P=900, W=112, H=64, focal=80.0, sh_degree=2, seed=24)
+    elif name == "ragged_image":   # W, H not multiples of 16 (1080 = 67.5 * 16 in the real config)
+        sc = make_scene(P=1500, W=123, H=77, focal=95.0, sh_degree=3, seed=25, bg=(0.0, 0.5, 0.0))
+    elif name == "colors_precomp":
+        sc = make_scene(P=1000, W=96, H=64, focal=80.0, sh_degree=0, seed=26)
+        mode["colors_precomp"] = True
+    elif name == "cov3D_precomp":
+        sc = make_scene(P=1000, W=96, H=64, focal=80.0, sh_degree=2, seed=27)
+        mode["cov3D_precomp"] = True
+    elif name == "scale_modifier":
+        sc = make_scene(P=1000, W=96, H=64, focal=80.0, sh_degree=1, seed=28)
+        mode["scale_modifier"] = 1.7
+    elif name == "long_lists":     # big opaque-ish splats: > 256 instances per tile (multi-batch), T<1e-4 early stop, alpha clamp
+        sc = make_scene(P=2500, W=64, H=48, focal=60.0, sh_degree=1, seed=29, s_px=(3.0, 12.0))
+        sc.opacities[: sc.P // 2] = 0.999
+    elif name == "world_camera":   # vanilla-3DGS style: non-identity viewmatrix + campos (gaussian_renderer/__init__3dgs.py)
+        sc = make_scene(P=1500, W=128, H=80, focal=100.0, sh_degree=3, seed=30)
+        eye = (0.7, -0.4, -1.5)
+        view_col = look_at_view(eye, (0.2, 0.1, 5.0))
+        fovx, fovy = 2 * math.atan(sc.tanfovx), 2 * math.atan(sc.tanfovy)
+        view = view_col.t().contiguous()                     # row-vector layout
+        proj = (view_col.t() @ projection_matrix(0.01, 100.0, fovx, fovy).t()).contiguous()
+        sc = Scene(**{**sc.__dict__, "viewmatrix": view, "projmatrix": proj, "campos": torch.tensor(eye, dtype=torch.float32)})
+    elif name == "culled":         # near-plane culls, behind-camera, off-screen rects, clamped EWA coordinates
+        sc = make_scene(P=1500, W=96, H=64, focal=80.0, sh_degree=1, seed=31)
+        sc.means3D[:200, 2] = torch.linspace(-1.0, 0.002, 200)          # behind / at the near plane
+        sc.means3D[200:400, 0] *= 4.0                                   # far off-screen -> empty rect or EWA clamp
+        sc.means3D[400:420, 2] = 0.0011                                 # just past the near plane, huge footprint
+    elif name == "depth_ties":     # duplicated splats: identical depth keys -> order by index
+        sc = make_scene(P=600, W=64, H=48, focal=60.0, sh_degree=0, seed=32, s_px=(1.0, 5.0))
+        for fld in ("means3D", "scales", "rotations"):
+            getattr(sc, fld)[300:] = getattr(sc, fld)[:300]
+    elif name == "single":
+        sc = make_scene(P=1, W=48, H=32, focal=40.0, sh_degree=3, seed=33, s_px=(4.0, 4.0))
+        sc.means3D[0] = torch.tensor([0.05, -0.02, 2.0])
+    else:
+        raise KeyError(name)
+    return sc, mode
+
+
+VARIANTS = ["basic_deg3", "deg0", "deg1", "deg2", "ragged_image", "colors_precomp", "cov3D_precomp", "scale_modifier",
+            "long_lists", "world_camera", "culled", "depth_ties", "single"]
+
+
+def cov3d_of(sc, scale_modifier=1.0):
+    """Sigma = R diag((mod*s)^2) R^T as 6-vector, float64 math -> float32 (independent of both implementations:
+    the formula of /root/reference/scene/gaussian_model.py:32-36 without the quaternion normalisation)."""
+    q = sc.rotations.double()
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                     2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                     2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+    Mm = R * (scale_modifier * sc.scales.double())[:, None, :]
+    S = Mm @ Mm.transpose(1, 2)
+    return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1).float().contiguous()
+
+
+def raster_inputs(sc, mode):
+    """dict of the tensor kwargs GaussianRasterizer.forward takes (CPU tensors)."""
+    kw = dict(means3D=sc.means3D, opacities=sc.opacities)
+    if mode["colors_precomp"]:
+        kw["colors_precomp"] = torch.sigmoid(sc.shs[:, 0, :] * 1.3).contiguous()
+    else:
+        kw["shs"] = sc.shs
+    if mode["cov3D_precomp"]:
+        kw["cov3D_precomp"] = cov3d_of(sc, 1.0)
+    else:
+        kw["scales"], kw["rotations"] = sc.scales, sc.rotations
+    return kw
+
+
+def settings_kwargs(sc, mode):
+    kw = sc.settings_kwargs()
+    kw["scale_modifier"] = mode["scale_modifier"]
+    return kw
+
+
+def run_oracle(sc, mode, backward=True):
+    from oracle import c_oracle
+    o = c_oracle.RasterOracle(**settings_kwargs(sc, mode))
+    kw = {k: v.numpy() for k, v in raster_inputs(sc, mode).items()}
+    color, radii = o.forward(kw.pop("means3D"), kw.pop("opacities"), **kw)
+    grads = o.backward(sc.dL_dpix.numpy()) if backward else None
+    saved = o.saved()
+    o.free()
+    return color, radii, grads, saved
+
+
+def assert_color_close(a, b, what=""):
+    d = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))
+    frac = float((d > COLOR_TOL).mean())
+    assert frac <= FLIP_FRACTION and d.max() <= FLIP_MAX, f"{what}: {frac:.2e} of values differ by > {COLOR_TOL}, max {d.max():.3e}"
+
+
+def assert_grad_close(a, b, what="", tol=GRAD_REL_TOL):
+    a, b = np.asarray(a, np.float64).reshape(-1), np.asarray(b, np.float64).reshape(-1)
+    assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
+    assert np.isfinite(a).all(), f"{what}: non-finite gradient"
+    scale = np.abs(b).max()
+    if scale == 0:
+        assert np.abs(a).max() == 0, f"{what}: expected all-zero gradient"
+        return
+    rel = np.abs(a - b).max() / scale
+    assert rel <= tol, f"{what}: max |delta| / max|ref| = {rel:.3e} > {tol}"
