@@ -83,7 +83,10 @@ class RasterOracle:
         self._keep = None
 
     def __del__(self):
-        self.free()
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
 
     def free(self):
         if self._state is not None:

@@ -23,11 +23,11 @@ def _view(buf, off, dtype, count):
 def _run_hip(sc, mode, backward=True):
     from das3r_amd import GaussianRasterizationSettings, GaussianRasterizer
     dev = _dev()
-    kw = {k: v.to(dev).clone().requires_grad_(backward) for k, v in util.raster_inputs(sc, mode).items()}
+    kw = {k: v.to(dev).clone().requires_grad_(True) for k, v in util.raster_inputs(sc, mode).items()}
     skw = util.settings_kwargs(sc, mode)
     skw = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in skw.items()}
     rs = GaussianRasterizationSettings(**skw)
-    means2D = torch.zeros(sc.P, 3, device=dev, requires_grad=backward)
+    means2D = torch.zeros(sc.P, 3, device=dev, requires_grad=True)
     color, radii = GaussianRasterizer(rs)(means2D=means2D, **kw)
     grads = None
     if backward:
@@ -62,9 +62,18 @@ def test_binning_bit_exact(name):
     from das3r_amd import _lib
     sc, mode = util.scene_variant(name)
     _, ref_radii, _, S = util.run_oracle(sc, mode, backward=False)
-    color, radii, _, fn = _run_hip(sc, mode, backward=True)  # backward=True so that grad_fn keeps the buffers
-    (_, _, _, _, _, _, _, _, geom, binning, img) = fn.saved_tensors
-    P, I, npix = sc.P, fn.num_rendered, sc.W * sc.H
+    from das3r_amd import GaussianRasterizationSettings
+    from das3r_amd.rasterizer import _forward_impl
+    dev = _dev()
+    kw = {k: v.to(dev) for k, v in util.raster_inputs(sc, mode).items()}
+    skw = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in util.settings_kwargs(sc, mode).items()}
+    e = torch.empty(0, device=dev)
+    I, color, radii, geom, binning, img = _forward_impl(
+        GaussianRasterizationSettings(**skw), kw["means3D"], kw.get("shs", e), kw.get("colors_precomp", e), kw["opacities"],
+        kw.get("scales", e), kw.get("rotations", e), kw.get("cov3D_precomp", e))
+    torch.cuda.synchronize()
+    assert np.array_equal(radii.cpu().numpy(), ref_radii)
+    P, npix = sc.P, sc.W * sc.H
     L = _lib.layout(P, I, sc.W, sc.H)
     vis = ref_radii > 0
     tt = _view(geom, L["tiles_touched"], torch.int32, P).cpu().numpy().astype(np.uint32)

@@ -55,6 +55,8 @@ def scene_variant(name):
     elif name == "long_lists":     # big opaque-ish splats: > 256 instances per tile (multi-batch), T<1e-4 early stop, alpha clamp
         sc = make_scene(P=2500, W=64, H=48, focal=60.0, sh_degree=1, seed=29, s_px=(3.0, 12.0))
         sc.opacities[: sc.P // 2] = 0.999
+    elif name == "deep":           # faint splats: hundreds of blended layers per pixel (n_contrib > 256: multi-batch backward)
+        sc = make_scene(P=6000, W=48, H=32, focal=40.0, sh_degree=0, seed=34, s_px=(3.0, 8.0), opacity=0.02)
     elif name == "world_camera":   # vanilla-3DGS style: non-identity viewmatrix + campos (gaussian_renderer/__init__3dgs.py)
         sc = make_scene(P=1500, W=128, H=80, focal=100.0, sh_degree=3, seed=30)
         eye = (0.7, -0.4, -1.5)
@@ -81,7 +83,7 @@ def scene_variant(name):
 
 
 VARIANTS = ["basic_deg3", "deg0", "deg1", "deg2", "ragged_image", "colors_precomp", "cov3D_precomp", "scale_modifier",
-            "long_lists", "world_camera", "culled", "depth_ties", "single"]
+            "long_lists", "deep", "world_camera", "culled", "depth_ties", "single"]
 
 
 def cov3d_of(sc, scale_modifier=1.0):
