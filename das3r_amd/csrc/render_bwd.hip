@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
     const float2 *__restrict__ xy, const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
     const float *__restrict__ bg, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
     const float *__restrict__ dL_dpix, float *__restrict__ dL_dmean2D /*[P,3]*/, float *__restrict__ dL_dconic /*[P,*] stride cs*/,
-    int conic_stride, float *__restrict__ dL_dopacity /*[P]*/, float *__restrict__ dL_dcolor /*[P,*] stride ls*/, int color_stride) {
+    int conic_stride, float *__restrict__ dL_dopacity /*[P]*/, float *__restrict__ dL_dcolor /*[P,*] stride ls*/, int color_stride, int ablate) {
     __shared__ StagedSplat stage[TILE_PIX];
     __shared__ uint32_t stage_id[TILE_PIX];
     __shared__ float acc[TILE_PIX][NACC];
@@ -112,7 +112,8 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
                 v[7] = -0.5f * gdy * dy * dL_dG;
                 v[8] = G * dL_dalpha;
             }
-            if (USE_DPP) {
+            if (ablate & 2) {
+            } else if (USE_DPP) {
 #pragma unroll
                 for (int k = 0; k < NACC; k++) v[k] = wave_sum_to_lane63(v[k]);
                 if (lane == 63) {
@@ -139,7 +140,7 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
                 a[k] = acc[tid][k];
                 any |= (a[k] != 0.f);
             }
-            if (any) {
+            if (any && !(ablate & 1)) {
                 unsafeAtomicAdd(&dL_dcolor[(size_t)g * color_stride + 0], a[0]);
                 unsafeAtomicAdd(&dL_dcolor[(size_t)g * color_stride + 1], a[1]);
                 unsafeAtomicAdd(&dL_dcolor[(size_t)g * color_stride + 2], a[2]);
@@ -160,12 +161,14 @@ int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, cha
                            hipStream_t s) {
     const char *e = getenv("DAS3R_BWD_REDUCE");  // "shfl" selects the ds_bpermute reference reduction (diagnostics)
     const bool use_dpp = !(e && e[0] == 's');
+    const char *ea = getenv("DAS3R_ABLATE");  // perf experiments only: bit0 = no global atomics, bit1 = no wave reduction
+    const int ablate = ea ? atoi(ea) : 0;
 #define ARGS                                                                                                                 \
     (const uint2 *)(img + L.pub.ranges), (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height,    \
         L.tiles_x, L.ntiles, (const float2 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),                \
         (const float4 *)(geom + L.pub.rgbd), a->bg, (const float *)(img + L.pub.final_T),                                    \
         (const uint32_t *)(img + L.pub.n_contrib), dL_dpix, dL_dmean2D, dL_dconic, 8, dL_dopacity, dL_dcolor,               \
-        color_stride
+        color_stride, ablate
     if (use_dpp) DAS3R_LAUNCH((render_backward_kernel<true>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS);
     else DAS3R_LAUNCH((render_backward_kernel<false>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS);
 #undef ARGS

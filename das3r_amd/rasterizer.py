@@ -40,8 +40,10 @@ def _ptr(t):
 
 def _prep(t, device, name):
     """contiguous fp32 tensor on `device` (empty tensors mean 'not provided', as upstream)."""
-    if t is None or t.numel() == 0:
+    if t is None:
         return torch.empty(0, device=device)
+    if t.numel() == 0:  # 'not provided' placeholders (upstream passes CPU torch.Tensor([])) and P == 0 inputs: keep the shape
+        return t.to(device=device, dtype=torch.float32)
     if t.numel() and t.dtype != torch.float32:
         raise TypeError(f"{name} must be float32 (got {t.dtype})")
     if t.device != device:

@@ -80,12 +80,14 @@ def test_full_size_properties(name):
     # (3) precomputed colours taken from the SH stage reproduce the SH path bit for bit
     _, c2, r2, _, _, _ = _forward_impl(rs, scd.means3D, e, rgb, scd.opacities, scd.scales, scd.rotations, e)
     assert torch.equal(c2, c0) and torch.equal(r2, r0)
-    # (4) permuting the input splats leaves the image unchanged (random depths: no ties)
+    # (4) permuting the input splats leaves the image unchanged, except where two overlapping splats share the exact same
+    #     fp32 depth (1M uniform depths do collide) and the index tie-break reorders them
     perm = torch.randperm(P, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
     _, c3, r3, _, _, _ = _forward_impl(rs, scd.means3D[perm].contiguous(), scd.shs[perm].contiguous(), e, scd.opacities[perm].contiguous(),
                                        scd.scales[perm].contiguous(), scd.rotations[perm].contiguous(), e)
     assert torch.equal(r3, r0[perm])
-    assert float((c3 - c0).abs().max()) <= 1e-6
+    dperm = (c3 - c0).abs()
+    assert float((dperm > 1e-6).float().mean()) <= 1e-4 and float(dperm.max()) <= 2e-2
     # (5) idempotence: same inputs, same image, bit for bit
     _, c4, _, _, _, _ = _forward_impl(rs, scd.means3D, scd.shs, e, scd.opacities, scd.scales, scd.rotations, e)
     assert torch.equal(c4, c0)

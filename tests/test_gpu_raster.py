@@ -167,15 +167,21 @@ def test_reduction_modes_agree(monkeypatch):
 
 
 def test_finite_difference_directional():
-    """Directional derivative of the HIP forward (central differences in fp32, smooth scene: low opacity, no splat near a
-    threshold dominates) against the HIP backward."""
+    """Directional derivative of the HIP forward (central differences) against the HIP backward, on a scene whose discrete
+    decisions are disabled by construction: a few huge, faint splats whose alpha stays above 1/255 over the
+    whole image (no alpha cut-off crossings, tile rect = whole grid whatever the radius ceil does, T never reaches 1e-4,
+    means well inside the EWA clamp).  Geometry gradients through thresholds are covered by oracle parity + the float64
+    finite-difference test of the oracle (tests/test_oracle.py)."""
     from das3r_amd import GaussianRasterizationSettings, GaussianRasterizer
-    dev = _dev()
     from das3r_amd.synth import make_scene
-    sc = make_scene(P=400, W=64, H=48, focal=60.0, sh_degree=2, seed=77, s_px=(2.0, 6.0), opacity=0.3).to(dev)
+    dev = _dev()
+    sc = make_scene(P=16, W=64, H=48, focal=60.0, sh_degree=2, seed=77, s_px=(100.0, 140.0), opacity=0.1)
+    sc.means3D[:, 0] *= 0.5
+    sc.means3D[:, 1] *= 0.5
+    sc = sc.to(dev)
     rs = GaussianRasterizationSettings(**sc.settings_kwargs())
     rast = GaussianRasterizer(rs)
-    w = torch.randn(3, sc.H, sc.W, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    w = torch.randn(3, sc.H, sc.W, device=dev, generator=torch.Generator(device=dev).manual_seed(1)).abs()
     names = ["means3D", "opacities", "shs", "scales", "rotations"]
     base = {k: getattr(sc, k).double() for k in names}
 
@@ -185,15 +191,16 @@ def test_finite_difference_directional():
         return float((c.double() * w.double()).sum())
 
     leaves = {k: v.float().clone().requires_grad_() for k, v in base.items()}
-    c, _ = rast(means2D=torch.zeros(sc.P, 3, device=dev, requires_grad=True), **leaves)
+    c, radii = rast(means2D=torch.zeros(sc.P, 3, device=dev, requires_grad=True), **leaves)
+    assert int((radii > 0).sum()) == sc.P
     (c * w).sum().backward()
     g = torch.Generator(device=dev).manual_seed(5)
     for k in names:
         d = torch.randn(base[k].shape, device=dev, generator=g, dtype=torch.float64)
-        d = d / d.norm() * base[k].norm() * 1e-3
+        d = d / d.norm() * base[k].norm() * 2e-3
         plus, minus = dict(base), dict(base)
         plus[k] = base[k] + d
         minus[k] = base[k] - d
         fd = (f(plus) - f(minus)) / 2.0
         an = float((leaves[k].grad.double() * d).sum())
-        assert abs(fd - an) <= 5e-2 * max(abs(fd), abs(an)) + 1e-6, f"{k}: finite difference {fd:.6e} vs analytic {an:.6e}"
+        assert abs(fd - an) <= 2e-2 * max(abs(fd), abs(an)) + 2e-4, f"{k}: finite difference {fd:.6e} vs analytic {an:.6e}"
