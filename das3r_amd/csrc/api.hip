@@ -55,7 +55,7 @@ void compute_layout(int P, int64_t I, int W, int H, Layout *L) {
     L->g_valB = take(4 * Pn);
     L->pub.sorted_idx = L->g_valA;  // 4 passes: A -> B -> A -> B -> A
     L->pub.depth_key = L->g_keyA;   // (clobbered by the sort; kept for the layout struct only)
-    L->pub.xy = take(8 * Pn);
+    L->pub.xy = take(16 * Pn);
     L->pub.conic_opacity = take(16 * Pn);
     L->pub.rgbd = take(16 * Pn);
     L->pub.clamped = take(Pn);

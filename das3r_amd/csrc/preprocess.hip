@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ shs,
     const float *__restrict__ cov3D_precomp, const float *__restrict__ colors_precomp, const float *__restrict__ viewmatrix,
     const float *__restrict__ projmatrix, const float *__restrict__ campos, int W, int H, float tanfovx, float tanfovy,
-    int tiles_x, int tiles_y, int32_t *__restrict__ radii, uint32_t *__restrict__ depth_key, float2 *__restrict__ xy,
+    int tiles_x, int tiles_y, int32_t *__restrict__ radii, uint32_t *__restrict__ depth_key, float4 *__restrict__ xyh,
     float4 *__restrict__ conic_opacity, float4 *__restrict__ rgbd, uint8_t *__restrict__ clamped,
     uint32_t *__restrict__ tiles_touched) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     int radius_out = 0;
     uint32_t key_out = 0xFFFFFFFFu, tiles_out = 0;
     uint8_t clamp_out = 0;
-    float2 xy_out = make_float2(0.f, 0.f);
+    float4 xy_out = make_float4(0.f, 0.f, -1e30f, -1e30f);
     float4 co_out = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 rgbd_out = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -85,8 +85,17 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
                 radius_out = r;
                 key_out = __float_as_uint(p_view.z);
                 tiles_out = (uint32_t)area;
-                xy_out = make_float2(px, py);
-                co_out = make_float4(conA, conB, conC, opacities[idx]);
+                // half extents of the axis-aligned box outside which alpha = opacity * exp(power) cannot reach 1/255
+                // (ellipse d^T Sigma'^-1 d <= 2 ln(255 o)); generous safety margin, used only for wave-level culling
+                const float op = opacities[idx];
+                float hx = -1e30f, hy = -1e30f;
+                if (255.0f * op > 1.0f) {
+                    const float tau2 = 2.0f * __logf(255.0f * op) * 1.0005f + 1e-3f;
+                    hx = sqrtf(tau2 * a) * 1.0005f + 0.02f;
+                    hy = sqrtf(tau2 * c) * 1.0005f + 0.02f;
+                }
+                xy_out = make_float4(px, py, hx, hy);
+                co_out = make_float4(conA, conB, conC, op);
                 rgbd_out = make_float4(col.x, col.y, col.z, p_view.z);
             }
         }
@@ -94,7 +103,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     radii[idx] = radius_out;
     depth_key[idx] = key_out;
     tiles_touched[idx] = tiles_out;
-    xy[idx] = xy_out;
+    xyh[idx] = xy_out;
     conic_opacity[idx] = co_out;
     rgbd[idx] = rgbd_out;
     clamped[idx] = clamp_out;
@@ -120,7 +129,7 @@ int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int
 #define ARGS                                                                                                              \
     P, a->sh_degree, a->M, in->means3D, in->scales, a->scale_modifier, in->rotations, in->opacities, in->shs,             \
         in->cov3D_precomp, in->colors_precomp, a->viewmatrix, a->projmatrix, a->campos, a->image_width, a->image_height,  \
-        a->tanfovx, a->tanfovy, L.tiles_x, L.tiles_y, radii, (uint32_t *)(geom + L.g_keyA), (float2 *)(geom + L.pub.xy),  \
+        a->tanfovx, a->tanfovy, L.tiles_x, L.tiles_y, radii, (uint32_t *)(geom + L.g_keyA), (float4 *)(geom + L.pub.xy),  \
         (float4 *)(geom + L.pub.conic_opacity), (float4 *)(geom + L.pub.rgbd), (uint8_t *)(geom + L.pub.clamped),         \
         (uint32_t *)(geom + L.pub.tiles_touched)
     if (has_sh && !has_cov) DAS3R_LAUNCH((preprocess_kernel<true, false>), grid, block, 0, s, ARGS);

@@ -2,10 +2,11 @@
 // dL/d(colour, mean2D, conic, opacity) per splat.  Replaces upstream:cuda_rasterizer/backward.cu renderCUDA
 // (SURVEY.md A.7), whose 9 float atomicAdds per (pixel, splat) pair are the classic 3DGS training hot spot.
 //
-// MI355X design: the 64 pixels of a wavefront are pre-reduced on the DPP network (wave_sum_to_lane63: 6 VALU ops per
-// value, no LDS traffic), the 4 waves of the tile are combined with one LDS float-add each, and only ONE global
-// atomic per (tile, splat, component) leaves the CU — 256x fewer device atomics than one per pair.  Splats that no
-// lane of a wave touches are skipped with a single wave vote.
+// MI355X design (decomposition in render_common.h): each wave64 owns an 8x8 quadrant and walks only the splats that can
+// touch it (ballot-culled sub-list).  The 64 pixels of the wave are reduced on the cross-lane network — 8 of the 9 sums
+// with the transposed reduction (permlane32/16 swap + DPP, 18 ops), the ninth with a 6-step DPP chain — the four waves
+// of the tile meet in LDS (one ds_add_f32 per wave and splat, 9 lanes -> 9 addresses), and only ONE global atomic per
+// (tile, splat, component) leaves the CU: 256x fewer device atomics than one per pair.
 #include "render_common.h"
 
 namespace das3r {
@@ -15,10 +16,11 @@ constexpr int NACC = 9;  // dcolor[3], dmean2D[2], dconic[3], dopacity
 template <bool USE_DPP>
 __global__ void __launch_bounds__(256) render_backward_kernel(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int tiles_x, int ntiles,
-    const float2 *__restrict__ xy, const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
+    const float4 *__restrict__ xyh, const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
     const float *__restrict__ bg, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
-    const float *__restrict__ dL_dpix, float *__restrict__ dL_dmean2D /*[P,3]*/, float *__restrict__ dL_dconic /*[P,*] stride cs*/,
-    int conic_stride, float *__restrict__ dL_dopacity /*[P]*/, float *__restrict__ dL_dcolor /*[P,*] stride ls*/, int color_stride, int ablate) {
+    const float *__restrict__ dL_dpix, float *__restrict__ dL_dmean2D /*[P,3]*/, float *__restrict__ dL_dconic /*row stride cs*/,
+    int conic_stride, float *__restrict__ dL_dopacity /*[P]*/, float *__restrict__ dL_dcolor /*row stride ls*/, int color_stride,
+    int ablate) {
     __shared__ StagedSplat stage[TILE_PIX];
     __shared__ uint32_t stage_id[TILE_PIX];
     __shared__ float acc[TILE_PIX][NACC];
@@ -28,9 +30,11 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
     if (tile < 0) return;
     const int tid = threadIdx.x, lane = __lane_id(), wave = tid >> 6;
     const int bx = tile % tiles_x, by = tile / tiles_x;
-    const int px = bx * TILE_X + (tid & 15), py = by * TILE_Y + (tid >> 4);
+    int px, py;
+    quadrant_pixel(bx, by, wave, lane, px, py);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
+    const float qcx = (float)(bx * TILE_X + ((wave & 1) << 3)) + 3.5f, qcy = (float)(by * TILE_Y + ((wave >> 1) << 3)) + 3.5f;
     const uint2 range = ranges[tile];
     const size_t pix = (size_t)py * W + px, plane = (size_t)H * W;
 
@@ -46,16 +50,19 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
 
     // no pixel of this tile blended anything past list position max_contrib: start the replay there
-    uint32_t m = last_contributor;
+    uint32_t mx = last_contributor;
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-    if (lane == 0) s_max[wave] = m;
+    for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+    if (lane == 0) s_max[wave] = mx;
     __syncthreads();
     const uint32_t max_contrib = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
     const int rounds = ((int)max_contrib + TILE_PIX - 1) / TILE_PIX;
 
     float T = T_final;
     float accum0 = 0.f, accum1 = 0.f, accum2 = 0.f, last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
+    // which accumulator this lane feeds after the cross-lane reduction
+    const bool writer = USE_DPP ? (((lane & 7) == 0) || lane == 63) : (lane < NACC);
+    const int widx = USE_DPP ? (lane == 63 ? 8 : (lane >> 3)) : lane;
 
     for (int i = 0; i < rounds; i++) {
         const int done_before = i * TILE_PIX;
@@ -64,7 +71,7 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
         if (tid < n) {
             const uint32_t g = point_list[range.x + max_contrib - 1 - done_before - tid];
             stage_id[tid] = g;
-            stage[tid].xy = xy[g];
+            stage[tid].xyh = xyh[g];
             stage[tid].co = conic_opacity[g];
             stage[tid].rgbd = rgbd[g];
         }
@@ -72,61 +79,74 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
         for (int k = 0; k < NACC; k++) acc[tid][k] = 0.f;
         __syncthreads();
 
-        for (int j = 0; j < n; j++) {
-            const uint32_t position = max_contrib - 1 - done_before - j;  // 0-based list position
-            float dx, dy, G, alpha;
-            const bool active = (position < last_contributor) && pair_alpha(stage[j].xy, stage[j].co, pxf, pyf, dx, dy, G, alpha);
-            if (__ballot(active) == 0ull) continue;  // wave-uniform skip
-            float v[NACC];
+        uint64_t masks[4];
 #pragma unroll
-            for (int k = 0; k < NACC; k++) v[k] = 0.f;
-            if (active) {
+        for (int k = 0; k < 4; k++) {
+            const int s = k * 64 + lane;
+            masks[k] = __ballot(s < n && quadrant_hit(stage[s].xyh, qcx, qcy));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint64_t m = masks[k];
+            while (m != 0ull) {
+                const int j = k * 64 + __builtin_ctzll(m);
+                m &= m - 1ull;
+                const uint32_t position = max_contrib - 1 - done_before - j;  // 0-based list position
+                const float4 p = stage[j].xyh;
                 const float4 co = stage[j].co;
-                const float4 c = stage[j].rgbd;
-                T = T / (1.f - alpha);
-                const float dchannel_dcolor = alpha * T;
-                float dL_dalpha = 0.f;
-                accum0 = last_alpha * lc0 + (1.f - last_alpha) * accum0;
-                lc0 = c.x;
-                dL_dalpha += (c.x - accum0) * dLp0;
-                accum1 = last_alpha * lc1 + (1.f - last_alpha) * accum1;
-                lc1 = c.y;
-                dL_dalpha += (c.y - accum1) * dLp1;
-                accum2 = last_alpha * lc2 + (1.f - last_alpha) * accum2;
-                lc2 = c.z;
-                dL_dalpha += (c.z - accum2) * dLp2;
-                v[0] = dchannel_dcolor * dLp0;
-                v[1] = dchannel_dcolor * dLp1;
-                v[2] = dchannel_dcolor * dLp2;
-                dL_dalpha *= T;
-                last_alpha = alpha;
-                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
-                const float dL_dG = co.w * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * co.x - gdy * co.y;
-                const float dG_ddely = -gdy * co.z - gdx * co.y;
-                v[3] = dL_dG * dG_ddelx * ddelx_dx;
-                v[4] = dL_dG * dG_ddely * ddely_dy;
-                v[5] = -0.5f * gdx * dx * dL_dG;
-                v[6] = -0.5f * gdx * dy * dL_dG;
-                v[7] = -0.5f * gdy * dy * dL_dG;
-                v[8] = G * dL_dalpha;
-            }
-            if (ablate & 2) {
-            } else if (USE_DPP) {
+                float dx, dy, G, alpha;
+                const bool active = (position < last_contributor) && pair_alpha(p.x, p.y, co, pxf, pyf, dx, dy, G, alpha);
+                if (__ballot(active) == 0ull) continue;  // wave-uniform skip
+                float v[NACC];
 #pragma unroll
-                for (int k = 0; k < NACC; k++) v[k] = wave_sum_to_lane63(v[k]);
-                if (lane == 63) {
-#pragma unroll
-                    for (int k = 0; k < NACC; k++) atomicAdd(&acc[j][k], v[k]);
+                for (int q = 0; q < NACC; q++) v[q] = 0.f;
+                if (active) {
+                    const float4 c = stage[j].rgbd;
+                    T = T / (1.f - alpha);
+                    const float dchannel_dcolor = alpha * T;
+                    float dL_dalpha = 0.f;
+                    accum0 = last_alpha * lc0 + (1.f - last_alpha) * accum0;
+                    lc0 = c.x;
+                    dL_dalpha += (c.x - accum0) * dLp0;
+                    accum1 = last_alpha * lc1 + (1.f - last_alpha) * accum1;
+                    lc1 = c.y;
+                    dL_dalpha += (c.y - accum1) * dLp1;
+                    accum2 = last_alpha * lc2 + (1.f - last_alpha) * accum2;
+                    lc2 = c.z;
+                    dL_dalpha += (c.z - accum2) * dLp2;
+                    v[0] = dchannel_dcolor * dLp0;
+                    v[1] = dchannel_dcolor * dLp1;
+                    v[2] = dchannel_dcolor * dLp2;
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+                    const float dL_dG = co.w * dL_dalpha;
+                    const float gdx = G * dx, gdy = G * dy;
+                    const float dG_ddelx = -gdx * co.x - gdy * co.y;
+                    const float dG_ddely = -gdy * co.z - gdx * co.y;
+                    v[3] = dL_dG * dG_ddelx * ddelx_dx;
+                    v[4] = dL_dG * dG_ddely * ddely_dy;
+                    v[5] = -0.5f * gdx * dx * dL_dG;
+                    v[6] = -0.5f * gdx * dy * dL_dG;
+                    v[7] = -0.5f * gdy * dy * dL_dG;
+                    v[8] = G * dL_dalpha;
                 }
-            } else {
+                if (ablate & 2) continue;
+                float out;
+                if (USE_DPP) {
+                    const float r8 = wave_reduce8_transposed(v, lane);   // lane l: total of v[l >> 3]
+                    const float r1 = wave_sum_to_lane63(v[8]);           // lane 63: total of v[8]
+                    out = lane == 63 ? r1 : r8;
+                } else {
+                    // reference reduction (ds_bpermute butterflies): every lane gets every total
+                    float tot[NACC];
 #pragma unroll
-                for (int k = 0; k < NACC; k++) v[k] = wave_sum_shfl(v[k]);
-                if (lane == 0) {
+                    for (int q = 0; q < NACC; q++) tot[q] = wave_sum_shfl(v[q]);
+                    out = 0.f;
 #pragma unroll
-                    for (int k = 0; k < NACC; k++) atomicAdd(&acc[j][k], v[k]);
+                    for (int q = 0; q < NACC; q++) out = lane == q ? tot[q] : out;
                 }
+                if (writer) atomicAdd(&acc[j][widx], out);  // divergent addresses: one ds_add_f32 for the whole wave
             }
         }
         __syncthreads();
@@ -165,10 +185,10 @@ int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, cha
     const int ablate = ea ? atoi(ea) : 0;
 #define ARGS                                                                                                                 \
     (const uint2 *)(img + L.pub.ranges), (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height,    \
-        L.tiles_x, L.ntiles, (const float2 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),                \
+        L.tiles_x, L.ntiles, (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),                \
         (const float4 *)(geom + L.pub.rgbd), a->bg, (const float *)(img + L.pub.final_T),                                    \
-        (const uint32_t *)(img + L.pub.n_contrib), dL_dpix, dL_dmean2D, dL_dconic, 8, dL_dopacity, dL_dcolor,               \
-        color_stride, ablate
+        (const uint32_t *)(img + L.pub.n_contrib), dL_dpix, dL_dmean2D, dL_dconic, 8, dL_dopacity, dL_dcolor, color_stride,  \
+        ablate
     if (use_dpp) DAS3R_LAUNCH((render_backward_kernel<true>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS);
     else DAS3R_LAUNCH((render_backward_kernel<false>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS);
 #undef ARGS

@@ -1,14 +1,21 @@
-// render_common.h — per-(pixel, splat) arithmetic shared by the forward (K6) and backward (K7) compositing
-// kernels, so both evaluate bit-identical alpha for the same pair.
+// render_common.h — per-(pixel, splat) arithmetic and wavefront helpers shared by the forward (K6) and backward (K7)
+// compositing kernels, so both evaluate bit-identical alpha for the same pair.
+//
+// Work decomposition (MI355X-first): one 256-lane workgroup per 16x16 tile (the upstream tile, which also defines the
+// hard 3-sigma gate), but each of its four wave64s owns one 8x8 pixel QUADRANT.  The tile's splat list is staged
+// through LDS in batches of 256; every wave first culls the batch against its own quadrant with one conservative
+// bounding-box test per lane (4 splats per lane) and a wavefront ballot, then walks only the surviving bits of the
+// ballot masks (scalar loop, wave-uniform LDS addresses => broadcast reads).  A skipped splat provably has
+// alpha < 1/255 on every pixel of the quadrant, so the image is bit-identical to walking the whole list.
 #pragma once
 #include "common.h"
 
 namespace das3r {
 
-struct StagedSplat {  // one LDS-staged entry of a tile's splat list
-    float2 xy;
-    float4 co;   // conic A,B,C + opacity
-    float4 rgbd; // r,g,b,(depth)
+struct StagedSplat {   // one LDS-staged entry of a tile's splat list (48 B)
+    float4 xyh;        // pixel centre x, y; half extents hx, hy of the region where alpha can reach 1/255
+    float4 co;         // conic A, B, C + opacity
+    float4 rgbd;       // r, g, b, (depth)
 };
 
 // XCD-aware block -> tile map: the dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md); give every XCD
@@ -20,18 +27,60 @@ __device__ __forceinline__ int xcd_tile(const int block, const int ntiles) {
 }
 static inline int xcd_grid(int ntiles) { return ((ntiles + 7) / 8) * 8; }
 
+// pixel owned by lane `lane` of wave `wave` inside tile (bx, by): wave -> 8x8 quadrant, lane -> pixel of the quadrant
+__device__ __forceinline__ void quadrant_pixel(const int bx, const int by, const int wave, const int lane, int &px, int &py) {
+    px = bx * TILE_X + ((wave & 1) << 3) + (lane & 7);
+    py = by * TILE_Y + ((wave >> 1) << 3) + (lane >> 3);
+}
+
 // Gaussian falloff of splat at pixel (px,py).  Returns false when the pair is skipped
 // (power > 0 or alpha < 1/255).  Explicit fma placement => same rounding in every kernel that inlines this.
-__device__ __forceinline__ bool pair_alpha(const float2 xy, const float4 co, const float px, const float py, float &dx, float &dy,
-                                           float &G, float &alpha) {
-    dx = xy.x - px;
-    dy = xy.y - py;
+__device__ __forceinline__ bool pair_alpha(const float x, const float y, const float4 co, const float px, const float py, float &dx,
+                                           float &dy, float &G, float &alpha) {
+    dx = x - px;
+    dy = y - py;
     const float q = __fmaf_rn(__fmul_rn(co.x, dx), dx, __fmul_rn(__fmul_rn(co.z, dy), dy));
     const float power = __fmaf_rn(-0.5f, q, -__fmul_rn(__fmul_rn(co.y, dx), dy));
     if (power > 0.0f) return false;
     G = __expf(power);
     alpha = fminf(0.99f, __fmul_rn(co.w, G));
     return alpha >= (1.0f / 255.0f);
+}
+
+// Conservative quadrant test: can the splat reach alpha >= 1/255 on any pixel centre of the 8x8 block centred at
+// (cx, cy)?  (hx, hy) already carry their safety margin (preprocess.hip).
+__device__ __forceinline__ bool quadrant_hit(const float4 xyh, const float cx, const float cy) {
+    return fabsf(xyh.x - cx) <= xyh.z + 3.5f && fabsf(xyh.y - cy) <= xyh.w + 3.5f;
+}
+
+// ---- transposed wavefront reduction -------------------------------------------------------------------------------
+// Sums 8 values across the 64 lanes in 18 cross-lane ops instead of 8 x 6: every exchange step also halves the number
+// of live values per lane (gfx950 v_permlane32_swap / v_permlane16_swap, then DPP inside the 16-lane rows).
+// On return every lane l holds the wave-wide total of value number (l >> 3).
+template <int CTRL>
+__device__ __forceinline__ float dpp_add_full(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float swap32_add(const float a, const float b) {  // lanes 0-31: sum(a) halves, lanes 32-63: sum(b) halves
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap16_add(const float a, const float b) {  // rows: [a0+a1, b0+b1, a2+a3, b2+b3]
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float wave_reduce8_transposed(const float v[8], const int lane) {
+    const float r0 = swap32_add(v[0], v[4]), r1 = swap32_add(v[1], v[5]);
+    const float r2 = swap32_add(v[2], v[6]), r3 = swap32_add(v[3], v[7]);
+    const float s02 = swap16_add(r0, r2);  // rows: v0, v2, v4, v6
+    const float s13 = swap16_add(r1, r3);  // rows: v1, v3, v5, v7
+    const float t0 = dpp_add_full<0x128>(s02);  // row_ror:8  -> lane l: x[l] + x[l^8]
+    const float t1 = dpp_add_full<0x128>(s13);
+    float m = (lane & 8) ? t1 : t0;             // row r: lanes 0-7 value 2r, lanes 8-15 value 2r+1  => value index l>>3
+    m = dpp_add_full<0x141>(m);                 // row_half_mirror
+    m = dpp_add_full<0x1B>(m);                  // quad_perm [3,2,1,0]
+    m = dpp_add_full<0xB1>(m);                  // quad_perm [1,0,3,2]
+    return m;
 }
 
 }  // namespace das3r

@@ -1,60 +1,77 @@
 // render_fwd.hip — K6: per-pixel front-to-back alpha compositing of a tile's depth-ordered splat list.
-// Replaces upstream:cuda_rasterizer/forward.cu renderCUDA.
-//
-// One 256-lane workgroup (4 wave64s) per 16x16 tile; wave w owns pixel rows 4w..4w+3.  The tile's list is
-// consumed in batches of 256: each lane gathers one splat record (xy 8 B + conic/opacity 16 B + rgb 16 B) into LDS,
-// then every lane walks the batch reading LDS at a wave-uniform address (broadcast, conflict-free).
+// Replaces upstream:cuda_rasterizer/forward.cu renderCUDA.  Decomposition: see render_common.h
+// (tile per workgroup, 8x8 quadrant per wave64, LDS-staged batches, ballot-culled per-wave sub-lists).
 #include "render_common.h"
 
 namespace das3r {
 
 __global__ void __launch_bounds__(256) render_forward_kernel(const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
-                                                             int W, int H, int tiles_x, int ntiles, const float2 *__restrict__ xy,
+                                                             int W, int H, int tiles_x, int ntiles, const float4 *__restrict__ xyh,
                                                              const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
                                                              const float *__restrict__ bg, float *__restrict__ final_T,
                                                              uint32_t *__restrict__ n_contrib, float *__restrict__ out_color) {
     __shared__ StagedSplat stage[TILE_PIX];
     const int tile = xcd_tile(blockIdx.x, ntiles);
     if (tile < 0) return;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = __lane_id(), wave = tid >> 6;
     const int bx = tile % tiles_x, by = tile / tiles_x;
-    const int px = bx * TILE_X + (tid & 15), py = by * TILE_Y + (tid >> 4);
+    int px, py;
+    quadrant_pixel(bx, by, wave, lane, px, py);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
+    const float qcx = (float)(bx * TILE_X + ((wave & 1) << 3)) + 3.5f, qcy = (float)(by * TILE_Y + ((wave >> 1) << 3)) + 3.5f;
     const uint2 range = ranges[tile];
     int toDo = (int)(range.y - range.x);
     const int rounds = (toDo + TILE_PIX - 1) / TILE_PIX;
 
     bool done = !inside;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
-    uint32_t contributor = 0, last_contributor = 0;
+    uint32_t last_contributor = 0;
 
     for (int i = 0; i < rounds; i++, toDo -= TILE_PIX) {
         if (__syncthreads_count(done) == TILE_PIX) break;
         const uint32_t progress = range.x + i * TILE_PIX + tid;
         if (progress < range.y) {
             const uint32_t g = point_list[progress];
-            stage[tid].xy = xy[g];
+            stage[tid].xyh = xyh[g];
             stage[tid].co = conic_opacity[g];
             stage[tid].rgbd = rgbd[g];
         }
         __syncthreads();
         const int n = toDo < TILE_PIX ? toDo : TILE_PIX;
-        for (int j = 0; !done && j < n; j++) {
-            contributor++;
-            float dx, dy, G, alpha;
-            if (!pair_alpha(stage[j].xy, stage[j].co, pxf, pyf, dx, dy, G, alpha)) continue;
-            const float test_T = T * (1.0f - alpha);
-            if (test_T < 0.0001f) {
-                done = true;
-                continue;
+        // wave-level cull of the batch against this wave's quadrant: 4 splats per lane, one ballot each
+        uint64_t masks[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int s = k * 64 + lane;
+            masks[k] = __ballot(s < n && quadrant_hit(stage[s].xyh, qcx, qcy));
+        }
+        bool wave_done = __ballot(!done) == 0ull;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint64_t m = masks[k];
+            while (m != 0ull && !wave_done) {
+                const int j = k * 64 + __builtin_ctzll(m);
+                m &= m - 1ull;
+                if (!done) {
+                    const float4 p = stage[j].xyh;
+                    float dx, dy, G, alpha;
+                    if (pair_alpha(p.x, p.y, stage[j].co, pxf, pyf, dx, dy, G, alpha)) {
+                        const float test_T = T * (1.0f - alpha);
+                        if (test_T < 0.0001f) {
+                            done = true;
+                        } else {
+                            const float4 c = stage[j].rgbd;
+                            C0 += c.x * alpha * T;
+                            C1 += c.y * alpha * T;
+                            C2 += c.z * alpha * T;
+                            T = test_T;
+                            last_contributor = (uint32_t)(i * TILE_PIX + j + 1);  // 1-based position in the tile list
+                        }
+                    }
+                }
+                wave_done = __ballot(!done) == 0ull;
             }
-            const float4 c = stage[j].rgbd;
-            C0 += c.x * alpha * T;
-            C1 += c.y * alpha * T;
-            C2 += c.z * alpha * T;
-            T = test_T;
-            last_contributor = contributor;
         }
     }
     if (inside) {
@@ -71,10 +88,10 @@ int launch_render_forward(const das3r_raster_args *a, const float *colors_precom
                           char *img, const Layout &L, hipStream_t s) {
     (void)colors_precomp;  // precomputed colours were copied into rgbd by the preprocess kernel
     DAS3R_LAUNCH(render_forward_kernel, dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, (const uint2 *)(img + L.pub.ranges),
-                       (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height, L.tiles_x, L.ntiles,
-                       (const float2 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),
-                       (const float4 *)(geom + L.pub.rgbd), a->bg, (float *)(img + L.pub.final_T), (uint32_t *)(img + L.pub.n_contrib),
-                       out_color);
+                 (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height, L.tiles_x, L.ntiles,
+                 (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),
+                 (const float4 *)(geom + L.pub.rgbd), a->bg, (float *)(img + L.pub.final_T), (uint32_t *)(img + L.pub.n_contrib),
+                 out_color);
     KERNEL_CHECK(s, a->debug, "render_forward");
     return DAS3R_OK;
 }

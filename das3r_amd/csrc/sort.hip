@@ -223,14 +223,14 @@ __global__ void __launch_bounds__(256) tt_scan_kernel(int P, int nblocks, const 
 // ---------------------------------------------------------------- instance emission (depth-rank order)
 __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, int tiles_y, const uint32_t *__restrict__ sorted_idx,
                                                    const uint32_t *__restrict__ tiles_touched, const uint32_t *__restrict__ offsets,
-                                                   const float2 *__restrict__ xy, const int32_t *__restrict__ radii,
+                                                   const float4 *__restrict__ xyh, const int32_t *__restrict__ radii,
                                                    uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ gids) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= P) return;
     const uint32_t g = sorted_idx[r];
     if (tiles_touched[g] == 0) return;
     uint32_t o = offsets[r];
-    const float2 p = xy[g];
+    const float4 p = xyh[g];
     int rminx, rminy, rmaxx, rmaxy;
     tile_rect(p.x, p.y, radii[g], tiles_x, tiles_y, rminx, rminy, rmaxx, rmaxy);
     for (int y = rminy; y < rmaxy; y++)
@@ -292,7 +292,7 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
     uint32_t *hist = (uint32_t *)(binning + L.b_hist), *totals = (uint32_t *)(binning + L.b_totals);
     DAS3R_LAUNCH(emit_kernel, dim3(div_up(P, 256)), dim3(256), 0, s, P, L.tiles_x, L.tiles_y,
                        (const uint32_t *)(geom + L.pub.sorted_idx), (const uint32_t *)(geom + L.pub.tiles_touched),
-                       (const uint32_t *)(geom + L.pub.offsets), (const float2 *)(geom + L.pub.xy), radii, keyA, valA);
+                       (const uint32_t *)(geom + L.pub.offsets), (const float4 *)(geom + L.pub.xy), radii, keyA, valA);
     KERNEL_CHECK(s, debug, "emit");
     // stable partition by tile id: tile_passes passes of <= 8 bits; ping-pong A -> B (-> A)
     uint32_t *kin = keyA, *vin = valA, *kout = keyB, *vout = valB;

@@ -133,7 +133,7 @@ typedef struct {
     size_t geom_bytes, binning_bytes, img_bytes;
     /* geom */
     size_t depth_key;      /* u32[P]  fp32 depth bits, 0xFFFFFFFF = culled */
-    size_t xy;             /* f32[P,2] */
+    size_t xy;             /* f32[P,4]  pixel centre x, y + culling half extents hx, hy */
     size_t conic_opacity;  /* f32[P,4] */
     size_t rgbd;           /* f32[P,4] (r,g,b,depth) */
     size_t clamped;        /* u8[P]    bit c set = channel c clamped */

@@ -78,7 +78,7 @@ def test_binning_bit_exact(name):
     vis = ref_radii > 0
     tt = _view(geom, L["tiles_touched"], torch.int32, P).cpu().numpy().astype(np.uint32)
     assert np.array_equal(tt, S["tiles_touched"])
-    xy = _view(geom, L["xy"], torch.float32, 2 * P).cpu().numpy().reshape(P, 2)
+    xy = _view(geom, L["xy"], torch.float32, 4 * P).cpu().numpy().reshape(P, 4)[:, :2]
     co = _view(geom, L["conic_opacity"], torch.float32, 4 * P).cpu().numpy().reshape(P, 4)
     rgbd = _view(geom, L["rgbd"], torch.float32, 4 * P).cpu().numpy().reshape(P, 4)
     assert np.array_equal(xy[vis], S["xy"][vis]), "pixel centres must be bit-exact (no FMA contraction in K1)"

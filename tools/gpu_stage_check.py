@@ -70,7 +70,7 @@ def main():
     ok = True
     ok &= report("radii", radii.cpu().numpy(), rr)
     ok &= report("tiles_touched", view(geom, L["tiles_touched"], torch.int32, P).cpu().numpy().astype(np.uint32), S["tiles_touched"])
-    xy = view(geom, L["xy"], torch.float32, 2 * P).cpu().numpy().reshape(P, 2)
+    xy = view(geom, L["xy"], torch.float32, 4 * P).cpu().numpy().reshape(P, 4)[:, :2]
     ok &= report("xy", xy[vis], S["xy"][vis])
     co = view(geom, L["conic_opacity"], torch.float32, 4 * P).cpu().numpy().reshape(P, 4)
     ok &= report("conic_opacity", co[vis], S["conic_opacity"][vis])
