@@ -95,42 +95,39 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
                 const float4 p = stage[j].xyh;
                 const float4 co = stage[j].co;
                 float dx, dy, G, alpha;
-                const bool active = (position < last_contributor) && pair_alpha(p.x, p.y, co, pxf, pyf, dx, dy, G, alpha);
+                const bool active = pair_alpha(p.x, p.y, co, pxf, pyf, dx, dy, G, alpha) & (position < last_contributor);
                 if (__ballot(active) == 0ull) continue;  // wave-uniform skip
+                // branch-free replay: inactive lanes run the same arithmetic with alpha = G = 0 (state and sums unchanged)
+                const float4 c = stage[j].rgbd;
+                const float am = active ? alpha : 0.f, Gm = active ? G : 0.f;
+                const float rinv = __builtin_amdgcn_rcpf(1.f - am);  // v_rcp_f32: T is itself a reconstruction, 1 ulp is noise
+                T = T * rinv;
+                const float dchannel_dcolor = am * T;
+                const float na0 = last_alpha * lc0 + (1.f - last_alpha) * accum0;
+                const float na1 = last_alpha * lc1 + (1.f - last_alpha) * accum1;
+                const float na2 = last_alpha * lc2 + (1.f - last_alpha) * accum2;
+                accum0 = active ? na0 : accum0;
+                accum1 = active ? na1 : accum1;
+                accum2 = active ? na2 : accum2;
+                lc0 = active ? c.x : lc0;
+                lc1 = active ? c.y : lc1;
+                lc2 = active ? c.z : lc2;
+                last_alpha = active ? alpha : last_alpha;
+                float dL_dalpha = (c.x - accum0) * dLp0 + (c.y - accum1) * dLp1 + (c.z - accum2) * dLp2;
+                dL_dalpha = dL_dalpha * T - (T_final * rinv) * bg_dot_dpixel;
+                const float gdl = Gm * dL_dalpha;           // G * dL/dalpha (0 on inactive lanes)
+                const float dL_dG_G = co.w * gdl;           // G * dL/dG
+                const float gdx = dL_dG_G * dx, gdy = dL_dG_G * dy;
                 float v[NACC];
-#pragma unroll
-                for (int q = 0; q < NACC; q++) v[q] = 0.f;
-                if (active) {
-                    const float4 c = stage[j].rgbd;
-                    T = T / (1.f - alpha);
-                    const float dchannel_dcolor = alpha * T;
-                    float dL_dalpha = 0.f;
-                    accum0 = last_alpha * lc0 + (1.f - last_alpha) * accum0;
-                    lc0 = c.x;
-                    dL_dalpha += (c.x - accum0) * dLp0;
-                    accum1 = last_alpha * lc1 + (1.f - last_alpha) * accum1;
-                    lc1 = c.y;
-                    dL_dalpha += (c.y - accum1) * dLp1;
-                    accum2 = last_alpha * lc2 + (1.f - last_alpha) * accum2;
-                    lc2 = c.z;
-                    dL_dalpha += (c.z - accum2) * dLp2;
-                    v[0] = dchannel_dcolor * dLp0;
-                    v[1] = dchannel_dcolor * dLp1;
-                    v[2] = dchannel_dcolor * dLp2;
-                    dL_dalpha *= T;
-                    last_alpha = alpha;
-                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
-                    const float dL_dG = co.w * dL_dalpha;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = -gdx * co.x - gdy * co.y;
-                    const float dG_ddely = -gdy * co.z - gdx * co.y;
-                    v[3] = dL_dG * dG_ddelx * ddelx_dx;
-                    v[4] = dL_dG * dG_ddely * ddely_dy;
-                    v[5] = -0.5f * gdx * dx * dL_dG;
-                    v[6] = -0.5f * gdx * dy * dL_dG;
-                    v[7] = -0.5f * gdy * dy * dL_dG;
-                    v[8] = G * dL_dalpha;
-                }
+                v[0] = dchannel_dcolor * dLp0;
+                v[1] = dchannel_dcolor * dLp1;
+                v[2] = dchannel_dcolor * dLp2;
+                v[3] = (-gdx * co.x - gdy * co.y) * ddelx_dx;
+                v[4] = (-gdy * co.z - gdx * co.y) * ddely_dy;
+                v[5] = -0.5f * gdx * dx;
+                v[6] = -0.5f * gdx * dy;
+                v[7] = -0.5f * gdy * dy;
+                v[8] = gdl;
                 if (ablate & 2) continue;
                 float out;
                 if (USE_DPP) {

@@ -41,10 +41,9 @@ __device__ __forceinline__ bool pair_alpha(const float x, const float y, const f
     dy = y - py;
     const float q = __fmaf_rn(__fmul_rn(co.x, dx), dx, __fmul_rn(__fmul_rn(co.z, dy), dy));
     const float power = __fmaf_rn(-0.5f, q, -__fmul_rn(__fmul_rn(co.y, dx), dy));
-    if (power > 0.0f) return false;
-    G = __expf(power);
+    G = __expf(power);  // evaluated unconditionally: the kernels' inner loops are branch-free (selects only)
     alpha = fminf(0.99f, __fmul_rn(co.w, G));
-    return alpha >= (1.0f / 255.0f);
+    return (!(power > 0.0f)) & (alpha >= (1.0f / 255.0f));
 }
 
 // Conservative quadrant test: can the splat reach alpha >= 1/255 on any pixel centre of the 8x8 block centred at

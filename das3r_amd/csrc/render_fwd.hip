@@ -46,31 +46,31 @@ __global__ void __launch_bounds__(256) render_forward_kernel(const uint2 *__rest
             const int s = k * 64 + lane;
             masks[k] = __ballot(s < n && quadrant_hit(stage[s].xyh, qcx, qcy));
         }
-        bool wave_done = __ballot(!done) == 0ull;
+        // branch-free inner loop: per-lane decisions are selects, the only branches are wave-uniform (scalar)
+        uint64_t alive = __ballot(!done);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             uint64_t m = masks[k];
-            while (m != 0ull && !wave_done) {
+            while (m != 0ull && alive != 0ull) {
                 const int j = k * 64 + __builtin_ctzll(m);
                 m &= m - 1ull;
-                if (!done) {
-                    const float4 p = stage[j].xyh;
-                    float dx, dy, G, alpha;
-                    if (pair_alpha(p.x, p.y, stage[j].co, pxf, pyf, dx, dy, G, alpha)) {
-                        const float test_T = T * (1.0f - alpha);
-                        if (test_T < 0.0001f) {
-                            done = true;
-                        } else {
-                            const float4 c = stage[j].rgbd;
-                            C0 += c.x * alpha * T;
-                            C1 += c.y * alpha * T;
-                            C2 += c.z * alpha * T;
-                            T = test_T;
-                            last_contributor = (uint32_t)(i * TILE_PIX + j + 1);  // 1-based position in the tile list
-                        }
-                    }
-                }
-                wave_done = __ballot(!done) == 0ull;
+                const float4 p = stage[j].xyh;
+                const float4 co = stage[j].co;
+                const float4 c = stage[j].rgbd;
+                float dx, dy, G, alpha;
+                const bool live = pair_alpha(p.x, p.y, co, pxf, pyf, dx, dy, G, alpha) && !done;
+                const float a = live ? alpha : 0.f;
+                const float test_T = T * (1.0f - a);
+                const bool stop = live && (test_T < 0.0001f);
+                const bool blend = live && !stop;
+                const float w = blend ? a : 0.f;
+                C0 += c.x * w * T;
+                C1 += c.y * w * T;
+                C2 += c.z * w * T;
+                T = blend ? test_T : T;
+                last_contributor = blend ? (uint32_t)(i * TILE_PIX + j + 1) : last_contributor;  // 1-based list position
+                done = done || stop;
+                if (__ballot(stop) != 0ull) alive = __ballot(!done);
             }
         }
     }
