@@ -65,6 +65,7 @@ void compute_layout(int P, int64_t I, int W, int H, Layout *L) {
     L->g_totals = take(4 * RADIX_SIZE);
     L->g_blocksums = take(4 * (size_t)div_up((int64_t)Pn, 4096));
     L->g_count = take(256);
+    L->g_off_by_gid = take(4 * Pn);
     L->pub.geom_bytes = o;
     // binning
     o = 0;
@@ -74,6 +75,8 @@ void compute_layout(int P, int64_t I, int W, int H, Layout *L) {
     L->b_valB = take(4 * In);
     L->b_hist = take(4 * (size_t)RADIX_SIZE * (size_t)(L->chunksI > 0 ? L->chunksI : 1));
     L->b_totals = take(4 * RADIX_SIZE);
+    L->b_gid_of = take(4 * In);
+    L->b_inv = take(4 * In);
     L->pub.binning_bytes = o;
     L->pub.point_list = (L->tile_passes & 1) ? L->b_valB : L->b_valA;
     // img
@@ -171,7 +174,7 @@ extern "C" int das3r_raster_backward(const das3r_raster_args *a, const das3r_ras
     if (rc) return rc;
     const int P = a->P;
     if (P == 0) return DAS3R_OK;
-    if (!saved || !saved->geom || !saved->img || !dL_dpix || !g || !g->dL_dmeans2D || !g->dL_dopacities || !g->dL_dmeans3D || !g->scratch) {
+    if (!saved || !saved->geom || !saved->img || !dL_dpix || !g || !g->dL_dmeans2D || !g->dL_dopacities || !g->dL_dmeans3D || (saved && saved->num_rendered > 0 && !g->scratch)) {
         set_error("das3r_raster_backward: null saved state / gradient buffer");
         return DAS3R_ERR_INVALID_ARG;
     }
@@ -183,20 +186,13 @@ extern "C" int das3r_raster_backward(const das3r_raster_args *a, const das3r_ras
     }
     Layout L;
     compute_layout(P, saved->num_rendered, a->image_width, a->image_height, &L);
-    float *dL_dconic = g->scratch;
-    float *dL_dcolor = has_sh ? g->scratch + 4 : g->dL_dcolors_precomp;
-    const int color_stride = has_sh ? 8 : 3;
-    HIP_TRY(hipMemsetAsync(g->dL_dmeans2D, 0, sizeof(float) * 3 * (size_t)P, s));
-    HIP_TRY(hipMemsetAsync(g->dL_dopacities, 0, sizeof(float) * (size_t)P, s));
-    HIP_TRY(hipMemsetAsync(g->scratch, 0, sizeof(float) * 8 * (size_t)P, s));
-    if (!has_sh) HIP_TRY(hipMemsetAsync(g->dL_dcolors_precomp, 0, sizeof(float) * 3 * (size_t)P, s));
+    // scratch = per-instance partial sums [num_rendered, 9]; no accumulator needs zeroing (no atomics anywhere)
+    float *partial = g->scratch;
     if (saved->num_rendered > 0) {
         if (!saved->binning) { set_error("das3r_raster_backward: binning buffer missing"); return DAS3R_ERR_INVALID_ARG; }
-        if ((rc = launch_render_backward(a, dL_dpix, saved->geom, saved->binning, saved->img, L, g->dL_dmeans2D, dL_dconic,
-                                         g->dL_dopacities, dL_dcolor, color_stride, s)))
-            return rc;
+        if ((rc = launch_render_backward(a, dL_dpix, saved->geom, saved->binning, saved->img, L, partial, s))) return rc;
     }
-    return launch_preprocess_backward(a, in, saved->geom, L, g, dL_dconic, dL_dcolor, color_stride, s);
+    return launch_preprocess_backward(a, in, saved->geom, saved->binning, L, g, partial, s);
 }
 
 extern "C" int das3r_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,

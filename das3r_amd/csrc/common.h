@@ -79,8 +79,8 @@ static inline int tile_bits(int ntiles) {
 struct Layout {
     das3r_raster_layout pub;
     // private scratch offsets
-    size_t g_keyA, g_keyB, g_valA, g_valB, g_hist, g_totals, g_blocksums, g_count;
-    size_t b_keyA, b_keyB, b_valA, b_valB, b_hist, b_totals;
+    size_t g_keyA, g_keyB, g_valA, g_valB, g_hist, g_totals, g_blocksums, g_count, g_off_by_gid;
+    size_t b_keyA, b_keyB, b_valA, b_valB, b_hist, b_totals, b_gid_of, b_inv;
     int tiles_x, tiles_y, ntiles, tbits, tile_passes;
     int chunksP, chunksI;
 };
@@ -95,14 +95,11 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
                    bool debug, hipStream_t s);
 int launch_render_forward(const das3r_raster_args *a, const float *colors_precomp, float *out_color, char *geom, char *binning,
                           char *img, const Layout &L, hipStream_t s);
-// dL_dconic has row stride 8 floats (the [P,8] scratch); dL_dcolor has row stride `color_stride` (8 inside the
-// scratch, 3 when it is the caller's dL_dcolors_precomp)
+// partial: [num_rendered, 9] per-instance sums written by the render backward, gathered by the preprocess backward
 int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
-                           float *dL_dmean2D, float *dL_dconic, float *dL_dopacity, float *dL_dcolor, int color_stride,
-                           hipStream_t s);
-int launch_preprocess_backward(const das3r_raster_args *a, const das3r_raster_in *in, char *geom, const Layout &L,
-                               const das3r_raster_grads *g, const float *dL_dconic, const float *dL_dcolor, int color_stride,
-                               hipStream_t s);
+                           float *partial, hipStream_t s);
+int launch_preprocess_backward(const das3r_raster_args *a, const das3r_raster_in *in, char *geom, char *binning, const Layout &L,
+                               const das3r_raster_grads *g, const float *partial, hipStream_t s);
 
 // ---- device helpers ----
 #ifdef __HIPCC__

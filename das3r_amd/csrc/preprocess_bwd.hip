@@ -16,12 +16,36 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(
     const float *__restrict__ rotations, const float *__restrict__ shs, const float *__restrict__ cov3D_precomp,
     const float *__restrict__ viewmatrix, const float *__restrict__ projmatrix, const float *__restrict__ campos, int W, int H,
     float tanfovx, float tanfovy, const uint32_t *__restrict__ tiles_touched, const uint8_t *__restrict__ clamped,
-    const float *__restrict__ dL_dmean2D /*[P,3]*/, const float *__restrict__ dL_dconic /*stride 8*/,
-    const float *__restrict__ dL_dcolor, int color_stride, float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dscales,
-    float *__restrict__ dL_drot, float *__restrict__ dL_dsh, float *__restrict__ dL_dcov3D) {
+    const float *__restrict__ partial /*[I,9]*/, const uint32_t *__restrict__ inv /*[I]*/, const uint32_t *__restrict__ off_by_gid,
+    float *__restrict__ dL_dmeans2D /*[P,3] out*/, float *__restrict__ dL_dopacity /*[P] out*/,
+    float *__restrict__ dL_dcolors_precomp /*[P,3] out, precomp mode*/, float *__restrict__ dL_dmeans3D,
+    float *__restrict__ dL_dscales, float *__restrict__ dL_drot, float *__restrict__ dL_dsh, float *__restrict__ dL_dcov3D) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= P) return;
-    const bool visible = tiles_touched[idx] > 0;
+    const uint32_t ntiles_g = tiles_touched[idx];
+    const bool visible = ntiles_g > 0;
+
+    // gather this splat's per-instance sums (one row per touched tile) through the inverse permutation of the binning
+    float acc[9];
+#pragma unroll
+    for (int q = 0; q < 9; q++) acc[q] = 0.f;
+    if (visible) {
+        const uint32_t e0 = off_by_gid[idx];
+        for (uint32_t k = 0; k < ntiles_g; k++) {
+            const float *row = partial + (size_t)inv[e0 + k] * 9;
+#pragma unroll
+            for (int q = 0; q < 9; q++) acc[q] += row[q];
+        }
+    }
+    dL_dmeans2D[3 * (size_t)idx] = acc[3];
+    dL_dmeans2D[3 * (size_t)idx + 1] = acc[4];
+    dL_dmeans2D[3 * (size_t)idx + 2] = 0.f;
+    dL_dopacity[idx] = acc[8];
+    if (!HAS_SH) {
+        dL_dcolors_precomp[3 * (size_t)idx] = acc[0];
+        dL_dcolors_precomp[3 * (size_t)idx + 1] = acc[1];
+        dL_dcolors_precomp[3 * (size_t)idx + 2] = acc[2];
+    }
 
     float dmean[3] = {0.f, 0.f, 0.f};
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -69,7 +93,7 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(
             const float ca = TS0[0] * T[0][0] + TS0[1] * T[0][1] + TS0[2] * T[0][2] + 0.3f;
             const float cb = TS0[0] * T[1][0] + TS0[1] * T[1][1] + TS0[2] * T[1][2];
             const float cc = TS1[0] * T[1][0] + TS1[1] * T[1][1] + TS1[2] * T[1][2] + 0.3f;
-            const float gA = dL_dconic[8 * (size_t)idx], gB = dL_dconic[8 * (size_t)idx + 1], gC = dL_dconic[8 * (size_t)idx + 2];
+            const float gA = acc[5], gB = acc[6], gC = acc[7];
             const float denom = ca * cc - cb * cb;
             float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
             const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
@@ -108,7 +132,7 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(
             const float m_w = 1.0f / (m_hom.w + 0.0000001f);
             const float mul1 = (PM[0] * mean.x + PM[4] * mean.y + PM[8] * mean.z + PM[12]) * m_w * m_w;
             const float mul2 = (PM[1] * mean.x + PM[5] * mean.y + PM[9] * mean.z + PM[13]) * m_w * m_w;
-            const float gx = dL_dmean2D[3 * (size_t)idx], gy = dL_dmean2D[3 * (size_t)idx + 1];
+            const float gx = acc[3], gy = acc[4];
             dmean[0] += (PM[0] * m_w - PM[3] * mul1) * gx + (PM[1] * m_w - PM[3] * mul2) * gy;
             dmean[1] += (PM[4] * m_w - PM[7] * mul1) * gx + (PM[5] * m_w - PM[7] * mul2) * gy;
             dmean[2] += (PM[8] * m_w - PM[11] * mul1) * gx + (PM[9] * m_w - PM[11] * mul2) * gy;
@@ -124,7 +148,7 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(
             const uint8_t cl = clamped[idx];
             float g[3];
 #pragma unroll
-            for (int c = 0; c < 3; c++) g[c] = ((cl >> c) & 1) ? 0.f : dL_dcolor[(size_t)idx * color_stride + c];
+            for (int c = 0; c < 3; c++) g[c] = ((cl >> c) & 1) ? 0.f : acc[c];
             float ddir[3] = {0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < 3; c++) {
@@ -237,18 +261,19 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(
     }
 }
 
-int launch_preprocess_backward(const das3r_raster_args *a, const das3r_raster_in *in, char *geom, const Layout &L,
-                               const das3r_raster_grads *g, const float *dL_dconic, const float *dL_dcolor, int color_stride,
-                               hipStream_t s) {
+int launch_preprocess_backward(const das3r_raster_args *a, const das3r_raster_in *in, char *geom, char *binning, const Layout &L,
+                               const das3r_raster_grads *g, const float *partial, hipStream_t s) {
     const int P = a->P;
     if (P == 0) return DAS3R_OK;
     dim3 grid(div_up(P, 256)), block(256);
     const bool has_sh = in->shs != nullptr, has_cov = in->cov3D_precomp != nullptr;
+    const uint32_t *inv = binning ? (const uint32_t *)(binning + L.b_inv) : nullptr;
 #define ARGS                                                                                                                 \
     P, a->sh_degree, a->M, in->means3D, in->scales, a->scale_modifier, in->rotations, in->shs, in->cov3D_precomp,            \
         a->viewmatrix, a->projmatrix, a->campos, a->image_width, a->image_height, a->tanfovx, a->tanfovy,                    \
-        (const uint32_t *)(geom + L.pub.tiles_touched), (const uint8_t *)(geom + L.pub.clamped), g->dL_dmeans2D, dL_dconic,  \
-        dL_dcolor, color_stride, g->dL_dmeans3D, g->dL_dscales, g->dL_drotations, g->dL_dshs, g->dL_dcov3D
+        (const uint32_t *)(geom + L.pub.tiles_touched), (const uint8_t *)(geom + L.pub.clamped), partial, inv,               \
+        (const uint32_t *)(geom + L.g_off_by_gid), g->dL_dmeans2D, g->dL_dopacities, g->dL_dcolors_precomp, g->dL_dmeans3D,  \
+        g->dL_dscales, g->dL_drotations, g->dL_dshs, g->dL_dcov3D
     if (has_sh && !has_cov) DAS3R_LAUNCH((preprocess_backward_kernel<true, false>), grid, block, 0, s, ARGS);
     else if (has_sh && has_cov) DAS3R_LAUNCH((preprocess_backward_kernel<true, true>), grid, block, 0, s, ARGS);
     else if (!has_sh && !has_cov) DAS3R_LAUNCH((preprocess_backward_kernel<false, false>), grid, block, 0, s, ARGS);

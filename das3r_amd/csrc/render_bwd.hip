@@ -1,12 +1,15 @@
-// render_bwd.hip — K7: back-to-front replay of the per-pixel compositing, accumulating
-// dL/d(colour, mean2D, conic, opacity) per splat.  Replaces upstream:cuda_rasterizer/backward.cu renderCUDA
-// (SURVEY.md A.7), whose 9 float atomicAdds per (pixel, splat) pair are the classic 3DGS training hot spot.
+// render_bwd.hip — K7: back-to-front replay of the per-pixel compositing, producing per-INSTANCE partial sums of
+// dL/d(colour, mean2D, conic, opacity).  Replaces upstream:cuda_rasterizer/backward.cu renderCUDA, whose
+// 9 float atomicAdds per (pixel, splat) pair are the classic 3DGS training hot spot.
 //
 // MI355X design (decomposition in render_common.h): each wave64 owns an 8x8 quadrant and walks only the splats that can
 // touch it (ballot-culled sub-list).  The 64 pixels of the wave are reduced on the cross-lane network — 8 of the 9 sums
-// with the transposed reduction (permlane32/16 swap + DPP, 18 ops), the ninth with a 6-step DPP chain — the four waves
-// of the tile meet in LDS (one ds_add_f32 per wave and splat, 9 lanes -> 9 addresses), and only ONE global atomic per
-// (tile, splat, component) leaves the CU: 256x fewer device atomics than one per pair.
+// with the transposed reduction (permlane32/16 swap + DPP, 18 ops), the ninth with a 6-step DPP chain — and the four
+// waves of the tile meet in LDS (one ds_add_f32 per wave and splat, 9 lanes -> 9 addresses).
+// NO global atomics: device-scope float atomics measured ~0.5 ms of a 1.2 ms kernel at 1M splats (they leave the XCD's
+// L2).  Instead the tile writes its 9 sums per list entry to partial[list position][9] — a contiguous, coalesced block
+// per tile — and the per-Gaussian backward kernel (preprocess_bwd.hip) gathers a splat's few instances through the
+// inverse permutation recorded by the binning pass.  Gradients are therefore bit-reproducible run to run.
 #include "render_common.h"
 
 namespace das3r {
@@ -18,12 +21,9 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int tiles_x, int ntiles,
     const float4 *__restrict__ xyh, const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
     const float *__restrict__ bg, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
-    const float *__restrict__ dL_dpix, float *__restrict__ dL_dmean2D /*[P,3]*/, float *__restrict__ dL_dconic /*row stride cs*/,
-    int conic_stride, float *__restrict__ dL_dopacity /*[P]*/, float *__restrict__ dL_dcolor /*row stride ls*/, int color_stride,
-    int ablate) {
+    const float *__restrict__ dL_dpix, float *__restrict__ partial /*[I,9]*/, int ablate) {
     __shared__ StagedSplat stage[TILE_PIX];
-    __shared__ uint32_t stage_id[TILE_PIX];
-    __shared__ float acc[TILE_PIX][NACC];
+    __shared__ float acc[TILE_PIX * NACC];
     __shared__ uint32_t s_max[4];
 
     const int tile = xcd_tile(blockIdx.x, ntiles);
@@ -58,8 +58,15 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
     const uint32_t max_contrib = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
     const int rounds = ((int)max_contrib + TILE_PIX - 1) / TILE_PIX;
 
-    float T = T_final;
-    float accum0 = 0.f, accum1 = 0.f, accum2 = 0.f, last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
+    // list entries beyond max_contrib receive no gradient from this tile: their partial rows are zero
+    {
+        const uint32_t len = range.y - range.x;
+        float *tail = partial + ((size_t)range.x + max_contrib) * NACC;
+        const uint32_t ntail = (len - max_contrib) * NACC;
+        for (uint32_t f = tid; f < ntail; f += TILE_PIX) tail[f] = 0.f;
+    }
+
+    ReplayState st = {T_final, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // which accumulator this lane feeds after the cross-lane reduction
     const bool writer = USE_DPP ? (((lane & 7) == 0) || lane == 63) : (lane < NACC);
     const int widx = USE_DPP ? (lane == 63 ? 8 : (lane >> 3)) : lane;
@@ -70,13 +77,12 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
         // stage the batch in reverse list order; entry j holds list position (max_contrib - 1 - done_before - j)
         if (tid < n) {
             const uint32_t g = point_list[range.x + max_contrib - 1 - done_before - tid];
-            stage_id[tid] = g;
             stage[tid].xyh = xyh[g];
             stage[tid].co = conic_opacity[g];
             stage[tid].rgbd = rgbd[g];
         }
 #pragma unroll
-        for (int k = 0; k < NACC; k++) acc[tid][k] = 0.f;
+        for (int k = 0; k < NACC; k++) acc[k * TILE_PIX + tid] = 0.f;   // acc[j*9 + q], zeroed with unit-stride stores
         __syncthreads();
 
         uint64_t masks[4];
@@ -97,40 +103,13 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
                 float dx, dy, G, alpha;
                 const bool active = pair_alpha(p.x, p.y, co, pxf, pyf, dx, dy, G, alpha) & (position < last_contributor);
                 if (__ballot(active) == 0ull) continue;  // wave-uniform skip
-                // branch-free replay: inactive lanes run the same arithmetic with alpha = G = 0 (state and sums unchanged)
                 const float4 c = stage[j].rgbd;
-                const float am = active ? alpha : 0.f, Gm = active ? G : 0.f;
-                const float rinv = __builtin_amdgcn_rcpf(1.f - am);  // v_rcp_f32: T is itself a reconstruction, 1 ulp is noise
-                T = T * rinv;
-                const float dchannel_dcolor = am * T;
-                const float na0 = last_alpha * lc0 + (1.f - last_alpha) * accum0;
-                const float na1 = last_alpha * lc1 + (1.f - last_alpha) * accum1;
-                const float na2 = last_alpha * lc2 + (1.f - last_alpha) * accum2;
-                accum0 = active ? na0 : accum0;
-                accum1 = active ? na1 : accum1;
-                accum2 = active ? na2 : accum2;
-                lc0 = active ? c.x : lc0;
-                lc1 = active ? c.y : lc1;
-                lc2 = active ? c.z : lc2;
-                last_alpha = active ? alpha : last_alpha;
-                float dL_dalpha = (c.x - accum0) * dLp0 + (c.y - accum1) * dLp1 + (c.z - accum2) * dLp2;
-                dL_dalpha = dL_dalpha * T - (T_final * rinv) * bg_dot_dpixel;
-                const float gdl = Gm * dL_dalpha;           // G * dL/dalpha (0 on inactive lanes)
-                const float dL_dG_G = co.w * gdl;           // G * dL/dG
-                const float gdx = dL_dG_G * dx, gdy = dL_dG_G * dy;
                 float v[NACC];
-                v[0] = dchannel_dcolor * dLp0;
-                v[1] = dchannel_dcolor * dLp1;
-                v[2] = dchannel_dcolor * dLp2;
-                v[3] = (-gdx * co.x - gdy * co.y) * ddelx_dx;
-                v[4] = (-gdy * co.z - gdx * co.y) * ddely_dy;
-                v[5] = -0.5f * gdx * dx;
-                v[6] = -0.5f * gdx * dy;
-                v[7] = -0.5f * gdy * dy;
-                v[8] = gdl;
-                if (ablate & 2) continue;
+                replay_pair(active, alpha, G, dx, dy, co, c, dLp0, dLp1, dLp2, T_final, bg_dot_dpixel, ddelx_dx, ddely_dy, st, v);
                 float out;
-                if (USE_DPP) {
+                if (ablate & 4) {  // experiment: no cross-lane traffic, heavy arithmetic kept alive
+                    out = v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] + v[8];
+                } else if (USE_DPP) {
                     const float r8 = wave_reduce8_transposed(v, lane);   // lane l: total of v[l >> 3]
                     const float r1 = wave_sum_to_lane63(v[8]);           // lane 63: total of v[8]
                     out = lane == 63 ? r1 : r8;
@@ -143,30 +122,16 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
 #pragma unroll
                     for (int q = 0; q < NACC; q++) out = lane == q ? tot[q] : out;
                 }
-                if (writer) atomicAdd(&acc[j][widx], out);  // divergent addresses: one ds_add_f32 for the whole wave
+                if (writer) atomicAdd(&acc[j * NACC + widx], out);  // divergent addresses: one ds_add_f32 for the whole wave
             }
         }
         __syncthreads();
-        // one global atomic per (tile, splat, component)
-        if (tid < n) {
-            const uint32_t g = stage_id[tid];
-            float a[NACC];
-            bool any = false;
-#pragma unroll
-            for (int k = 0; k < NACC; k++) {
-                a[k] = acc[tid][k];
-                any |= (a[k] != 0.f);
-            }
-            if (any && !(ablate & 1)) {
-                unsafeAtomicAdd(&dL_dcolor[(size_t)g * color_stride + 0], a[0]);
-                unsafeAtomicAdd(&dL_dcolor[(size_t)g * color_stride + 1], a[1]);
-                unsafeAtomicAdd(&dL_dcolor[(size_t)g * color_stride + 2], a[2]);
-                unsafeAtomicAdd(&dL_dmean2D[(size_t)g * 3 + 0], a[3]);
-                unsafeAtomicAdd(&dL_dmean2D[(size_t)g * 3 + 1], a[4]);
-                unsafeAtomicAdd(&dL_dconic[(size_t)g * conic_stride + 0], a[5]);
-                unsafeAtomicAdd(&dL_dconic[(size_t)g * conic_stride + 1], a[6]);
-                unsafeAtomicAdd(&dL_dconic[(size_t)g * conic_stride + 2], a[7]);
-                unsafeAtomicAdd(&dL_dopacity[g], a[8]);
+        // the batch's n x 9 sums form one contiguous block of `partial` (rows in reverse order): coalesced stores
+        if (!(ablate & 1)) {
+            const size_t top = (size_t)range.x + max_contrib - 1 - done_before;  // list position of entry j = 0
+            for (int f = tid; f < n * NACC; f += TILE_PIX) {
+                const int j = f / NACC, q = f - j * NACC;
+                partial[(top - j) * NACC + q] = acc[f];
             }
         }
         __syncthreads();
@@ -174,18 +139,16 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
 }
 
 int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
-                           float *dL_dmean2D, float *dL_dconic, float *dL_dopacity, float *dL_dcolor, int color_stride,
-                           hipStream_t s) {
+                           float *partial, hipStream_t s) {
     const char *e = getenv("DAS3R_BWD_REDUCE");  // "shfl" selects the ds_bpermute reference reduction (diagnostics)
     const bool use_dpp = !(e && e[0] == 's');
-    const char *ea = getenv("DAS3R_ABLATE");  // perf experiments only: bit0 = no global atomics, bit1 = no wave reduction
+    const char *ea = getenv("DAS3R_ABLATE");  // perf experiments only: bit0 = no partial stores, bit2 = no cross-lane reduction
     const int ablate = ea ? atoi(ea) : 0;
 #define ARGS                                                                                                                 \
     (const uint2 *)(img + L.pub.ranges), (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height,    \
         L.tiles_x, L.ntiles, (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),                \
         (const float4 *)(geom + L.pub.rgbd), a->bg, (const float *)(img + L.pub.final_T),                                    \
-        (const uint32_t *)(img + L.pub.n_contrib), dL_dpix, dL_dmean2D, dL_dconic, 8, dL_dopacity, dL_dcolor, color_stride,  \
-        ablate
+        (const uint32_t *)(img + L.pub.n_contrib), dL_dpix, partial, ablate
     if (use_dpp) DAS3R_LAUNCH((render_backward_kernel<true>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS);
     else DAS3R_LAUNCH((render_backward_kernel<false>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS);
 #undef ARGS

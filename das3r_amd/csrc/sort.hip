@@ -90,7 +90,8 @@ __global__ void __launch_bounds__(256) radix_rowscan_kernel(uint32_t *__restrict
 __global__ void __launch_bounds__(256) radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                             uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
                                                             uint32_t n, int shift, int bits, int ipl, int nchunks,
-                                                            const uint32_t *__restrict__ hist, const uint32_t *__restrict__ totals) {
+                                                            const uint32_t *__restrict__ hist, const uint32_t *__restrict__ totals,
+                                                            const uint32_t *__restrict__ gather_src, uint32_t *__restrict__ inv_out) {
     __shared__ uint32_t off_s[SORT_WAVES_PER_BLOCK][RADIX_SIZE];
     const int lane = __lane_id(), wave = threadIdx.x >> 6;
     const int chunk = blockIdx.x * SORT_WAVES_PER_BLOCK + wave;
@@ -141,13 +142,17 @@ __global__ void __launch_bounds__(256) radix_scatter_kernel(const uint32_t *__re
         if (valid) {
             const uint32_t dst = o + rank;
             if (keys_out) keys_out[dst] = key;
-            vals_out[dst] = val;
+            // final pass of the tile partition: the payload is the emission slot e; store the splat id it stands for
+            // and remember where slot e ended up (inverse permutation, used by the gather in the backward pass)
+            vals_out[dst] = gather_src ? gather_src[val] : val;
+            if (inv_out) inv_out[val] = dst;
         }
     }
 }
 
 static int radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t n, int shift, int bits,
-                      uint32_t *hist, uint32_t *totals, bool debug, hipStream_t s) {
+                      uint32_t *hist, uint32_t *totals, bool debug, hipStream_t s, const uint32_t *gather_src = nullptr,
+                      uint32_t *inv_out = nullptr) {
     const int ipl = sort_items_per_lane(n), nchunks = sort_num_chunks(n);
     const int nblocks = div_up(nchunks, SORT_WAVES_PER_BLOCK);
     DAS3R_LAUNCH(radix_hist_kernel, dim3(nblocks), dim3(256), 0, s, kin, (uint32_t)n, shift, (1u << bits) - 1u, ipl, nchunks, hist);
@@ -155,7 +160,7 @@ static int radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, 
     DAS3R_LAUNCH(radix_rowscan_kernel, dim3(RADIX_SIZE), dim3(256), 0, s, hist, nchunks, totals);
     KERNEL_CHECK(s, debug, "radix_rowscan");
     DAS3R_LAUNCH(radix_scatter_kernel, dim3(nblocks), dim3(256), 0, s, kin, vin, kout, vout, (uint32_t)n, shift, bits, ipl,
-                       nchunks, hist, totals);
+                       nchunks, hist, totals, gather_src, inv_out);
     KERNEL_CHECK(s, debug, "radix_scatter");
     return DAS3R_OK;
 }
@@ -201,7 +206,8 @@ __global__ void __launch_bounds__(256) tt_blocksum_kernel(int P, const uint32_t 
 
 __global__ void __launch_bounds__(256) tt_scan_kernel(int P, int nblocks, const uint32_t *__restrict__ sorted_idx,
                                                       const uint32_t *__restrict__ tiles_touched, const uint32_t *__restrict__ block_sums,
-                                                      uint32_t *__restrict__ offsets, uint32_t *__restrict__ count) {
+                                                      uint32_t *__restrict__ offsets, uint32_t *__restrict__ off_by_gid,
+                                                      uint32_t *__restrict__ count) {
     __shared__ uint32_t ws[4];
     // prefix of earlier blocks (nblocks is small: P / 4096)
     uint32_t part = 0;
@@ -211,10 +217,14 @@ __global__ void __launch_bounds__(256) tt_scan_kernel(int P, int nblocks, const 
     const int base = blockIdx.x * 256 * SCAN_ITEMS;
     for (int k = 0; k < SCAN_ITEMS; k++) {
         const int r = base + k * 256 + threadIdx.x;
-        const uint32_t v = r < P ? tiles_touched[sorted_idx[r]] : 0u;
+        const uint32_t g = r < P ? sorted_idx[r] : 0u;
+        const uint32_t v = r < P ? tiles_touched[g] : 0u;
         uint32_t tot;
         const uint32_t ex = block_exclusive_scan_256(v, ws, &tot);
-        if (r < P) offsets[r] = carry + ex;
+        if (r < P) {
+            offsets[r] = carry + ex;
+            off_by_gid[g] = carry + ex;  // first emission slot of splat g (its instances are emitted contiguously)
+        }
         carry += tot;
     }
     if (blockIdx.x == nblocks - 1 && threadIdx.x == 0) *count = carry;
@@ -236,7 +246,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, int tiles
     for (int y = rminy; y < rmaxy; y++)
         for (int x = rminx; x < rmaxx; x++) {
             tile_keys[o] = (uint32_t)(y * tiles_x + x);
-            gids[o] = g;
+            gids[o] = g;  // gid_of[emission slot]
             o++;
         }
 }
@@ -276,7 +286,7 @@ int launch_depth_sort_and_scan(int P, char *geom, const Layout &L, bool debug, h
     DAS3R_LAUNCH(tt_blocksum_kernel, dim3(nblocks), dim3(256), 0, s, P, valA, tt, bsums);
     KERNEL_CHECK(s, debug, "tt_blocksum");
     DAS3R_LAUNCH(tt_scan_kernel, dim3(nblocks), dim3(256), 0, s, P, nblocks, valA, tt, bsums,
-                       (uint32_t *)(geom + L.pub.offsets), count);
+                       (uint32_t *)(geom + L.pub.offsets), (uint32_t *)(geom + L.g_off_by_gid), count);
     KERNEL_CHECK(s, debug, "tt_scan");
     return DAS3R_OK;
 }
@@ -290,20 +300,24 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
     uint32_t *keyA = (uint32_t *)(binning + L.b_keyA), *keyB = (uint32_t *)(binning + L.b_keyB);
     uint32_t *valA = (uint32_t *)(binning + L.b_valA), *valB = (uint32_t *)(binning + L.b_valB);
     uint32_t *hist = (uint32_t *)(binning + L.b_hist), *totals = (uint32_t *)(binning + L.b_totals);
+    uint32_t *gid_of = (uint32_t *)(binning + L.b_gid_of), *inv = (uint32_t *)(binning + L.b_inv);
     DAS3R_LAUNCH(emit_kernel, dim3(div_up(P, 256)), dim3(256), 0, s, P, L.tiles_x, L.tiles_y,
                        (const uint32_t *)(geom + L.pub.sorted_idx), (const uint32_t *)(geom + L.pub.tiles_touched),
-                       (const uint32_t *)(geom + L.pub.offsets), (const float4 *)(geom + L.pub.xy), radii, keyA, valA);
+                       (const uint32_t *)(geom + L.pub.offsets), (const float4 *)(geom + L.pub.xy), radii, keyA, gid_of);
     KERNEL_CHECK(s, debug, "emit");
     // stable partition by tile id: tile_passes passes of <= 8 bits; ping-pong A -> B (-> A)
-    uint32_t *kin = keyA, *vin = valA, *kout = keyB, *vout = valB;
+    // payload = emission slot e (identity on the first pass); the last pass turns it into the splat id and records inv[e]
+    uint32_t *kin = keyA, *vin = nullptr, *kout = keyB, *vout = valB;
     int shift = 0, rc;
     for (int p = 0; p < L.tile_passes; p++) {
         const int bits = (L.tbits - shift) < 8 ? (L.tbits - shift) : 8;
-        if ((rc = radix_pass(kin, vin, kout, vout, I, shift, bits, hist, totals, debug, s))) return rc;
+        const bool last = p == L.tile_passes - 1;
+        if ((rc = radix_pass(kin, vin, kout, vout, I, shift, bits, hist, totals, debug, s, last ? gid_of : nullptr, last ? inv : nullptr)))
+            return rc;
         shift += bits;
-        uint32_t *t;
-        t = kin; kin = kout; kout = t;
-        t = vin; vin = vout; vout = t;
+        uint32_t *t = kin; kin = kout; kout = t;
+        vin = vout;
+        vout = (vout == valB) ? valA : valB;
     }
     // kin/vin now hold the partitioned (tile id, gaussian id) lists; vin == binning + pub.point_list by construction
     DAS3R_LAUNCH(tile_ranges_kernel, dim3(div_up(I, 256)), dim3(256), 0, s, (uint32_t)I, kin, ranges);

@@ -153,7 +153,7 @@ def _backward_impl(rs, num_rendered, grad_out_color, means3D, sh, colors_precomp
     if P == 0:
         return g_means2D, g_colors, g_opac, g_means3D, g_cov, g_sh, g_scales, g_rot
     has_sh, has_cov = sh.numel() > 0, cov3Ds_precomp.numel() > 0
-    scratch = z(P, 8)
+    scratch = z(max(int(num_rendered), 1), 9)   # per-instance partial sums, fully written by the render backward
     keep = []
     a = _fill_args(rs, P, M, device, keep)
     i = _fill_in(means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp)

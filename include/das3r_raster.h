@@ -101,11 +101,11 @@ typedef struct {
     float *dL_dopacities;      /* [P,1] */
     float *dL_dmeans3D;        /* [P,3] */
     float *dL_dshs;            /* [P,M,3] dense; NULL when colors_precomp was used */
-    float *dL_dcolors_precomp; /* [P,3]; may be NULL when shs was used (internal scratch is used then) */
+    float *dL_dcolors_precomp; /* [P,3]; NULL when shs was used */
     float *dL_dscales;         /* [P,3]; NULL when cov3D_precomp was used */
     float *dL_drotations;      /* [P,4]; NULL when cov3D_precomp was used */
     float *dL_dcov3D;          /* [P,6]; NULL unless cov3D_precomp was used */
-    float *scratch;            /* [P,8] caller-provided scratch (dL_dconic[3] + dL_dcolor[3] + pad) */
+    float *scratch;            /* [num_rendered,9] caller-provided scratch: per-instance partial sums (no atomics) */
 } das3r_raster_grads;
 
 /* Returns num_rendered (>= 0) or a negative das3r_status.  Fills *saved. */
