@@ -48,26 +48,33 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
 }
 
 // ---------------------------------------------------------------- radix pass
+// IPL = keys per lane (compile time): the whole chunk is fetched into registers before any of it is ranked, so the
+// HBM/L2 latency is paid once per wave instead of once per 64 keys.
+template <int IPL>
 __global__ void __launch_bounds__(256) radix_hist_kernel(const uint32_t *__restrict__ keys, uint32_t n, int shift, uint32_t mask,
-                                                         int ipl, int nchunks, uint32_t *__restrict__ hist) {
+                                                         int nchunks, uint32_t *__restrict__ hist) {
     __shared__ uint32_t cnt[SORT_WAVES_PER_BLOCK][RADIX_SIZE];
     const int lane = __lane_id(), wave = threadIdx.x >> 6;
     const int chunk = blockIdx.x * SORT_WAVES_PER_BLOCK + wave;
+    const uint32_t base = (uint32_t)chunk * 64u * (uint32_t)IPL;
+    uint32_t k[IPL];
+#pragma unroll
+    for (int s = 0; s < IPL; s++) {
+        const uint32_t i = base + s * 64 + lane;
+        k[s] = (chunk < nchunks && i < n) ? keys[i] : 0u;
+    }
 #pragma unroll
     for (int d = lane; d < RADIX_SIZE; d += 64) cnt[wave][d] = 0;
-    __syncthreads();
-    if (chunk < nchunks) {
-        const uint32_t base = (uint32_t)chunk * 64u * (uint32_t)ipl;
-        for (int s = 0; s < ipl; s++) {
-            const uint32_t i = base + s * 64 + lane;
-            if (i < n) atomicAdd(&cnt[wave][(keys[i] >> shift) & mask], 1u);
-        }
-    }
-    __syncthreads();
-    if (chunk < nchunks) {
+    __builtin_amdgcn_wave_barrier();
+    if (chunk >= nchunks) return;
 #pragma unroll
-        for (int d = lane; d < RADIX_SIZE; d += 64) hist[(size_t)d * nchunks + chunk] = cnt[wave][d];
+    for (int s = 0; s < IPL; s++) {
+        const uint32_t i = base + s * 64 + lane;
+        if (i < n) atomicAdd(&cnt[wave][(k[s] >> shift) & mask], 1u);
     }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int d = lane; d < RADIX_SIZE; d += 64) hist[(size_t)d * nchunks + chunk] = cnt[wave][d];
 }
 
 // one block per digit: exclusive scan of that digit's per-chunk counts (in place) + digit total
@@ -86,10 +93,12 @@ __global__ void __launch_bounds__(256) radix_rowscan_kernel(uint32_t *__restrict
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
-// keys_out may be null (last pass of a sort whose keys are not needed); vals_in null => identity (index)
+// keys_out may be null (last pass of a sort whose keys are not needed); vals_in null => identity (index).
+// gather_src / inv_out: see launch_binning (final pass of the tile partition).
+template <int IPL>
 __global__ void __launch_bounds__(256) radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                             uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
-                                                            uint32_t n, int shift, int bits, int ipl, int nchunks,
+                                                            uint32_t n, int shift, int bits, int nchunks,
                                                             const uint32_t *__restrict__ hist, const uint32_t *__restrict__ totals,
                                                             const uint32_t *__restrict__ gather_src, uint32_t *__restrict__ inv_out) {
     __shared__ uint32_t off_s[SORT_WAVES_PER_BLOCK][RADIX_SIZE];
@@ -98,32 +107,44 @@ __global__ void __launch_bounds__(256) radix_scatter_kernel(const uint32_t *__re
     if (chunk >= nchunks) return;  // no block-level barriers below
     volatile uint32_t *off = off_s[wave];
     const uint32_t mask = (1u << bits) - 1u;
+    const uint32_t base = (uint32_t)chunk * 64u * (uint32_t)IPL;
 
+    // fetch the whole chunk (keys, payloads and, on the final partition pass, the gathered splat ids) up front
+    uint32_t k[IPL], v[IPL], out[IPL];
+#pragma unroll
+    for (int s = 0; s < IPL; s++) {
+        const uint32_t i = base + s * 64 + lane;
+        k[s] = i < n ? keys_in[i] : 0u;
+        v[s] = (vals_in && i < n) ? vals_in[i] : i;
+    }
+#pragma unroll
+    for (int s = 0; s < IPL; s++) {
+        const uint32_t i = base + s * 64 + lane;
+        out[s] = (gather_src && i < n) ? gather_src[v[s]] : v[s];
+    }
     // digit base = exclusive scan of the 256 digit totals (4 consecutive digits per lane)
     {
-        uint32_t t[4], sum = 0;
+        uint32_t t[4], h[4], sum = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            t[k] = totals[4 * lane + k];
-            sum += t[k];
+        for (int q = 0; q < 4; q++) {
+            t[q] = totals[4 * lane + q];
+            h[q] = hist[(size_t)(4 * lane + q) * nchunks + chunk];
+            sum += t[q];
         }
         uint32_t ex = wave_inclusive_scan_u32(sum) - sum;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int d = 4 * lane + k;
-            off[d] = ex + hist[(size_t)d * nchunks + chunk];
-            ex += t[k];
+        for (int q = 0; q < 4; q++) {
+            off[4 * lane + q] = ex + h[q];
+            ex += t[q];
         }
     }
     __builtin_amdgcn_wave_barrier();
 
-    const uint32_t base = (uint32_t)chunk * 64u * (uint32_t)ipl;
-    for (int s = 0; s < ipl; s++) {
+#pragma unroll
+    for (int s = 0; s < IPL; s++) {
         const uint32_t i = base + s * 64 + lane;
         const bool valid = i < n;
-        const uint32_t key = valid ? keys_in[i] : 0u;
-        const uint32_t val = valid ? (vals_in ? vals_in[i] : i) : 0u;
-        const uint32_t digit = (key >> shift) & mask;
+        const uint32_t digit = (k[s] >> shift) & mask;
         // match-any: lanes holding the same digit
         uint64_t peers = __ballot(valid);
         for (int b = 0; b < bits; b++) {
@@ -141,11 +162,11 @@ __global__ void __launch_bounds__(256) radix_scatter_kernel(const uint32_t *__re
         __builtin_amdgcn_wave_barrier();
         if (valid) {
             const uint32_t dst = o + rank;
-            if (keys_out) keys_out[dst] = key;
+            if (keys_out) keys_out[dst] = k[s];
             // final pass of the tile partition: the payload is the emission slot e; store the splat id it stands for
             // and remember where slot e ended up (inverse permutation, used by the gather in the backward pass)
-            vals_out[dst] = gather_src ? gather_src[val] : val;
-            if (inv_out) inv_out[val] = dst;
+            vals_out[dst] = out[s];
+            if (inv_out) inv_out[v[s]] = dst;
         }
     }
 }
@@ -155,13 +176,19 @@ static int radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, 
                       uint32_t *inv_out = nullptr) {
     const int ipl = sort_items_per_lane(n), nchunks = sort_num_chunks(n);
     const int nblocks = div_up(nchunks, SORT_WAVES_PER_BLOCK);
-    DAS3R_LAUNCH(radix_hist_kernel, dim3(nblocks), dim3(256), 0, s, kin, (uint32_t)n, shift, (1u << bits) - 1u, ipl, nchunks, hist);
+    const uint32_t mask = (1u << bits) - 1u;
+#define HIST(IPL) DAS3R_LAUNCH((radix_hist_kernel<IPL>), dim3(nblocks), dim3(256), 0, s, kin, (uint32_t)n, shift, mask, nchunks, hist)
+#define SCAT(IPL)                                                                                                             \
+    DAS3R_LAUNCH((radix_scatter_kernel<IPL>), dim3(nblocks), dim3(256), 0, s, kin, vin, kout, vout, (uint32_t)n, shift, bits, \
+                 nchunks, hist, totals, gather_src, inv_out)
+    if (ipl == 4) HIST(4); else if (ipl == 8) HIST(8); else HIST(16);
     KERNEL_CHECK(s, debug, "radix_hist");
     DAS3R_LAUNCH(radix_rowscan_kernel, dim3(RADIX_SIZE), dim3(256), 0, s, hist, nchunks, totals);
     KERNEL_CHECK(s, debug, "radix_rowscan");
-    DAS3R_LAUNCH(radix_scatter_kernel, dim3(nblocks), dim3(256), 0, s, kin, vin, kout, vout, (uint32_t)n, shift, bits, ipl,
-                       nchunks, hist, totals, gather_src, inv_out);
+    if (ipl == 4) SCAT(4); else if (ipl == 8) SCAT(8); else SCAT(16);
     KERNEL_CHECK(s, debug, "radix_scatter");
+#undef HIST
+#undef SCAT
     return DAS3R_OK;
 }
 

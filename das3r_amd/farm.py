@@ -1,0 +1,105 @@
+"""Multi-GPU sequence farm: independent sequences are optimised one per GPU; the only collective is the
+gather of one fixed-size record per sequence at the end (RCCL on GPUs, gloo in the CPU tests).
+
+The reference runs its per-scene loops serially on GPU 0 (/root/reference/scripts/testing_psnr_davis.sh:3,35-59) and
+scrapes the PSNR out of log files (/root/reference/scripts/get_testing_psnr_davis.py:8-22); the slicing idiom follows
+the reference's own farm for the predictor stage (/root/reference/dynamic_predictor/dust3r/pose_eval.py:53-68).
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m das3r_amd.farm \
+        --sequences 8 --iterations 200
+"""
+import argparse
+import os
+
+import torch
+import torch.distributed as dist
+
+RECORD_FIELDS = ("scene_id", "psnr", "l1", "iters_per_s", "n_splats", "ok")   # one float64 row per sequence
+
+
+def assign(n_sequences, rank, world, costs=None):
+    """Sequence indices for `rank`.  Without costs: round-robin (rank, rank+world, ...).  With costs (e.g. N_VIEWS*H*W):
+    longest-processing-time-first greedy, deterministic, same result on every rank."""
+    if costs is None:
+        return list(range(rank, n_sequences, world))
+    order = sorted(range(n_sequences), key=lambda i: (-costs[i], i))
+    loads, bins = [0.0] * world, [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (loads[k], k))
+        bins[r].append(i)
+        loads[r] += costs[i]
+    return sorted(bins[rank])
+
+
+def gather_records(local_records, n_sequences, device):
+    """all_gather of fixed-size records; returns an (n_sequences, len(RECORD_FIELDS)) float64 tensor on every rank, rows
+    ordered by scene id; sequences nobody reported (failed before producing a record) have ok = 0."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    per_rank = (n_sequences + world - 1) // world
+    buf = torch.full((per_rank, len(RECORD_FIELDS)), -1.0, dtype=torch.float64, device=device)
+    for k, rec in enumerate(local_records[:per_rank]):
+        buf[k] = torch.tensor([float(rec[f]) for f in RECORD_FIELDS], dtype=torch.float64)
+    if world > 1:
+        out = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(out, buf)
+        allrec = torch.cat(out, 0)
+    else:
+        allrec = buf
+    table = torch.zeros(n_sequences, len(RECORD_FIELDS), dtype=torch.float64)
+    table[:, 0] = torch.arange(n_sequences, dtype=torch.float64)
+    for row in allrec.cpu():
+        sid = int(row[0])
+        if 0 <= sid < n_sequences:
+            table[sid] = row
+    return table
+
+
+def run_sequence_job(scene_id, iterations, device, frames=6):
+    """One independent 'sequence': build a synthetic multi-frame scene, optimise it with the train-step harness, report the
+    held-out PSNR.  Failures are isolated per sequence (the reference's predictor farm does the same, pose_eval.py:209-222)."""
+    from .model import OptimParams
+    from .train import build_from_sequence, is_test_index, psnr_report, synthetic_sequence, train
+    try:
+        seq = synthetic_sequence(frames=frames, seed=scene_id, device=device)
+        model, cams = build_from_sequence(seq)
+        opt = OptimParams(iterations=iterations)
+        model.training_setup(opt)
+        test = [c for c in cams if is_test_index(c.uid)] or cams[-1:]
+        train_cams = [c for c in cams if c not in test] or cams
+        stats = train(model, train_cams, opt, iterations, seed=scene_id)
+        rep = psnr_report(model, test)
+        return dict(scene_id=scene_id, psnr=rep["psnr"], l1=rep["l1"], iters_per_s=stats["iters_per_s"],
+                    n_splats=model.get_xyz.shape[0], ok=1)
+    except Exception as ex:  # noqa: BLE001 - keep the farm alive, report the failure in the table
+        print(f"[farm] sequence {scene_id} failed: {ex!r}")
+        return dict(scene_id=scene_id, psnr=float("nan"), l1=float("nan"), iters_per_s=0.0, n_splats=0, ok=0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sequences", type=int, default=8)
+    ap.add_argument("--iterations", type=int, default=200)
+    ap.add_argument("--backend", default=None)
+    args = ap.parse_args()
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    use_gpu = torch.cuda.is_available()
+    device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=args.backend or ("nccl" if use_gpu else "gloo"))
+    mine = assign(args.sequences, rank, world)
+    records = [run_sequence_job(s, args.iterations, device) for s in mine]
+    table = gather_records(records, args.sequences, device)
+    if rank == 0:
+        good = table[table[:, 5] > 0]
+        print(" & ".join(f"{p:.2f}" for p in table[:, 1].tolist()))     # the LaTeX row get_testing_psnr_davis.py prints
+        print(f"mean PSNR {good[:, 1].mean().item():.2f} over {good.shape[0]}/{args.sequences} sequences")
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

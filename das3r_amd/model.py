@@ -1,0 +1,140 @@
+"""SplatModel — the parameter container of the train-step harness: the repo's counterpart of the
+parts of /root/reference/scene/gaussian_model.py the hot loop touches.
+
+Reproduced: activations (exp / sigmoid / identity, :32-47); per-pixel initialisation create_from_cameras (:573-659):
+every confident pixel of every frame becomes one Gaussian, xyz = unprojected depth, SH dc = RGB2SH(rgb), scales =
+log(sqrt(clamp_min(distCUDA2(xyz), 1e-7))) repeated 3x, identity quaternions, opacity = inverse_sigmoid(1/num_frames),
+conf_static = 1 - dyna_avg with shape (frames, H, W); the two Adam optimizers (lr=0, eps=1e-15) with the reference's
+groups and LRs and the exponential schedules (:228-323; defaults /root/reference/arguments/__init__.py:73-90);
+oneupSHdegree (:199-201); pose parameters Q/T as (frames,4)/(frames,3) tensors (:149-184).
+"""
+from dataclasses import dataclass
+
+import torch
+from torch import nn
+
+from .knn import distCUDA2
+from .losses import expon_lr_func, inverse_sigmoid, rgb_to_sh
+
+
+@dataclass
+class OptimParams:   # /root/reference/arguments/__init__.py:73-90 (densification is disabled in DAS3R: SURVEY.md C1)
+    iterations: int = 4000
+    position_lr_init: float = 0.00016
+    position_lr_final: float = 0.0000016
+    position_lr_delay_mult: float = 0.01
+    position_lr_max_steps: int = 30_000
+    feature_lr: float = 0.0025
+    opacity_lr: float = 0.05
+    scaling_lr: float = 0.005
+    rotation_lr: float = 0.001
+    lambda_dssim: float = 0.2
+    psnr_threshold: float = 26.0   # train_gui.py:584 camera-optimizer gate
+
+
+def depth_to_points(K, cam2world, depth):
+    """Unproject per-frame depth maps: K (F,3,3) with fx == fy, cam2world (F,4,4), depth (F,H,W) -> (F,H,W,3) world points
+    (/root/reference/utils/pose_utils.py:572-583,672-682: x = d (u - cx)/f, y = d (v - cy)/f, z = d, then the pose)."""
+    F, H, W = depth.shape
+    v, u = torch.meshgrid(torch.arange(H, device=depth.device, dtype=depth.dtype),
+                          torch.arange(W, device=depth.device, dtype=depth.dtype), indexing="ij")
+    f = K[:, 0, 0][:, None, None]
+    cx, cy = K[:, 0, 2][:, None, None], K[:, 1, 2][:, None, None]
+    pts = torch.stack([depth * (u[None] - cx) / f, depth * (v[None] - cy) / f, depth], -1)
+    return torch.einsum("bij,bhwj->bhwi", cam2world[:, :3, :3], pts) + cam2world[:, None, None, :3, 3]
+
+
+class SplatModel:
+    def __init__(self, sh_degree=3):
+        self.max_sh_degree = sh_degree
+        self.active_sh_degree = 0
+        self.spatial_lr_scale = 1.0
+        self.optimizer = self.optimizer_cam = None
+
+    # ---- activations
+    @property
+    def get_xyz(self):
+        return self._xyz
+
+    @property
+    def get_scaling(self):
+        return torch.exp(self._scaling)
+
+    @property
+    def get_rotation(self):
+        return torch.nn.functional.normalize(self._rotation)
+
+    @property
+    def get_opacity(self):
+        return torch.sigmoid(self._opacity)
+
+    @property
+    def get_features(self):
+        return torch.cat((self._features_dc, self._features_rest), dim=1)
+
+    def get_RT(self, idx):
+        return torch.cat([self.Q[idx], self.T[idx]])
+
+    def oneupSHdegree(self):
+        if self.active_sh_degree < self.max_sh_degree:
+            self.active_sh_degree += 1
+
+    # ---- initialisation from per-frame depth / confidence / dynamic maps
+    def create_from_frames(self, images, depths, confs, dyna_avg, K, cam2world, w2c_pose7, spatial_lr_scale=1.0, conf_thre=1.0):
+        """images (F,3,H,W) in [0,1]; depths/confs/dyna_avg (F,H,W); K (F,3,3); cam2world (F,4,4); w2c_pose7 (F,7)."""
+        dev = images.device
+        self.spatial_lr_scale = spatial_lr_scale
+        F = images.shape[0]
+        pts = depth_to_points(K.float(), cam2world.float(), depths.float()).reshape(-1, 3)
+        col = images.permute(0, 2, 3, 1).reshape(-1, 3)
+        self.aggregated_mask = confs.reshape(-1) > torch.tensor(conf_thre).log()
+        pts = pts[self.aggregated_mask].contiguous()
+        col = col[self.aggregated_mask]
+        n = pts.shape[0]
+        feats = torch.zeros(n, 3, (self.max_sh_degree + 1) ** 2, device=dev)
+        feats[:, :3, 0] = rgb_to_sh(col)
+        dist2 = torch.clamp_min(distCUDA2(pts), 0.0000001)
+        scales = torch.log(torch.sqrt(dist2))[..., None].repeat(1, 3)
+        rots = torch.zeros(n, 4, device=dev)
+        rots[:, 0] = 1
+        opac = inverse_sigmoid((1.0 / F) * torch.ones(n, 1, device=dev))
+        self._xyz = nn.Parameter(pts.requires_grad_(True))
+        self._features_dc = nn.Parameter(feats[:, :, 0:1].transpose(1, 2).contiguous())
+        self._features_rest = nn.Parameter(feats[:, :, 1:].transpose(1, 2).contiguous())
+        self._scaling = nn.Parameter(scales)
+        self._rotation = nn.Parameter(rots)
+        self._opacity = nn.Parameter(opac)
+        self._conf_static = nn.Parameter((1 - dyna_avg.float()).contiguous())
+        self.Q = nn.Parameter(w2c_pose7[:, :4].clone().contiguous())
+        self.T = nn.Parameter(w2c_pose7[:, 4:].clone().contiguous())
+        return self
+
+    # ---- optimizers and schedules
+    def training_setup(self, opt: OptimParams):
+        s = self.spatial_lr_scale
+        groups = [
+            {"params": [self._xyz], "lr": opt.position_lr_init * s, "name": "xyz"},
+            {"params": [self._features_dc], "lr": opt.feature_lr, "name": "f_dc"},
+            {"params": [self._features_rest], "lr": opt.feature_lr / 20.0, "name": "f_rest"},
+            {"params": [self._opacity], "lr": opt.opacity_lr, "name": "opacity"},
+            {"params": [self._scaling], "lr": opt.scaling_lr, "name": "scaling"},
+            {"params": [self._rotation], "lr": opt.rotation_lr, "name": "rotation"},
+            {"params": [self._conf_static], "lr": 3e-3, "name": "conf_static"},
+        ]
+        cam = [{"params": [self.Q], "lr": 0.00003, "name": "pose_Q"}, {"params": [self.T], "lr": 0.00003, "name": "pose_T"}]
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        self.optimizer_cam = torch.optim.Adam(cam, lr=0.0, eps=1e-15)
+        self._lr_xyz = expon_lr_func(opt.position_lr_init * s, opt.position_lr_final * s, lr_delay_mult=opt.position_lr_delay_mult,
+                                     max_steps=opt.position_lr_max_steps)
+        self._lr_cam = expon_lr_func(0.00003, 0.000003, lr_delay_mult=opt.position_lr_delay_mult, max_steps=1000)
+        self._lr_conf = expon_lr_func(3e-3, 3e-4, lr_delay_mult=opt.position_lr_delay_mult, max_steps=opt.iterations)
+
+    def update_learning_rate(self, iteration):
+        for g in self.optimizer_cam.param_groups:
+            if g["name"] in ("pose_Q", "pose_T"):
+                g["lr"] = self._lr_cam(iteration)
+        for g in self.optimizer.param_groups:
+            if g["name"] == "xyz":
+                g["lr"] = self._lr_xyz(iteration)
+            elif g["name"] == "conf_static":
+                g["lr"] = self._lr_conf(iteration)
