@@ -117,7 +117,9 @@ def main():
                 ent["alg_bytes"] = per_kernel[name]
                 ent["GBps"] = round(per_kernel[name] / (avg_ms * 1e-3) / 1e9, 2)
             kernels_json[name] = ent
-        dom = next(k for k in kernels_json if k in per_kernel)  # largest share of the step's kernel time
+        # dominant KERNEL = the single kernel with the largest time per step (the 'binning' entry is a group of ~20 small
+        # launches and is reported in `kernels`, not as a roofline kernel)
+        dom = next(k for k in kernels_json if k in per_kernel and k != "binning")
         dom_ms = kernels_json[dom]["ms_per_step"]
         achieved = per_kernel[dom] / (dom_ms * 1e-3) / 1e9
         total_ms = sum(v["ms_per_step"] for v in kernels_json.values())
