@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdas3r_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
@@ -18,7 +18,7 @@ class RasterArgs(C.Structure):
     _fields_ = [("P", C.c_int32), ("sh_degree", C.c_int32), ("M", C.c_int32), ("image_width", C.c_int32),
                 ("image_height", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
                 ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
-                ("prefiltered", C.c_int32), ("debug", C.c_int32)]
+                ("prefiltered", C.c_int32), ("debug", C.c_int32), ("capacity_hint", C.c_int64)]
 
 
 class RasterIn(C.Structure):
@@ -31,7 +31,7 @@ class RasterOut(C.Structure):
 
 
 class RasterSaved(C.Structure):
-    _fields_ = [("geom", C.c_void_p), ("binning", C.c_void_p), ("img", C.c_void_p), ("num_rendered", C.c_int64)]
+    _fields_ = [("geom", C.c_void_p), ("binning", C.c_void_p), ("img", C.c_void_p), ("num_rendered", C.c_int64), ("capacity", C.c_int64)]
 
 
 class RasterGrads(C.Structure):
@@ -122,7 +122,7 @@ def check(rc, what):
     return rc
 
 
-def layout(P, num_rendered, W, H):
+def layout(P, capacity, W, H):
     out = RasterLayout()
-    check(load().das3r_raster_get_layout(int(P), int(num_rendered), int(W), int(H), C.byref(out)), "das3r_raster_get_layout")
+    check(load().das3r_raster_get_layout(int(P), int(capacity), int(W), int(H), C.byref(out)), "das3r_raster_get_layout")
     return {n: getattr(out, n) for n, _ in RasterLayout._fields_}

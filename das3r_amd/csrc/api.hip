@@ -140,6 +140,7 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     saved->img = alloc_img(user, L.pub.img_bytes);
     saved->binning = nullptr;
     saved->num_rendered = 0;
+    saved->capacity = 0;
     if (!saved->geom || !saved->img) { set_error("scratch allocation failed (geom %zu B, img %zu B)", L.pub.geom_bytes, L.pub.img_bytes); return DAS3R_ERR_ALLOC; }
     if (P == 0) {
         // upstream:rasterize_points.cu skips the rasterizer when P == 0: the image stays zero (background NOT applied)
@@ -151,19 +152,36 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     if ((rc = launch_preprocess(a, in, out->radii, saved->geom, L, s))) return rc;
     if ((rc = launch_depth_sort_and_scan(P, saved->geom, L, a->debug != 0, s))) return rc;
 
-    // num_rendered sizes the binning buffer: one 4-byte D2H + stream sync (upstream does the same after its scan)
+    // num_rendered: 4-byte D2H right behind the scan.  Without a capacity hint the host waits for it here (upstream does the
+    // same); with a hint the rest of the forward is enqueued first and the count is only collected afterwards.
     static thread_local uint32_t *h_count = nullptr;
+    static thread_local hipEvent_t ev_count = nullptr;
     if (!h_count) HIP_TRY(hipHostMalloc((void **)&h_count, 64, hipHostMallocDefault));
+    if (!ev_count) HIP_TRY(hipEventCreateWithFlags(&ev_count, hipEventDisableTiming));
     HIP_TRY(hipMemcpyAsync(h_count, saved->geom + L.g_count, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    const int64_t I = (int64_t)*h_count;
-    if (I > (int64_t)0x7FFFFF00) { set_error("num_rendered %lld exceeds 2^31", (long long)I); return DAS3R_ERR_OVERFLOW; }
-    compute_layout(P, I, W, H, &L);
-    saved->binning = alloc_binning(user, L.pub.binning_bytes);
-    if (!saved->binning) { set_error("scratch allocation failed (binning %zu B)", L.pub.binning_bytes); return DAS3R_ERR_ALLOC; }
+    HIP_TRY(hipEventRecord(ev_count, s));
+    int64_t cap = a->capacity_hint > 0 ? a->capacity_hint : -1, I = -1;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (cap < 0) {  // exact sizing: wait for the count now
+            HIP_TRY(hipEventSynchronize(ev_count));
+            I = (int64_t)*h_count;
+            cap = I;
+        }
+        if (cap > (int64_t)0x7FFFFF00) { set_error("num_rendered %lld exceeds 2^31", (long long)cap); return DAS3R_ERR_OVERFLOW; }
+        compute_layout(P, cap, W, H, &L);
+        saved->binning = alloc_binning(user, L.pub.binning_bytes);
+        if (!saved->binning) { set_error("scratch allocation failed (binning %zu B)", L.pub.binning_bytes); return DAS3R_ERR_ALLOC; }
+        if ((rc = launch_binning(P, cap, W, H, out->radii, saved->geom, saved->binning, saved->img, L, a->debug != 0, s))) return rc;
+        if ((rc = launch_render_forward(a, in->colors_precomp, out->out_color, saved->geom, saved->binning, saved->img, L, s))) return rc;
+        if (I < 0) {  // hinted path: everything is enqueued; now collect the count (available since the scan finished)
+            HIP_TRY(hipEventSynchronize(ev_count));
+            I = (int64_t)*h_count;
+        }
+        if (I <= cap) break;
+        cap = -1;  // hint too small: lists were truncated, redo binning + render with the exact size
+    }
     saved->num_rendered = I;
-    if ((rc = launch_binning(P, I, W, H, out->radii, saved->geom, saved->binning, saved->img, L, a->debug != 0, s))) return rc;
-    if ((rc = launch_render_forward(a, in->colors_precomp, out->out_color, saved->geom, saved->binning, saved->img, L, s))) return rc;
+    saved->capacity = cap;
     return I;
 }
 
@@ -185,7 +203,7 @@ extern "C" int das3r_raster_backward(const das3r_raster_args *a, const das3r_ras
         return DAS3R_ERR_INVALID_ARG;
     }
     Layout L;
-    compute_layout(P, saved->num_rendered, a->image_width, a->image_height, &L);
+    compute_layout(P, saved->capacity > 0 ? saved->capacity : saved->num_rendered, a->image_width, a->image_height, &L);
     // scratch = per-instance partial sums [num_rendered, 9]; no accumulator needs zeroing (no atomics anywhere)
     float *partial = g->scratch;
     if (saved->num_rendered > 0) {

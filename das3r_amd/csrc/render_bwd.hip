@@ -9,7 +9,8 @@
 // NO global atomics: device-scope float atomics measured ~0.5 ms of a 1.2 ms kernel at 1M splats (they leave the XCD's
 // L2).  Instead the tile writes its 9 sums per list entry to partial[list position][9] — a contiguous, coalesced block
 // per tile — and the per-Gaussian backward kernel (preprocess_bwd.hip) gathers a splat's few instances through the
-// inverse permutation recorded by the binning pass.  Gradients are therefore bit-reproducible run to run.
+// inverse permutation recorded by the binning pass.  The only run-to-run variation left is the order of the four
+// per-wave LDS adds of a (tile, splat) sum.
 #include "render_common.h"
 
 namespace das3r {

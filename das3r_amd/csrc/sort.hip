@@ -51,8 +51,9 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
 // IPL = keys per lane (compile time): the whole chunk is fetched into registers before any of it is ranked, so the
 // HBM/L2 latency is paid once per wave instead of once per 64 keys.
 template <int IPL>
-__global__ void __launch_bounds__(256) radix_hist_kernel(const uint32_t *__restrict__ keys, uint32_t n, int shift, uint32_t mask,
-                                                         int nchunks, uint32_t *__restrict__ hist) {
+__global__ void __launch_bounds__(256) radix_hist_kernel(const uint32_t *__restrict__ keys, uint32_t cap, const uint32_t *__restrict__ n_ptr,
+                                                         int shift, uint32_t mask, int nchunks, uint32_t *__restrict__ hist) {
+    const uint32_t n = n_ptr ? min(*n_ptr, cap) : cap;  // element count lives in device memory when the host did not wait for it
     __shared__ uint32_t cnt[SORT_WAVES_PER_BLOCK][RADIX_SIZE];
     const int lane = __lane_id(), wave = threadIdx.x >> 6;
     const int chunk = blockIdx.x * SORT_WAVES_PER_BLOCK + wave;
@@ -98,9 +99,11 @@ __global__ void __launch_bounds__(256) radix_rowscan_kernel(uint32_t *__restrict
 template <int IPL>
 __global__ void __launch_bounds__(256) radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                             uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
-                                                            uint32_t n, int shift, int bits, int nchunks,
-                                                            const uint32_t *__restrict__ hist, const uint32_t *__restrict__ totals,
-                                                            const uint32_t *__restrict__ gather_src, uint32_t *__restrict__ inv_out) {
+                                                            uint32_t cap, const uint32_t *__restrict__ n_ptr, int shift, int bits,
+                                                            int nchunks, const uint32_t *__restrict__ hist,
+                                                            const uint32_t *__restrict__ totals, const uint32_t *__restrict__ gather_src,
+                                                            uint32_t *__restrict__ inv_out) {
+    const uint32_t n = n_ptr ? min(*n_ptr, cap) : cap;
     __shared__ uint32_t off_s[SORT_WAVES_PER_BLOCK][RADIX_SIZE];
     const int lane = __lane_id(), wave = threadIdx.x >> 6;
     const int chunk = blockIdx.x * SORT_WAVES_PER_BLOCK + wave;
@@ -173,13 +176,13 @@ __global__ void __launch_bounds__(256) radix_scatter_kernel(const uint32_t *__re
 
 static int radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t n, int shift, int bits,
                       uint32_t *hist, uint32_t *totals, bool debug, hipStream_t s, const uint32_t *gather_src = nullptr,
-                      uint32_t *inv_out = nullptr) {
+                      uint32_t *inv_out = nullptr, const uint32_t *n_ptr = nullptr) {
     const int ipl = sort_items_per_lane(n), nchunks = sort_num_chunks(n);
     const int nblocks = div_up(nchunks, SORT_WAVES_PER_BLOCK);
     const uint32_t mask = (1u << bits) - 1u;
-#define HIST(IPL) DAS3R_LAUNCH((radix_hist_kernel<IPL>), dim3(nblocks), dim3(256), 0, s, kin, (uint32_t)n, shift, mask, nchunks, hist)
+#define HIST(IPL) DAS3R_LAUNCH((radix_hist_kernel<IPL>), dim3(nblocks), dim3(256), 0, s, kin, (uint32_t)n, n_ptr, shift, mask, nchunks, hist)
 #define SCAT(IPL)                                                                                                             \
-    DAS3R_LAUNCH((radix_scatter_kernel<IPL>), dim3(nblocks), dim3(256), 0, s, kin, vin, kout, vout, (uint32_t)n, shift, bits, \
+    DAS3R_LAUNCH((radix_scatter_kernel<IPL>), dim3(nblocks), dim3(256), 0, s, kin, vin, kout, vout, (uint32_t)n, n_ptr, shift, bits, \
                  nchunks, hist, totals, gather_src, inv_out)
     if (ipl == 4) HIST(4); else if (ipl == 8) HIST(8); else HIST(16);
     KERNEL_CHECK(s, debug, "radix_hist");
@@ -261,7 +264,7 @@ __global__ void __launch_bounds__(256) tt_scan_kernel(int P, int nblocks, const 
 __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, int tiles_y, const uint32_t *__restrict__ sorted_idx,
                                                    const uint32_t *__restrict__ tiles_touched, const uint32_t *__restrict__ offsets,
                                                    const float4 *__restrict__ xyh, const int32_t *__restrict__ radii,
-                                                   uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ gids) {
+                                                   uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ gids, uint32_t cap) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= P) return;
     const uint32_t g = sorted_idx[r];
@@ -272,13 +275,17 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, int tiles
     tile_rect(p.x, p.y, radii[g], tiles_x, tiles_y, rminx, rminy, rmaxx, rmaxy);
     for (int y = rminy; y < rmaxy; y++)
         for (int x = rminx; x < rmaxx; x++) {
-            tile_keys[o] = (uint32_t)(y * tiles_x + x);
-            gids[o] = g;  // gid_of[emission slot]
+            if (o < cap) {  // cap < num_rendered only when a capacity hint was too small (the forward is then re-run)
+                tile_keys[o] = (uint32_t)(y * tiles_x + x);
+                gids[o] = g;  // gid_of[emission slot]
+            }
             o++;
         }
 }
 
-__global__ void __launch_bounds__(256) tile_ranges_kernel(uint32_t I, const uint32_t *__restrict__ tile_keys, uint2 *__restrict__ ranges) {
+__global__ void __launch_bounds__(256) tile_ranges_kernel(uint32_t cap, const uint32_t *__restrict__ n_ptr,
+                                                          const uint32_t *__restrict__ tile_keys, uint2 *__restrict__ ranges) {
+    const uint32_t I = n_ptr ? min(*n_ptr, cap) : cap;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= I) return;
     const uint32_t t = tile_keys[i];
@@ -318,8 +325,10 @@ int launch_depth_sort_and_scan(int P, char *geom, const Layout &L, bool debug, h
     return DAS3R_OK;
 }
 
+// I = capacity of the binning buffer; the true instance count is read by the kernels from geom + L.g_count
 int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *geom, char *binning, char *img, const Layout &L,
                    bool debug, hipStream_t s) {
+    const uint32_t *n_ptr = (const uint32_t *)(geom + L.g_count);
     (void)W; (void)H;
     uint2 *ranges = (uint2 *)(img + L.pub.ranges);
     HIP_TRY(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)L.ntiles, s));
@@ -330,7 +339,7 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
     uint32_t *gid_of = (uint32_t *)(binning + L.b_gid_of), *inv = (uint32_t *)(binning + L.b_inv);
     DAS3R_LAUNCH(emit_kernel, dim3(div_up(P, 256)), dim3(256), 0, s, P, L.tiles_x, L.tiles_y,
                        (const uint32_t *)(geom + L.pub.sorted_idx), (const uint32_t *)(geom + L.pub.tiles_touched),
-                       (const uint32_t *)(geom + L.pub.offsets), (const float4 *)(geom + L.pub.xy), radii, keyA, gid_of);
+                       (const uint32_t *)(geom + L.pub.offsets), (const float4 *)(geom + L.pub.xy), radii, keyA, gid_of, (uint32_t)I);
     KERNEL_CHECK(s, debug, "emit");
     // stable partition by tile id: tile_passes passes of <= 8 bits; ping-pong A -> B (-> A)
     // payload = emission slot e (identity on the first pass); the last pass turns it into the splat id and records inv[e]
@@ -339,7 +348,7 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
     for (int p = 0; p < L.tile_passes; p++) {
         const int bits = (L.tbits - shift) < 8 ? (L.tbits - shift) : 8;
         const bool last = p == L.tile_passes - 1;
-        if ((rc = radix_pass(kin, vin, kout, vout, I, shift, bits, hist, totals, debug, s, last ? gid_of : nullptr, last ? inv : nullptr)))
+        if ((rc = radix_pass(kin, vin, kout, vout, I, shift, bits, hist, totals, debug, s, last ? gid_of : nullptr, last ? inv : nullptr, n_ptr)))
             return rc;
         shift += bits;
         uint32_t *t = kin; kin = kout; kout = t;
@@ -347,7 +356,7 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
         vout = (vout == valB) ? valA : valB;
     }
     // kin/vin now hold the partitioned (tile id, gaussian id) lists; vin == binning + pub.point_list by construction
-    DAS3R_LAUNCH(tile_ranges_kernel, dim3(div_up(I, 256)), dim3(256), 0, s, (uint32_t)I, kin, ranges);
+    DAS3R_LAUNCH(tile_ranges_kernel, dim3(div_up(I, 256)), dim3(256), 0, s, (uint32_t)I, n_ptr, kin, ranges);
     KERNEL_CHECK(s, debug, "tile_ranges");
     return DAS3R_OK;
 }

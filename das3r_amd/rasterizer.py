@@ -104,7 +104,17 @@ def _stream(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+# last num_rendered per (P, W, H): lets the next forward size its binning buffer without waiting for the device
+_CAPACITY_CACHE = {}
+
+
 def _forward_impl(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp):
+    """Exact-size forward (one blocking count read-back): -> (num_rendered, color, radii, geom, binning, img)."""
+    return _forward_full(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, exact=True)[:6]
+
+
+def _forward_full(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, exact=False):
+    """-> (num_rendered, color, radii, geom, binning, img, capacity)."""
     lib = _lib.load()
     device = means3D.device
     if device.type != "cuda":
@@ -124,9 +134,12 @@ def _forward_impl(rs, means3D, sh, colors_precomp, opacities, scales, rotations,
     alloc = _Alloc(device)
     if P == 0:
         e = torch.empty(0, dtype=torch.uint8, device=device)
-        return 0, color, radii, e, e, e
+        return 0, color, radii, e, e, e, 0
     keep = []
     a = _fill_args(rs, P, M, device, keep)
+    key = (P, W, H, device.index)
+    last = _CAPACITY_CACHE.get(key)
+    a.capacity_hint = 0 if (exact or not last) else int(last * 1.25) + 4096
     i = _fill_in(means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp)
     o = _lib.RasterOut()
     o.out_color, o.radii = color.data_ptr(), radii.data_ptr()
@@ -135,12 +148,15 @@ def _forward_impl(rs, means3D, sh, colors_precomp, opacities, scales, rotations,
         rc = lib.das3r_raster_forward(C.byref(a), C.byref(i), C.byref(o), alloc.fns["geom"], alloc.fns["binning"],
                                       alloc.fns["img"], None, C.byref(saved), _stream(device))
     _lib.check(rc, "das3r_raster_forward")
+    _CAPACITY_CACHE[key] = int(rc)
     empty = torch.empty(0, dtype=torch.uint8, device=device)
-    return int(rc), color, radii, alloc.bufs.get("geom", empty), alloc.bufs.get("binning", empty), alloc.bufs.get("img", empty)
+    return (int(rc), color, radii, alloc.bufs.get("geom", empty), alloc.bufs.get("binning", empty), alloc.bufs.get("img", empty),
+            int(saved.capacity))
 
 
 def _backward_impl(rs, num_rendered, grad_out_color, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                   geom, binning, img):
+                   geom, binning, img, capacity=None):
+    capacity = int(num_rendered) if capacity is None else int(capacity)
     lib = _lib.load()
     device = means3D.device
     P = means3D.shape[0]
@@ -153,13 +169,14 @@ def _backward_impl(rs, num_rendered, grad_out_color, means3D, sh, colors_precomp
     if P == 0:
         return g_means2D, g_colors, g_opac, g_means3D, g_cov, g_sh, g_scales, g_rot
     has_sh, has_cov = sh.numel() > 0, cov3Ds_precomp.numel() > 0
-    scratch = z(max(int(num_rendered), 1), 9)   # per-instance partial sums, fully written by the render backward
+    scratch = z(max(capacity, 1), 9)   # per-instance partial sums (rows < num_rendered are fully written by the render backward)
     keep = []
     a = _fill_args(rs, P, M, device, keep)
     i = _fill_in(means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp)
     saved = _lib.RasterSaved()
     saved.geom, saved.binning, saved.img = _ptr(geom), _ptr(binning), _ptr(img)
     saved.num_rendered = int(num_rendered)
+    saved.capacity = capacity
     g = _lib.RasterGrads()
     g.dL_dmeans2D, g.dL_dopacities, g.dL_dmeans3D = g_means2D.data_ptr(), g_opac.data_ptr(), g_means3D.data_ptr()
     g.dL_dshs = _ptr(g_sh) if has_sh else None
@@ -198,15 +215,16 @@ class _RasterizeGaussians(torch.autograd.Function):
         if raster_settings.debug:
             cpu_args = cpu_deep_copy_tuple(args)  # copy them before they can be corrupted
             try:
-                num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _forward_impl(*args)
+                num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, capacity = _forward_full(*args)
             except Exception as ex:
                 torch.save(cpu_args, "snapshot_fw.dump")
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                 raise ex
         else:
-            num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _forward_impl(*args)
+            num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, capacity = _forward_full(*args)
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
+        ctx.capacity = capacity
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities, geomBuffer,
                               binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii)
@@ -218,7 +236,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities, geomBuffer, binningBuffer,
          imgBuffer) = ctx.saved_tensors
         args = (rs, ctx.num_rendered, grad_out_color, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                geomBuffer, binningBuffer, imgBuffer)
+                geomBuffer, binningBuffer, imgBuffer, ctx.capacity)
         if rs.debug:
             cpu_args = cpu_deep_copy_tuple(args)
             try:

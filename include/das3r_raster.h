@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DAS3R_ABI_VERSION 1
+#define DAS3R_ABI_VERSION 2
 
 typedef enum {
     DAS3R_OK = 0,
@@ -68,6 +68,10 @@ typedef struct {
     const float *campos;     /* [3]    device */
     int32_t prefiltered;
     int32_t debug;           /* !=0: synchronise + check after every kernel */
+    int64_t capacity_hint;   /* 0: size the binning buffer exactly (one blocking 4-byte read-back mid-forward, like upstream).
+                              * >0: expected upper bound of num_rendered (e.g. last call's value + 25 %): the binning buffer is
+                              * sized for it, the whole forward is enqueued without waiting, and the count is read back off the
+                              * critical path; if it turns out larger than the hint the binning + render are re-run exactly. */
 } das3r_raster_args;
 
 /* Inputs of GaussianRasterizer.forward.  Exactly one of shs/colors_precomp and exactly one of
@@ -93,6 +97,7 @@ typedef struct {
     char *binning;
     char *img;
     int64_t num_rendered;
+    int64_t capacity;        /* instances the binning buffer was laid out for (>= num_rendered) */
 } das3r_raster_saved;
 
 /* Gradient outputs of backward.  Every buffer is fully written by the call (no pre-zeroing needed). */
@@ -105,7 +110,7 @@ typedef struct {
     float *dL_dscales;         /* [P,3]; NULL when cov3D_precomp was used */
     float *dL_drotations;      /* [P,4]; NULL when cov3D_precomp was used */
     float *dL_dcov3D;          /* [P,6]; NULL unless cov3D_precomp was used */
-    float *scratch;            /* [num_rendered,9] caller-provided scratch: per-instance partial sums (no atomics) */
+    float *scratch;            /* [saved->capacity,9] caller-provided scratch: per-instance partial sums (no atomics) */
 } das3r_raster_grads;
 
 /* Returns num_rendered (>= 0) or a negative das3r_status.  Fills *saved. */
@@ -148,7 +153,7 @@ typedef struct {
     size_t ranges;         /* u32[tiles,2] */
 } das3r_raster_layout;
 
-int das3r_raster_get_layout(int32_t P, int64_t num_rendered, int32_t W, int32_t H, das3r_raster_layout *out);
+int das3r_raster_get_layout(int32_t P, int64_t capacity, int32_t W, int32_t H, das3r_raster_layout *out);
 
 /* Optional per-kernel timing: when enabled, every kernel launch of the library is bracketed by HIP events recorded on
  * the launch stream.  das3r_profile_report synchronises and writes one line per kernel, "<kernel> <launches> <total_ms>\n",

@@ -34,9 +34,9 @@ def test_abi_version_and_layout(hip_lib):
     offs = [L[k] for k in ("xy", "conic_opacity", "rgbd", "clamped", "tiles_touched", "offsets")]
     assert all(o % 256 == 0 for o in offs) and len(set(offs)) == len(offs)
     # struct sizes seen by ctypes must match what the header lays out (plain C ABI: ints, floats, pointers)
-    assert ctypes.sizeof(_lib.RasterArgs) == 5 * 4 + 3 * 4 + 4 * 8 + 2 * 4
+    assert ctypes.sizeof(_lib.RasterArgs) == 5 * 4 + 3 * 4 + 4 * 8 + 2 * 4 + 8
     assert ctypes.sizeof(_lib.RasterIn) == 7 * 8 and ctypes.sizeof(_lib.RasterGrads) == 9 * 8
-    assert ctypes.sizeof(_lib.RasterSaved) == 4 * 8
+    assert ctypes.sizeof(_lib.RasterSaved) == 5 * 8
 
 
 def test_invalid_arguments_are_reported_not_thrown(hip_lib):

@@ -204,3 +204,27 @@ def test_finite_difference_directional():
         fd = (f(plus) - f(minus)) / 2.0
         an = float((leaves[k].grad.double() * d).sum())
         assert abs(fd - an) <= 2e-2 * max(abs(fd), abs(an)) + 2e-4, f"{k}: finite difference {fd:.6e} vs analytic {an:.6e}"
+
+
+def test_capacity_hint_paths_agree():
+    """The sync-free forward (binning buffer sized from the previous call's num_rendered) must give the same image and
+    gradients as the exact-size forward, also when the hint is too small and the binning has to be redone."""
+    from das3r_amd import GaussianRasterizationSettings, rasterizer
+    dev = _dev()
+    sc, mode = util.scene_variant("long_lists")
+    scd = sc.to(dev)
+    rs = GaussianRasterizationSettings(**scd.settings_kwargs())
+    e = torch.empty(0, device=dev)
+    args = (rs, scd.means3D, scd.shs, e, scd.opacities, scd.scales, scd.rotations, e)
+    I0, c0, r0, g0, b0, i0, cap0 = rasterizer._forward_full(*args, exact=True)
+    assert cap0 == I0 and I0 > 10000
+    grads0 = rasterizer._backward_impl(rs, I0, scd.dL_dpix, scd.means3D, scd.shs, e, scd.opacities, scd.scales, scd.rotations, e, g0, b0, i0, cap0)
+    key = (sc.P, sc.W, sc.H, dev.index)
+    for last, expect_redo in ((I0, False), (100, True)):
+        rasterizer._CAPACITY_CACHE[key] = last
+        I1, c1, r1, g1, b1, i1, cap1 = rasterizer._forward_full(*args, exact=False)
+        assert I1 == I0 and torch.equal(c1, c0) and torch.equal(r1, r0)
+        assert (cap1 == I0) if expect_redo else (cap1 > I0)
+        grads1 = rasterizer._backward_impl(rs, I1, scd.dL_dpix, scd.means3D, scd.shs, e, scd.opacities, scd.scales, scd.rotations, e, g1, b1, i1, cap1)
+        for a, b in zip(grads0, grads1):   # only the order of the four per-wave LDS adds differs run to run
+            util.assert_grad_close(a.cpu().numpy(), b.cpu().numpy(), "hinted vs exact forward", tol=1e-5)
