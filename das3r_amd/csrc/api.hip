@@ -36,6 +36,11 @@ void profile_end(hipStream_t s) {
     if (!g_prof.empty()) hipEventRecord(g_prof.back().stop, s);
 }
 
+bool use_onesweep() {
+    const char *e = getenv("DAS3R_SORT");  // "classic" = histogram + row scan + scatter per digit
+    return !(e && e[0] == 'c');
+}
+
 void compute_layout(int P, int64_t I, int W, int H, Layout *L) {
     memset(L, 0, sizeof(*L));
     const size_t Pn = P > 0 ? (size_t)P : 1, In = I > 0 ? (size_t)I : 1;
@@ -66,6 +71,10 @@ void compute_layout(int P, int64_t I, int W, int H, Layout *L) {
     L->g_blocksums = take(4 * (size_t)div_up((int64_t)Pn, 4096));
     L->g_count = take(256);
     L->g_off_by_gid = take(4 * Pn);
+    L->g_ghist = take(4 * 4 * RADIX_SIZE);
+    L->g_ticket = take(256);
+    L->g_status = take(onesweep_status_bytes((int64_t)Pn, 4));
+    L->g_ctrl_bytes = o - L->g_ghist;
     L->pub.geom_bytes = o;
     // binning
     o = 0;
@@ -77,6 +86,10 @@ void compute_layout(int P, int64_t I, int W, int H, Layout *L) {
     L->b_totals = take(4 * RADIX_SIZE);
     L->b_gid_of = take(4 * In);
     L->b_inv = take(4 * In);
+    L->b_ghist = take(4 * 4 * RADIX_SIZE);
+    L->b_ticket = take(256);
+    L->b_status = take(onesweep_status_bytes((int64_t)In, L->tile_passes));
+    L->b_ctrl_bytes = o - L->b_ghist;
     L->pub.binning_bytes = o;
     L->pub.point_list = (L->tile_passes & 1) ? L->b_valB : L->b_valA;
     // img
@@ -149,7 +162,7 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         saved->binning = alloc_binning(user, 256);
         return 0;
     }
-    if ((rc = launch_preprocess(a, in, out->radii, saved->geom, L, s))) return rc;
+    if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, L, s))) return rc;
     if ((rc = launch_depth_sort_and_scan(P, saved->geom, L, a->debug != 0, s))) return rc;
 
     // num_rendered: 4-byte D2H right behind the scan.  Without a capacity hint the host waits for it here (upstream does the
@@ -158,13 +171,13 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     static thread_local hipEvent_t ev_count = nullptr;
     if (!h_count) HIP_TRY(hipHostMalloc((void **)&h_count, 64, hipHostMallocDefault));
     if (!ev_count) HIP_TRY(hipEventCreateWithFlags(&ev_count, hipEventDisableTiming));
-    HIP_TRY(hipMemcpyAsync(h_count, saved->geom + L.g_count, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h_count, saved->geom + L.g_count, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(ev_count, s));
     int64_t cap = a->capacity_hint > 0 ? a->capacity_hint : -1, I = -1;
     for (int attempt = 0; attempt < 2; attempt++) {
         if (cap < 0) {  // exact sizing: wait for the count now
             HIP_TRY(hipEventSynchronize(ev_count));
-            I = (int64_t)*h_count;
+            I = (int64_t)h_count[0];
             cap = I;
         }
         if (cap > (int64_t)0x7FFFFF00) { set_error("num_rendered %lld exceeds 2^31", (long long)cap); return DAS3R_ERR_OVERFLOW; }
@@ -175,8 +188,9 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         if ((rc = launch_render_forward(a, in->colors_precomp, out->out_color, saved->geom, saved->binning, saved->img, L, s))) return rc;
         if (I < 0) {  // hinted path: everything is enqueued; now collect the count (available since the scan finished)
             HIP_TRY(hipEventSynchronize(ev_count));
-            I = (int64_t)*h_count;
+            I = (int64_t)h_count[0];
         }
+        if (h_count[1] != 0) { set_error("radix look-back timed out (flags 0x%x)", h_count[1]); return DAS3R_ERR_HIP; }
         if (I <= cap) break;
         cap = -1;  // hint too small: lists were truncated, redo binning + render with the exact size
     }

@@ -20,8 +20,13 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     const float *__restrict__ projmatrix, const float *__restrict__ campos, int W, int H, float tanfovx, float tanfovy,
     int tiles_x, int tiles_y, int32_t *__restrict__ radii, uint32_t *__restrict__ depth_key, float4 *__restrict__ xyh,
     float4 *__restrict__ conic_opacity, float4 *__restrict__ rgbd, uint8_t *__restrict__ clamped,
-    uint32_t *__restrict__ tiles_touched) {
+    uint32_t *__restrict__ tiles_touched, uint32_t *__restrict__ zero_a, uint32_t zero_a_words, uint32_t *__restrict__ zero_b,
+    uint32_t zero_b_words) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    // this kernel runs before every consumer of the radix control words (geom side) and of the tile ranges: zero them here
+    // instead of spending two memset launches
+    for (uint32_t i = idx; i < zero_a_words; i += gridDim.x * blockDim.x) zero_a[i] = 0u;
+    for (uint32_t i = idx; i < zero_b_words; i += gridDim.x * blockDim.x) zero_b[i] = 0u;
     if (idx >= P) return;
 
     float V[16], PM[16];
@@ -120,7 +125,7 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float *_
     present[idx] = xform43(p, V).z > NEAR_PLANE ? 1 : 0;
 }
 
-int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int32_t *radii, char *geom, const Layout &L,
+int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int32_t *radii, char *geom, char *img, const Layout &L,
                       hipStream_t s) {
     const int P = a->P;
     if (P == 0) return DAS3R_OK;
@@ -131,7 +136,8 @@ int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int
         in->cov3D_precomp, in->colors_precomp, a->viewmatrix, a->projmatrix, a->campos, a->image_width, a->image_height,  \
         a->tanfovx, a->tanfovy, L.tiles_x, L.tiles_y, radii, (uint32_t *)(geom + L.g_keyA), (float4 *)(geom + L.pub.xy),  \
         (float4 *)(geom + L.pub.conic_opacity), (float4 *)(geom + L.pub.rgbd), (uint8_t *)(geom + L.pub.clamped),         \
-        (uint32_t *)(geom + L.pub.tiles_touched)
+        (uint32_t *)(geom + L.pub.tiles_touched), (uint32_t *)(geom + L.g_ghist), (uint32_t)(L.g_ctrl_bytes / 4),                 \
+        (uint32_t *)(img + L.pub.ranges), (uint32_t)(2 * L.ntiles)
     if (has_sh && !has_cov) DAS3R_LAUNCH((preprocess_kernel<true, false>), grid, block, 0, s, ARGS);
     else if (has_sh && has_cov) DAS3R_LAUNCH((preprocess_kernel<true, true>), grid, block, 0, s, ARGS);
     else if (!has_sh && !has_cov) DAS3R_LAUNCH((preprocess_kernel<false, false>), grid, block, 0, s, ARGS);

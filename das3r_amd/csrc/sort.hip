@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(256) tt_blocksum_kernel(int P, const uint32_t 
 __global__ void __launch_bounds__(256) tt_scan_kernel(int P, int nblocks, const uint32_t *__restrict__ sorted_idx,
                                                       const uint32_t *__restrict__ tiles_touched, const uint32_t *__restrict__ block_sums,
                                                       uint32_t *__restrict__ offsets, uint32_t *__restrict__ off_by_gid,
-                                                      uint32_t *__restrict__ count) {
+                                                      uint32_t *__restrict__ count, const uint32_t *__restrict__ err_src) {
     __shared__ uint32_t ws[4];
     // prefix of earlier blocks (nblocks is small: P / 4096)
     uint32_t part = 0;
@@ -257,30 +257,56 @@ __global__ void __launch_bounds__(256) tt_scan_kernel(int P, int nblocks, const 
         }
         carry += tot;
     }
-    if (blockIdx.x == nblocks - 1 && threadIdx.x == 0) *count = carry;
+    if (blockIdx.x == nblocks - 1 && threadIdx.x == 0) {
+        count[0] = carry;
+        count[1] = *err_src;  // radix look-back timeout flag of the depth sort travels with the count
+    }
 }
 
 // ---------------------------------------------------------------- instance emission (depth-rank order)
 __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, int tiles_y, const uint32_t *__restrict__ sorted_idx,
                                                    const uint32_t *__restrict__ tiles_touched, const uint32_t *__restrict__ offsets,
                                                    const float4 *__restrict__ xyh, const int32_t *__restrict__ radii,
-                                                   uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ gids, uint32_t cap) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= P) return;
-    const uint32_t g = sorted_idx[r];
-    if (tiles_touched[g] == 0) return;
-    uint32_t o = offsets[r];
-    const float4 p = xyh[g];
-    int rminx, rminy, rmaxx, rmaxy;
-    tile_rect(p.x, p.y, radii[g], tiles_x, tiles_y, rminx, rminy, rmaxx, rmaxy);
-    for (int y = rminy; y < rmaxy; y++)
-        for (int x = rminx; x < rmaxx; x++) {
-            if (o < cap) {  // cap < num_rendered only when a capacity hint was too small (the forward is then re-run)
-                tile_keys[o] = (uint32_t)(y * tiles_x + x);
-                gids[o] = g;  // gid_of[emission slot]
+                                                   uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ gids, uint32_t cap,
+                                                   uint32_t *__restrict__ ghist /*[passes][256] or null*/, int tbits) {
+    // grid-stride over depth ranks; the digit histograms of the tile ids (needed by the single-pass partition) are
+    // accumulated in LDS and flushed with one global atomic per non-empty bin and workgroup
+    __shared__ uint32_t h[4][RADIX_SIZE];
+    if (ghist) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) h[q][threadIdx.x] = 0;
+        __syncthreads();
+    }
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < P; r += gridDim.x * blockDim.x) {
+        const uint32_t g = sorted_idx[r];
+        if (tiles_touched[g] == 0) continue;
+        uint32_t o = offsets[r];
+        const float4 p = xyh[g];
+        int rminx, rminy, rmaxx, rmaxy;
+        tile_rect(p.x, p.y, radii[g], tiles_x, tiles_y, rminx, rminy, rmaxx, rmaxy);
+        for (int y = rminy; y < rmaxy; y++)
+            for (int x = rminx; x < rmaxx; x++) {
+                if (o < cap) {  // cap < num_rendered only when a capacity hint was too small (the forward is then re-run)
+                    const uint32_t t = (uint32_t)(y * tiles_x + x);
+                    tile_keys[o] = t;
+                    gids[o] = g;  // gid_of[emission slot]
+                    if (ghist) {
+                        for (int q = 0, sh = 0; sh < tbits; q++, sh += 8) {
+                            const int bits = (tbits - sh) < 8 ? (tbits - sh) : 8;
+                            atomicAdd(&h[q][(t >> sh) & ((1u << bits) - 1u)], 1u);
+                        }
+                    }
+                }
+                o++;
             }
-            o++;
+    }
+    if (ghist) {
+        __syncthreads();
+        for (int q = 0, sh = 0; sh < tbits; q++, sh += 8) {
+            const uint32_t c = h[q][threadIdx.x];
+            if (c) atomicAdd(&ghist[q * RADIX_SIZE + threadIdx.x], c);
         }
+    }
 }
 
 __global__ void __launch_bounds__(256) tile_ranges_kernel(uint32_t cap, const uint32_t *__restrict__ n_ptr,
@@ -309,10 +335,14 @@ int launch_depth_sort_and_scan(int P, char *geom, const Layout &L, bool debug, h
     if (P == 0) return hipMemsetAsync(count, 0, 4, s) == hipSuccess ? DAS3R_OK : DAS3R_ERR_HIP;
     // 4 passes: A -> B -> A -> B -> A ; final ranks land in valA (== pub.sorted_idx)
     int rc;
-    if ((rc = radix_pass(keyA, nullptr, keyB, valB, P, 0, 8, hist, totals, debug, s))) return rc;
-    if ((rc = radix_pass(keyB, valB, keyA, valA, P, 8, 8, hist, totals, debug, s))) return rc;
-    if ((rc = radix_pass(keyA, valA, keyB, valB, P, 16, 8, hist, totals, debug, s))) return rc;
-    if ((rc = radix_pass(keyB, valB, nullptr, valA, P, 24, 8, hist, totals, debug, s))) return rc;
+    if (use_onesweep()) {
+        if ((rc = launch_onesweep_depth_sort(P, geom, L, debug, s))) return rc;
+    } else {
+        if ((rc = radix_pass(keyA, nullptr, keyB, valB, P, 0, 8, hist, totals, debug, s))) return rc;
+        if ((rc = radix_pass(keyB, valB, keyA, valA, P, 8, 8, hist, totals, debug, s))) return rc;
+        if ((rc = radix_pass(keyA, valA, keyB, valB, P, 16, 8, hist, totals, debug, s))) return rc;
+        if ((rc = radix_pass(keyB, valB, nullptr, valA, P, 24, 8, hist, totals, debug, s))) return rc;
+    }
 
     const int nblocks = div_up(P, 256 * SCAN_ITEMS);
     uint32_t *bsums = (uint32_t *)(geom + L.g_blocksums);
@@ -320,7 +350,7 @@ int launch_depth_sort_and_scan(int P, char *geom, const Layout &L, bool debug, h
     DAS3R_LAUNCH(tt_blocksum_kernel, dim3(nblocks), dim3(256), 0, s, P, valA, tt, bsums);
     KERNEL_CHECK(s, debug, "tt_blocksum");
     DAS3R_LAUNCH(tt_scan_kernel, dim3(nblocks), dim3(256), 0, s, P, nblocks, valA, tt, bsums,
-                       (uint32_t *)(geom + L.pub.offsets), (uint32_t *)(geom + L.g_off_by_gid), count);
+                       (uint32_t *)(geom + L.pub.offsets), (uint32_t *)(geom + L.g_off_by_gid), count, (const uint32_t *)(geom + L.g_ticket) + 8);
     KERNEL_CHECK(s, debug, "tt_scan");
     return DAS3R_OK;
 }
@@ -330,17 +360,28 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
                    bool debug, hipStream_t s) {
     const uint32_t *n_ptr = (const uint32_t *)(geom + L.g_count);
     (void)W; (void)H;
-    uint2 *ranges = (uint2 *)(img + L.pub.ranges);
-    HIP_TRY(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)L.ntiles, s));
+    uint2 *ranges = (uint2 *)(img + L.pub.ranges);  // zeroed by preprocess_kernel
     if (I == 0 || P == 0) return DAS3R_OK;
     uint32_t *keyA = (uint32_t *)(binning + L.b_keyA), *keyB = (uint32_t *)(binning + L.b_keyB);
     uint32_t *valA = (uint32_t *)(binning + L.b_valA), *valB = (uint32_t *)(binning + L.b_valB);
     uint32_t *hist = (uint32_t *)(binning + L.b_hist), *totals = (uint32_t *)(binning + L.b_totals);
     uint32_t *gid_of = (uint32_t *)(binning + L.b_gid_of), *inv = (uint32_t *)(binning + L.b_inv);
-    DAS3R_LAUNCH(emit_kernel, dim3(div_up(P, 256)), dim3(256), 0, s, P, L.tiles_x, L.tiles_y,
-                       (const uint32_t *)(geom + L.pub.sorted_idx), (const uint32_t *)(geom + L.pub.tiles_touched),
-                       (const uint32_t *)(geom + L.pub.offsets), (const float4 *)(geom + L.pub.xy), radii, keyA, gid_of, (uint32_t)I);
+    const bool onesweep = use_onesweep();
+    if (onesweep) HIP_TRY(hipMemsetAsync(binning + L.b_ghist, 0, L.b_ctrl_bytes, s));  // digit histograms, tickets, status words
+    const int emit_blocks = div_up(P, 256) < 1024 ? div_up(P, 256) : 1024;
+    DAS3R_LAUNCH(emit_kernel, dim3(emit_blocks), dim3(256), 0, s, P, L.tiles_x, L.tiles_y,
+                 (const uint32_t *)(geom + L.pub.sorted_idx), (const uint32_t *)(geom + L.pub.tiles_touched),
+                 (const uint32_t *)(geom + L.pub.offsets), (const float4 *)(geom + L.pub.xy), radii, keyA, gid_of, (uint32_t)I,
+                 onesweep ? (uint32_t *)(binning + L.b_ghist) : (uint32_t *)nullptr, L.tbits);
     KERNEL_CHECK(s, debug, "emit");
+    if (onesweep) {
+        uint32_t *kfinal = nullptr;
+        int rc1 = launch_onesweep_partition(I, geom, binning, L, &kfinal, debug, s);
+        if (rc1) return rc1;
+        DAS3R_LAUNCH(tile_ranges_kernel, dim3(div_up(I, 256)), dim3(256), 0, s, (uint32_t)I, n_ptr, kfinal, ranges);
+        KERNEL_CHECK(s, debug, "tile_ranges");
+        return DAS3R_OK;
+    }
     // stable partition by tile id: tile_passes passes of <= 8 bits; ping-pong A -> B (-> A)
     // payload = emission slot e (identity on the first pass); the last pass turns it into the splat id and records inv[e]
     uint32_t *kin = keyA, *vin = nullptr, *kout = keyB, *vout = valB;

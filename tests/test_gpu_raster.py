@@ -226,5 +226,7 @@ def test_capacity_hint_paths_agree():
         assert I1 == I0 and torch.equal(c1, c0) and torch.equal(r1, r0)
         assert (cap1 == I0) if expect_redo else (cap1 > I0)
         grads1 = rasterizer._backward_impl(rs, I1, scd.dL_dpix, scd.means3D, scd.shs, e, scd.opacities, scd.scales, scd.rotations, e, g1, b1, i1, cap1)
-        for a, b in zip(grads0, grads1):   # only the order of the four per-wave LDS adds differs run to run
+        for k, (a, b) in enumerate(zip(grads0, grads1)):   # only the order of the four per-wave LDS adds differs run to run
+            if k in (1, 4):   # dL_dcolors_precomp / dL_dcov3D are not produced in SH + scale/rotation mode
+                continue
             util.assert_grad_close(a.cpu().numpy(), b.cpu().numpy(), "hinted vs exact forward", tol=1e-5)
