@@ -41,6 +41,11 @@ bool use_onesweep() {
     return !(e && e[0] == 'c');
 }
 
+bool use_tight_rect() {
+    const char *e = getenv("DAS3R_RECT");
+    return !(e && e[0] == 'u');
+}
+
 void compute_layout(int P, int64_t I, int W, int H, Layout *L) {
     memset(L, 0, sizeof(*L));
     const size_t Pn = P > 0 ? (size_t)P : 1, In = I > 0 ? (size_t)I : 1;

@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     const float *__restrict__ projmatrix, const float *__restrict__ campos, int W, int H, float tanfovx, float tanfovy,
     int tiles_x, int tiles_y, int32_t *__restrict__ radii, uint32_t *__restrict__ depth_key, float4 *__restrict__ xyh,
     float4 *__restrict__ conic_opacity, float4 *__restrict__ rgbd, uint8_t *__restrict__ clamped,
-    uint32_t *__restrict__ tiles_touched, uint32_t *__restrict__ zero_a, uint32_t zero_a_words, uint32_t *__restrict__ zero_b,
+    uint32_t *__restrict__ tiles_touched, int tight_rect, uint32_t *__restrict__ zero_a, uint32_t zero_a_words, uint32_t *__restrict__ zero_b,
     uint32_t zero_b_words) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     // this kernel runs before every consumer of the radix control words (geom side) and of the tile ranges: zero them here
@@ -89,7 +89,6 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
                 }
                 radius_out = r;
                 key_out = __float_as_uint(p_view.z);
-                tiles_out = (uint32_t)area;
                 // half extents of the axis-aligned box outside which alpha = opacity * exp(power) cannot reach 1/255
                 // (ellipse d^T Sigma'^-1 d <= 2 ln(255 o)); generous safety margin, used only for wave-level culling
                 const float op = opacities[idx];
@@ -100,6 +99,11 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
                     hy = sqrtf(tau2 * c) * 1.0005f + 0.02f;
                 }
                 xy_out = make_float4(px, py, hx, hy);
+                {   // instances are binned over the clipped rectangle (radii keeps upstream's value)
+                    int bx0, by0, bx1, by1;
+                    binned_rect(xy_out, r, tiles_x, tiles_y, tight_rect != 0, bx0, by0, bx1, by1);
+                    tiles_out = (uint32_t)((bx1 - bx0) * (by1 - by0));
+                }
                 co_out = make_float4(conA, conB, conC, op);
                 rgbd_out = make_float4(col.x, col.y, col.z, p_view.z);
             }
@@ -136,7 +140,7 @@ int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int
         in->cov3D_precomp, in->colors_precomp, a->viewmatrix, a->projmatrix, a->campos, a->image_width, a->image_height,  \
         a->tanfovx, a->tanfovy, L.tiles_x, L.tiles_y, radii, (uint32_t *)(geom + L.g_keyA), (float4 *)(geom + L.pub.xy),  \
         (float4 *)(geom + L.pub.conic_opacity), (float4 *)(geom + L.pub.rgbd), (uint8_t *)(geom + L.pub.clamped),         \
-        (uint32_t *)(geom + L.pub.tiles_touched), (uint32_t *)(geom + L.g_ghist), (uint32_t)(L.g_ctrl_bytes / 4),                 \
+        (uint32_t *)(geom + L.pub.tiles_touched), use_tight_rect() ? 1 : 0, (uint32_t *)(geom + L.g_ghist), (uint32_t)(L.g_ctrl_bytes / 4),                 \
         (uint32_t *)(img + L.pub.ranges), (uint32_t)(2 * L.ntiles)
     if (has_sh && !has_cov) DAS3R_LAUNCH((preprocess_kernel<true, false>), grid, block, 0, s, ARGS);
     else if (has_sh && has_cov) DAS3R_LAUNCH((preprocess_kernel<true, true>), grid, block, 0, s, ARGS);

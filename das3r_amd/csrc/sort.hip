@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, int tiles
                                                    const uint32_t *__restrict__ tiles_touched, const uint32_t *__restrict__ offsets,
                                                    const float4 *__restrict__ xyh, const int32_t *__restrict__ radii,
                                                    uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ gids, uint32_t cap,
-                                                   uint32_t *__restrict__ ghist /*[passes][256] or null*/, int tbits) {
+                                                   uint32_t *__restrict__ ghist /*[passes][256] or null*/, int tbits, int tight_rect) {
     // grid-stride over depth ranks; the digit histograms of the tile ids (needed by the single-pass partition) are
     // accumulated in LDS and flushed with one global atomic per non-empty bin and workgroup
     __shared__ uint32_t h[4][RADIX_SIZE];
@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, int tiles
         uint32_t o = offsets[r];
         const float4 p = xyh[g];
         int rminx, rminy, rmaxx, rmaxy;
-        tile_rect(p.x, p.y, radii[g], tiles_x, tiles_y, rminx, rminy, rmaxx, rmaxy);
+        binned_rect(p, radii[g], tiles_x, tiles_y, tight_rect != 0, rminx, rminy, rmaxx, rmaxy);
         for (int y = rminy; y < rmaxy; y++)
             for (int x = rminx; x < rmaxx; x++) {
                 if (o < cap) {  // cap < num_rendered only when a capacity hint was too small (the forward is then re-run)
@@ -372,7 +372,7 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
     DAS3R_LAUNCH(emit_kernel, dim3(emit_blocks), dim3(256), 0, s, P, L.tiles_x, L.tiles_y,
                  (const uint32_t *)(geom + L.pub.sorted_idx), (const uint32_t *)(geom + L.pub.tiles_touched),
                  (const uint32_t *)(geom + L.pub.offsets), (const float4 *)(geom + L.pub.xy), radii, keyA, gid_of, (uint32_t)I,
-                 onesweep ? (uint32_t *)(binning + L.b_ghist) : (uint32_t *)nullptr, L.tbits);
+                 onesweep ? (uint32_t *)(binning + L.b_ghist) : (uint32_t *)nullptr, L.tbits, use_tight_rect() ? 1 : 0);
     KERNEL_CHECK(s, debug, "emit");
     if (onesweep) {
         uint32_t *kfinal = nullptr;

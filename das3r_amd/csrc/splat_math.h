@@ -90,6 +90,30 @@ __device__ __forceinline__ void tile_rect(const float px, const float py, const 
     rmaxy = min(tiles_y, max(0, (int)((py + r + TILE_Y - 1) / TILE_Y)));
 }
 
+// Tile rectangle actually binned: the upstream 3-sigma square clipped to the axis-aligned box (half extents hx, hy, already
+// padded) outside which alpha = opacity*exp(power) < 1/255 on every pixel centre.  Tiles dropped by the clip can only hold
+// pairs upstream would `continue` on, so image and gradients are unchanged; only list lengths / num_rendered shrink.
+// tight == false reproduces upstream's lists exactly (used by the bit-exact binning tests).
+__device__ __forceinline__ void binned_rect(const float4 xyh, const int r, const int tiles_x, const int tiles_y, const bool tight,
+                                            int &rminx, int &rminy, int &rmaxx, int &rmaxy) {
+    tile_rect(xyh.x, xyh.y, r, tiles_x, tiles_y, rminx, rminy, rmaxx, rmaxy);
+    if (tight) {
+        if (xyh.z < 0.f) {  // opacity <= 1/255: never visible
+            rmaxx = rminx;
+            return;
+        }
+        // pixel centres are integers; tile of pixel x is floor(x / 16)
+        const int tx0 = (int)(fmaxf(xyh.x - xyh.z, 0.f) * (1.0f / TILE_X));
+        const int ty0 = (int)(fmaxf(xyh.y - xyh.w, 0.f) * (1.0f / TILE_Y));
+        const int tx1 = (xyh.x + xyh.z < 0.f) ? 0 : (int)((xyh.x + xyh.z) * (1.0f / TILE_X)) + 1;
+        const int ty1 = (xyh.y + xyh.w < 0.f) ? 0 : (int)((xyh.y + xyh.w) * (1.0f / TILE_Y)) + 1;
+        rminx = max(rminx, tx0);
+        rminy = max(rminy, ty0);
+        rmaxx = max(rminx, min(rmaxx, tx1));
+        rmaxy = max(rminy, min(rmaxy, ty1));
+    }
+}
+
 // Load the first n3 = 3*(D+1)^2 floats of a (M,3) SH row into registers.  Rows are 16-byte aligned when
 // 3*M is a multiple of 4 (M = 4 or 16): read float4; otherwise scalar.
 __device__ __forceinline__ void load_sh_row(const float *__restrict__ row, const int D, const bool vec_ok, float sh[48]) {
