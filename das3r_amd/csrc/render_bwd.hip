@@ -67,7 +67,8 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
         for (uint32_t f = tid; f < ntail; f += TILE_PIX) tail[f] = 0.f;
     }
 
-    ReplayState st = {T_final, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    ReplayState st = {T_final, 0.f};
+    const float tfbg = T_final * bg_dot_dpixel;
     // which accumulator this lane feeds after the cross-lane reduction
     const bool writer = USE_DPP ? (((lane & 7) == 0) || lane == 63) : (lane < NACC);
     const int widx = USE_DPP ? (lane == 63 ? 8 : (lane >> 3)) : lane;
@@ -106,7 +107,7 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
                 if (__ballot(active) == 0ull) continue;  // wave-uniform skip
                 const float4 c = stage[j].rgbd;
                 float v[NACC];
-                replay_pair(active, alpha, G, dx, dy, co, c, dLp0, dLp1, dLp2, T_final, bg_dot_dpixel, ddelx_dx, ddely_dy, st, v);
+                replay_pair(active, alpha, G, dx, dy, co, c, dLp0, dLp1, dLp2, tfbg, ddelx_dx, ddely_dy, st, v);
                 float out;
                 if (ablate & 4) {  // experiment: no cross-lane traffic, heavy arithmetic kept alive
                     out = v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] + v[8];

@@ -83,43 +83,39 @@ __device__ __forceinline__ float wave_reduce8_transposed(const float v[8], const
 }
 
 // ---- backward replay of one (pixel, splat) pair, branch-free --------------------------------------------------------
-struct ReplayState {   // per-pixel recurrence carried back-to-front
-    float T, accum0, accum1, accum2, last_alpha, lc0, lc1, lc2;
+// Per-pixel recurrence carried back-to-front.  Upstream keeps the colour behind the splat per channel
+// (accum_rec, last_color, last_alpha: 7 floats).  Only its dot product with dL/dpixel is ever used, so the state here is
+// two scalars: T (transmittance in front of the current splat) and R = sum over the splats behind of
+// (c_j . dL/dpix) alpha_j T_j.  With cd = c_i . dL/dpix:
+//     dL/dalpha_i = T_i * sum_ch (c_i - accum_i) dL/dpix  - T_final/(1-alpha_i) * (bg . dL/dpix)
+//                 = T_i * cd - (R + T_final * (bg . dL/dpix)) / (1 - alpha_i)          (accum_i * T_i = R / (1 - alpha_i))
+struct ReplayState {
+    float T, R;
 };
 // Inactive lanes run the same arithmetic with alpha = G = 0: state and sums are unchanged.  v[0..2] dL/dcolour,
 // v[3..4] dL/dmean2D (already scaled by W/2, H/2), v[5..7] dL/dconic (B entry = half the true derivative, upstream
-// convention), v[8] dL/dopacity.
+// convention), v[8] dL/dopacity.  tfbg = T_final * (bg . dL/dpix).
 __device__ __forceinline__ void replay_pair(const bool active, const float alpha, const float G, const float dx, const float dy,
                                             const float4 co, const float4 c, const float dLp0, const float dLp1, const float dLp2,
-                                            const float T_final, const float bg_dot_dpixel, const float ddelx_dx, const float ddely_dy,
-                                            ReplayState &st, float v[9]) {
+                                            const float tfbg, const float ddelx_dx, const float ddely_dy, ReplayState &st, float v[9]) {
     const float am = active ? alpha : 0.f, Gm = active ? G : 0.f;
     const float rinv = __builtin_amdgcn_rcpf(1.f - am);  // v_rcp_f32: T is itself a reconstruction, 1 ulp is noise
     st.T = st.T * rinv;
-    const float dchannel_dcolor = am * st.T;
-    const float na0 = st.last_alpha * st.lc0 + (1.f - st.last_alpha) * st.accum0;
-    const float na1 = st.last_alpha * st.lc1 + (1.f - st.last_alpha) * st.accum1;
-    const float na2 = st.last_alpha * st.lc2 + (1.f - st.last_alpha) * st.accum2;
-    st.accum0 = active ? na0 : st.accum0;
-    st.accum1 = active ? na1 : st.accum1;
-    st.accum2 = active ? na2 : st.accum2;
-    st.lc0 = active ? c.x : st.lc0;
-    st.lc1 = active ? c.y : st.lc1;
-    st.lc2 = active ? c.z : st.lc2;
-    st.last_alpha = active ? alpha : st.last_alpha;
-    float dL_dalpha = (c.x - st.accum0) * dLp0 + (c.y - st.accum1) * dLp1 + (c.z - st.accum2) * dLp2;
-    dL_dalpha = dL_dalpha * st.T - (T_final * rinv) * bg_dot_dpixel;
+    const float w = am * st.T;                            // alpha_i * T_i = d(pixel colour)/d(c_i)
+    const float cd = c.x * dLp0 + c.y * dLp1 + c.z * dLp2;
+    const float dL_dalpha = st.T * cd - (st.R + tfbg) * rinv;
+    st.R = st.R + cd * w;
     const float gdl = Gm * dL_dalpha;   // G * dL/dalpha (0 on inactive lanes)
-    const float dL_dG_G = co.w * gdl;   // G * dL/dG
-    const float gdx = dL_dG_G * dx, gdy = dL_dG_G * dy;
-    v[0] = dchannel_dcolor * dLp0;
-    v[1] = dchannel_dcolor * dLp1;
-    v[2] = dchannel_dcolor * dLp2;
-    v[3] = (-gdx * co.x - gdy * co.y) * ddelx_dx;
-    v[4] = (-gdy * co.z - gdx * co.y) * ddely_dy;
-    v[5] = -0.5f * gdx * dx;
-    v[6] = -0.5f * gdx * dy;
-    v[7] = -0.5f * gdy * dy;
+    const float hd = -0.5f * co.w * gdl;  // -1/2 * G * dL/dG
+    const float gx = hd * dx, gy = hd * dy;
+    v[0] = w * dLp0;
+    v[1] = w * dLp1;
+    v[2] = w * dLp2;
+    v[3] = (gx * co.x + gy * co.y) * (2.0f * ddelx_dx);
+    v[4] = (gy * co.z + gx * co.y) * (2.0f * ddely_dy);
+    v[5] = gx * dx;
+    v[6] = gx * dy;
+    v[7] = gy * dy;
     v[8] = gdl;
 }
 
