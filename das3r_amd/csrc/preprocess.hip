@@ -12,7 +12,7 @@
 
 namespace das3r {
 
-template <bool HAS_SH, bool HAS_COV>
+template <bool HAS_SH, bool HAS_COV, bool STAGE>
 __global__ void __launch_bounds__(256) preprocess_kernel(
     int P, int D, int M, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ shs,
@@ -27,6 +27,21 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     // instead of spending two memset launches
     for (uint32_t i = idx; i < zero_a_words; i += gridDim.x * blockDim.x) zero_a[i] = 0u;
     for (uint32_t i = idx; i < zero_b_words; i += gridDim.x * blockDim.x) zero_b[i] = 0u;
+    // STAGE (M == 16, degree >= 2): the workgroup's 256 SH rows (192 B each, contiguous) are fetched with fully coalesced
+    // float4 loads — every 128-B line exactly once — and re-read per lane from LDS.  Per-lane strided row loads re-fetch
+    // lines evicted from L1/L2 between the 12 loads of a row: measured 2.5x the algorithmic HBM traffic at 1M splats.
+    // Rows are padded to 13 float4 (208 B) so that the per-lane ds_read_b128 of a 16-lane group hit 16 distinct bank slots.
+    __shared__ float4 sh_lds[STAGE ? 256 * 13 : 1];
+    if (STAGE) {
+        const float4 *src = reinterpret_cast<const float4 *>(shs) + (size_t)blockIdx.x * 256 * 12;
+        const size_t limit = (size_t)P * 12 - (size_t)blockIdx.x * 256 * 12;  // float4s available from src
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const int f = i * 256 + threadIdx.x;
+            if ((size_t)f < limit) sh_lds[(f / 12) * 13 + (f % 12)] = src[f];
+        }
+        __syncthreads();
+    }
     if (idx >= P) return;
 
     float V[16], PM[16];
@@ -82,7 +97,18 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
             const int area = (rmaxx - rminx) * (rmaxy - rminy);
             if (area != 0) {
                 float3 col;
-                if (HAS_SH) {
+                if (HAS_SH && STAGE) {
+                    float sh[48];
+                    const int n4 = (3 * (D + 1) * (D + 1) + 3) >> 2;
+#pragma unroll
+                    for (int i = 0; i < 12; i++) {
+                        if (i < n4) {
+                            const float4 v = sh_lds[threadIdx.x * 13 + i];
+                            sh[4 * i] = v.x; sh[4 * i + 1] = v.y; sh[4 * i + 2] = v.z; sh[4 * i + 3] = v.w;
+                        }
+                    }
+                    col = sh_regs_to_rgb(D, sh, p, campos, clamp_out);
+                } else if (HAS_SH) {
                     col = sh_to_rgb(D, M, shs + (size_t)idx * M * 3, p, campos, clamp_out);
                 } else {
                     col = make_float3(colors_precomp[3 * idx], colors_precomp[3 * idx + 1], colors_precomp[3 * idx + 2]);
@@ -142,10 +168,13 @@ int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int
         (float4 *)(geom + L.pub.conic_opacity), (float4 *)(geom + L.pub.rgbd), (uint8_t *)(geom + L.pub.clamped),         \
         (uint32_t *)(geom + L.pub.tiles_touched), use_tight_rect() ? 1 : 0, (uint32_t *)(geom + L.g_ghist), (uint32_t)(L.g_ctrl_bytes / 4),                 \
         (uint32_t *)(img + L.pub.ranges), (uint32_t)(2 * L.ntiles)
-    if (has_sh && !has_cov) DAS3R_LAUNCH((preprocess_kernel<true, false>), grid, block, 0, s, ARGS);
-    else if (has_sh && has_cov) DAS3R_LAUNCH((preprocess_kernel<true, true>), grid, block, 0, s, ARGS);
-    else if (!has_sh && !has_cov) DAS3R_LAUNCH((preprocess_kernel<false, false>), grid, block, 0, s, ARGS);
-    else DAS3R_LAUNCH((preprocess_kernel<false, true>), grid, block, 0, s, ARGS);
+    const bool stage = has_sh && a->M == 16 && a->sh_degree >= 2 && ((uintptr_t)in->shs & 15) == 0 && !getenv("DAS3R_NO_SH_STAGE");
+    if (has_sh && !has_cov && stage) DAS3R_LAUNCH((preprocess_kernel<true, false, true>), grid, block, 0, s, ARGS);
+    else if (has_sh && has_cov && stage) DAS3R_LAUNCH((preprocess_kernel<true, true, true>), grid, block, 0, s, ARGS);
+    else if (has_sh && !has_cov) DAS3R_LAUNCH((preprocess_kernel<true, false, false>), grid, block, 0, s, ARGS);
+    else if (has_sh && has_cov) DAS3R_LAUNCH((preprocess_kernel<true, true, false>), grid, block, 0, s, ARGS);
+    else if (!has_sh && !has_cov) DAS3R_LAUNCH((preprocess_kernel<false, false, false>), grid, block, 0, s, ARGS);
+    else DAS3R_LAUNCH((preprocess_kernel<false, true, false>), grid, block, 0, s, ARGS);
 #undef ARGS
     KERNEL_CHECK(s, a->debug, "preprocess");
     return DAS3R_OK;

@@ -167,6 +167,15 @@ __device__ __forceinline__ bool sh_vec_ok(const float *row, const int D, const i
     return (((uintptr_t)row & 15) == 0) && (((n3 + 3) & ~3) <= 3 * M);
 }
 
+__device__ __forceinline__ float3 sh_regs_to_rgb(const int D, const float sh[48], const float3 p, const float *campos,
+                                                 uint8_t &clamp_bits) {
+    const float dx = p.x - campos[0], dy = p.y - campos[1], dz = p.z - campos[2];
+    const float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+    const float3 r = sh_eval(D, sh, dx * inv, dy * inv, dz * inv);
+    clamp_bits = (uint8_t)((r.x < 0.f ? 1 : 0) | (r.y < 0.f ? 2 : 0) | (r.z < 0.f ? 4 : 0));
+    return make_float3(fmaxf(r.x, 0.f), fmaxf(r.y, 0.f), fmaxf(r.z, 0.f));
+}
+
 __device__ __forceinline__ float3 sh_to_rgb(const int D, const int M, const float *__restrict__ row, const float3 p,
                                             const float *campos, uint8_t &clamp_bits) {
     float sh[48];
