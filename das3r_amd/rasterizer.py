@@ -52,14 +52,31 @@ def _prep(t, device, name):
 
 
 def _small(t, device, n, name):
-    t = torch.as_tensor(t, dtype=torch.float32, device=device).contiguous()
+    if not (isinstance(t, torch.Tensor) and t.dtype == torch.float32 and t.device == device and t.is_contiguous()):
+        t = torch.as_tensor(t, dtype=torch.float32, device=device).contiguous()
     if t.numel() != n:
         raise ValueError(f"{name} must have {n} elements")
     return t
 
 
 class _Alloc:
-    """Allocator callbacks handed to the library (upstream's resizeFunctional): torch owns the bytes."""
+    """Allocator callbacks handed to the library (upstream's resizeFunctional): torch owns the bytes.  One instance per
+    device is kept alive (building ctypes callbacks costs tens of microseconds); `take()` hands the buffers of the call that
+    just finished to the caller and forgets them."""
+
+    _per_device = {}
+
+    @classmethod
+    def get(cls, device):
+        a = cls._per_device.get(device)
+        if a is None:
+            a = cls._per_device[device] = cls(device)
+        a.bufs = {}
+        return a
+
+    def take(self):
+        b, self.bufs = self.bufs, {}
+        return b
 
     def __init__(self, device):
         self.device = device
@@ -129,12 +146,14 @@ def _forward_full(rs, means3D, sh, colors_precomp, opacities, scales, rotations,
         if sh.dim() != 3 or sh.shape[0] != P or sh.shape[2] != 3:
             raise RuntimeError("shs must have dimensions (num_points, M, 3)")
         M = sh.shape[1]
-    color = torch.zeros(3, H, W, dtype=torch.float32, device=device)
-    radii = torch.zeros(P, dtype=torch.int32, device=device)
-    alloc = _Alloc(device)
-    if P == 0:
+    if P == 0:   # upstream: zero image, background not applied, empty radii
         e = torch.empty(0, dtype=torch.uint8, device=device)
-        return 0, color, radii, e, e, e, 0
+        return (0, torch.zeros(3, H, W, dtype=torch.float32, device=device), torch.zeros(0, dtype=torch.int32, device=device),
+                e, e, e, 0)
+    # every pixel and every radii entry is written by the kernels: no memset needed
+    color = torch.empty(3, H, W, dtype=torch.float32, device=device)
+    radii = torch.empty(P, dtype=torch.int32, device=device)
+    alloc = _Alloc.get(device)
     keep = []
     a = _fill_args(rs, P, M, device, keep)
     key = (P, W, H, device.index)
@@ -150,8 +169,8 @@ def _forward_full(rs, means3D, sh, colors_precomp, opacities, scales, rotations,
     _lib.check(rc, "das3r_raster_forward")
     _CAPACITY_CACHE[key] = int(rc)
     empty = torch.empty(0, dtype=torch.uint8, device=device)
-    return (int(rc), color, radii, alloc.bufs.get("geom", empty), alloc.bufs.get("binning", empty), alloc.bufs.get("img", empty),
-            int(saved.capacity))
+    bufs = alloc.take()
+    return (int(rc), color, radii, bufs.get("geom", empty), bufs.get("binning", empty), bufs.get("img", empty), int(saved.capacity))
 
 
 def _backward_impl(rs, num_rendered, grad_out_color, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
