@@ -1,0 +1,96 @@
+// adam.hip — SURVEY.md §8(f)-2: one multi-tensor Adam step for the seven per-Gaussian parameter groups DAS3R optimises
+// (/root/reference/scene/gaussian_model.py:236-261: torch.optim.Adam(lr=0, eps=1e-15), no weight decay, no amsgrad).
+// torch makes ~7 passes over every array (59 floats per Gaussian); here each element's (p, g, m, v) is read once and
+// (p, m, v) written once, all groups in ONE launch, and the update is DEGREE-AWARE: a tensor laid out as rows
+// (f_rest: [P, 15, 3]) only touches the first `active_len` floats of each row.  Coefficients above the active SH degree
+// have g = m = v = 0, for which Adam's update is exactly 0, so skipping them is exact and removes 45 of the 59 floats
+// per Gaussian from the sweep while the active degree is 0 (iterations 1..2999 of a 4000-iteration DAS3R run).
+// Same arithmetic as torch's single-tensor path: m += (g - m)(1 - b1); v = v b2 + (1 - b2) g g;
+// p -= step_size * m / (sqrt(v) / sqrt(bc2) + eps) with step_size = lr / bc1 computed on the host in double.
+#include <string.h>
+
+#include "common.h"
+
+namespace das3r {
+
+constexpr int ADAM_MAX_TENSORS = 16;
+constexpr int ADAM_CHUNK = 256 * 8;
+
+struct AdamTable {
+    float *p[ADAM_MAX_TENSORS];
+    const float *g[ADAM_MAX_TENSORS];
+    float *m[ADAM_MAX_TENSORS];
+    float *v[ADAM_MAX_TENSORS];
+    long long n_active[ADAM_MAX_TENSORS];     // rows * active_len
+    int row_len[ADAM_MAX_TENSORS], active_len[ADAM_MAX_TENSORS];
+    int first_chunk[ADAM_MAX_TENSORS + 1];    // prefix of chunk counts
+    float step_size[ADAM_MAX_TENSORS], bc2_sqrt[ADAM_MAX_TENSORS];
+    int n;
+};
+
+__global__ void __launch_bounds__(256) adam_kernel(const AdamTable T, float beta1, float beta2, float eps) {
+    int t = 0;
+#pragma unroll 1
+    while (t + 1 < T.n && (int)blockIdx.x >= T.first_chunk[t + 1]) t++;
+    const long long base = (long long)(blockIdx.x - T.first_chunk[t]) * ADAM_CHUNK;
+    float *__restrict__ p = T.p[t];
+    const float *__restrict__ g = T.g[t];
+    float *__restrict__ m = T.m[t];
+    float *__restrict__ v = T.v[t];
+    const long long n = T.n_active[t];
+    const int row_len = T.row_len[t], active_len = T.active_len[t];
+    const float step_size = T.step_size[t], bc2_sqrt = T.bc2_sqrt[t];
+#pragma unroll
+    for (int k = 0; k < ADAM_CHUNK / 256; k++) {
+        const long long e = base + k * 256 + threadIdx.x;
+        if (e < n) {
+            const long long off = (row_len == active_len) ? e : (e / active_len) * row_len + (e % active_len);
+            const float gr = g[off];
+            float mm = m[off], vv = v[off];
+            mm = mm + (gr - mm) * (1.0f - beta1);
+            vv = vv * beta2 + (1.0f - beta2) * gr * gr;
+            const float denom = sqrtf(vv) / bc2_sqrt + eps;
+            p[off] = p[off] - step_size * (mm / denom);
+            m[off] = mm;
+            v[off] = vv;
+        }
+    }
+}
+
+}  // namespace das3r
+
+using namespace das3r;
+
+// tensors: host array of n entries.  rows * row_len = numel; only the first active_len floats of every row are updated
+// (active_len == row_len: the whole tensor).  step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t).
+extern "C" int das3r_adam_step(int32_t n, const das3r_adam_tensor *tensors, float beta1, float beta2, float eps, das3r_stream_t stream) {
+    if (n < 0 || n > ADAM_MAX_TENSORS || (n > 0 && !tensors)) {
+        set_error("das3r_adam_step: between 0 and %d tensors per call", ADAM_MAX_TENSORS);
+        return DAS3R_ERR_INVALID_ARG;
+    }
+    AdamTable T;
+    memset(&T, 0, sizeof(T));
+    int chunks = 0, k = 0;
+    for (int i = 0; i < n; i++) {
+        const das3r_adam_tensor &a = tensors[i];
+        if (a.rows < 0 || a.row_len <= 0 || a.active_len < 0 || a.active_len > a.row_len || !a.param || !a.grad || !a.exp_avg || !a.exp_avg_sq) {
+            set_error("das3r_adam_step: bad tensor %d", i);
+            return DAS3R_ERR_INVALID_ARG;
+        }
+        const long long na = (long long)a.rows * a.active_len;
+        if (na == 0) continue;   // nothing active in this tensor (e.g. f_rest while the SH degree is 0)
+        T.p[k] = a.param; T.g[k] = a.grad; T.m[k] = a.exp_avg; T.v[k] = a.exp_avg_sq;
+        T.n_active[k] = na; T.row_len[k] = a.row_len; T.active_len[k] = a.active_len;
+        T.step_size[k] = a.step_size; T.bc2_sqrt[k] = a.bc2_sqrt;
+        T.first_chunk[k] = chunks;
+        chunks += (int)((na + ADAM_CHUNK - 1) / ADAM_CHUNK);
+        k++;
+    }
+    T.first_chunk[k] = chunks;
+    T.n = k;
+    if (chunks == 0) return DAS3R_OK;
+    hipStream_t s = (hipStream_t)stream;
+    DAS3R_LAUNCH(adam_kernel, dim3(chunks), dim3(256), 0, s, T, beta1, beta2, eps);
+    KERNEL_CHECK(s, false, "adam");
+    return DAS3R_OK;
+}

@@ -1,0 +1,157 @@
+"""Opt-in fused work around the rasterizer, host side.  Hand-written HIP behind the C-ABI
+(include/das3r_raster.h: das3r_pretransform_*, das3r_adam_step); the default DAS3R-compatible path never needs this module.
+
+  pretransform(...)  : fused counterpart of /root/reference/gaussian_renderer/__init__.py:83-97,107 (autograd.Function)
+  FusedAdam          : torch.optim.Adam semantics for the reference's parameter groups
+                       (/root/reference/scene/gaussian_model.py:236-261), one launch per step, SH-degree aware
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from .camera import quat_to_rotation
+
+
+class AdamTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("rows", C.c_int64),
+                ("row_len", C.c_int32), ("active_len", C.c_int32), ("step_size", C.c_float), ("bc2_sqrt", C.c_float)]
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def quat_left_matrix(q):
+    """4x4 matrix L with quat_multiply(q, r) == L @ r (differentiable in q)."""
+    w, x, y, z = q.unbind(-1)
+    return torch.stack([torch.stack([w, -x, -y, -z]), torch.stack([x, w, -z, y]), torch.stack([y, z, w, -x]),
+                        torch.stack([z, -y, x, w])])
+
+
+class _PreTransform(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, rot, scaling, opacity_raw, conf, mask_index, R, t, Lq):
+        lib = _lib.load()
+        dev = xyz.device
+        if dev.type != "cuda":
+            raise RuntimeError("das3r_amd.fused.pretransform: tensors must live on a HIP device; there is no CPU path")
+        xyz, rot, scaling, opacity_raw = (a.contiguous() for a in (xyz, rot, scaling, opacity_raw))
+        conf_flat = conf.contiguous().view(-1)
+        R, t, Lq = R.contiguous().float(), t.contiguous().float(), Lq.contiguous().float()
+        P = xyz.shape[0]
+        means3D, rotations = torch.empty_like(xyz), torch.empty_like(rot)
+        scales, opac = torch.empty_like(scaling), torch.empty(P, 1, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.das3r_pretransform_forward(P, _p(xyz), _p(rot), _p(scaling), _p(opacity_raw), _p(conf_flat),
+                                                _p(mask_index) if mask_index is not None else None, _p(R), _p(t), _p(Lq),
+                                                _p(means3D), _p(rotations), _p(scales), _p(opac), _stream(dev))
+        _lib.check(rc, "das3r_pretransform_forward")
+        ctx.save_for_backward(xyz, rot, scaling, opacity_raw, conf_flat, R, Lq)
+        ctx.mask_index = mask_index
+        ctx.conf_shape = conf.shape
+        return means3D, rotations, scales, opac
+
+    @staticmethod
+    def backward(ctx, g_means3D, g_rot, g_scales, g_opac):
+        lib = _lib.load()
+        xyz, rot, scaling, opacity_raw, conf_flat, R, Lq = ctx.saved_tensors
+        dev, P = xyz.device, xyz.shape[0]
+        z = lambda t: torch.zeros_like(t) if t is None else t.contiguous()
+        g_means3D = z(g_means3D) if g_means3D is not None else torch.zeros_like(xyz)
+        g_rot = z(g_rot) if g_rot is not None else torch.zeros_like(rot)
+        g_scales = z(g_scales) if g_scales is not None else torch.zeros_like(scaling)
+        g_opac = z(g_opac) if g_opac is not None else torch.zeros(P, 1, device=dev)
+        g_xyz, g_rotation, g_scaling = torch.empty_like(xyz), torch.empty_like(rot), torch.empty_like(scaling)
+        g_opacity_raw = torch.empty_like(opacity_raw)
+        g_conf = torch.zeros_like(conf_flat)
+        g_small = torch.zeros(28, device=dev)
+        mi = ctx.mask_index
+        with torch.cuda.device(dev):
+            rc = lib.das3r_pretransform_backward(P, _p(xyz), _p(rot), _p(scaling), _p(opacity_raw), _p(conf_flat),
+                                                 _p(mi) if mi is not None else None, _p(R), _p(Lq), _p(g_means3D), _p(g_rot), _p(g_scales),
+                                                 _p(g_opac), _p(g_xyz), _p(g_rotation), _p(g_scaling), _p(g_opacity_raw), _p(g_conf),
+                                                 _p(g_small), _stream(dev))
+        _lib.check(rc, "das3r_pretransform_backward")
+        return (g_xyz, g_rotation, g_scaling, g_opacity_raw, g_conf.view(ctx.conf_shape), None, g_small[:9].view(3, 3), g_small[9:12],
+                g_small[12:].view(4, 4))
+
+
+def pretransform(xyz, rot, scaling, opacity_raw, conf, mask_index, pose):
+    """-> (means3D, rotations, scales, opacities) exactly as DAS3R's render() builds them from the raw parameters and the
+    7-vector pose (qw,qx,qy,qz,tx,ty,tz).  The pose -> (R, t, Lq) step stays in PyTorch (tiny, autograd-tracked)."""
+    R = quat_to_rotation(pose[None, :4])[0]       # normalises the quaternion, like get_camera_from_tensor
+    t = pose[4:]
+    Lq = quat_left_matrix(pose[:4])               # quadmultiply(pose[:4], .) uses the raw quaternion
+    return _PreTransform.apply(xyz, rot, scaling, opacity_raw, conf, mask_index, R, t, Lq)
+
+
+class FusedAdam:
+    """torch.optim.Adam(lr=0.0, eps=1e-15)-compatible optimizer for lists of fp32 device tensors: same param_groups / step() /
+    zero_grad() surface as the reference uses, one HIP launch per step.  A group may carry "sh_rest": True — its tensor is
+    [P, K, 3] SH coefficients of which only those of the active degree are swept (set_active_sh_degree)."""
+
+    def __init__(self, params, lr=0.0, betas=(0.9, 0.999), eps=1e-15):
+        self.param_groups = []
+        for g in params:
+            g = dict(g)
+            g.setdefault("lr", lr)
+            g["params"] = list(g["params"])
+            self.param_groups.append(g)
+        self.betas, self.eps = betas, eps
+        self.state = {}
+        self.active_sh_degree = None
+
+    def set_active_sh_degree(self, d):
+        self.active_sh_degree = d
+
+    def zero_grad(self, set_to_none=True):
+        for g in self.param_groups:
+            for p in g["params"]:
+                if set_to_none:
+                    p.grad = None
+                elif p.grad is not None:
+                    p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self):
+        lib = _lib.load()
+        b1, b2 = self.betas
+        entries, keep, dev = [], [], None
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is None:
+                    continue
+                if p.device.type != "cuda" or p.dtype != torch.float32:
+                    raise RuntimeError("FusedAdam: fp32 tensors on a HIP device only (no CPU path)")
+                dev = p.device
+                st = self.state.get(p)
+                if st is None:
+                    st = self.state[p] = dict(step=0, exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p))
+                st["step"] += 1
+                t = st["step"]
+                grad = p.grad.contiguous()
+                keep.append(grad)
+                e = AdamTensor()
+                e.param, e.grad, e.exp_avg, e.exp_avg_sq = p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                if g.get("sh_rest") and self.active_sh_degree is not None and p.dim() == 3:
+                    e.rows, e.row_len = p.shape[0], p.shape[1] * p.shape[2]
+                    e.active_len = min(e.row_len, 3 * ((self.active_sh_degree + 1) ** 2 - 1))
+                else:
+                    e.rows, e.row_len, e.active_len = 1, p.numel(), p.numel()
+                    if p.numel() >= 2 ** 31:
+                        raise RuntimeError("FusedAdam: tensor too large")
+                e.step_size = g["lr"] / (1.0 - b1 ** t)
+                e.bc2_sqrt = math.sqrt(1.0 - b2 ** t)
+                entries.append(e)
+        for i in range(0, len(entries), 16):
+            chunk = entries[i:i + 16]
+            arr = (AdamTensor * len(chunk))(*chunk)
+            with torch.cuda.device(dev):
+                rc = lib.das3r_adam_step(len(chunk), arr, C.c_float(b1), C.c_float(b2), C.c_float(self.eps), _stream(dev))
+            _lib.check(rc, "das3r_adam_step")

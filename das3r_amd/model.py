@@ -78,6 +78,8 @@ class SplatModel:
     def oneupSHdegree(self):
         if self.active_sh_degree < self.max_sh_degree:
             self.active_sh_degree += 1
+        if hasattr(self.optimizer, "set_active_sh_degree"):
+            self.optimizer.set_active_sh_degree(self.active_sh_degree)
 
     # ---- initialisation from per-frame depth / confidence / dynamic maps
     def create_from_frames(self, images, depths, confs, dyna_avg, K, cam2world, w2c_pose7, spatial_lr_scale=1.0, conf_thre=1.0):
@@ -110,7 +112,7 @@ class SplatModel:
         return self
 
     # ---- optimizers and schedules
-    def training_setup(self, opt: OptimParams):
+    def training_setup(self, opt: OptimParams, fused=False):
         s = self.spatial_lr_scale
         groups = [
             {"params": [self._xyz], "lr": opt.position_lr_init * s, "name": "xyz"},
@@ -122,12 +124,19 @@ class SplatModel:
             {"params": [self._conf_static], "lr": 3e-3, "name": "conf_static"},
         ]
         cam = [{"params": [self.Q], "lr": 0.00003, "name": "pose_Q"}, {"params": [self.T], "lr": 0.00003, "name": "pose_T"}]
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        if fused:   # opt-in: one HIP launch per step, f_rest swept only up to the active SH degree
+            from .fused import FusedAdam
+            groups[2]["sh_rest"] = True
+            self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
+        else:
+            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
         self.optimizer_cam = torch.optim.Adam(cam, lr=0.0, eps=1e-15)
         self._lr_xyz = expon_lr_func(opt.position_lr_init * s, opt.position_lr_final * s, lr_delay_mult=opt.position_lr_delay_mult,
                                      max_steps=opt.position_lr_max_steps)
         self._lr_cam = expon_lr_func(0.00003, 0.000003, lr_delay_mult=opt.position_lr_delay_mult, max_steps=1000)
         self._lr_conf = expon_lr_func(3e-3, 3e-4, lr_delay_mult=opt.position_lr_delay_mult, max_steps=opt.iterations)
+        if hasattr(self.optimizer, "set_active_sh_degree"):
+            self.optimizer.set_active_sh_degree(self.active_sh_degree)
 
     def update_learning_rate(self, iteration):
         for g in self.optimizer_cam.param_groups:

@@ -25,13 +25,13 @@ def make_camera(uid, image, focal, W, H, device):
                            projection_matrix=projection_matrix(0.01, 100.0, fovx, fovy).transpose(0, 1).to(device))
 
 
-def train_step(model: SplatModel, cam, opt: OptimParams, iteration, pipe, background):
+def train_step(model: SplatModel, cam, opt: OptimParams, iteration, pipe, background, fused=False):
     """One iteration of the reference hot loop (train_gui.py:532-589).  Returns (loss, psnr_frame, render package)."""
     model.update_learning_rate(iteration)
     if iteration % 3000 == 0:
         model.oneupSHdegree()
     pose = model.get_RT(cam.uid)
-    pkg = das3r_render(cam, model, pipe, background, camera_pose=pose)
+    pkg = das3r_render(cam, model, pipe, background, camera_pose=pose, fused=fused)
     image = pkg["render"]
     gt = cam.original_image
     static = model._conf_static[cam.uid]

@@ -131,6 +131,38 @@ size_t das3r_knn3_workspace_bytes(int32_t P);
 int das3r_knn3_mean_dist2(int32_t P, const float *points /* [P,3] */, float *out /* [P] */, char *workspace,
                           das3r_stream_t stream);
 
+/* ---- opt-in fused callers' work around the rasterizer (the default DAS3R path does not need them) ---- */
+
+/* §8f-1: the per-Gaussian pre-transform + activations of /root/reference/gaussian_renderer/__init__.py:83-97,107 in one
+ * pass: means3D = R xyz + t, rotations = Lq rot (quadmultiply(pose[:4], .) as a 4x4 matrix), scales = exp(scaling),
+ * opacities = sigmoid(opacity_raw) * conf_flat[mask_index[i]] (mask_index NULL = identity).  R [3,3], t [3], Lq [4,4]:
+ * row-major device tensors.  backward: g_conf_flat (size of conf_flat) and g_small [28] = dL/dR (9), dL/dt (3),
+ * dL/dLq (16) must be zero on entry. */
+int das3r_pretransform_forward(int32_t P, const float *xyz, const float *rot, const float *scaling, const float *opacity_raw,
+                               const float *conf_flat, const int64_t *mask_index, const float *R, const float *t, const float *Lq,
+                               float *means3D, float *rotations, float *scales, float *opacities, das3r_stream_t stream);
+int das3r_pretransform_backward(int32_t P, const float *xyz, const float *rot, const float *scaling, const float *opacity_raw,
+                                const float *conf_flat, const int64_t *mask_index, const float *R, const float *Lq,
+                                const float *g_means3D, const float *g_rot, const float *g_scales, const float *g_opac, float *g_xyz,
+                                float *g_rotation, float *g_scaling, float *g_opacity_raw, float *g_conf_flat, float *g_small,
+                                das3r_stream_t stream);
+
+/* §8f-2: one multi-tensor Adam step (torch.optim.Adam semantics, no weight decay / amsgrad;
+ * /root/reference/scene/gaussian_model.py:236-261).  A tensor is `rows` rows of `row_len` floats of which only the first
+ * `active_len` are updated (degree-aware f_rest; active_len == row_len for ordinary tensors).  `tensors` is a HOST array. */
+typedef struct {
+    float *param;
+    const float *grad;
+    float *exp_avg;
+    float *exp_avg_sq;
+    int64_t rows;
+    int32_t row_len;
+    int32_t active_len;
+    float step_size;  /* lr / (1 - beta1^t) */
+    float bc2_sqrt;   /* sqrt(1 - beta2^t) */
+} das3r_adam_tensor;
+int das3r_adam_step(int32_t n, const das3r_adam_tensor *tensors, float beta1, float beta2, float eps, das3r_stream_t stream);
+
 /* ---- introspection (used by the parity tests and the roofline accounting) ---- */
 
 /* Byte offsets of the saved intermediates inside geom / binning / img for given extents. */
