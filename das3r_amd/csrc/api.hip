@@ -36,6 +36,12 @@ void profile_end(hipStream_t s) {
     if (!g_prof.empty()) hipEventRecord(g_prof.back().stop, s);
 }
 
+int sort_ipl_override() {
+    const char *e = getenv("DAS3R_SORT_IPL");
+    const int v = e ? atoi(e) : 0;
+    return (v == 4 || v == 8 || v == 16) ? v : 0;
+}
+
 bool use_onesweep() {
     const char *e = getenv("DAS3R_SORT");  // "classic" = histogram + row scan + scatter per digit
     return !(e && e[0] == 'c');
@@ -167,6 +173,23 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         saved->binning = alloc_binning(user, 256);
         return 0;
     }
+    // The tile partition can only raise its error word after the count has been copied back.  It is collected without
+    // ever blocking the host: copied to pinned memory at the end of this forward and examined at the start of the next one
+    // (debug mode waits for it right away).  Bits: 1 look-back timeout, 2 index out of range (write suppressed), 8 counts
+    // do not add up to the histogram.
+    static thread_local uint32_t *h_late = nullptr;
+    static thread_local hipEvent_t ev_late = nullptr;
+    static thread_local bool late_pending = false;
+    if (!h_late) { HIP_TRY(hipHostMalloc((void **)&h_late, 64, hipHostMallocDefault)); h_late[0] = 0; }
+    if (!ev_late) HIP_TRY(hipEventCreateWithFlags(&ev_late, hipEventDisableTiming));
+    if (late_pending && hipEventQuery(ev_late) == hipSuccess) {
+        late_pending = false;
+        if (h_late[0]) {
+            set_error("the previous forward's tile partition failed its self-check (flags 0x%x); its output was invalid", h_late[0]);
+            h_late[0] = 0;
+            return DAS3R_ERR_HIP;
+        }
+    }
     if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, L, s))) return rc;
     if ((rc = launch_depth_sort_and_scan(P, saved->geom, L, a->debug != 0, s))) return rc;
 
@@ -198,6 +221,18 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         if (h_count[1] != 0) { set_error("radix look-back timed out (flags 0x%x)", h_count[1]); return DAS3R_ERR_HIP; }
         if (I <= cap) break;
         cap = -1;  // hint too small: lists were truncated, redo binning + render with the exact size
+    }
+    if (use_onesweep()) {
+        if (late_pending) HIP_TRY(hipEventSynchronize(ev_late));   // rare: the previous copy has not landed yet
+        if (late_pending && h_late[0]) { late_pending = false; set_error("an earlier forward's tile partition failed its self-check (flags 0x%x)", h_late[0]); h_late[0] = 0; return DAS3R_ERR_HIP; }
+        HIP_TRY(hipMemcpyAsync(h_late, (const uint32_t *)(saved->geom + L.g_ticket) + 8, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(ev_late, s));
+        late_pending = true;
+        if (a->debug) {
+            HIP_TRY(hipEventSynchronize(ev_late));
+            late_pending = false;
+            if (h_late[0]) { set_error("tile partition self-check failed (flags 0x%x)", h_late[0]); h_late[0] = 0; return DAS3R_ERR_HIP; }
+        }
     }
     saved->num_rendered = I;
     saved->capacity = cap;

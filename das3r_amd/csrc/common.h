@@ -68,7 +68,11 @@ constexpr int RADIX_BITS = 8;
 constexpr int RADIX_SIZE = 1 << RADIX_BITS;
 constexpr int SORT_WAVES_PER_BLOCK = 4;
 // keys handled by one wave ("chunk"); chosen per problem size so that small sorts still fill the chip
-static inline int sort_items_per_lane(int64_t n) { return n >= (int64_t)(1 << 21) ? 16 : (n >= (1 << 17) ? 8 : 4); }
+int sort_ipl_override();   // api.hip: DAS3R_SORT_IPL (perf experiments), 0 = none
+static inline int sort_items_per_lane(int64_t n) {
+    const int o = sort_ipl_override();
+    return o ? o : (n >= (int64_t)(1 << 21) ? 16 : (n >= (1 << 17) ? 8 : 4));
+}
 static inline int sort_num_chunks(int64_t n) { return n == 0 ? 0 : div_up(n, (int64_t)WAVE * sort_items_per_lane(n)); }
 static inline int tile_bits(int ntiles) {
     int b = 0;

@@ -1,11 +1,11 @@
-// sort_onesweep.hip — single-pass-per-digit stable radix passes (chained scan with decoupled look-back) used by the
+// sort_onesweep.hip — single-pass-per-digit stable radix passes (two-level look-back over published counts) used by the
 // rasterizer's binning: ONE kernel per 8-bit digit instead of histogram + row scan + scatter, and no second read of the
 // keys.  At 100 k splats the binning was launch/latency bound (22 launches of ~4.5 us each); this path needs 11.
 //
 // Each 256-lane workgroup takes a ticket (arrival order => every predecessor is already running: no dependence on
 // dispatch order), ranks its 256*IPL keys exactly like the classic scatter kernel (wave-private LDS counters, ballot
-// match-any), publishes its per-digit counts and finds the number of equal-digit keys in all earlier workgroups by
-// walking back over their published words.
+// match-any), publishes its per-digit counts and finds the number of equal-digit keys in all earlier workgroups from
+// their published words (two levels: workgroups of its own group + totals of the earlier groups, see the kernel).
 //
 // Inter-workgroup hand-off follows the MI355X rule for XCD-private L2s (cdna_hip_programming.md §6 G16, recipe R2): the
 // payload IS the flag — one naturally aligned 8-byte {tag, value} word per (workgroup, digit), written with ONE relaxed
@@ -18,8 +18,9 @@
 namespace das3r {
 
 typedef unsigned long long u64;
-constexpr u64 TAG_AGG = 1ull << 62, TAG_PREFIX = 2ull << 62, TAG_MASK = 3ull << 62;
+constexpr u64 TAG_AGG = 1ull << 62, TAG_MASK = 3ull << 62;
 constexpr unsigned SPIN_LIMIT = 1u << 22;
+constexpr uint32_t ERR_TIMEOUT = 1u, ERR_RANGE = 2u, ERR_COUNTS = 8u;   // bits of the error word
 
 __device__ __forceinline__ void granule_store(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u64 granule_load(const u64 *p) {
@@ -34,6 +35,36 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
         if (lane >= o) v += n;
     }
     return v;
+}
+
+// Sum of the values of `count` published words spaced RADIX_SIZE granules apart (one column of the status matrix).  Loads
+// go out in windows of LB independent requests; a window with an unpublished word is re-polled as a whole.
+// Slots past `count` are NOT loaded.  (Measured on MI355X: padding the window by re-reading the last word — up to LB
+// back-to-back sc1 loads of one address per poll — made published words invisible to some pollers for seconds, i.e.
+// look-back timeouts in ~30 % of 1M-splat forwards; sc1 loads are L2-served, MI355X_MICROARCH.md.)
+template <int LB = 16>
+__device__ __forceinline__ uint32_t sum_published(const u64 *col, const int count, uint32_t *err) {
+    uint32_t sum = 0;
+    unsigned spins = 0;
+    for (int p = 0; p < count; p += LB) {
+        u64 x[LB];
+        while (true) {
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < LB; j++) x[j] = (p + j < count) ? granule_load(col + (size_t)(p + j) * RADIX_SIZE) : TAG_AGG;
+#pragma unroll
+            for (int j = 0; j < LB; j++) ok &= (x[j] & TAG_MASK) != 0;
+            if (ok) break;
+            if (++spins > SPIN_LIMIT) {  // a predecessor never published: give up loudly instead of hanging
+                atomicOr(err, ERR_TIMEOUT);
+                return sum;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int j = 0; j < LB; j++) sum += (p + j < count) ? (uint32_t)(x[j] & 0xFFFFFFFFull) : 0u;
+    }
+    return sum;
 }
 
 // global histograms of all four 8-bit digits of the depth keys (read once, LDS-privatised, few global atomics)
@@ -58,17 +89,21 @@ __global__ void __launch_bounds__(256) depth_hist_kernel(const uint32_t *__restr
 }
 
 // One digit of a stable LSD sort / partition.  keys_out may be null; vals_in null => payload = index.
-// gather_src / inv_out: final pass of the tile partition (payload = emission slot e): store gather_src[e] and inv[e] = dst.
-template <int IPL>
+// gather_src / inv_out (FINAL): last pass of the tile partition (payload = emission slot e): store gather_src[e], inv[e] = dst.
+template <int IPL, bool FINAL>
 __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                             uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
                                                             uint32_t cap, const uint32_t *__restrict__ n_ptr, int shift, int bits,
                                                             const uint32_t *__restrict__ ghist /*[256] this digit*/,
-                                                            u64 *__restrict__ status /*[nblocks][256]*/, uint32_t *__restrict__ ticket,
+                                                            u64 *__restrict__ status /*[nblocks][256]*/,
+                                                            u64 *__restrict__ group_status /*[ngroups][256]*/, int gs_log2,
+                                                            uint32_t *__restrict__ ticket,
                                                             const uint32_t *__restrict__ gather_src, uint32_t *__restrict__ inv_out,
                                                             uint32_t *__restrict__ err) {
     __shared__ uint32_t cnt[4][RADIX_SIZE];  // per-wave digit counts, then per-wave running offsets
-    __shared__ uint32_t ws[4];
+    __shared__ uint32_t gdelta[RADIX_SIZE];
+    __shared__ uint32_t sk[256 * IPL], sv[256 * IPL], sx[FINAL ? 256 * IPL : 1];  // staging: key, payload, (emission slot)
+    __shared__ uint32_t ws[8];
     __shared__ uint32_t s_block;
     const int tid = threadIdx.x, lane = __lane_id(), wave = tid >> 6;
     const uint32_t n = n_ptr ? min(*n_ptr, cap) : cap;
@@ -90,6 +125,10 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
 #pragma unroll
     for (int s = 0; s < IPL; s++) {
         const uint32_t i = base + s * 64 + lane;
+        if (gather_src && i < n && v[s] >= n) {
+            atomicOr(err, ERR_RANGE);
+            v[s] = 0;
+        }
         out[s] = (gather_src && i < n) ? gather_src[v[s]] : v[s];
         if (i < n) atomicAdd(&cnt[wave][(k[s] >> shift) & mask], 1u);
     }
@@ -99,108 +138,136 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
     {
         const uint32_t c0 = cnt[0][tid], c1 = cnt[1][tid], c2 = cnt[2][tid], c3 = cnt[3][tid];
         const uint32_t total = c0 + c1 + c2 + c3;
-        u64 *mine = status + (size_t)b * RADIX_SIZE + tid;
-        uint32_t excl = 0;
-        if (b == 0) {
-            granule_store(mine, TAG_PREFIX | total);
-        } else {
-            granule_store(mine, TAG_AGG | total);
-            // windowed look-back: LB predecessors are fetched with independent loads per step (one L2 round trip per
-            // window instead of one per predecessor), then consumed in order
-            constexpr int LB = 8;
-            unsigned spins = 0;
-            int p = (int)b - 1;
-            bool found = false;
-            while (p >= 0 && !found) {
-                u64 x[LB];
-#pragma unroll
-                for (int j = 0; j < LB; j++) x[j] = (p - j >= 0) ? granule_load(status + (size_t)(p - j) * RADIX_SIZE + tid) : TAG_PREFIX;
-                int used = 0;
-#pragma unroll
-                for (int j = 0; j < LB; j++) {
-                    if (found || used < j) continue;  // stop consuming behind an unpublished word / after a prefix
-                    const u64 tag = x[j] & TAG_MASK;
-                    if (tag == 0) continue;           // not published yet: retry from here
-                    excl += (uint32_t)(x[j] & 0xFFFFFFFFull);
-                    used = j + 1;
-                    found = tag == TAG_PREFIX;
-                }
-                p -= used;
-                if (used == 0) {
-                    if (++spins > SPIN_LIMIT) {  // predecessor never published: give up loudly instead of hanging
-                        atomicOr(err, 1u);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            granule_store(mine, TAG_PREFIX | (u64)(excl + total));
-        }
-        // first output slot of digit d = (keys with smaller digits) + (same digit in earlier workgroups)
+        // Two-level look-back.  Workgroups are grouped GS = 2^gs_log2 at a time; the last workgroup of a group also
+        // publishes the group's total.  Every workgroup then needs (its predecessors inside its group) + (the totals of
+        // all earlier groups): <= GS - 1 + ngroups - 1 ~ 2 sqrt(nblocks) words, ALL INDEPENDENT loads (no chain of
+        // prefixes to chase), i.e. about three far-memory round trips per pass however many workgroups run at once.
+        // (The one-level chained scan degenerates when every workgroup is resident from the start — the normal case for
+        // 0.1-4 M keys on 256 CUs: nobody owns a prefix yet, so workgroup b walks over all b predecessors.)
+        const uint32_t gs_mask = (1u << gs_log2) - 1u;
+        const uint32_t grp = b >> gs_log2, r = b & gs_mask;
+        granule_store(status + (size_t)b * RADIX_SIZE + tid, TAG_AGG | total);
+        const uint32_t in_group = sum_published(status + (size_t)(b - r) * RADIX_SIZE + tid, (int)r, err);
+        if (r == gs_mask) granule_store(group_status + (size_t)grp * RADIX_SIZE + tid, TAG_AGG | (u64)(in_group + total));
+        const uint32_t excl = in_group + sum_published(group_status + tid, (int)grp, err);
+        if (b == gridDim.x - 1 && excl + total != ghist[tid]) atomicOr(err, ERR_COUNTS);   // self-check: all counts add up to the histogram
+        // global: first output slot of digit d = (keys with smaller digits) + (same digit in earlier workgroups);
+        // local: slot of this workgroup's first digit-d key inside its own LDS staging area (keys grouped by digit)
         const uint32_t g = ghist[tid];
-        const uint32_t incl = wave_incl_scan_u32(g);
-        if (lane == 63) ws[wave] = incl;
+        const uint32_t incl = wave_incl_scan_u32(g), lincl = wave_incl_scan_u32(total);
+        if (lane == 63) {
+            ws[wave] = incl;
+            ws[4 + wave] = lincl;
+        }
         __syncthreads();
-        uint32_t wbase = 0;
+        uint32_t wbase = 0, lbase = 0;
 #pragma unroll
         for (int w = 0; w < 4; w++)
-            if (w < wave) wbase += ws[w];
-        const uint32_t digit_base = wbase + incl - g;
-        const uint32_t start = digit_base + excl;
-        cnt[0][tid] = start;
-        cnt[1][tid] = start + c0;
-        cnt[2][tid] = start + c0 + c1;
-        cnt[3][tid] = start + c0 + c1 + c2;
+            if (w < wave) {
+                wbase += ws[w];
+                lbase += ws[4 + w];
+            }
+        const uint32_t lstart = lbase + lincl - total;
+        gdelta[tid] = wbase + incl - g + excl - lstart;   // destination of staged slot i holding digit d: i + gdelta[d]
+        cnt[0][tid] = lstart;
+        cnt[1][tid] = lstart + c0;
+        cnt[2][tid] = lstart + c0 + c1;
+        cnt[3][tid] = lstart + c0 + c1 + c2;
     }
     __syncthreads();
 
+    // rank every key inside the workgroup and stage it at its local slot: the staging area ends up grouped by digit, in
+    // stable order
     volatile uint32_t *off = cnt[wave];
 #pragma unroll
     for (int s = 0; s < IPL; s++) {
         const uint32_t i = base + s * 64 + lane;
         const bool valid = i < n;
         const uint32_t digit = (k[s] >> shift) & mask;
-        uint64_t peers = __ballot(valid);
-        for (int bb = 0; bb < bits; bb++) {
-            const bool bit = (digit >> bb) & 1u;
-            const uint64_t m = __ballot(valid && bit);
-            peers &= bit ? m : ~m;
+        // match-any over the 8 digit bits (bits above `bits` are zero in every lane: harmless).  Kept in 32-bit halves so
+        // that every step is v_xnor + v_and on VGPRs; rank = v_mbcnt of the peer mask
+        const uint64_t vm = __ballot(valid);
+        uint32_t plo = (uint32_t)vm, phi = (uint32_t)(vm >> 32);
+#pragma unroll
+        for (int bb = 0; bb < RADIX_BITS; bb++) {
+            const uint32_t sel = 0u - ((digit >> bb) & 1u);          // all ones if my bit is set
+            const uint64_t m = __ballot((digit >> bb) & 1u);
+            plo &= ~((uint32_t)m ^ sel);
+            phi &= ~((uint32_t)(m >> 32) ^ sel);
         }
-        const uint64_t lt = (1ull << lane) - 1ull;
-        const uint32_t rank = (uint32_t)__popcll(peers & lt);
-        const uint32_t count = (uint32_t)__popcll(peers);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+        const uint32_t count = (uint32_t)__popc(plo) + (uint32_t)__popc(phi);
         uint32_t o = 0;
         if (valid) o = off[digit];
         __builtin_amdgcn_wave_barrier();
         if (valid && rank == 0) off[digit] = o + count;
         __builtin_amdgcn_wave_barrier();
         if (valid) {
-            const uint32_t dst = o + rank;
-            if (keys_out) keys_out[dst] = k[s];
-            vals_out[dst] = out[s];
-            if (inv_out) inv_out[v[s]] = dst;
+            const uint32_t slot = o + rank;
+            sk[slot] = k[s];
+            sv[slot] = out[s];
+            if (FINAL) sx[FINAL ? slot : 0] = v[s];
+        }
+    }
+    __syncthreads();
+
+    // write out in staged order: neighbouring lanes hold neighbouring slots of the same digit => every digit's run of this
+    // workgroup goes out as contiguous, coalesced stores (a direct scatter issues 64 separate 4-byte writes per
+    // instruction, which the L2 cannot merge once 256 digits x hundreds of workgroups have open write heads)
+    const uint32_t block_first = b * 256u * (uint32_t)IPL;
+    const uint32_t nvalid = n > block_first ? min(n - block_first, 256u * (uint32_t)IPL) : 0u;
+#pragma unroll
+    for (int s = 0; s < IPL; s++) {
+        const uint32_t i = s * 256 + tid;
+        if (i < nvalid) {
+            const uint32_t key = sk[i];
+            const uint32_t dst = i + gdelta[(key >> shift) & mask];
+            if (dst >= n || (FINAL && sx[FINAL ? i : 0] >= n)) {  // never write out of bounds, whatever went wrong upstream
+                atomicOr(err, ERR_RANGE);
+                continue;
+            }
+            if (keys_out) keys_out[dst] = key;
+            vals_out[dst] = sv[i];
+            if (FINAL) inv_out[sx[FINAL ? i : 0]] = dst;
         }
     }
 }
+
+static int onesweep_group_log2(int nblocks);
 
 static int onesweep_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t cap, const uint32_t *n_ptr,
                          int shift, int bits, const uint32_t *ghist, u64 *status, uint32_t *ticket, const uint32_t *gather_src,
                          uint32_t *inv_out, uint32_t *err, bool debug, hipStream_t s) {
     const int ipl = sort_items_per_lane(cap);
     const int nblocks = div_up(cap, (int64_t)256 * ipl);
-#define PASS(IPL)                                                                                                              \
-    DAS3R_LAUNCH((onesweep_pass_kernel<IPL>), dim3(nblocks), dim3(256), 0, s, kin, vin, kout, vout, (uint32_t)cap, n_ptr, shift, \
-                 bits, ghist, status, ticket, gather_src, inv_out, err)
-    if (ipl == 4) PASS(4); else if (ipl == 8) PASS(8); else PASS(16);
+    const int gs_log2 = onesweep_group_log2(nblocks);
+    u64 *group_status = status + (size_t)nblocks * RADIX_SIZE;
+#define PASS(IPL, FINAL)                                                                                                  \
+    DAS3R_LAUNCH((onesweep_pass_kernel<IPL, FINAL>), dim3(nblocks), dim3(256), 0, s, kin, vin, kout, vout, (uint32_t)cap, n_ptr, \
+                 shift, bits, ghist, status, group_status, gs_log2, ticket, gather_src, inv_out, err)
+    if (inv_out) {
+        if (ipl == 4) PASS(4, true); else if (ipl == 8) PASS(8, true); else PASS(16, true);
+    } else {
+        if (ipl == 4) PASS(4, false); else if (ipl == 8) PASS(8, false); else PASS(16, false);
+    }
 #undef PASS
     KERNEL_CHECK(s, debug, "onesweep_pass");
     return DAS3R_OK;
 }
 
+// group size of the two-level look-back: the power of two nearest above sqrt(nblocks), within [4, 128]
+static int onesweep_group_log2(int nblocks) {
+    int l = 2;
+    while (l < 7 && (1 << (2 * l)) < nblocks) l++;
+    return l;
+}
+
+// per pass: one row of 256 granules per workgroup + one per group
 size_t onesweep_status_bytes(int64_t n, int passes) {
     if (n <= 0) return 256;
     const int nblocks = div_up(n, (int64_t)256 * sort_items_per_lane(n));
-    return (size_t)passes * (size_t)nblocks * RADIX_SIZE * sizeof(u64);
+    const int ngroups = div_up(nblocks, 1 << onesweep_group_log2(nblocks));
+    return (size_t)passes * (size_t)(nblocks + ngroups) * RADIX_SIZE * sizeof(u64);
 }
 
 // Depth sort of the P splats: ctrl = [ghist 4x256 u32][tickets 4 u32 (+pad)][status 4 passes], zeroed by preprocess_kernel.
