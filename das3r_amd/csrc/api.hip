@@ -85,6 +85,7 @@ void compute_layout(int P, int64_t I, int W, int H, Layout *L) {
     L->g_ghist = take(4 * 4 * RADIX_SIZE);
     L->g_ticket = take(256);
     L->g_status = take(onesweep_status_bytes((int64_t)Pn, 4));
+    L->g_scan_status = take(scan_status_bytes((int)Pn));
     L->g_ctrl_bytes = o - L->g_ghist;
     L->pub.geom_bytes = o;
     // binning
@@ -191,18 +192,28 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         }
     }
     if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, L, s))) return rc;
-    if ((rc = launch_depth_sort_and_scan(P, saved->geom, L, a->debug != 0, s))) return rc;
+    if ((rc = launch_depth_sort(P, saved->geom, L, a->debug != 0, s))) return rc;
 
-    // num_rendered: 4-byte D2H right behind the scan.  Without a capacity hint the host waits for it here (upstream does the
-    // same); with a hint the rest of the forward is enqueued first and the count is only collected afterwards.
+    // num_rendered comes out of the scan of tiles_touched.  Without a capacity hint the scan runs alone and the host waits
+    // for its 8-byte result (upstream does the same) before sizing the binning buffer; with a hint the scan is fused with
+    // the instance emission, everything is enqueued first and the count is only collected afterwards.
     static thread_local uint32_t *h_count = nullptr;
     static thread_local hipEvent_t ev_count = nullptr;
     if (!h_count) HIP_TRY(hipHostMalloc((void **)&h_count, 64, hipHostMallocDefault));
     if (!ev_count) HIP_TRY(hipEventCreateWithFlags(&ev_count, hipEventDisableTiming));
-    HIP_TRY(hipMemcpyAsync(h_count, saved->geom + L.g_count, 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipEventRecord(ev_count, s));
     int64_t cap = a->capacity_hint > 0 ? a->capacity_hint : -1, I = -1;
+    bool scanned = false;
+    auto collect_count = [&]() -> int {
+        HIP_TRY(hipMemcpyAsync(h_count, saved->geom + L.g_count, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(ev_count, s));
+        return DAS3R_OK;
+    };
     for (int attempt = 0; attempt < 2; attempt++) {
+        if ((cap < 0 || !use_onesweep()) && !scanned) {
+            if ((rc = launch_scan(P, saved->geom, L, a->debug != 0, s))) return rc;
+            if ((rc = collect_count())) return rc;
+            scanned = true;
+        }
         if (cap < 0) {  // exact sizing: wait for the count now
             HIP_TRY(hipEventSynchronize(ev_count));
             I = (int64_t)h_count[0];
@@ -212,7 +223,13 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         compute_layout(P, cap, W, H, &L);
         saved->binning = alloc_binning(user, L.pub.binning_bytes);
         if (!saved->binning) { set_error("scratch allocation failed (binning %zu B)", L.pub.binning_bytes); return DAS3R_ERR_ALLOC; }
-        if ((rc = launch_binning(P, cap, W, H, out->radii, saved->geom, saved->binning, saved->img, L, a->debug != 0, s))) return rc;
+        const bool fused_scan = !scanned;
+        if (fused_scan) {   // the count leaves right behind the scan, ahead of the partition passes
+            if ((rc = launch_binning_scan_emit(P, cap, out->radii, saved->geom, saved->binning, L, a->debug != 0, s))) return rc;
+            if ((rc = collect_count())) return rc;
+            scanned = true;
+        }
+        if ((rc = launch_binning(P, cap, W, H, out->radii, saved->geom, saved->binning, saved->img, L, fused_scan, a->debug != 0, s))) return rc;
         if ((rc = launch_render_forward(a, in->colors_precomp, out->out_color, saved->geom, saved->binning, saved->img, L, s))) return rc;
         if (I < 0) {  // hinted path: everything is enqueued; now collect the count (available since the scan finished)
             HIP_TRY(hipEventSynchronize(ev_count));

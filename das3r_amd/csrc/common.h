@@ -87,7 +87,7 @@ struct Layout {
     size_t b_keyA, b_keyB, b_valA, b_valB, b_hist, b_totals, b_gid_of, b_inv;
     // single-pass radix control words (sort_onesweep.hip): [global digit histograms][tickets][status granules], contiguous
     // so that one store loop / one memset zeroes them: geom side by preprocess_kernel, binning side by a memset before emit
-    size_t g_ghist, g_ticket, g_status, g_ctrl_bytes;
+    size_t g_ghist, g_ticket, g_status, g_scan_status, g_ctrl_bytes;
     size_t b_ghist, b_ticket, b_status, b_ctrl_bytes;
     int tiles_x, tiles_y, ntiles, tbits, tile_passes;
     int chunksP, chunksI;
@@ -98,14 +98,20 @@ void compute_layout(int P, int64_t I, int W, int H, Layout *L);
 int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int32_t *radii, char *geom, char *img, const Layout &L,
                       hipStream_t s);
 int launch_mark_visible(int P, const float *means3D, const float *viewmatrix, uint8_t *present, hipStream_t s);
-int launch_depth_sort_and_scan(int P, char *geom, const Layout &L, bool debug, hipStream_t s);
+int launch_depth_sort(int P, char *geom, const Layout &L, bool debug, hipStream_t s);
+// scan of tiles_touched in depth order -> offsets / off_by_gid / count (exact path: the host then reads the count)
+int launch_scan(int P, char *geom, const Layout &L, bool debug, hipStream_t s);
+// the same scan with the instance emission fused in (hinted path; sort_onesweep.hip)
+int launch_scan_emit(int P, int64_t cap, const int32_t *radii, char *geom, char *binning, const Layout &L, bool debug, hipStream_t s);
+size_t scan_status_bytes(int P);
+int launch_binning_scan_emit(int P, int64_t I, const int32_t *radii, char *geom, char *binning, const Layout &L, bool debug, hipStream_t s);
 size_t onesweep_status_bytes(int64_t n, int passes);
 int launch_onesweep_depth_sort(int P, char *geom, const Layout &L, bool debug, hipStream_t s);
 int launch_onesweep_partition(int64_t cap, char *geom, char *binning, const Layout &L, uint32_t **keys_final, bool debug, hipStream_t s);
 bool use_onesweep();  // DAS3R_SORT=classic selects the three-kernel radix passes (diagnostics / A-B)
 bool use_tight_rect();  // DAS3R_RECT=upstream bins over upstream's 3-sigma square (bit-exact list tests)
 int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *geom, char *binning, char *img, const Layout &L,
-                   bool debug, hipStream_t s);
+                   bool fused_scan, bool debug, hipStream_t s);
 int launch_render_forward(const das3r_raster_args *a, const float *colors_precomp, float *out_color, char *geom, char *binning,
                           char *img, const Layout &L, hipStream_t s);
 // partial: [num_rendered, 9] per-instance sums written by the render backward, gathered by the preprocess backward

@@ -1,0 +1,175 @@
+// scan_emit.hip — exclusive scan of tiles_touched in depth-rank order (instance offsets, num_rendered) as ONE kernel, and,
+// fused behind it, the emission of the (tile id, emission slot) instances.  Replaces upstream's cub::DeviceScan::InclusiveSum
+// + duplicateWithKeys (cuda_rasterizer/rasterizer_impl.cu) and this repo's earlier tt_blocksum -> tt_scan ->
+// emit chain: at 100 k splats those three launches were 45 us of a 300 us step, almost all of it launch/drain latency.
+//
+// Chained scan: a workgroup takes a ticket (arrival order), sums its 4096 ranks, publishes the sum as a granule and gets
+// its exclusive prefix from the granules of the earlier workgroups — two levels (own group + totals of earlier groups), 64
+// lanes of one wave polling 64 words at a time, so the wait is ~3 round trips for any grid size.  Granules, tickets and the
+// histograms are zeroed earlier in the same forward (preprocess_kernel / the binning memset).
+#include "granule.h"
+#include "splat_math.h"
+
+namespace das3r {
+
+constexpr int SCAN_GROUP_LOG2 = 6;     // group size 64 = one wave-wide poll
+
+// sum of `count` (<= 64 per round) published granules starting at g[0]; executed by ONE wave, result in every lane
+__device__ __forceinline__ uint32_t wave_sum_published(const u64 *g, const int count, uint32_t *err) {
+    const int lane = __lane_id();
+    uint32_t sum = 0;
+    unsigned spins = 0;
+    for (int p = 0; p < count; p += 64) {
+        const bool mine = p + lane < count;
+        u64 x = TAG_AGG;
+        while (true) {
+            if (mine) x = granule_load(g + p + lane);
+            if (__all((x & TAG_MASK) != 0)) break;   // wave-uniform exit: every lane's word is published
+            if (++spins > SPIN_LIMIT) {
+                if (lane == 0) atomicOr(err, ERR_TIMEOUT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        sum += mine ? (uint32_t)(x & 0xFFFFFFFFull) : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sum += (uint32_t)__shfl_xor((int)sum, o, 64);
+    return sum;
+}
+
+// SCAN_ITEMS = ranks per thread; a workgroup owns 256 * SCAN_ITEMS consecutive depth ranks
+template <bool EMIT, int SCAN_ITEMS>
+__global__ void __launch_bounds__(256) scan_emit_kernel(
+    int P, const uint32_t *__restrict__ sorted_idx, const uint32_t *__restrict__ tiles_touched, uint32_t *__restrict__ offsets,
+    uint32_t *__restrict__ off_by_gid, uint32_t *__restrict__ count, u64 *__restrict__ status, u64 *__restrict__ group_status,
+    uint32_t *__restrict__ ticket, uint32_t *__restrict__ err,
+    // emission (EMIT only)
+    int tiles_x, int tiles_y, const float4 *__restrict__ xyh, const int32_t *__restrict__ radii, uint32_t *__restrict__ tile_keys,
+    uint32_t *__restrict__ gids, uint32_t cap, uint32_t *__restrict__ ghist /*[passes][256]*/, int tbits, int tight_rect) {
+    __shared__ uint32_t ws[4];
+    __shared__ uint32_t s_block, s_carry;
+    __shared__ uint32_t h[EMIT ? 4 : 1][RADIX_SIZE];
+    const int tid = threadIdx.x, lane = __lane_id(), wave = tid >> 6;
+    if (tid == 0) s_block = atomicAdd(ticket, 1u);
+    if (EMIT) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) h[EMIT ? q : 0][tid] = 0;
+    }
+    __syncthreads();
+    const uint32_t b = s_block;
+    const int base = (int)b * 256 * SCAN_ITEMS;
+
+    uint32_t g[SCAN_ITEMS], v[SCAN_ITEMS], sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        const int r = base + k * 256 + tid;
+        g[k] = r < P ? sorted_idx[r] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        const int r = base + k * 256 + tid;
+        v[k] = r < P ? tiles_touched[g[k]] : 0u;
+        sum += v[k];
+    }
+    uint32_t total;
+    block_exclusive_scan_256(sum, ws, &total);
+
+    if (wave == 0) {   // one wave publishes and looks back for the whole workgroup
+        const uint32_t grp = b >> SCAN_GROUP_LOG2, r = b & ((1u << SCAN_GROUP_LOG2) - 1u);
+        if (lane == 0) granule_store(status + b, TAG_AGG | total);
+        const uint32_t in_group = wave_sum_published(status + (b - r), (int)r, err);
+        if (r == (1u << SCAN_GROUP_LOG2) - 1u && lane == 0) granule_store(group_status + grp, TAG_AGG | (u64)(in_group + total));
+        const uint32_t before = wave_sum_published(group_status, (int)grp, err);
+        if (lane == 0) s_carry = in_group + before;
+    }
+    __syncthreads();
+    uint32_t carry = s_carry;
+
+#pragma unroll 1
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        const int r = base + k * 256 + tid;
+        uint32_t tot;
+        const uint32_t ex = block_exclusive_scan_256(v[k], ws, &tot);
+        if (r < P) {
+            uint32_t o = carry + ex;
+            offsets[r] = o;
+            off_by_gid[g[k]] = o;   // first emission slot of splat g (its instances are emitted contiguously)
+            if (EMIT && v[k] != 0u) {
+                const float4 p = xyh[g[k]];
+                int rminx, rminy, rmaxx, rmaxy;
+                binned_rect(p, radii[g[k]], tiles_x, tiles_y, tight_rect != 0, rminx, rminy, rmaxx, rmaxy);
+                for (int y = rminy; y < rmaxy; y++)
+                    for (int x = rminx; x < rmaxx; x++) {
+                        if (o < cap) {   // cap < num_rendered only when the capacity hint was too small (the binning is then redone)
+                            const uint32_t t = (uint32_t)(y * tiles_x + x);
+                            tile_keys[o] = t;
+                            gids[o] = g[k];   // gid_of[emission slot]
+                            for (int q = 0, sh = 0; sh < tbits; q++, sh += 8) {
+                                const int bits = (tbits - sh) < 8 ? (tbits - sh) : 8;
+                                atomicAdd(&h[EMIT ? q : 0][(t >> sh) & ((1u << bits) - 1u)], 1u);
+                            }
+                        }
+                        o++;
+                    }
+            }
+        }
+        carry += tot;
+    }
+    if (b == gridDim.x - 1 && tid == 0) {
+        count[0] = carry;
+        count[1] = *err;   // look-back timeout flags of the depth sort / this scan travel with the count
+    }
+    if (EMIT) {
+        __syncthreads();
+        for (int q = 0, sh = 0; sh < tbits; q++, sh += 8) {
+            const uint32_t c = h[EMIT ? q : 0][tid];
+            if (c) atomicAdd(&ghist[q * RADIX_SIZE + tid], c);
+        }
+    }
+}
+
+// ranks per thread: as many as keeps >= 256 workgroups in flight (the emission loop is the long pole, it wants parallelism;
+// the chain wants few workgroups), between 1 and 16
+static inline int scan_items(int P) {
+    int it = 1;
+    while (it < 16 && (int64_t)P >= (int64_t)256 * 256 * (it * 2)) it *= 2;
+    return it;
+}
+static inline int scan_blocks(int P) { return div_up(P > 0 ? P : 1, 256 * scan_items(P)); }
+
+size_t scan_status_bytes(int P) {
+    const int nblocks = scan_blocks(P);
+    return (size_t)(nblocks + div_up(nblocks, 1 << SCAN_GROUP_LOG2)) * sizeof(u64);
+}
+
+#define SCAN_COMMON                                                                                                           \
+    P, (const uint32_t *)(geom + L.pub.sorted_idx), (const uint32_t *)(geom + L.pub.tiles_touched),                          \
+        (uint32_t *)(geom + L.pub.offsets), (uint32_t *)(geom + L.g_off_by_gid), (uint32_t *)(geom + L.g_count),             \
+        (u64 *)(geom + L.g_scan_status), (u64 *)(geom + L.g_scan_status) + nblocks, (uint32_t *)(geom + L.g_ticket) + 16,   \
+        (uint32_t *)(geom + L.g_ticket) + 8
+
+int launch_scan(int P, char *geom, const Layout &L, bool debug, hipStream_t s) {
+    const int nblocks = scan_blocks(P);
+#define GO(IT)                                                                                                               \
+    DAS3R_LAUNCH((scan_emit_kernel<false, IT>), dim3(nblocks), dim3(256), 0, s, SCAN_COMMON, 0, 0, (const float4 *)nullptr,    \
+                 (const int32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (uint32_t *)nullptr, 0, 0)
+    switch (scan_items(P)) { case 1: GO(1); break; case 2: GO(2); break; case 4: GO(4); break; case 8: GO(8); break; default: GO(16); }
+#undef GO
+    KERNEL_CHECK(s, debug, "scan");
+    return DAS3R_OK;
+}
+
+int launch_scan_emit(int P, int64_t cap, const int32_t *radii, char *geom, char *binning, const Layout &L, bool debug, hipStream_t s) {
+    const int nblocks = scan_blocks(P);
+#define GO(IT)                                                                                                               \
+    DAS3R_LAUNCH((scan_emit_kernel<true, IT>), dim3(nblocks), dim3(256), 0, s, SCAN_COMMON, L.tiles_x, L.tiles_y,              \
+                 (const float4 *)(geom + L.pub.xy), radii, (uint32_t *)(binning + L.b_keyA), (uint32_t *)(binning + L.b_gid_of), \
+                 (uint32_t)cap, (uint32_t *)(binning + L.b_ghist), L.tbits, use_tight_rect() ? 1 : 0)
+    switch (scan_items(P)) { case 1: GO(1); break; case 2: GO(2); break; case 4: GO(4); break; case 8: GO(8); break; default: GO(16); }
+#undef GO
+    KERNEL_CHECK(s, debug, "scan_emit");
+    return DAS3R_OK;
+}
+
+}  // namespace das3r

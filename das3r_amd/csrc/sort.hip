@@ -14,38 +14,10 @@
 // Radix pass = hist -> rowscan -> scatter.  The unit of work is a WAVE: each 64-lane wave owns a contiguous
 // chunk of 64*ipl keys, keeps its 256 digit counters in LDS and ranks keys with wavefront ballots
 // (match-any over the digit bits + popcount prefix) — no block barriers in the ranking loop.
-#include "common.h"
+#include "granule.h"
 #include "splat_math.h"
 
 namespace das3r {
-
-__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
-    const int lane = __lane_id();
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t n = __shfl_up(v, o, 64);
-        if (lane >= o) v += n;
-    }
-    return v;
-}
-
-// exclusive scan across a 256-thread block; returns the exclusive prefix of `v`, *total = block sum
-__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t *lds_wave_sums /*[4]*/, uint32_t *total) {
-    const int lane = __lane_id(), wave = threadIdx.x >> 6;
-    const uint32_t incl = wave_inclusive_scan_u32(v);
-    __syncthreads();  // protect lds_wave_sums reuse across calls
-    if (lane == 63) lds_wave_sums[wave] = incl;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        const uint32_t s = lds_wave_sums[w];
-        if (w < wave) base += s;
-        tot += s;
-    }
-    *total = tot;
-    return base + incl - v;
-}
 
 // ---------------------------------------------------------------- radix pass
 // IPL = keys per lane (compile time): the whole chunk is fetched into registers before any of it is ranked, so the
@@ -217,52 +189,6 @@ int radix_sort_u32_pairs(const uint32_t *keys_in, uint32_t *keyA, uint32_t *keyB
     return DAS3R_OK;
 }
 
-// ---------------------------------------------------------------- scan of tiles_touched in depth-rank order
-constexpr int SCAN_ITEMS = 16;  // sub-tiles of 256 per block
-__global__ void __launch_bounds__(256) tt_blocksum_kernel(int P, const uint32_t *__restrict__ sorted_idx,
-                                                          const uint32_t *__restrict__ tiles_touched, uint32_t *__restrict__ block_sums) {
-    __shared__ uint32_t ws[4];
-    const int base = blockIdx.x * 256 * SCAN_ITEMS;
-    uint32_t sum = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) {
-        const int r = base + k * 256 + threadIdx.x;
-        if (r < P) sum += tiles_touched[sorted_idx[r]];
-    }
-    uint32_t tot;
-    block_exclusive_scan_256(sum, ws, &tot);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
-}
-
-__global__ void __launch_bounds__(256) tt_scan_kernel(int P, int nblocks, const uint32_t *__restrict__ sorted_idx,
-                                                      const uint32_t *__restrict__ tiles_touched, const uint32_t *__restrict__ block_sums,
-                                                      uint32_t *__restrict__ offsets, uint32_t *__restrict__ off_by_gid,
-                                                      uint32_t *__restrict__ count, const uint32_t *__restrict__ err_src) {
-    __shared__ uint32_t ws[4];
-    // prefix of earlier blocks (nblocks is small: P / 4096)
-    uint32_t part = 0;
-    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) part += block_sums[b];
-    uint32_t carry;
-    block_exclusive_scan_256(part, ws, &carry);
-    const int base = blockIdx.x * 256 * SCAN_ITEMS;
-    for (int k = 0; k < SCAN_ITEMS; k++) {
-        const int r = base + k * 256 + threadIdx.x;
-        const uint32_t g = r < P ? sorted_idx[r] : 0u;
-        const uint32_t v = r < P ? tiles_touched[g] : 0u;
-        uint32_t tot;
-        const uint32_t ex = block_exclusive_scan_256(v, ws, &tot);
-        if (r < P) {
-            offsets[r] = carry + ex;
-            off_by_gid[g] = carry + ex;  // first emission slot of splat g (its instances are emitted contiguously)
-        }
-        carry += tot;
-    }
-    if (blockIdx.x == nblocks - 1 && threadIdx.x == 0) {
-        count[0] = carry;
-        count[1] = *err_src;  // radix look-back timeout flag of the depth sort travels with the count
-    }
-}
-
 // ---------------------------------------------------------------- instance emission (depth-rank order)
 __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, int tiles_y, const uint32_t *__restrict__ sorted_idx,
                                                    const uint32_t *__restrict__ tiles_touched, const uint32_t *__restrict__ offsets,
@@ -327,37 +253,32 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(uint32_t cap, const ui
 }
 
 // ---------------------------------------------------------------- host side
-int launch_depth_sort_and_scan(int P, char *geom, const Layout &L, bool debug, hipStream_t s) {
+int launch_depth_sort(int P, char *geom, const Layout &L, bool debug, hipStream_t s) {
     uint32_t *keyA = (uint32_t *)(geom + L.g_keyA), *keyB = (uint32_t *)(geom + L.g_keyB);
     uint32_t *valA = (uint32_t *)(geom + L.g_valA), *valB = (uint32_t *)(geom + L.g_valB);
     uint32_t *hist = (uint32_t *)(geom + L.g_hist), *totals = (uint32_t *)(geom + L.g_totals);
-    uint32_t *count = (uint32_t *)(geom + L.g_count);
-    if (P == 0) return hipMemsetAsync(count, 0, 4, s) == hipSuccess ? DAS3R_OK : DAS3R_ERR_HIP;
+    if (P == 0) return DAS3R_OK;
     // 4 passes: A -> B -> A -> B -> A ; final ranks land in valA (== pub.sorted_idx)
     int rc;
-    if (use_onesweep()) {
-        if ((rc = launch_onesweep_depth_sort(P, geom, L, debug, s))) return rc;
-    } else {
-        if ((rc = radix_pass(keyA, nullptr, keyB, valB, P, 0, 8, hist, totals, debug, s))) return rc;
-        if ((rc = radix_pass(keyB, valB, keyA, valA, P, 8, 8, hist, totals, debug, s))) return rc;
-        if ((rc = radix_pass(keyA, valA, keyB, valB, P, 16, 8, hist, totals, debug, s))) return rc;
-        if ((rc = radix_pass(keyB, valB, nullptr, valA, P, 24, 8, hist, totals, debug, s))) return rc;
-    }
-
-    const int nblocks = div_up(P, 256 * SCAN_ITEMS);
-    uint32_t *bsums = (uint32_t *)(geom + L.g_blocksums);
-    const uint32_t *tt = (const uint32_t *)(geom + L.pub.tiles_touched);
-    DAS3R_LAUNCH(tt_blocksum_kernel, dim3(nblocks), dim3(256), 0, s, P, valA, tt, bsums);
-    KERNEL_CHECK(s, debug, "tt_blocksum");
-    DAS3R_LAUNCH(tt_scan_kernel, dim3(nblocks), dim3(256), 0, s, P, nblocks, valA, tt, bsums,
-                       (uint32_t *)(geom + L.pub.offsets), (uint32_t *)(geom + L.g_off_by_gid), count, (const uint32_t *)(geom + L.g_ticket) + 8);
-    KERNEL_CHECK(s, debug, "tt_scan");
+    if (use_onesweep()) return launch_onesweep_depth_sort(P, geom, L, debug, s);
+    if ((rc = radix_pass(keyA, nullptr, keyB, valB, P, 0, 8, hist, totals, debug, s))) return rc;
+    if ((rc = radix_pass(keyB, valB, keyA, valA, P, 8, 8, hist, totals, debug, s))) return rc;
+    if ((rc = radix_pass(keyA, valA, keyB, valB, P, 16, 8, hist, totals, debug, s))) return rc;
+    if ((rc = radix_pass(keyB, valB, nullptr, valA, P, 24, 8, hist, totals, debug, s))) return rc;
     return DAS3R_OK;
+}
+
+// Hinted path, first half of the binning: zero the control words, then scan + emit in one kernel.  The caller copies the
+// count back right behind it and then calls launch_binning(..., fused_scan = true) for the partition.
+int launch_binning_scan_emit(int P, int64_t I, const int32_t *radii, char *geom, char *binning, const Layout &L, bool debug, hipStream_t s) {
+    if (I == 0 || P == 0) return DAS3R_OK;
+    HIP_TRY(hipMemsetAsync(binning + L.b_ghist, 0, L.b_ctrl_bytes, s));
+    return launch_scan_emit(P, I, radii, geom, binning, L, debug, s);
 }
 
 // I = capacity of the binning buffer; the true instance count is read by the kernels from geom + L.g_count
 int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *geom, char *binning, char *img, const Layout &L,
-                   bool debug, hipStream_t s) {
+                   bool fused_scan, bool debug, hipStream_t s) {
     const uint32_t *n_ptr = (const uint32_t *)(geom + L.g_count);
     (void)W; (void)H;
     uint2 *ranges = (uint2 *)(img + L.pub.ranges);  // zeroed by preprocess_kernel
@@ -367,13 +288,15 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
     uint32_t *hist = (uint32_t *)(binning + L.b_hist), *totals = (uint32_t *)(binning + L.b_totals);
     uint32_t *gid_of = (uint32_t *)(binning + L.b_gid_of), *inv = (uint32_t *)(binning + L.b_inv);
     const bool onesweep = use_onesweep();
-    if (onesweep) HIP_TRY(hipMemsetAsync(binning + L.b_ghist, 0, L.b_ctrl_bytes, s));  // digit histograms, tickets, status words
+    if (onesweep && !fused_scan) HIP_TRY(hipMemsetAsync(binning + L.b_ghist, 0, L.b_ctrl_bytes, s));  // digit histograms, tickets, status words
+    if (!fused_scan) {   // (hinted path: launch_binning_scan_emit has already emitted the instances)
     const int emit_blocks = div_up(P, 256) < 1024 ? div_up(P, 256) : 1024;
     DAS3R_LAUNCH(emit_kernel, dim3(emit_blocks), dim3(256), 0, s, P, L.tiles_x, L.tiles_y,
                  (const uint32_t *)(geom + L.pub.sorted_idx), (const uint32_t *)(geom + L.pub.tiles_touched),
                  (const uint32_t *)(geom + L.pub.offsets), (const float4 *)(geom + L.pub.xy), radii, keyA, gid_of, (uint32_t)I,
                  onesweep ? (uint32_t *)(binning + L.b_ghist) : (uint32_t *)nullptr, L.tbits, use_tight_rect() ? 1 : 0);
     KERNEL_CHECK(s, debug, "emit");
+    }
     if (onesweep) {
         uint32_t *kfinal = nullptr;
         int rc1 = launch_onesweep_partition(I, geom, binning, L, &kfinal, debug, s);
