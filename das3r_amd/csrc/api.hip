@@ -55,6 +55,7 @@ bool use_tight_rect() {
 void compute_layout(int P, int64_t I, int W, int H, Layout *L) {
     memset(L, 0, sizeof(*L));
     const size_t Pn = P > 0 ? (size_t)P : 1, In = I > 0 ? (size_t)I : 1;
+    L->capacity = I;
     L->tiles_x = (W + TILE_X - 1) / TILE_X;
     L->tiles_y = (H + TILE_Y - 1) / TILE_Y;
     L->ntiles = L->tiles_x * L->tiles_y;

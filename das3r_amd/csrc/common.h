@@ -88,6 +88,7 @@ struct Layout {
     // single-pass radix control words (sort_onesweep.hip): [global digit histograms][tickets][status granules], contiguous
     // so that one store loop / one memset zeroes them: geom side by preprocess_kernel, binning side by a memset before emit
     size_t g_ghist, g_ticket, g_status, g_scan_status, g_ctrl_bytes;
+    int64_t capacity;  // instance capacity the binning buffer was laid out for
     size_t b_ghist, b_ticket, b_status, b_ctrl_bytes;
     int tiles_x, tiles_y, ntiles, tbits, tile_passes;
     int chunksP, chunksI;
@@ -108,6 +109,9 @@ int launch_binning_scan_emit(int P, int64_t I, const int32_t *radii, char *geom,
 size_t onesweep_status_bytes(int64_t n, int passes);
 int launch_onesweep_depth_sort(int P, char *geom, const Layout &L, bool debug, hipStream_t s);
 int launch_onesweep_partition(int64_t cap, char *geom, char *binning, const Layout &L, uint32_t **keys_final, bool debug, hipStream_t s);
+bool use_row_private(int64_t instances, int ntiles);  // forward: 4x4-block-per-row kernel for long tile lists (render_rows.hip)
+int launch_render_forward_rows(const das3r_raster_args *a, float *out_color, char *geom, char *binning, char *img, const Layout &L,
+                               hipStream_t s);
 bool use_onesweep();  // DAS3R_SORT=classic selects the three-kernel radix passes (diagnostics / A-B)
 bool use_tight_rect();  // DAS3R_RECT=upstream bins over upstream's 3-sigma square (bit-exact list tests)
 int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *geom, char *binning, char *img, const Layout &L,

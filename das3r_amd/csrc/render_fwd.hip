@@ -87,6 +87,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(const uint2 *__rest
 int launch_render_forward(const das3r_raster_args *a, const float *colors_precomp, float *out_color, char *geom, char *binning,
                           char *img, const Layout &L, hipStream_t s) {
     (void)colors_precomp;  // precomputed colours were copied into rgbd by the preprocess kernel
+    if (use_row_private(L.capacity, L.ntiles)) return launch_render_forward_rows(a, out_color, geom, binning, img, L, s);
     DAS3R_LAUNCH(render_forward_kernel, dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, (const uint2 *)(img + L.pub.ranges),
                  (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height, L.tiles_x, L.ntiles,
                  (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),

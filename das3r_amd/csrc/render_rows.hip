@@ -1,0 +1,152 @@
+// render_rows.hip — row-private variant of the forward compositing kernel (K6): every 16-lane DPP row of a wave64 owns a
+// 4x4 pixel block and walks ITS OWN culled sub-list of the tile's splats.
+//
+// Why: with one sub-list per 8x8 quadrant (render_fwd.hip) a wave spends one iteration per (splat, quadrant) whatever the
+// footprint; measured lane utilisation (tools/pair_stats.py) is 36 % on the 1080p benchmarks (23 of 64 pixels see
+// alpha >= 1/255) and 10 % on DAS3R-shaped scenes (one tiny Gaussian per pixel: 6.5 of 64).  Four independent 4x4 blocks per
+// wave cut the iteration count to 0.73-0.78x (1080p) and 0.47x (DAS3R shape): the four rows of a wave process four
+// DIFFERENT splats in one pass of the instruction stream.  Measured: forward 1.12 -> 0.84 ms on the 5 M-splat DAS3R-shaped
+// scene, 0.294 -> 0.273 ms at 1 M splats / 1080p, 0.045 -> 0.050 ms at 100 k (list building dominates short lists, hence the
+// switch in use_row_private()).
+//
+// Per batch of 256 LDS-staged splats every wave builds four compacted index lists (one per row: ballot + mbcnt prefix, u8
+// indices in LDS), then iterates i = 0 .. longest list; a row whose list is exhausted idles (predicated off).  The per-pixel
+// arithmetic is the shared pair_alpha of render_common.h and every pixel still sees its splats in list order, so the image,
+// n_contrib and final_T are bit-identical to the quadrant kernel.
+//
+// The same decomposition was tried for the BACKWARD kernel and lost (0.91 vs 0.605 ms at 1 M splats): a row's nine sums must
+// be combined with the other 15 rows of the tile, and LDS float atomics cost ~4 clocks per active lane whether or not the
+// addresses collide (36 lanes per iteration instead of 9: 0.45 ms of the 0.91; the row-private arithmetic alone took 0.37 ms).
+#include "render_common.h"
+
+namespace das3r {
+
+// pixel owned by `lane` of `wave`: wave -> 8x8 quadrant, row (lane >> 4) -> 4x4 block of the quadrant, lane & 15 -> pixel
+__device__ __forceinline__ void block_pixel(const int bx, const int by, const int wave, const int lane, int &px, int &py) {
+    const int row = lane >> 4;
+    px = bx * TILE_X + ((wave & 1) << 3) + ((row & 1) << 2) + (lane & 3);
+    py = by * TILE_Y + ((wave >> 1) << 3) + ((row >> 1) << 2) + ((lane >> 2) & 3);
+}
+
+// can the splat reach alpha >= 1/255 on a pixel centre of the 4x4 block centred at (cx, cy)?  (see quadrant_hit)
+__device__ __forceinline__ bool block_hit(const float4 xyh, const float cx, const float cy) {
+    return fabsf(xyh.x - cx) <= xyh.z + 1.5f && fabsf(xyh.y - cy) <= xyh.w + 1.5f;
+}
+
+// Build the four per-row index lists of this wave for a staged batch of n splats.  lists: this wave's [4][256] bytes.
+// Returns the four lengths (wave-uniform).
+__device__ __forceinline__ void build_row_lists(const StagedSplat *stage, const int n, const float q0x, const float q0y, const int lane,
+                                                uint8_t (*lists)[TILE_PIX], int len[4]) {
+    len[0] = len[1] = len[2] = len[3] = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int s = k * 64 + lane;
+        const bool valid = s < n;
+        const float4 p = stage[valid ? s : 0].xyh;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const bool hit = valid && block_hit(p, q0x + (float)((r & 1) << 2) + 1.5f, q0y + (float)((r >> 1) << 2) + 1.5f);
+            const uint64_t m = __ballot(hit);
+            const int pos = len[r] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (hit) lists[r][pos] = (uint8_t)s;
+            len[r] += __popcll(m);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
+                                                                  int W, int H, int tiles_x, int ntiles, const float4 *__restrict__ xyh,
+                                                                  const float4 *__restrict__ conic_opacity,
+                                                                  const float4 *__restrict__ rgbd, const float *__restrict__ bg,
+                                                                  float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
+                                                                  float *__restrict__ out_color) {
+    __shared__ StagedSplat stage[TILE_PIX];
+    __shared__ uint8_t lists[4][4][TILE_PIX];   // [wave][row][position]
+    const int tile = xcd_tile(blockIdx.x, ntiles);
+    if (tile < 0) return;
+    const int tid = threadIdx.x, lane = __lane_id(), wave = tid >> 6, row = lane >> 4;
+    const int bx = tile % tiles_x, by = tile / tiles_x;
+    int px, py;
+    block_pixel(bx, by, wave, lane, px, py);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float q0x = (float)(bx * TILE_X + ((wave & 1) << 3)), q0y = (float)(by * TILE_Y + ((wave >> 1) << 3));
+    const uint2 range = ranges[tile];
+    int toDo = (int)(range.y - range.x);
+    const int rounds = (toDo + TILE_PIX - 1) / TILE_PIX;
+
+    bool done = !inside;
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    uint32_t last_contributor = 0;
+
+    for (int i = 0; i < rounds; i++, toDo -= TILE_PIX) {
+        if (__syncthreads_count(done) == TILE_PIX) break;
+        const uint32_t progress = range.x + i * TILE_PIX + tid;
+        if (progress < range.y) {
+            const uint32_t g = point_list[progress];
+            stage[tid].xyh = xyh[g];
+            stage[tid].co = conic_opacity[g];
+            stage[tid].rgbd = rgbd[g];
+        }
+        __syncthreads();
+        const int n = toDo < TILE_PIX ? toDo : TILE_PIX;
+        int len[4];
+        build_row_lists(stage, n, q0x, q0y, lane, lists[wave], len);
+        const int my_len = row == 0 ? len[0] : (row == 1 ? len[1] : (row == 2 ? len[2] : len[3]));
+        const int longest = max(max(len[0], len[1]), max(len[2], len[3]));
+        const uint8_t *mine = lists[wave][row];
+        uint64_t alive = __ballot(!done);
+        for (int t = 0; t < longest && alive != 0ull; t++) {
+            const bool has = t < my_len;
+            const int j = mine[has ? t : 0];
+            const float4 p = stage[j].xyh;
+            const float4 co = stage[j].co;
+            float dx, dy, G, alpha;
+            const bool live = pair_alpha(p.x, p.y, co, pxf, pyf, dx, dy, G, alpha) && has && !done;
+            if (__ballot(live) == 0ull) continue;
+            const float4 c = stage[j].rgbd;
+            const float a = live ? alpha : 0.f;
+            const float test_T = T * (1.0f - a);
+            const bool stop = live && (test_T < 0.0001f);
+            const bool blend = live && !stop;
+            const float w = blend ? a : 0.f;
+            C0 += c.x * w * T;
+            C1 += c.y * w * T;
+            C2 += c.z * w * T;
+            T = blend ? test_T : T;
+            last_contributor = blend ? (uint32_t)(i * TILE_PIX + j + 1) : last_contributor;  // 1-based list position
+            done = done || stop;
+            if (__ballot(stop) != 0ull) alive = __ballot(!done);
+        }
+    }
+    if (inside) {
+        const size_t pix = (size_t)py * W + px, plane = (size_t)H * W;
+        final_T[pix] = T;
+        n_contrib[pix] = last_contributor;
+        out_color[pix] = C0 + T * bg[0];
+        out_color[plane + pix] = C1 + T * bg[1];
+        out_color[2 * plane + pix] = C2 + T * bg[2];
+    }
+}
+
+// The row lists cost ~200 instructions per wave and batch to build: worth it once a tile's list is long.  DAS3R_RENDER=quad /
+// rows forces one of the two forward kernels (A-B runs, tests).
+bool use_row_private(int64_t instances, int ntiles) {
+    const char *e = getenv("DAS3R_RENDER");
+    if (e && e[0] == 'q') return false;
+    if (e && e[0] == 'r') return true;
+    return instances >= (int64_t)128 * ntiles;
+}
+
+int launch_render_forward_rows(const das3r_raster_args *a, float *out_color, char *geom, char *binning, char *img, const Layout &L,
+                               hipStream_t s) {
+    DAS3R_LAUNCH(render_forward_rows_kernel, dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, (const uint2 *)(img + L.pub.ranges),
+                 (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height, L.tiles_x, L.ntiles,
+                 (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),
+                 (const float4 *)(geom + L.pub.rgbd), a->bg, (float *)(img + L.pub.final_T), (uint32_t *)(img + L.pub.n_contrib),
+                 out_color);
+    KERNEL_CHECK(s, a->debug, "render_forward_rows");
+    return DAS3R_OK;
+}
+
+}  // namespace das3r

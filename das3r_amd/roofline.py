@@ -37,11 +37,14 @@ def algorithmic_bytes(P, D, M, I, W, H):
     return per_kernel, b_fwd, b_bwd
 
 
+ALIASES = {"render_forward_rows_kernel": "render_forward_kernel"}   # two implementations of the same stage (render_rows.hip)
+
+
 def group_kernel_times(report):
     """{kernel: (launches, total_ms)} -> same with the binning kernels folded into one 'binning' entry."""
     out = {}
     for name, (n, ms) in report.items():
-        key = "binning" if name in BINNING_KERNELS else name
+        key = "binning" if name in BINNING_KERNELS else ALIASES.get(name, name)
         c, t = out.get(key, (0, 0.0))
         out[key] = (c + n, t + ms)
     return out
