@@ -192,7 +192,17 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
             return DAS3R_ERR_HIP;
         }
     }
-    if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, L, s))) return rc;
+    // hinted path: the binning buffer can be allocated up front, and its control words are zeroed by the preprocess kernel
+    // instead of a separate memset
+    bool binning_ready = false;
+    if (a->capacity_hint > 0 && use_onesweep() && a->capacity_hint <= (int64_t)0x7FFFFF00) {
+        Layout Lb;
+        compute_layout(P, a->capacity_hint, W, H, &Lb);
+        saved->binning = alloc_binning(user, Lb.pub.binning_bytes);
+        if (!saved->binning) { set_error("scratch allocation failed (binning %zu B)", Lb.pub.binning_bytes); return DAS3R_ERR_ALLOC; }
+        if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, saved->binning + Lb.b_ghist, Lb.b_ctrl_bytes, L, s))) return rc;
+        binning_ready = true;
+    } else if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, nullptr, 0, L, s))) return rc;
     if ((rc = launch_depth_sort(P, saved->geom, L, a->debug != 0, s))) return rc;
 
     // num_rendered comes out of the scan of tiles_touched.  Without a capacity hint the scan runs alone and the host waits
@@ -222,11 +232,13 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         }
         if (cap > (int64_t)0x7FFFFF00) { set_error("num_rendered %lld exceeds 2^31", (long long)cap); return DAS3R_ERR_OVERFLOW; }
         compute_layout(P, cap, W, H, &L);
-        saved->binning = alloc_binning(user, L.pub.binning_bytes);
-        if (!saved->binning) { set_error("scratch allocation failed (binning %zu B)", L.pub.binning_bytes); return DAS3R_ERR_ALLOC; }
+        if (!(binning_ready && attempt == 0)) {
+            saved->binning = alloc_binning(user, L.pub.binning_bytes);
+            if (!saved->binning) { set_error("scratch allocation failed (binning %zu B)", L.pub.binning_bytes); return DAS3R_ERR_ALLOC; }
+        }
         const bool fused_scan = !scanned;
         if (fused_scan) {   // the count leaves right behind the scan, ahead of the partition passes
-            if ((rc = launch_binning_scan_emit(P, cap, out->radii, saved->geom, saved->binning, L, a->debug != 0, s))) return rc;
+            if ((rc = launch_binning_scan_emit(P, cap, out->radii, saved->geom, saved->binning, L, binning_ready && attempt == 0, a->debug != 0, s))) return rc;
             if ((rc = collect_count())) return rc;
             scanned = true;
         }

@@ -96,8 +96,9 @@ struct Layout {
 void compute_layout(int P, int64_t I, int W, int H, Layout *L);
 
 // ---- launchers implemented in the individual .hip files ----
-int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int32_t *radii, char *geom, char *img, const Layout &L,
-                      hipStream_t s);
+// binning_ctrl (may be null): the binning buffer's control words, zeroed by the same kernel when the buffer already exists
+int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int32_t *radii, char *geom, char *img, char *binning_ctrl,
+                      size_t binning_ctrl_bytes, const Layout &L, hipStream_t s);
 int launch_mark_visible(int P, const float *means3D, const float *viewmatrix, uint8_t *present, hipStream_t s);
 int launch_depth_sort(int P, char *geom, const Layout &L, bool debug, hipStream_t s);
 // scan of tiles_touched in depth order -> offsets / off_by_gid / count (exact path: the host then reads the count)
@@ -105,7 +106,8 @@ int launch_scan(int P, char *geom, const Layout &L, bool debug, hipStream_t s);
 // the same scan with the instance emission fused in (hinted path; sort_onesweep.hip)
 int launch_scan_emit(int P, int64_t cap, const int32_t *radii, char *geom, char *binning, const Layout &L, bool debug, hipStream_t s);
 size_t scan_status_bytes(int P);
-int launch_binning_scan_emit(int P, int64_t I, const int32_t *radii, char *geom, char *binning, const Layout &L, bool debug, hipStream_t s);
+int launch_binning_scan_emit(int P, int64_t I, const int32_t *radii, char *geom, char *binning, const Layout &L, bool ctrl_zeroed, bool debug,
+                             hipStream_t s);
 size_t onesweep_status_bytes(int64_t n, int passes);
 int launch_onesweep_depth_sort(int P, char *geom, const Layout &L, bool debug, hipStream_t s);
 int launch_onesweep_partition(int64_t cap, char *geom, char *binning, const Layout &L, uint32_t **keys_final, bool debug, hipStream_t s);

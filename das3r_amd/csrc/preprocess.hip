@@ -21,12 +21,13 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     int tiles_x, int tiles_y, int32_t *__restrict__ radii, uint32_t *__restrict__ depth_key, float4 *__restrict__ xyh,
     float4 *__restrict__ conic_opacity, float4 *__restrict__ rgbd, uint8_t *__restrict__ clamped,
     uint32_t *__restrict__ tiles_touched, int tight_rect, uint32_t *__restrict__ zero_a, uint32_t zero_a_words, uint32_t *__restrict__ zero_b,
-    uint32_t zero_b_words) {
+    uint32_t zero_b_words, uint32_t *__restrict__ zero_c, uint32_t zero_c_words) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     // this kernel runs before every consumer of the radix control words (geom side) and of the tile ranges: zero them here
     // instead of spending two memset launches
     for (uint32_t i = idx; i < zero_a_words; i += gridDim.x * blockDim.x) zero_a[i] = 0u;
     for (uint32_t i = idx; i < zero_b_words; i += gridDim.x * blockDim.x) zero_b[i] = 0u;
+    for (uint32_t i = idx; i < zero_c_words; i += gridDim.x * blockDim.x) zero_c[i] = 0u;   // binning control words (hinted path)
     // STAGE (M == 16, degree >= 2): the workgroup's 256 SH rows (192 B each, contiguous) are fetched with fully coalesced
     // float4 loads — every 128-B line exactly once — and re-read per lane from LDS.  Per-lane strided row loads re-fetch
     // lines evicted from L1/L2 between the 12 loads of a row: measured 2.5x the algorithmic HBM traffic at 1M splats.
@@ -155,8 +156,8 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float *_
     present[idx] = xform43(p, V).z > NEAR_PLANE ? 1 : 0;
 }
 
-int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int32_t *radii, char *geom, char *img, const Layout &L,
-                      hipStream_t s) {
+int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int32_t *radii, char *geom, char *img, char *binning_ctrl,
+                      size_t binning_ctrl_bytes, const Layout &L, hipStream_t s) {
     const int P = a->P;
     if (P == 0) return DAS3R_OK;
     dim3 grid(div_up(P, 256)), block(256);
@@ -167,7 +168,7 @@ int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int
         a->tanfovx, a->tanfovy, L.tiles_x, L.tiles_y, radii, (uint32_t *)(geom + L.g_keyA), (float4 *)(geom + L.pub.xy),  \
         (float4 *)(geom + L.pub.conic_opacity), (float4 *)(geom + L.pub.rgbd), (uint8_t *)(geom + L.pub.clamped),         \
         (uint32_t *)(geom + L.pub.tiles_touched), use_tight_rect() ? 1 : 0, (uint32_t *)(geom + L.g_ghist), (uint32_t)(L.g_ctrl_bytes / 4),                 \
-        (uint32_t *)(img + L.pub.ranges), (uint32_t)(2 * L.ntiles)
+        (uint32_t *)(img + L.pub.ranges), (uint32_t)(2 * L.ntiles), (uint32_t *)binning_ctrl, (uint32_t)(binning_ctrl_bytes / 4)
     const bool stage = has_sh && a->M == 16 && a->sh_degree >= 2 && ((uintptr_t)in->shs & 15) == 0 && !getenv("DAS3R_NO_SH_STAGE");
     if (has_sh && !has_cov && stage) DAS3R_LAUNCH((preprocess_kernel<true, false, true>), grid, block, 0, s, ARGS);
     else if (has_sh && has_cov && stage) DAS3R_LAUNCH((preprocess_kernel<true, true, true>), grid, block, 0, s, ARGS);

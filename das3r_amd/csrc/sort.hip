@@ -270,9 +270,10 @@ int launch_depth_sort(int P, char *geom, const Layout &L, bool debug, hipStream_
 
 // Hinted path, first half of the binning: zero the control words, then scan + emit in one kernel.  The caller copies the
 // count back right behind it and then calls launch_binning(..., fused_scan = true) for the partition.
-int launch_binning_scan_emit(int P, int64_t I, const int32_t *radii, char *geom, char *binning, const Layout &L, bool debug, hipStream_t s) {
+int launch_binning_scan_emit(int P, int64_t I, const int32_t *radii, char *geom, char *binning, const Layout &L, bool ctrl_zeroed, bool debug,
+                             hipStream_t s) {
     if (I == 0 || P == 0) return DAS3R_OK;
-    HIP_TRY(hipMemsetAsync(binning + L.b_ghist, 0, L.b_ctrl_bytes, s));
+    if (!ctrl_zeroed) HIP_TRY(hipMemsetAsync(binning + L.b_ghist, 0, L.b_ctrl_bytes, s));
     return launch_scan_emit(P, I, radii, geom, binning, L, debug, s);
 }
 
