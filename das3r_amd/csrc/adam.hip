@@ -24,7 +24,8 @@ struct AdamTable {
     long long n_active[ADAM_MAX_TENSORS];     // rows * active_len
     int row_len[ADAM_MAX_TENSORS], active_len[ADAM_MAX_TENSORS];
     int first_chunk[ADAM_MAX_TENSORS + 1];    // prefix of chunk counts
-    float step_size[ADAM_MAX_TENSORS], bc2_sqrt[ADAM_MAX_TENSORS];
+    float step_size[ADAM_MAX_TENSORS], bc2_sqrt[ADAM_MAX_TENSORS], step_size_tail[ADAM_MAX_TENSORS];
+    int head_len[ADAM_MAX_TENSORS];
     int n;
 };
 
@@ -39,18 +40,20 @@ __global__ void __launch_bounds__(256) adam_kernel(const AdamTable T, float beta
     float *__restrict__ v = T.v[t];
     const long long n = T.n_active[t];
     const int row_len = T.row_len[t], active_len = T.active_len[t];
-    const float step_size = T.step_size[t], bc2_sqrt = T.bc2_sqrt[t];
+    const float step_size = T.step_size[t], bc2_sqrt = T.bc2_sqrt[t], step_size_tail = T.step_size_tail[t];
+    const int head_len = T.head_len[t];
 #pragma unroll
     for (int k = 0; k < ADAM_CHUNK / 256; k++) {
         const long long e = base + k * 256 + threadIdx.x;
         if (e < n) {
-            const long long off = (row_len == active_len) ? e : (e / active_len) * row_len + (e % active_len);
+            const int col = (int)(e % active_len);
+            const long long off = (row_len == active_len) ? e : (e / active_len) * row_len + col;
             const float gr = g[off];
             float mm = m[off], vv = v[off];
             mm = mm + (gr - mm) * (1.0f - beta1);
             vv = vv * beta2 + (1.0f - beta2) * gr * gr;
             const float denom = sqrtf(vv) / bc2_sqrt + eps;
-            p[off] = p[off] - step_size * (mm / denom);
+            p[off] = p[off] - (col < head_len ? step_size : step_size_tail) * (mm / denom);
             m[off] = mm;
             v[off] = vv;
         }
@@ -82,6 +85,9 @@ extern "C" int das3r_adam_step(int32_t n, const das3r_adam_tensor *tensors, floa
         T.p[k] = a.param; T.g[k] = a.grad; T.m[k] = a.exp_avg; T.v[k] = a.exp_avg_sq;
         T.n_active[k] = na; T.row_len[k] = a.row_len; T.active_len[k] = a.active_len;
         T.step_size[k] = a.step_size; T.bc2_sqrt[k] = a.bc2_sqrt;
+        const bool split = a.head_len > 0 && a.head_len < a.active_len;   // otherwise one rate for the whole row
+        T.head_len[k] = split ? a.head_len : a.row_len;
+        T.step_size_tail[k] = split ? a.step_size_tail : a.step_size;
         T.first_chunk[k] = chunks;
         chunks += (int)((na + ADAM_CHUNK - 1) / ADAM_CHUNK);
         k++;

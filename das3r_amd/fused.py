@@ -16,7 +16,8 @@ from .camera import quat_to_rotation
 
 class AdamTensor(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("rows", C.c_int64),
-                ("row_len", C.c_int32), ("active_len", C.c_int32), ("step_size", C.c_float), ("bc2_sqrt", C.c_float)]
+                ("row_len", C.c_int32), ("active_len", C.c_int32), ("step_size", C.c_float), ("bc2_sqrt", C.c_float),
+                ("head_len", C.c_int32), ("step_size_tail", C.c_float)]
 
 
 def _stream(device):
@@ -94,7 +95,9 @@ def pretransform(xyz, rot, scaling, opacity_raw, conf, mask_index, pose):
 class FusedAdam:
     """torch.optim.Adam(lr=0.0, eps=1e-15)-compatible optimizer for lists of fp32 device tensors: same param_groups / step() /
     zero_grad() surface as the reference uses, one HIP launch per step.  A group may carry "sh_rest": True — its tensor is
-    [P, K, 3] SH coefficients of which only those of the active degree are swept (set_active_sh_degree)."""
+    [P, K, 3] SH coefficients of which only those of the active degree are swept (set_active_sh_degree) — or "sh_all": True
+    with "lr_rest": one [P, 1 + K, 3] tensor holding DC + rest (no torch.cat in the render path, no split in its backward),
+    DC stepping with "lr", the rest with "lr_rest"."""
 
     def __init__(self, params, lr=0.0, betas=(0.9, 0.999), eps=1e-15):
         self.param_groups = []
@@ -139,7 +142,14 @@ class FusedAdam:
                 keep.append(grad)
                 e = AdamTensor()
                 e.param, e.grad, e.exp_avg, e.exp_avg_sq = p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
-                if g.get("sh_rest") and self.active_sh_degree is not None and p.dim() == 3:
+                e.head_len, e.step_size_tail = 0, 0.0
+                if g.get("sh_all") and p.dim() == 3:     # one [P, K, 3] tensor: DC coefficient (lr) + the rest (lr_rest)
+                    e.rows, e.row_len = p.shape[0], p.shape[1] * p.shape[2]
+                    deg = self.active_sh_degree if self.active_sh_degree is not None else 99
+                    e.active_len = min(e.row_len, 3 * (deg + 1) ** 2)
+                    e.head_len = 3
+                    e.step_size_tail = g["lr_rest"] / (1.0 - b1 ** t)
+                elif g.get("sh_rest") and self.active_sh_degree is not None and p.dim() == 3:
                     e.rows, e.row_len = p.shape[0], p.shape[1] * p.shape[2]
                     e.active_len = min(e.row_len, 3 * ((self.active_sh_degree + 1) ** 2 - 1))
                 else:

@@ -124,7 +124,7 @@ class SplatModel:
             {"params": [self._conf_static], "lr": 3e-3, "name": "conf_static"},
         ]
         cam = [{"params": [self.Q], "lr": 0.00003, "name": "pose_Q"}, {"params": [self.T], "lr": 0.00003, "name": "pose_T"}]
-        if fused:   # opt-in: one HIP launch per step, f_rest swept only up to the active SH degree
+        if fused:   # opt-in: one HIP launch per step, SH coefficients swept only up to the active degree
             from .fused import FusedAdam
             groups[2]["sh_rest"] = True
             self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)

@@ -51,7 +51,11 @@ def das3r_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ove
             idx = pc._mask_index = torch.nonzero(pc.aggregated_mask.reshape(-1), as_tuple=False).reshape(-1).contiguous()
         means3D, rotations, scales, opacity = pretransform(pc._xyz, pc._rotation, pc._scaling, pc._opacity, pc._conf_static, idx,
                                                            camera_pose)
-        rendered_image, radii = rasterizer(means3D=means3D, means2D=screenspace_points, shs=pc.get_features, colors_precomp=None,
+        # while the active SH degree is 0 (iterations < 3000 of DAS3R's 4000) only the DC coefficient is read: hand the
+        # rasterizer the [P, 1, 3] DC tensor itself (M = 1) instead of cat(f_dc, f_rest) — same image bit for bit, 12 instead
+        # of 192 bytes of SH per splat each way, and f_rest gets no gradient at all (Adam skips it)
+        shs = pc._features_dc if pc.active_sh_degree == 0 else pc.get_features
+        rendered_image, radii = rasterizer(means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=None,
                                            opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=None)
         return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
 

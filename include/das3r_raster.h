@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DAS3R_ABI_VERSION 2
+#define DAS3R_ABI_VERSION 3
 
 typedef enum {
     DAS3R_OK = 0,
@@ -149,7 +149,10 @@ int das3r_pretransform_backward(int32_t P, const float *xyz, const float *rot, c
 
 /* §8f-2: one multi-tensor Adam step (torch.optim.Adam semantics, no weight decay / amsgrad;
  * /root/reference/scene/gaussian_model.py:236-261).  A tensor is `rows` rows of `row_len` floats of which only the first
- * `active_len` are updated (degree-aware f_rest; active_len == row_len for ordinary tensors).  `tensors` is a HOST array. */
+ * `active_len` are updated (degree-aware SH coefficients; active_len == row_len for ordinary tensors).  The first `head_len`
+ * floats of a row may use a different learning rate (one [P,16,3] SH tensor whose DC part and rest part belong to the
+ * reference's two parameter groups f_dc / f_rest): they step with step_size, the others with step_size_tail; head_len == 0 or
+ * >= active_len means one rate (step_size) for the whole row.  `tensors` is a HOST array. */
 typedef struct {
     float *param;
     const float *grad;
@@ -160,6 +163,8 @@ typedef struct {
     int32_t active_len;
     float step_size;  /* lr / (1 - beta1^t) */
     float bc2_sqrt;   /* sqrt(1 - beta2^t) */
+    int32_t head_len;
+    float step_size_tail;
 } das3r_adam_tensor;
 int das3r_adam_step(int32_t n, const das3r_adam_tensor *tensors, float beta1, float beta2, float eps, das3r_stream_t stream);
 

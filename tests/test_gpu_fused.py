@@ -120,6 +120,30 @@ def test_fused_adam_matches_torch_adam(degree):
     assert float(st["exp_avg"][:, active:, :].abs().max() if active < 15 else 0.0) == 0.0
 
 
+@pytest.mark.parametrize("degree", [0, 2, 3])
+def test_fused_adam_single_sh_tensor_matches_two_torch_groups(degree):
+    """One [P, 16, 3] SH tensor with two learning rates (DC / rest) against torch.optim.Adam on the reference's two tensors."""
+    from das3r_amd.fused import FusedAdam
+    g = torch.Generator().manual_seed(3)
+    P = 501
+    full = torch.randn(P, 16, 3, generator=g).cuda()
+    pa = torch.nn.Parameter(full.clone())
+    dc, rest = torch.nn.Parameter(full[:, :1].clone()), torch.nn.Parameter(full[:, 1:].clone())
+    fa = FusedAdam([dict(params=[pa], lr=2.5e-3, lr_rest=1.25e-4, name="f_dc", sh_all=True)], lr=0.0, eps=1e-15)
+    fa.set_active_sh_degree(degree)
+    ta = torch.optim.Adam([dict(params=[dc], lr=2.5e-3), dict(params=[rest], lr=1.25e-4)], lr=0.0, eps=1e-15)
+    active = (degree + 1) ** 2
+    for step in range(5):
+        gr = torch.randn(P, 16, 3, generator=g).cuda() * (10.0 ** (step - 2))
+        gr[:, active:, :] = 0
+        pa.grad, dc.grad, rest.grad = gr.clone(), gr[:, :1].clone(), gr[:, 1:].clone()
+        fa.step()
+        ta.step()
+    ref = torch.cat((dc, rest), 1).detach()
+    assert float((pa.detach() - ref).abs().max()) <= ADAM_TOL * float(ref.abs().max())
+    assert torch.equal(pa.detach()[:, active:, :], full[:, active:, :])
+
+
 def test_fused_adam_skips_params_without_grad_and_rejects_cpu():
     from das3r_amd.fused import FusedAdam
     p, q = torch.nn.Parameter(torch.ones(5).cuda()), torch.nn.Parameter(torch.ones(5).cuda())
