@@ -50,7 +50,7 @@ class RasterLayout(C.Structure):
 EXPORTS = ("das3r_raster_forward", "das3r_raster_backward", "das3r_mark_visible", "das3r_knn3_workspace_bytes",
            "das3r_knn3_mean_dist2", "das3r_raster_get_layout", "das3r_abi_version", "das3r_last_error",
            "das3r_profile_enable", "das3r_profile_report", "das3r_pretransform_forward", "das3r_pretransform_backward",
-           "das3r_adam_step")
+           "das3r_adam_step", "das3r_photometric_blocks", "das3r_photometric_forward", "das3r_photometric_backward")
 
 _lib = None
 
@@ -88,6 +88,13 @@ def load():
     L.das3r_pretransform_forward.argtypes = [C.c_int32] + [C.c_void_p] * 13 + [C.c_void_p]
     L.das3r_pretransform_backward.restype = C.c_int
     L.das3r_pretransform_backward.argtypes = [C.c_int32] + [C.c_void_p] * 18 + [C.c_void_p]
+    L.das3r_photometric_blocks.restype = C.c_int64
+    L.das3r_photometric_blocks.argtypes = [C.c_int32, C.c_int32]
+    L.das3r_photometric_forward.restype = C.c_int
+    L.das3r_photometric_forward.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.das3r_photometric_backward.restype = C.c_int
+    L.das3r_photometric_backward.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]
     L.das3r_adam_step.restype = C.c_int
     L.das3r_adam_step.argtypes = [C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]
     L.das3r_raster_get_layout.restype = C.c_int

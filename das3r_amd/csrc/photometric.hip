@@ -1,0 +1,201 @@
+// photometric.hip — SURVEY.md §8(f)-3: DAS3R's per-iteration photometric loss as two kernels (forward, backward) instead of
+// the ~60 PyTorch launches (6 depthwise 11x11 convolutions each way + elementwise chains) the reference spends on it:
+//     image = render * static, gt' = gt * static                                    (/root/reference/train_gui.py:560-566)
+//     loss  = mean over (c, y, x) of (1 - lambda) |image - gt'| + lambda (1 - SSIM_map(image, gt'))          (:567-571)
+//     mse_c = mean over (y, x) of (image - gt')^2                         (psnr_frame, utils/image_utils.py:17-19)
+// SSIM_map: 11x11 Gaussian window (sigma 1.5), zero padding, per channel (/root/reference/utils/loss_utils.py:39-66).
+//
+// One workgroup = one 16x16 pixel tile.  The Gaussian window is separable: the (16+10)^2 halo tile of each input goes to LDS
+// once, a horizontal pass leaves 26 x 16 partial rows in LDS, the vertical pass finishes in registers.  The forward keeps, per
+// pixel and channel, the four derivative maps the backward needs (dm/dmu1, dm/dmu2, dm/dE[a^2] = dm/dE[b^2], dm/dE[ab]); since
+// dL/dSSIM_map is the same constant for every pixel, the backward is the same separable convolution applied to those maps.
+// Reductions are deterministic: every tile writes its partial sums, the host side adds the few hundred rows.
+#include "common.h"
+
+namespace das3r {
+
+constexpr int PT = 16, PR = 5, PH = PT + 2 * PR;   // tile, window radius, halo tile edge (26)
+constexpr float SSIM_C1 = 0.01f * 0.01f, SSIM_C2 = 0.03f * 0.03f;
+
+struct GaussWin {
+    float w[2 * PR + 1];
+};
+
+// horizontal pass over a PH x PH tile in LDS -> PH x PT, then vertical pass for this thread's pixel
+template <int NQ>
+__device__ __forceinline__ void separable(const float (*halo)[PH][PH + 1], float (*tmp)[PH][PT + 1], const GaussWin &g, const int tid,
+                                          float out[NQ]) {
+    for (int e = tid; e < PH * PT; e += PT * PT) {
+        const int r = e / PT, c = e % PT;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k <= 2 * PR; k++) s = fmaf(g.w[k], halo[q][r][c + k], s);
+            tmp[q][r][c] = s;
+        }
+    }
+    __syncthreads();
+    const int ty = tid / PT, tx = tid % PT;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k <= 2 * PR; k++) s = fmaf(g.w[k], tmp[q][ty + k][tx], s);
+        out[q] = s;
+    }
+}
+
+__global__ void __launch_bounds__(256) photometric_forward_kernel(int H, int W, const float *__restrict__ render, const float *__restrict__ gt,
+                                                                  const float *__restrict__ stat, float lambda, GaussWin g,
+                                                                  float *__restrict__ partials /*[blocks][8]*/,
+                                                                  float *__restrict__ dmaps /*[4][3][H][W]*/) {
+    __shared__ float halo[5][PH][PH + 1];
+    __shared__ float tmp[5][PH][PT + 1];
+    __shared__ float red[4][8];
+    const int tid = threadIdx.x, ty = tid / PT, tx = tid % PT;
+    const int x0 = blockIdx.x * PT, y0 = blockIdx.y * PT;
+    const int x = x0 + tx, y = y0 + ty;
+    const bool inside = x < W && y < H;
+    const size_t plane = (size_t)H * W;
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};   // l1, 1 - ssim, squared error per channel
+    for (int c = 0; c < 3; c++) {
+        for (int e = tid; e < PH * PH; e += PT * PT) {
+            const int r = e / PH, col = e % PH;
+            const int yy = y0 + r - PR, xx = x0 + col - PR;
+            float a = 0.f, b = 0.f;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                const float s = stat[(size_t)yy * W + xx];
+                a = render[c * plane + (size_t)yy * W + xx] * s;
+                b = gt[c * plane + (size_t)yy * W + xx] * s;
+            }
+            halo[0][r][col] = a;
+            halo[1][r][col] = b;
+            halo[2][r][col] = a * a;
+            halo[3][r][col] = b * b;
+            halo[4][r][col] = a * b;
+        }
+        __syncthreads();
+        float o[5];
+        separable<5>(halo, tmp, g, tid, o);
+        if (inside) {
+            const float mu1 = o[0], mu2 = o[1], e1 = o[2], e2 = o[3], e12 = o[4];
+            const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
+            const float s1 = e1 - mu1s, s2 = e2 - mu2s, s12 = e12 - mu12;
+            const float A = 2.f * mu12 + SSIM_C1, B = 2.f * s12 + SSIM_C2, C = mu1s + mu2s + SSIM_C1, D = s1 + s2 + SSIM_C2;
+            const float rC = 1.f / C, rD = 1.f / D, rCD = rC * rD;
+            const float m = A * B * rCD;
+            const float a = halo[0][ty + PR][tx + PR], b = halo[1][ty + PR][tx + PR];
+            const float d = a - b;
+            acc[0] += fabsf(d);
+            acc[1] += 1.f - m;
+            acc[2 + c] = d * d;
+            const size_t pix = (size_t)y * W + x;
+            const float common = 2.f * (B - A) * rCD;                      // d m / d mu1 = mu2 * common - m * 2 mu1 (1/C - 1/D)
+            dmaps[(0 * 3 + c) * plane + pix] = mu2 * common - 2.f * m * mu1 * (rC - rD);
+            dmaps[(1 * 3 + c) * plane + pix] = mu1 * common - 2.f * m * mu2 * (rC - rD);
+            dmaps[(2 * 3 + c) * plane + pix] = -m * rD;                    // d m / d E[a^2] = d m / d E[b^2]
+            dmaps[(3 * 3 + c) * plane + pix] = 2.f * A * rCD;              // d m / d E[ab]
+        }
+        __syncthreads();
+    }
+    // deterministic tile sums: DPP-free plain LDS tree is plenty here (5 values, once per tile)
+    const int lane = __lane_id(), wave = tid >> 6;
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+        float v = acc[q];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[wave][q] = v;
+    }
+    __syncthreads();
+    if (tid < 5) partials[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+__global__ void __launch_bounds__(256) photometric_backward_kernel(int H, int W, const float *__restrict__ render, const float *__restrict__ gt,
+                                                                   const float *__restrict__ stat, float lambda, GaussWin g,
+                                                                   const float *__restrict__ dmaps, const float *__restrict__ grad_loss,
+                                                                   float *__restrict__ d_render, float *__restrict__ d_static) {
+    __shared__ float halo[4][PH][PH + 1];
+    __shared__ float tmp[4][PH][PT + 1];
+    const int tid = threadIdx.x, ty = tid / PT, tx = tid % PT;
+    const int x0 = blockIdx.x * PT, y0 = blockIdx.y * PT;
+    const int x = x0 + tx, y = y0 + ty;
+    const bool inside = x < W && y < H;
+    const size_t plane = (size_t)H * W, pix = (size_t)y * W + x;
+    const float scale = grad_loss[0] / (3.f * (float)plane);       // d loss / d (per-element term)
+    const float s = inside ? stat[pix] : 0.f;
+    float ds = 0.f;
+    for (int c = 0; c < 3; c++) {
+        for (int e = tid; e < PH * PH; e += PT * PT) {
+            const int r = e / PH, col = e % PH;
+            const int yy = y0 + r - PR, xx = x0 + col - PR;
+            const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const size_t p = (size_t)yy * W + xx;
+#pragma unroll
+            for (int q = 0; q < 4; q++) halo[q][r][col] = in ? dmaps[(q * 3 + c) * plane + p] : 0.f;
+        }
+        __syncthreads();
+        float o[4];
+        separable<4>(halo, tmp, g, tid, o);
+        if (inside) {
+            const float R = render[c * plane + pix], G = gt[c * plane + pix];
+            const float a = R * s, b = G * s;
+            const float sgn = a > b ? 1.f : (a < b ? -1.f : 0.f);
+            const float l1 = (1.f - lambda) * sgn;
+            const float da = scale * (l1 - lambda * (o[0] + 2.f * a * o[2] + b * o[3]));
+            const float db = scale * (-l1 - lambda * (o[1] + 2.f * b * o[2] + a * o[3]));
+            d_render[c * plane + pix] = da * s;
+            ds += da * R + db * G;
+        }
+        __syncthreads();
+    }
+    if (inside) d_static[pix] = ds;
+}
+
+static GaussWin make_window() {
+    GaussWin g;
+    double v[2 * PR + 1], sum = 0.0;
+    for (int i = 0; i <= 2 * PR; i++) {
+        v[i] = exp(-(double)((i - PR) * (i - PR)) / (2.0 * 1.5 * 1.5));
+        sum += v[i];
+    }
+    for (int i = 0; i <= 2 * PR; i++) g.w[i] = (float)(v[i] / sum);
+    return g;
+}
+
+}  // namespace das3r
+
+using namespace das3r;
+
+extern "C" int64_t das3r_photometric_blocks(int32_t H, int32_t W) {
+    if (H <= 0 || W <= 0) return 0;
+    return (int64_t)div_up(W, PT) * div_up(H, PT);
+}
+
+extern "C" int das3r_photometric_forward(int32_t H, int32_t W, const float *render, const float *gt, const float *static_mask, float lambda,
+                                         float *partials, float *dmaps, das3r_stream_t stream) {
+    if (H <= 0 || W <= 0 || !render || !gt || !static_mask || !partials || !dmaps) {
+        set_error("das3r_photometric_forward: invalid argument");
+        return DAS3R_ERR_INVALID_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    DAS3R_LAUNCH(photometric_forward_kernel, dim3(div_up(W, PT), div_up(H, PT)), dim3(PT * PT), 0, s, H, W, render, gt, static_mask, lambda,
+                 make_window(), partials, dmaps);
+    KERNEL_CHECK(s, false, "photometric_forward");
+    return DAS3R_OK;
+}
+
+extern "C" int das3r_photometric_backward(int32_t H, int32_t W, const float *render, const float *gt, const float *static_mask, float lambda,
+                                          const float *dmaps, const float *grad_loss, float *d_render, float *d_static,
+                                          das3r_stream_t stream) {
+    if (H <= 0 || W <= 0 || !render || !gt || !static_mask || !dmaps || !grad_loss || !d_render || !d_static) {
+        set_error("das3r_photometric_backward: invalid argument");
+        return DAS3R_ERR_INVALID_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    DAS3R_LAUNCH(photometric_backward_kernel, dim3(div_up(W, PT), div_up(H, PT)), dim3(PT * PT), 0, s, H, W, render, gt, static_mask,
+                 lambda, make_window(), dmaps, grad_loss, d_render, d_static);
+    KERNEL_CHECK(s, false, "photometric_backward");
+    return DAS3R_OK;
+}

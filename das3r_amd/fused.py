@@ -165,3 +165,51 @@ class FusedAdam:
             with torch.cuda.device(dev):
                 rc = lib.das3r_adam_step(len(chunk), arr, C.c_float(b1), C.c_float(b2), C.c_float(self.eps), _stream(dev))
             _lib.check(rc, "das3r_adam_step")
+
+
+class _Photometric(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, render, gt, static, lam):
+        lib = _lib.load()
+        dev = render.device
+        if dev.type != "cuda":
+            raise RuntimeError("das3r_amd.fused.masked_photometric_loss: tensors must live on a HIP device; there is no CPU path")
+        if render.dim() != 3 or render.shape[0] != 3 or gt.shape != render.shape or static.shape != render.shape[1:]:
+            raise ValueError("render / gt must be [3, H, W] and static [H, W]")
+        render, gt, static = render.contiguous().float(), gt.contiguous().float(), static.contiguous().float()
+        H, W = int(render.shape[1]), int(render.shape[2])
+        nb = int(lib.das3r_photometric_blocks(H, W))
+        partials = torch.empty(nb, 8, device=dev)
+        dmaps = torch.empty(4, 3, H, W, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.das3r_photometric_forward(H, W, _p(render), _p(gt), _p(static), C.c_float(lam), _p(partials), _p(dmaps), _stream(dev))
+        _lib.check(rc, "das3r_photometric_forward")
+        sums = partials[:, :5].sum(0)
+        n = float(H * W)
+        loss = ((1.0 - lam) * sums[0] + lam * sums[1]) / (3.0 * n)
+        mse = sums[2:5] / n
+        ctx.save_for_backward(render, gt, static, dmaps)
+        ctx.lam = float(lam)
+        ctx.mark_non_differentiable(mse)
+        return loss, mse
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_mse):
+        lib = _lib.load()
+        render, gt, static, dmaps = ctx.saved_tensors
+        dev = render.device
+        H, W = int(render.shape[1]), int(render.shape[2])
+        g = g_loss.reshape(1).contiguous().float()
+        d_render, d_static = torch.empty_like(render), torch.empty_like(static)
+        with torch.cuda.device(dev):
+            rc = lib.das3r_photometric_backward(H, W, _p(render), _p(gt), _p(static), C.c_float(ctx.lam), _p(dmaps), _p(g), _p(d_render),
+                                                _p(d_static), _stream(dev))
+        _lib.check(rc, "das3r_photometric_backward")
+        return d_render, None, d_static, None
+
+
+def masked_photometric_loss(render, gt, static, lambda_dssim):
+    """-> (loss, mse[3]): DAS3R's iteration loss mean[(1 - lambda) |image - gt'| + lambda (1 - SSIM_map(image, gt'))] with
+    image = render * static, gt' = gt * static, and the per-channel mean squared error of the same pair (for psnr_frame).
+    Differentiable in `render` and `static`; two HIP kernels instead of PyTorch's convolution / elementwise chains."""
+    return _Photometric.apply(render, gt, static, float(lambda_dssim))

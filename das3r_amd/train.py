@@ -35,6 +35,18 @@ def train_step(model: SplatModel, cam, opt: OptimParams, iteration, pipe, backgr
     image = pkg["render"]
     gt = cam.original_image
     static = model._conf_static[cam.uid]
+    if fused:   # opt-in: the masked L1 + SSIM loss and the frame MSE as one HIP kernel each way
+        from .fused import masked_photometric_loss
+        loss, mse = masked_photometric_loss(image, gt, static, opt.lambda_dssim)
+        psnr_frame = (20 * torch.log10(1.0 / torch.sqrt(mse))).mean()
+        loss.backward(retain_graph=True)
+        with torch.no_grad():
+            model.optimizer.step()
+            model.optimizer.zero_grad(set_to_none=True)
+            if psnr_frame > opt.psnr_threshold:
+                model.optimizer_cam.step()
+            model.optimizer_cam.zero_grad(set_to_none=True)
+        return loss.detach(), psnr_frame.detach(), pkg
     image = image * static
     gt = gt * static
     Ll1 = l1_loss(image, gt, reduce=False)

@@ -168,6 +168,19 @@ typedef struct {
 } das3r_adam_tensor;
 int das3r_adam_step(int32_t n, const das3r_adam_tensor *tensors, float beta1, float beta2, float eps, das3r_stream_t stream);
 
+/* ---- fused photometric loss (opt-in) ------------------------------------------------------------------
+ * DAS3R's per-iteration loss (/root/reference/train_gui.py:560-571, utils/loss_utils.py:39-66): with image = render * static,
+ * gt' = gt * static:  loss = mean[(1 - lambda) |image - gt'| + lambda (1 - SSIM_map(image, gt'))] over all 3*H*W elements.
+ * forward: every 16x16 tile writes partials[tile][8] = {sum |d|, sum (1 - ssim), sum d^2 for channels 0, 1, 2, -, -, -}
+ * (the caller adds the das3r_photometric_blocks(H, W) rows: loss = ((1-lambda) S0 + lambda S1) / (3HW), mse_c = S(2+c) / (HW))
+ * and the derivative maps dmaps[4][3][H][W] the backward consumes.  backward: d_render[3,H,W], d_static[H,W] for the device
+ * scalar grad_loss = dL/dloss.  render/gt are [3,H,W], static_mask [H,W], all fp32 device pointers. */
+int64_t das3r_photometric_blocks(int32_t H, int32_t W);
+int das3r_photometric_forward(int32_t H, int32_t W, const float *render, const float *gt, const float *static_mask, float lambda,
+                              float *partials, float *dmaps, das3r_stream_t stream);
+int das3r_photometric_backward(int32_t H, int32_t W, const float *render, const float *gt, const float *static_mask, float lambda,
+                               const float *dmaps, const float *grad_loss, float *d_render, float *d_static, das3r_stream_t stream);
+
 /* ---- introspection (used by the parity tests and the roofline accounting) ---- */
 
 /* Byte offsets of the saved intermediates inside geom / binning / img for given extents. */

@@ -157,6 +157,32 @@ def test_fused_adam_skips_params_without_grad_and_rejects_cpu():
         FusedAdam([dict(params=[c], lr=0.1)]).step()
 
 
+@pytest.mark.parametrize("hw", [(16, 16), (37, 53), (208, 512)])
+def test_photometric_loss_matches_torch_ops(hw):
+    """Fused masked L1 + SSIM loss against the PyTorch ops of das3r_amd.losses (pinned to the reference's helpers by
+    tests/golden): value, frame MSE and the gradients w.r.t. the render and the static-confidence map."""
+    from das3r_amd.fused import masked_photometric_loss
+    from das3r_amd.losses import l1_loss, ssim
+    H, W = hw
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    render = torch.rand(3, H, W, generator=g).cuda().requires_grad_(True)
+    gt = torch.rand(3, H, W, generator=g).cuda()
+    static = (0.2 + 0.8 * torch.rand(H, W, generator=g)).cuda().requires_grad_(True)
+    lam = 0.2
+    loss_f, mse_f = masked_photometric_loss(render, gt, static, lam)
+    (3.0 * loss_f).backward()
+    gr_f, gs_f = render.grad.clone(), static.grad.clone()
+    render.grad = static.grad = None
+    a, b = render * static, gt * static
+    loss_t = ((1.0 - lam) * l1_loss(a, b, reduce=False) + lam * (1.0 - ssim(a, b, size_average=False))).mean()
+    mse_t = ((a - b) ** 2).reshape(3, -1).mean(1)
+    (3.0 * loss_t).backward()
+    assert abs(float(loss_f) - float(loss_t)) <= 2e-6 * abs(float(loss_t))
+    assert float((mse_f - mse_t.detach()).abs().max()) <= 2e-6 * float(mse_t.abs().max())
+    for name, gf, gtc in (("render", gr_f, render.grad), ("static", gs_f, static.grad)):
+        assert float((gf - gtc).abs().max()) <= 2e-5 * float(gtc.abs().max()), name
+
+
 def test_train_step_fused_matches_default():
     """Three optimisation iterations of the DAS3R hot loop with the fused pre-transform + fused Adam against the default
     (PyTorch ops + torch.optim.Adam) from the same initial state."""
