@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdas3r_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
@@ -42,7 +42,7 @@ class RasterGrads(C.Structure):
 
 class RasterLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in
-                ("geom_bytes", "binning_bytes", "img_bytes", "depth_key", "xy", "conic_opacity", "rgbd", "clamped",
+                ("geom_bytes", "binning_bytes", "img_bytes", "depth_key", "xy", "conic_opacity", "rgbd", "splat_stride", "clamped",
                  "tiles_touched", "sorted_idx", "offsets", "point_list", "final_T", "n_contrib", "ranges")]
 
 
@@ -124,6 +124,14 @@ def profile_report():
         c, t = out.get(name, (0, 0.0))
         out[name] = (c + int(n), t + float(ms))
     return out
+
+
+def splat_field(geom, L, name, P):
+    """[P, 4] float32 view of one field ("xy" / "conic_opacity" / "rgbd") of the per-Gaussian 64-byte records in `geom`."""
+    import torch
+    nbytes = (P - 1) * L["splat_stride"] + 16 if P > 0 else 0
+    fl = geom[L[name]:L[name] + nbytes].view(torch.float32)
+    return torch.as_strided(fl, (P, 4), (L["splat_stride"] // 4, 1))
 
 
 def last_error():

@@ -72,9 +72,10 @@ void compute_layout(int P, int64_t I, int W, int H, Layout *L) {
     L->g_valB = take(4 * Pn);
     L->pub.sorted_idx = L->g_valA;  // 4 passes: A -> B -> A -> B -> A
     L->pub.depth_key = L->g_keyA;   // (clobbered by the sort; kept for the layout struct only)
-    L->pub.xy = take(16 * Pn);
-    L->pub.conic_opacity = take(16 * Pn);
-    L->pub.rgbd = take(16 * Pn);
+    L->pub.xy = take(16 * SPLAT_REC * Pn);      // one 64-byte record per Gaussian: xyh | conic+opacity | rgb+depth | pad
+    L->pub.conic_opacity = L->pub.xy + 16;
+    L->pub.rgbd = L->pub.xy + 32;
+    L->pub.splat_stride = 16 * SPLAT_REC;
     L->pub.clamped = take(Pn);
     L->pub.tiles_touched = take(4 * Pn);
     L->pub.offsets = take(4 * Pn);

@@ -80,6 +80,8 @@ static inline int tile_bits(int ntiles) {
     return b < 1 ? 1 : b;
 }
 
+constexpr int SPLAT_REC = 4;   // float4s per Gaussian record (xyh, conic+opacity, rgb+depth, pad): 64 bytes, one cache-line gather
+
 struct Layout {
     das3r_raster_layout pub;
     // private scratch offsets

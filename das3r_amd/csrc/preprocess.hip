@@ -139,9 +139,10 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     radii[idx] = radius_out;
     depth_key[idx] = key_out;
     tiles_touched[idx] = tiles_out;
-    xyh[idx] = xy_out;
-    conic_opacity[idx] = co_out;
-    rgbd[idx] = rgbd_out;
+    xyh[(size_t)idx * SPLAT_REC] = xy_out;            // three fields of the Gaussian's 64-byte record
+    conic_opacity[(size_t)idx * SPLAT_REC] = co_out;
+    rgbd[(size_t)idx * SPLAT_REC] = rgbd_out;
+    rgbd[(size_t)idx * SPLAT_REC + 1] = make_float4(0.f, 0.f, 0.f, 0.f);   // pad: the whole 64-byte line is written (no partial-line write-back)
     clamped[idx] = clamp_out;
 }
 

@@ -79,9 +79,9 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
         // stage the batch in reverse list order; entry j holds list position (max_contrib - 1 - done_before - j)
         if (tid < n) {
             const uint32_t g = point_list[range.x + max_contrib - 1 - done_before - tid];
-            stage[tid].xyh = xyh[g];
-            stage[tid].co = conic_opacity[g];
-            stage[tid].rgbd = rgbd[g];
+            stage[tid].xyh = xyh[(size_t)g * SPLAT_REC];           // one 64-byte record: a single cache line per splat
+            stage[tid].co = conic_opacity[(size_t)g * SPLAT_REC];
+            stage[tid].rgbd = rgbd[(size_t)g * SPLAT_REC];
         }
 #pragma unroll
         for (int k = 0; k < NACC; k++) acc[k * TILE_PIX + tid] = 0.f;   // acc[j*9 + q], zeroed with unit-stride stores

@@ -33,9 +33,9 @@ __global__ void __launch_bounds__(256) render_forward_kernel(const uint2 *__rest
         const uint32_t progress = range.x + i * TILE_PIX + tid;
         if (progress < range.y) {
             const uint32_t g = point_list[progress];
-            stage[tid].xyh = xyh[g];
-            stage[tid].co = conic_opacity[g];
-            stage[tid].rgbd = rgbd[g];
+            stage[tid].xyh = xyh[(size_t)g * SPLAT_REC];           // one 64-byte record: a single cache line per splat
+            stage[tid].co = conic_opacity[(size_t)g * SPLAT_REC];
+            stage[tid].rgbd = rgbd[(size_t)g * SPLAT_REC];
         }
         __syncthreads();
         const int n = toDo < TILE_PIX ? toDo : TILE_PIX;

@@ -14,9 +14,13 @@
 // arithmetic is the shared pair_alpha of render_common.h and every pixel still sees its splats in list order, so the image,
 // n_contrib and final_T are bit-identical to the quadrant kernel.
 //
-// The same decomposition was tried for the BACKWARD kernel and lost (0.91 vs 0.605 ms at 1 M splats): a row's nine sums must
-// be combined with the other 15 rows of the tile, and LDS float atomics cost ~4 clocks per active lane whether or not the
-// addresses collide (36 lanes per iteration instead of 9: 0.45 ms of the 0.91; the row-private arithmetic alone took 0.37 ms).
+// The same decomposition was tried twice for the BACKWARD kernel and lost both times at 1080p.  (1) Rows add their nine sums
+// into the tile's LDS accumulators: 0.91 vs 0.605 ms at 1 M splats — LDS float atomics cost ~4 clocks per active lane whether
+// or not the addresses collide (36 lanes per iteration instead of 9: 0.45 ms of the 0.91; the row-private arithmetic alone
+// took 0.37 ms).  (2) Rows STORE their sums into private slots racc[16 rows][64 splats][9] (a row meets a splat once per
+// batch) and the workgroup adds the listed slots per splat afterwards: no atomics, but 36 KB of slots force 64-splat batches
+// and 3 workgroups per CU; 0.92 ms at 1 M splats, 1.76 vs 1.96 ms on the 5 M-splat DAS3R-shaped scene — not worth a second
+// code path.
 #include "render_common.h"
 
 namespace das3r {
@@ -84,9 +88,9 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
         const uint32_t progress = range.x + i * TILE_PIX + tid;
         if (progress < range.y) {
             const uint32_t g = point_list[progress];
-            stage[tid].xyh = xyh[g];
-            stage[tid].co = conic_opacity[g];
-            stage[tid].rgbd = rgbd[g];
+            stage[tid].xyh = xyh[(size_t)g * SPLAT_REC];           // one 64-byte record: a single cache line per splat
+            stage[tid].co = conic_opacity[(size_t)g * SPLAT_REC];
+            stage[tid].rgbd = rgbd[(size_t)g * SPLAT_REC];
         }
         __syncthreads();
         const int n = toDo < TILE_PIX ? toDo : TILE_PIX;

@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
             offsets[r] = o;
             off_by_gid[g[k]] = o;   // first emission slot of splat g (its instances are emitted contiguously)
             if (EMIT && v[k] != 0u) {
-                const float4 p = xyh[g[k]];
+                const float4 p = xyh[(size_t)g[k] * SPLAT_REC];
                 int rminx, rminy, rmaxx, rmaxy;
                 binned_rect(p, radii[g[k]], tiles_x, tiles_y, tight_rect != 0, rminx, rminy, rmaxx, rmaxy);
                 for (int y = rminy; y < rmaxy; y++)

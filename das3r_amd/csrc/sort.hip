@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, int tiles
         const uint32_t g = sorted_idx[r];
         if (tiles_touched[g] == 0) continue;
         uint32_t o = offsets[r];
-        const float4 p = xyh[g];
+        const float4 p = xyh[(size_t)g * SPLAT_REC];
         int rminx, rminy, rmaxx, rmaxy;
         binned_rect(p, radii[g], tiles_x, tiles_y, tight_rect != 0, rminx, rminy, rmaxx, rmaxy);
         for (int y = rminy; y < rmaxy; y++)

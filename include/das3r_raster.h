@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DAS3R_ABI_VERSION 3
+#define DAS3R_ABI_VERSION 4
 
 typedef enum {
     DAS3R_OK = 0,
@@ -188,9 +188,12 @@ typedef struct {
     size_t geom_bytes, binning_bytes, img_bytes;
     /* geom */
     size_t depth_key;      /* u32[P]  fp32 depth bits, 0xFFFFFFFF = culled */
-    size_t xy;             /* f32[P,4]  pixel centre x, y + culling half extents hx, hy */
-    size_t conic_opacity;  /* f32[P,4] */
-    size_t rgbd;           /* f32[P,4] (r,g,b,depth) */
+    /* xy / conic_opacity / rgbd are the three float4 fields of ONE 64-byte record per Gaussian (a tile's gather of a splat
+     * touches one cache line instead of three): element g of each lives at its offset + g * splat_stride bytes */
+    size_t xy;             /* f32[4] per record: pixel centre x, y + culling half extents hx, hy */
+    size_t conic_opacity;  /* f32[4] per record */
+    size_t rgbd;           /* f32[4] per record (r,g,b,depth) */
+    size_t splat_stride;   /* bytes between consecutive Gaussians' records (64) */
     size_t clamped;        /* u8[P]    bit c set = channel c clamped */
     size_t tiles_touched;  /* u32[P] */
     size_t sorted_idx;     /* u32[P]   depth rank -> gaussian index */

@@ -31,8 +31,10 @@ def test_abi_version_and_layout(hip_lib):
     assert hip_lib.das3r_abi_version() == _lib.ABI_VERSION
     L = _lib.layout(1000, 5000, 1920, 1080)
     assert L["img_bytes"] >= 1920 * 1080 * 8 + 8160 * 8 and L["geom_bytes"] > 1000 * 60 and L["binning_bytes"] >= 5000 * 16
-    offs = [L[k] for k in ("xy", "conic_opacity", "rgbd", "clamped", "tiles_touched", "offsets")]
+    offs = [L[k] for k in ("xy", "clamped", "tiles_touched", "offsets")]
     assert all(o % 256 == 0 for o in offs) and len(set(offs)) == len(offs)
+    # xy / conic_opacity / rgbd: three float4 fields of one 64-byte record per Gaussian
+    assert L["splat_stride"] == 64 and L["conic_opacity"] == L["xy"] + 16 and L["rgbd"] == L["xy"] + 32
     # struct sizes seen by ctypes must match what the header lays out (plain C ABI: ints, floats, pointers)
     assert ctypes.sizeof(_lib.RasterArgs) == 5 * 4 + 3 * 4 + 4 * 8 + 2 * 4 + 8
     assert ctypes.sizeof(_lib.RasterIn) == 7 * 8 and ctypes.sizeof(_lib.RasterGrads) == 9 * 8

@@ -55,8 +55,8 @@ def test_full_size_properties(name):
     L = _lib.layout(sc.P, I, sc.W, sc.H)
     npix, P = sc.W * sc.H, sc.P
     final_T = _view(img, L["final_T"], torch.float32, npix).reshape(sc.H, sc.W).clone()
-    rgb = _view(geom, L["rgbd"], torch.float32, 4 * P).reshape(P, 4)[:, :3].contiguous().clone()
-    depth = _view(geom, L["rgbd"], torch.float32, 4 * P).reshape(P, 4)[:, 3].clone()
+    rgb = _lib.splat_field(geom, L, "rgbd", P)[:, :3].contiguous().clone()
+    depth = _lib.splat_field(geom, L, "rgbd", P)[:, 3].clone()
     # (1) per-tile lists: contiguous ranges covering [0, I), sorted by (depth, index) inside every tile
     tiles = ((sc.W + 15) // 16) * ((sc.H + 15) // 16)
     rg = _view(img, L["ranges"], torch.int32, 2 * tiles).reshape(tiles, 2).long()

@@ -80,9 +80,9 @@ def test_binning_bit_exact(name, monkeypatch):
     vis = ref_radii > 0
     tt = _view(geom, L["tiles_touched"], torch.int32, P).cpu().numpy().astype(np.uint32)
     assert np.array_equal(tt, S["tiles_touched"])
-    xy = _view(geom, L["xy"], torch.float32, 4 * P).cpu().numpy().reshape(P, 4)[:, :2]
-    co = _view(geom, L["conic_opacity"], torch.float32, 4 * P).cpu().numpy().reshape(P, 4)
-    rgbd = _view(geom, L["rgbd"], torch.float32, 4 * P).cpu().numpy().reshape(P, 4)
+    xy = _lib.splat_field(geom, L, "xy", P).cpu().numpy()[:, :2]
+    co = _lib.splat_field(geom, L, "conic_opacity", P).cpu().numpy()
+    rgbd = _lib.splat_field(geom, L, "rgbd", P).cpu().numpy()
     assert np.array_equal(xy[vis], S["xy"][vis]), "pixel centres must be bit-exact (no FMA contraction in K1)"
     assert np.array_equal(co[vis], S["conic_opacity"][vis]), "conics must be bit-exact"
     assert np.array_equal(rgbd[vis, 3], S["depths"][vis])

@@ -70,11 +70,11 @@ def main():
     ok = True
     ok &= report("radii", radii.cpu().numpy(), rr)
     ok &= report("tiles_touched", view(geom, L["tiles_touched"], torch.int32, P).cpu().numpy().astype(np.uint32), S["tiles_touched"])
-    xy = view(geom, L["xy"], torch.float32, 4 * P).cpu().numpy().reshape(P, 4)[:, :2]
+    xy = _lib.splat_field(geom, L, "xy", P).cpu().numpy()[:, :2]
     ok &= report("xy", xy[vis], S["xy"][vis])
-    co = view(geom, L["conic_opacity"], torch.float32, 4 * P).cpu().numpy().reshape(P, 4)
+    co = _lib.splat_field(geom, L, "conic_opacity", P).cpu().numpy()
     ok &= report("conic_opacity", co[vis], S["conic_opacity"][vis])
-    rgbd = view(geom, L["rgbd"], torch.float32, 4 * P).cpu().numpy().reshape(P, 4)
+    rgbd = _lib.splat_field(geom, L, "rgbd", P).cpu().numpy()
     ok &= report("rgb", rgbd[vis, :3], S["rgb"][vis])
     ok &= report("depth", rgbd[vis, 3], S["depths"][vis])
     cl = view(geom, L["clamped"], torch.uint8, P).cpu().numpy()

@@ -33,8 +33,8 @@ def main():
     tiles = tx * ty
     rg = _view(img, L["ranges"], torch.int32, 2 * tiles).reshape(tiles, 2).long()
     pl = _view(binning, L["point_list"], torch.int32, I).long()
-    xyh = _view(geom, L["xy"], torch.float32, 4 * P).reshape(P, 4)
-    co = _view(geom, L["conic_opacity"], torch.float32, 4 * P).reshape(P, 4)
+    xyh = _lib.splat_field(geom, L, "xy", P)
+    co = _lib.splat_field(geom, L, "conic_opacity", P)
     tile_of = torch.repeat_interleave(torch.arange(tiles, device=dev), rg[:, 1] - rg[:, 0])
     bx, by = (tile_of % tx).float() * 16, (tile_of // tx).float() * 16
     s = xyh[pl]
@@ -90,7 +90,7 @@ def row_private_estimate(workload):
     tiles = tx * ty
     rg = _view(img, L["ranges"], torch.int32, 2 * tiles).reshape(tiles, 2).long()
     pl = _view(binning, L["point_list"], torch.int32, I).long()
-    xyh = _view(geom, L["xy"], torch.float32, 4 * P).reshape(P, 4)
+    xyh = _lib.splat_field(geom, L, "xy", P)
     lens = rg[:, 1] - rg[:, 0]
     tile_of = torch.repeat_interleave(torch.arange(tiles, device=dev), lens)
     pos = torch.arange(I, device=dev) - rg[tile_of, 0]
