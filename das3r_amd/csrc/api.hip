@@ -99,7 +99,7 @@ void compute_layout(int P, int64_t I, int W, int H, Layout *L) {
     L->b_hist = take(4 * (size_t)RADIX_SIZE * (size_t)(L->chunksI > 0 ? L->chunksI : 1));
     L->b_totals = take(4 * RADIX_SIZE);
     L->b_gid_of = take(4 * In);
-    L->b_inv = take(4 * In);
+    L->b_slot = take(4 * In);
     L->b_ghist = take(4 * 4 * RADIX_SIZE);
     L->b_ticket = take(256);
     L->b_status = take(onesweep_status_bytes((int64_t)In, L->tile_passes));

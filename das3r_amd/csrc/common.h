@@ -86,7 +86,7 @@ struct Layout {
     das3r_raster_layout pub;
     // private scratch offsets
     size_t g_keyA, g_keyB, g_valA, g_valB, g_hist, g_totals, g_blocksums, g_count, g_off_by_gid;
-    size_t b_keyA, b_keyB, b_valA, b_valB, b_hist, b_totals, b_gid_of, b_inv;
+    size_t b_keyA, b_keyB, b_valA, b_valB, b_hist, b_totals, b_gid_of, b_slot;
     // single-pass radix control words (sort_onesweep.hip): [global digit histograms][tickets][status granules], contiguous
     // so that one store loop / one memset zeroes them: geom side by preprocess_kernel, binning side by a memset before emit
     size_t g_ghist, g_ticket, g_status, g_scan_status, g_ctrl_bytes;

@@ -5,7 +5,7 @@
 //
 // HBM-bound streaming map, lane per splat:
 //   * the screen-space gradients are GATHERED: the render backward left one row of 9 sums per (tile, splat) instance in
-//     partial[]; a splat's instances are found through off_by_gid[] / inv[] (no atomics, no accumulator memsets);
+//     partial[]; a splat's instances own the consecutive rows off_by_gid[g] .. + tiles_touched[g] (no atomics, no memsets);
 //   * every output row is written in full (zeros for culled splats and for SH coefficients above the active degree), so
 //     no output needs pre-zeroing and the dense (P,M,3) dL_dsh tensor is touched exactly once;
 //   * M == 16: the workgroup's 256 dL_dsh rows (192 B each, contiguous) are assembled in LDS and stored with fully
@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(
     const float *__restrict__ rotations, const float *__restrict__ shs, const float *__restrict__ cov3D_precomp,
     const float *__restrict__ viewmatrix, const float *__restrict__ projmatrix, const float *__restrict__ campos, int W, int H,
     float tanfovx, float tanfovy, const uint32_t *__restrict__ tiles_touched, const uint8_t *__restrict__ clamped,
-    const float *__restrict__ partial /*[I,9]*/, const uint32_t *__restrict__ inv /*[I]*/, const uint32_t *__restrict__ off_by_gid,
+    const float *__restrict__ partial /*[I,9], row = emission slot*/, const uint32_t *__restrict__ off_by_gid,
     float *__restrict__ dL_dmeans2D /*[P,3] out*/, float *__restrict__ dL_dopacity /*[P] out*/,
     float *__restrict__ dL_dcolors_precomp /*[P,3] out, precomp mode*/, float *__restrict__ dL_dmeans3D,
     float *__restrict__ dL_dscales, float *__restrict__ dL_drot, float *__restrict__ dL_dsh, float *__restrict__ dL_dcov3D) {
@@ -100,14 +100,14 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(
         const uint32_t ntiles_g = tiles_touched[idx];
         const bool visible = ntiles_g > 0;
 
-        // gather this splat's per-instance sums (one row per touched tile) through the inverse permutation of the binning
+        // add this splat's per-instance sums (one row per touched tile; the render backward wrote them at the emission slots)
         float acc[9];
 #pragma unroll
         for (int q = 0; q < 9; q++) acc[q] = 0.f;
         if (visible) {
             const uint32_t e0 = off_by_gid[idx];
             for (uint32_t k = 0; k < ntiles_g; k++) {
-                const float *row = partial + (size_t)inv[e0 + k] * 9;
+                const float *row = partial + (size_t)(e0 + k) * 9;   // rows are indexed by emission slot: contiguous per splat
 #pragma unroll
                 for (int q = 0; q < 9; q++) acc[q] += row[q];
             }
@@ -342,14 +342,13 @@ int launch_preprocess_backward(const das3r_raster_args *a, const das3r_raster_in
     if (P == 0) return DAS3R_OK;
     dim3 grid(div_up(P, 256)), block(256);
     const bool has_sh = in->shs != nullptr, has_cov = in->cov3D_precomp != nullptr;
-    const uint32_t *inv = binning ? (const uint32_t *)(binning + L.b_inv) : nullptr;
     const bool nostage = getenv("DAS3R_NO_SH_STAGE") != nullptr;
     const bool stage_out = has_sh && a->M == 16 && ((uintptr_t)g->dL_dshs & 15) == 0 && !nostage;
     const bool stage_in = stage_out && a->sh_degree >= 2 && ((uintptr_t)in->shs & 15) == 0;
 #define ARGS                                                                                                                 \
     P, a->sh_degree, a->M, in->means3D, in->scales, a->scale_modifier, in->rotations, in->shs, in->cov3D_precomp,            \
         a->viewmatrix, a->projmatrix, a->campos, a->image_width, a->image_height, a->tanfovx, a->tanfovy,                    \
-        (const uint32_t *)(geom + L.pub.tiles_touched), (const uint8_t *)(geom + L.pub.clamped), partial, inv,               \
+        (const uint32_t *)(geom + L.pub.tiles_touched), (const uint8_t *)(geom + L.pub.clamped), partial,               \
         (const uint32_t *)(geom + L.g_off_by_gid), g->dL_dmeans2D, g->dL_dopacities, g->dL_dcolors_precomp, g->dL_dmeans3D,  \
         g->dL_dscales, g->dL_drotations, g->dL_dshs, g->dL_dcov3D
 #define LAUNCH(SH, COV, SI, SO) DAS3R_LAUNCH((preprocess_backward_kernel<SH, COV, SI, SO>), grid, block, 0, s, ARGS)

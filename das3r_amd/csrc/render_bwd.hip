@@ -7,9 +7,9 @@
 // with the transposed reduction (permlane32/16 swap + DPP, 18 ops), the ninth with a 6-step DPP chain — and the four
 // waves of the tile meet in LDS (one ds_add_f32 per wave and splat, 9 lanes -> 9 addresses).
 // NO global atomics: device-scope float atomics measured ~0.5 ms of a 1.2 ms kernel at 1M splats (they leave the XCD's
-// L2).  Instead the tile writes its 9 sums per list entry to partial[list position][9] — a contiguous, coalesced block
-// per tile — and the per-Gaussian backward kernel (preprocess_bwd.hip) gathers a splat's few instances through the
-// inverse permutation recorded by the binning pass.  The only run-to-run variation left is the order of the four
+// L2).  Instead the tile writes its 9 sums per list entry to partial[emission slot][9] (the binning keeps every list entry's
+// emission slot in list order) — a splat's instances own consecutive slots, so the per-Gaussian backward kernel
+// (preprocess_bwd.hip) reads its few rows contiguously.  The only run-to-run variation left is the order of the four
 // per-wave LDS adds of a (tile, splat) sum.
 #include "render_common.h"
 
@@ -22,8 +22,9 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int tiles_x, int ntiles,
     const float4 *__restrict__ xyh, const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
     const float *__restrict__ bg, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
-    const float *__restrict__ dL_dpix, float *__restrict__ partial /*[I,9]*/, int ablate) {
+    const float *__restrict__ dL_dpix, const uint32_t *__restrict__ slot_list, float *__restrict__ partial /*[I,9]*/, int ablate) {
     __shared__ StagedSplat stage[TILE_PIX];
+    __shared__ uint32_t s_slot[TILE_PIX];   // emission slot of every staged entry = its row of `partial`
     __shared__ float acc[TILE_PIX * NACC];
     __shared__ uint32_t s_max[4];
 
@@ -62,9 +63,11 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
     // list entries beyond max_contrib receive no gradient from this tile: their partial rows are zero
     {
         const uint32_t len = range.y - range.x;
-        float *tail = partial + ((size_t)range.x + max_contrib) * NACC;
         const uint32_t ntail = (len - max_contrib) * NACC;
-        for (uint32_t f = tid; f < ntail; f += TILE_PIX) tail[f] = 0.f;
+        for (uint32_t f = tid; f < ntail; f += TILE_PIX) {
+            const uint32_t t = f / NACC, q = f - t * NACC;
+            partial[(size_t)slot_list[range.x + max_contrib + t] * NACC + q] = 0.f;
+        }
     }
 
     ReplayState st = {T_final, 0.f};
@@ -78,7 +81,9 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
         const int n = min(TILE_PIX, (int)max_contrib - done_before);
         // stage the batch in reverse list order; entry j holds list position (max_contrib - 1 - done_before - j)
         if (tid < n) {
-            const uint32_t g = point_list[range.x + max_contrib - 1 - done_before - tid];
+            const uint32_t pos = range.x + max_contrib - 1 - done_before - tid;
+            const uint32_t g = point_list[pos];
+            s_slot[tid] = slot_list[pos];
             stage[tid].xyh = xyh[(size_t)g * SPLAT_REC];           // one 64-byte record: a single cache line per splat
             stage[tid].co = conic_opacity[(size_t)g * SPLAT_REC];
             stage[tid].rgbd = rgbd[(size_t)g * SPLAT_REC];
@@ -128,12 +133,12 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
             }
         }
         __syncthreads();
-        // the batch's n x 9 sums form one contiguous block of `partial` (rows in reverse order): coalesced stores
+        // every staged entry's 9 sums go to the row of its emission slot: a splat's rows are then contiguous for the
+        // per-Gaussian backward kernel (36-byte row stores, 9 lanes each)
         if (!(ablate & 1)) {
-            const size_t top = (size_t)range.x + max_contrib - 1 - done_before;  // list position of entry j = 0
             for (int f = tid; f < n * NACC; f += TILE_PIX) {
                 const int j = f / NACC, q = f - j * NACC;
-                partial[(top - j) * NACC + q] = acc[f];
+                partial[(size_t)s_slot[j] * NACC + q] = acc[f];
             }
         }
         __syncthreads();
@@ -150,7 +155,7 @@ int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, cha
     (const uint2 *)(img + L.pub.ranges), (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height,    \
         L.tiles_x, L.ntiles, (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),                \
         (const float4 *)(geom + L.pub.rgbd), a->bg, (const float *)(img + L.pub.final_T),                                    \
-        (const uint32_t *)(img + L.pub.n_contrib), dL_dpix, partial, ablate
+        (const uint32_t *)(img + L.pub.n_contrib), dL_dpix, (const uint32_t *)(binning + L.b_slot), partial, ablate
     if (use_dpp) DAS3R_LAUNCH((render_backward_kernel<true>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS);
     else DAS3R_LAUNCH((render_backward_kernel<false>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS);
 #undef ARGS

@@ -139,9 +139,9 @@ __global__ void __launch_bounds__(256) radix_scatter_kernel(const uint32_t *__re
             const uint32_t dst = o + rank;
             if (keys_out) keys_out[dst] = k[s];
             // final pass of the tile partition: the payload is the emission slot e; store the splat id it stands for
-            // and remember where slot e ended up (inverse permutation, used by the gather in the backward pass)
+            // and keep e itself in list order (slot list: where the backward pass puts this instance's partial sums)
             vals_out[dst] = out[s];
-            if (inv_out) inv_out[v[s]] = dst;
+            if (inv_out) inv_out[dst] = v[s];   // slot list
         }
     }
 }
@@ -287,7 +287,7 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
     uint32_t *keyA = (uint32_t *)(binning + L.b_keyA), *keyB = (uint32_t *)(binning + L.b_keyB);
     uint32_t *valA = (uint32_t *)(binning + L.b_valA), *valB = (uint32_t *)(binning + L.b_valB);
     uint32_t *hist = (uint32_t *)(binning + L.b_hist), *totals = (uint32_t *)(binning + L.b_totals);
-    uint32_t *gid_of = (uint32_t *)(binning + L.b_gid_of), *inv = (uint32_t *)(binning + L.b_inv);
+    uint32_t *gid_of = (uint32_t *)(binning + L.b_gid_of), *inv = (uint32_t *)(binning + L.b_slot);
     const bool onesweep = use_onesweep();
     if (onesweep && !fused_scan) HIP_TRY(hipMemsetAsync(binning + L.b_ghist, 0, L.b_ctrl_bytes, s));  // digit histograms, tickets, status words
     if (!fused_scan) {   // (hinted path: launch_binning_scan_emit has already emitted the instances)

@@ -69,7 +69,8 @@ __global__ void __launch_bounds__(256) depth_hist_kernel(const uint32_t *__restr
 }
 
 // One digit of a stable LSD sort / partition.  keys_out may be null; vals_in null => payload = index.
-// gather_src / inv_out (FINAL): last pass of the tile partition (payload = emission slot e): store gather_src[e], inv[e] = dst.
+// gather_src / inv_out (FINAL): last pass of the tile partition (payload = emission slot e): vals_out = gather_src[e] (splat
+// id), inv_out = e (slot list: where the backward pass puts this instance's partial sums), both in list order.
 template <int IPL, bool FINAL>
 __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                             uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
@@ -105,11 +106,7 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
 #pragma unroll
     for (int s = 0; s < IPL; s++) {
         const uint32_t i = base + s * 64 + lane;
-        if (gather_src && i < n && v[s] >= n) {
-            atomicOr(err, ERR_RANGE);
-            v[s] = 0;
-        }
-        out[s] = (gather_src && i < n) ? gather_src[v[s]] : v[s];
+        out[s] = v[s];   // FINAL: the staged payload stays the emission slot; the splat id is gathered at write-out
         if (i < n) atomicAdd(&cnt[wave][(k[s] >> shift) & mask], 1u);
     }
     __syncthreads();
@@ -186,9 +183,6 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
             const uint32_t slot = o + rank;
             sk[slot] = k[s];
             sv[slot] = out[s];
-            // inverse permutation (emission slot -> list position): a random 4-byte scatter whichever way it is done, so it
-            // goes out from here, straight from registers, instead of taking a third staging array (LDS 54 -> 38 KB)
-            if (FINAL) inv_out[v[s]] = slot + gdelta[digit];
         }
     }
     __syncthreads();
@@ -209,7 +203,17 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
                 continue;
             }
             if (keys_out) keys_out[dst] = key;
-            vals_out[dst] = sv[i];
+            if (FINAL) {   // point_list[dst] = splat id of emission slot e, slot_list[dst] = e: both coalesced, no inverse scatter
+                const uint32_t e = sv[i];
+                if (e >= n) {
+                    atomicOr(err, ERR_RANGE);
+                    continue;
+                }
+                vals_out[dst] = gather_src[e];
+                inv_out[dst] = e;
+            } else {
+                vals_out[dst] = sv[i];
+            }
         }
     }
 }
@@ -278,7 +282,7 @@ int launch_onesweep_partition(int64_t cap, char *geom, char *binning, const Layo
     uint32_t *err = (uint32_t *)(geom + L.g_ticket) + 8;  // inside the zeroed control region
     uint32_t *keyA = (uint32_t *)(binning + L.b_keyA), *keyB = (uint32_t *)(binning + L.b_keyB);
     uint32_t *valA = (uint32_t *)(binning + L.b_valA), *valB = (uint32_t *)(binning + L.b_valB);
-    uint32_t *gid_of = (uint32_t *)(binning + L.b_gid_of), *inv = (uint32_t *)(binning + L.b_inv);
+    uint32_t *gid_of = (uint32_t *)(binning + L.b_gid_of), *inv = (uint32_t *)(binning + L.b_slot);
     uint32_t *ghist = (uint32_t *)(binning + L.b_ghist), *ticket = (uint32_t *)(binning + L.b_ticket);
     u64 *status = (u64 *)(binning + L.b_status);
     const size_t per_pass = onesweep_status_bytes(cap, 1) / sizeof(u64);
