@@ -150,6 +150,40 @@ extern "C" int das3r_raster_get_layout(int32_t P, int64_t num_rendered, int32_t 
     return DAS3R_OK;
 }
 
+// Host mailbox: a pinned, device-visible 64-byte block per host thread.  The scan kernel stores {count, flags} and then the
+// tag of the call (system-scope release) into words 0..2; the last binning kernel stores {self-check word, tag} into words
+// 8..9.  The host polls the tag — no D2H copy kernel, no event, no parked thread (hipEventSynchronize's wake-up alone cost
+// ~100 us per forward, a third of a 100 k-splat step).
+struct Mailbox {
+    volatile uint32_t *host = nullptr;
+    uint32_t *dev = nullptr;
+    uint32_t seq = 0;
+};
+static int mailbox_get(Mailbox **out) {
+    static thread_local Mailbox mb;
+    if (!mb.host) {
+        uint32_t *h = nullptr;
+        HIP_TRY(hipHostMalloc((void **)&h, 64, hipHostMallocMapped));
+        memset(h, 0, 64);
+        HIP_TRY(hipHostGetDevicePointer((void **)&mb.dev, h, 0));
+        mb.host = h;
+    }
+    *out = &mb;
+    return DAS3R_OK;
+}
+// spin until word `idx` carries `tag` (bounded: falls back to a stream synchronise, then gives up loudly)
+static int mailbox_wait(Mailbox *mb, int idx, uint32_t tag, hipStream_t s) {
+    for (long spins = 0; spins < 200000000L; spins++) {
+        if (__atomic_load_n(&mb->host[idx], __ATOMIC_ACQUIRE) == tag) return DAS3R_OK;
+        __builtin_ia32_pause();
+        if ((spins & 0xFFFFF) == 0xFFFFF && hipStreamQuery(s) != hipErrorNotReady) break;   // stream drained (or failed): stop spinning
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    if (__atomic_load_n(&mb->host[idx], __ATOMIC_ACQUIRE) == tag) return DAS3R_OK;
+    set_error("the device never delivered the result of this forward to the host mailbox");
+    return DAS3R_ERR_HIP;
+}
+
 extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_raster_in *in, const das3r_raster_out *out,
                                         das3r_alloc_fn alloc_geom, das3r_alloc_fn alloc_binning, das3r_alloc_fn alloc_img,
                                         void *user, das3r_raster_saved *saved, das3r_stream_t stream) {
@@ -180,19 +214,19 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     // ever blocking the host: copied to pinned memory at the end of this forward and examined at the start of the next one
     // (debug mode waits for it right away).  Bits: 1 look-back timeout, 2 index out of range (write suppressed), 8 counts
     // do not add up to the histogram.
-    static thread_local uint32_t *h_late = nullptr;
-    static thread_local hipEvent_t ev_late = nullptr;
-    static thread_local bool late_pending = false;
-    if (!h_late) { HIP_TRY(hipHostMalloc((void **)&h_late, 64, hipHostMallocDefault)); h_late[0] = 0; }
-    if (!ev_late) HIP_TRY(hipEventCreateWithFlags(&ev_late, hipEventDisableTiming));
-    if (late_pending && hipEventQuery(ev_late) == hipSuccess) {
-        late_pending = false;
-        if (h_late[0]) {
-            set_error("the previous forward's tile partition failed its self-check (flags 0x%x); its output was invalid", h_late[0]);
-            h_late[0] = 0;
-            return DAS3R_ERR_HIP;
-        }
-    }
+    Mailbox *mb = nullptr;
+    if ((rc = mailbox_get(&mb))) return rc;
+    static thread_local uint32_t late_tag = 0;   // tag of the forward whose self-check word has not been examined yet
+    auto check_late = [&](bool wait) -> int {
+        if (!late_tag) return DAS3R_OK;
+        if (wait) { int r = mailbox_wait(mb, 9, late_tag, s); if (r) return r; }
+        if (__atomic_load_n(&mb->host[9], __ATOMIC_ACQUIRE) != late_tag) return DAS3R_OK;   // not there yet: look again next time
+        late_tag = 0;
+        const uint32_t flags = mb->host[8];
+        if (flags) { set_error("a forward's tile partition failed its self-check (flags 0x%x); its output was invalid", flags); return DAS3R_ERR_HIP; }
+        return DAS3R_OK;
+    };
+    if ((rc = check_late(false))) return rc;
     // hinted path: the binning buffer can be allocated up front, and its control words are zeroed by the preprocess kernel
     // instead of a separate memset
     bool binning_ready = false;
@@ -209,26 +243,18 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     // num_rendered comes out of the scan of tiles_touched.  Without a capacity hint the scan runs alone and the host waits
     // for its 8-byte result (upstream does the same) before sizing the binning buffer; with a hint the scan is fused with
     // the instance emission, everything is enqueued first and the count is only collected afterwards.
-    static thread_local uint32_t *h_count = nullptr;
-    static thread_local hipEvent_t ev_count = nullptr;
-    if (!h_count) HIP_TRY(hipHostMalloc((void **)&h_count, 64, hipHostMallocDefault));
-    if (!ev_count) HIP_TRY(hipEventCreateWithFlags(&ev_count, hipEventDisableTiming));
     int64_t cap = a->capacity_hint > 0 ? a->capacity_hint : -1, I = -1;
     bool scanned = false;
-    auto collect_count = [&]() -> int {
-        HIP_TRY(hipMemcpyAsync(h_count, saved->geom + L.g_count, 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipEventRecord(ev_count, s));
-        return DAS3R_OK;
-    };
+    uint32_t count_tag = 0;
     for (int attempt = 0; attempt < 2; attempt++) {
         if ((cap < 0 || !use_onesweep()) && !scanned) {
-            if ((rc = launch_scan(P, saved->geom, L, a->debug != 0, s))) return rc;
-            if ((rc = collect_count())) return rc;
+            count_tag = ++mb->seq ? mb->seq : ++mb->seq;
+            if ((rc = launch_scan(P, saved->geom, L, mb->dev, count_tag, a->debug != 0, s))) return rc;
             scanned = true;
         }
         if (cap < 0) {  // exact sizing: wait for the count now
-            HIP_TRY(hipEventSynchronize(ev_count));
-            I = (int64_t)h_count[0];
+            if ((rc = mailbox_wait(mb, 2, count_tag, s))) return rc;
+            I = (int64_t)mb->host[0];
             cap = I;
         }
         if (cap > (int64_t)0x7FFFFF00) { set_error("num_rendered %lld exceeds 2^31", (long long)cap); return DAS3R_ERR_OVERFLOW; }
@@ -239,32 +265,27 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         }
         const bool fused_scan = !scanned;
         if (fused_scan) {   // the count leaves right behind the scan, ahead of the partition passes
-            if ((rc = launch_binning_scan_emit(P, cap, out->radii, saved->geom, saved->binning, L, binning_ready && attempt == 0, a->debug != 0, s))) return rc;
-            if ((rc = collect_count())) return rc;
+            count_tag = ++mb->seq ? mb->seq : ++mb->seq;
+            if ((rc = launch_binning_scan_emit(P, cap, out->radii, saved->geom, saved->binning, L, binning_ready && attempt == 0, mb->dev,
+                                               count_tag, a->debug != 0, s))) return rc;
             scanned = true;
         }
-        if ((rc = launch_binning(P, cap, W, H, out->radii, saved->geom, saved->binning, saved->img, L, fused_scan, a->debug != 0, s))) return rc;
+        if (cap > 0) {
+            if ((rc = check_late(true))) return rc;   // one self-check word in flight at a time (only ever waits on a redo)
+            late_tag = ++mb->seq ? mb->seq : ++mb->seq;
+        }
+        if ((rc = launch_binning(P, cap, W, H, out->radii, saved->geom, saved->binning, saved->img, L, fused_scan, mb->dev + 8, late_tag,
+                                 a->debug != 0, s))) return rc;
         if ((rc = launch_render_forward(a, in->colors_precomp, out->out_color, saved->geom, saved->binning, saved->img, L, s))) return rc;
         if (I < 0) {  // hinted path: everything is enqueued; now collect the count (available since the scan finished)
-            HIP_TRY(hipEventSynchronize(ev_count));
-            I = (int64_t)h_count[0];
+            if ((rc = mailbox_wait(mb, 2, count_tag, s))) return rc;
+            I = (int64_t)mb->host[0];
         }
-        if (h_count[1] != 0) { set_error("radix look-back timed out (flags 0x%x)", h_count[1]); return DAS3R_ERR_HIP; }
+        if (mb->host[1] != 0) { set_error("radix look-back timed out (flags 0x%x)", mb->host[1]); return DAS3R_ERR_HIP; }
         if (I <= cap) break;
         cap = -1;  // hint too small: lists were truncated, redo binning + render with the exact size
     }
-    if (use_onesweep()) {
-        if (late_pending) HIP_TRY(hipEventSynchronize(ev_late));   // rare: the previous copy has not landed yet
-        if (late_pending && h_late[0]) { late_pending = false; set_error("an earlier forward's tile partition failed its self-check (flags 0x%x)", h_late[0]); h_late[0] = 0; return DAS3R_ERR_HIP; }
-        HIP_TRY(hipMemcpyAsync(h_late, (const uint32_t *)(saved->geom + L.g_ticket) + 8, 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipEventRecord(ev_late, s));
-        late_pending = true;
-        if (a->debug) {
-            HIP_TRY(hipEventSynchronize(ev_late));
-            late_pending = false;
-            if (h_late[0]) { set_error("tile partition self-check failed (flags 0x%x)", h_late[0]); h_late[0] = 0; return DAS3R_ERR_HIP; }
-        }
-    }
+    if (a->debug && (rc = check_late(true))) return rc;   // debug: report this forward's self-check word right away
     saved->num_rendered = I;
     saved->capacity = cap;
     return I;

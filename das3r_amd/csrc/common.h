@@ -104,12 +104,13 @@ int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int
 int launch_mark_visible(int P, const float *means3D, const float *viewmatrix, uint8_t *present, hipStream_t s);
 int launch_depth_sort(int P, char *geom, const Layout &L, bool debug, hipStream_t s);
 // scan of tiles_touched in depth order -> offsets / off_by_gid / count (exact path: the host then reads the count)
-int launch_scan(int P, char *geom, const Layout &L, bool debug, hipStream_t s);
+int launch_scan(int P, char *geom, const Layout &L, uint32_t *host_out, uint32_t tag, bool debug, hipStream_t s);
 // the same scan with the instance emission fused in (hinted path; sort_onesweep.hip)
-int launch_scan_emit(int P, int64_t cap, const int32_t *radii, char *geom, char *binning, const Layout &L, bool debug, hipStream_t s);
+int launch_scan_emit(int P, int64_t cap, const int32_t *radii, char *geom, char *binning, const Layout &L, uint32_t *host_out, uint32_t tag,
+                     bool debug, hipStream_t s);
 size_t scan_status_bytes(int P);
-int launch_binning_scan_emit(int P, int64_t I, const int32_t *radii, char *geom, char *binning, const Layout &L, bool ctrl_zeroed, bool debug,
-                             hipStream_t s);
+int launch_binning_scan_emit(int P, int64_t I, const int32_t *radii, char *geom, char *binning, const Layout &L, bool ctrl_zeroed,
+                             uint32_t *host_out, uint32_t tag, bool debug, hipStream_t s);
 size_t onesweep_status_bytes(int64_t n, int passes);
 int launch_onesweep_depth_sort(int P, char *geom, const Layout &L, bool debug, hipStream_t s);
 int launch_onesweep_partition(int64_t cap, char *geom, char *binning, const Layout &L, uint32_t **keys_final, bool debug, hipStream_t s);
@@ -118,8 +119,9 @@ int launch_render_forward_rows(const das3r_raster_args *a, float *out_color, cha
                                hipStream_t s);
 bool use_onesweep();  // DAS3R_SORT=classic selects the three-kernel radix passes (diagnostics / A-B)
 bool use_tight_rect();  // DAS3R_RECT=upstream bins over upstream's 3-sigma square (bit-exact list tests)
+// host_late / tag: pinned mailbox the last binning kernel copies the self-check word to (see api.hip)
 int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *geom, char *binning, char *img, const Layout &L,
-                   bool fused_scan, bool debug, hipStream_t s);
+                   bool fused_scan, uint32_t *host_late, uint32_t tag, bool debug, hipStream_t s);
 int launch_render_forward(const das3r_raster_args *a, const float *colors_precomp, float *out_color, char *geom, char *binning,
                           char *img, const Layout &L, hipStream_t s);
 // partial: [num_rendered, 9] per-instance sums written by the render backward, gathered by the preprocess backward

@@ -129,7 +129,8 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
 #pragma unroll
                     for (int q = 0; q < NACC; q++) out = lane == q ? tot[q] : out;
                 }
-                if (writer) atomicAdd(&acc[j * NACC + widx], out);  // divergent addresses: one ds_add_f32 for the whole wave
+                if (ablate & 8) { if (writer) acc[j * NACC + widx] = out; }   // timing experiment: plain store instead of the atomic
+                else if (writer) atomicAdd(&acc[j * NACC + widx], out);  // divergent addresses: one ds_add_f32 for the whole wave
             }
         }
         __syncthreads();

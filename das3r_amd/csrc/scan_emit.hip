@@ -43,7 +43,7 @@ template <bool EMIT, int SCAN_ITEMS>
 __global__ void __launch_bounds__(256) scan_emit_kernel(
     int P, const uint32_t *__restrict__ sorted_idx, const uint32_t *__restrict__ tiles_touched, uint32_t *__restrict__ offsets,
     uint32_t *__restrict__ off_by_gid, uint32_t *__restrict__ count, u64 *__restrict__ status, u64 *__restrict__ group_status,
-    uint32_t *__restrict__ ticket, uint32_t *__restrict__ err,
+    uint32_t *__restrict__ ticket, uint32_t *__restrict__ err, uint32_t *__restrict__ host_out /*pinned host mailbox*/, uint32_t tag,
     // emission (EMIT only)
     int tiles_x, int tiles_y, const float4 *__restrict__ xyh, const int32_t *__restrict__ radii, uint32_t *__restrict__ tile_keys,
     uint32_t *__restrict__ gids, uint32_t cap, uint32_t *__restrict__ ghist /*[passes][256]*/, int tbits, int tight_rect) {
@@ -117,8 +117,14 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
         carry += tot;
     }
     if (b == gridDim.x - 1 && tid == 0) {
+        const uint32_t flags = *err;   // look-back timeout flags of the depth sort / this scan travel with the count
         count[0] = carry;
-        count[1] = *err;   // look-back timeout flags of the depth sort / this scan travel with the count
+        count[1] = flags;
+        // the host polls a pinned mailbox instead of waiting for a copy + event: count and flags first, then the tag of this
+        // call with system-scope release semantics
+        host_out[0] = carry;
+        host_out[1] = flags;
+        __hip_atomic_store(host_out + 2, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (EMIT) {
         __syncthreads();
@@ -147,9 +153,9 @@ size_t scan_status_bytes(int P) {
     P, (const uint32_t *)(geom + L.pub.sorted_idx), (const uint32_t *)(geom + L.pub.tiles_touched),                          \
         (uint32_t *)(geom + L.pub.offsets), (uint32_t *)(geom + L.g_off_by_gid), (uint32_t *)(geom + L.g_count),             \
         (u64 *)(geom + L.g_scan_status), (u64 *)(geom + L.g_scan_status) + nblocks, (uint32_t *)(geom + L.g_ticket) + 16,   \
-        (uint32_t *)(geom + L.g_ticket) + 8
+        (uint32_t *)(geom + L.g_ticket) + 8, host_out, tag
 
-int launch_scan(int P, char *geom, const Layout &L, bool debug, hipStream_t s) {
+int launch_scan(int P, char *geom, const Layout &L, uint32_t *host_out, uint32_t tag, bool debug, hipStream_t s) {
     const int nblocks = scan_blocks(P);
 #define GO(IT)                                                                                                               \
     DAS3R_LAUNCH((scan_emit_kernel<false, IT>), dim3(nblocks), dim3(256), 0, s, SCAN_COMMON, 0, 0, (const float4 *)nullptr,    \
@@ -160,7 +166,8 @@ int launch_scan(int P, char *geom, const Layout &L, bool debug, hipStream_t s) {
     return DAS3R_OK;
 }
 
-int launch_scan_emit(int P, int64_t cap, const int32_t *radii, char *geom, char *binning, const Layout &L, bool debug, hipStream_t s) {
+int launch_scan_emit(int P, int64_t cap, const int32_t *radii, char *geom, char *binning, const Layout &L, uint32_t *host_out, uint32_t tag,
+                     bool debug, hipStream_t s) {
     const int nblocks = scan_blocks(P);
 #define GO(IT)                                                                                                               \
     DAS3R_LAUNCH((scan_emit_kernel<true, IT>), dim3(nblocks), dim3(256), 0, s, SCAN_COMMON, L.tiles_x, L.tiles_y,              \

@@ -236,9 +236,14 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, int tiles
 }
 
 __global__ void __launch_bounds__(256) tile_ranges_kernel(uint32_t cap, const uint32_t *__restrict__ n_ptr,
-                                                          const uint32_t *__restrict__ tile_keys, uint2 *__restrict__ ranges) {
+                                                          const uint32_t *__restrict__ tile_keys, uint2 *__restrict__ ranges,
+                                                          const uint32_t *__restrict__ err, uint32_t *__restrict__ host_late, uint32_t tag) {
     const uint32_t I = n_ptr ? min(*n_ptr, cap) : cap;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && host_late) {   // last binning kernel: hand the self-check word of this forward to the host mailbox
+        host_late[0] = *err;
+        __hip_atomic_store(host_late + 1, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (i >= I) return;
     const uint32_t t = tile_keys[i];
     if (i == 0) ranges[t].x = 0;
@@ -270,16 +275,16 @@ int launch_depth_sort(int P, char *geom, const Layout &L, bool debug, hipStream_
 
 // Hinted path, first half of the binning: zero the control words, then scan + emit in one kernel.  The caller copies the
 // count back right behind it and then calls launch_binning(..., fused_scan = true) for the partition.
-int launch_binning_scan_emit(int P, int64_t I, const int32_t *radii, char *geom, char *binning, const Layout &L, bool ctrl_zeroed, bool debug,
-                             hipStream_t s) {
+int launch_binning_scan_emit(int P, int64_t I, const int32_t *radii, char *geom, char *binning, const Layout &L, bool ctrl_zeroed,
+                             uint32_t *host_out, uint32_t tag, bool debug, hipStream_t s) {
     if (I == 0 || P == 0) return DAS3R_OK;
     if (!ctrl_zeroed) HIP_TRY(hipMemsetAsync(binning + L.b_ghist, 0, L.b_ctrl_bytes, s));
-    return launch_scan_emit(P, I, radii, geom, binning, L, debug, s);
+    return launch_scan_emit(P, I, radii, geom, binning, L, host_out, tag, debug, s);
 }
 
 // I = capacity of the binning buffer; the true instance count is read by the kernels from geom + L.g_count
 int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *geom, char *binning, char *img, const Layout &L,
-                   bool fused_scan, bool debug, hipStream_t s) {
+                   bool fused_scan, uint32_t *host_late, uint32_t tag, bool debug, hipStream_t s) {
     const uint32_t *n_ptr = (const uint32_t *)(geom + L.g_count);
     (void)W; (void)H;
     uint2 *ranges = (uint2 *)(img + L.pub.ranges);  // zeroed by preprocess_kernel
@@ -302,7 +307,8 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
         uint32_t *kfinal = nullptr;
         int rc1 = launch_onesweep_partition(I, geom, binning, L, &kfinal, debug, s);
         if (rc1) return rc1;
-        DAS3R_LAUNCH(tile_ranges_kernel, dim3(div_up(I, 256)), dim3(256), 0, s, (uint32_t)I, n_ptr, kfinal, ranges);
+        DAS3R_LAUNCH(tile_ranges_kernel, dim3(div_up(I, 256)), dim3(256), 0, s, (uint32_t)I, n_ptr, kfinal, ranges,
+                     (const uint32_t *)(geom + L.g_ticket) + 8, host_late, tag);
         KERNEL_CHECK(s, debug, "tile_ranges");
         return DAS3R_OK;
     }
@@ -321,7 +327,8 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
         vout = (vout == valB) ? valA : valB;
     }
     // kin/vin now hold the partitioned (tile id, gaussian id) lists; vin == binning + pub.point_list by construction
-    DAS3R_LAUNCH(tile_ranges_kernel, dim3(div_up(I, 256)), dim3(256), 0, s, (uint32_t)I, n_ptr, kin, ranges);
+    DAS3R_LAUNCH(tile_ranges_kernel, dim3(div_up(I, 256)), dim3(256), 0, s, (uint32_t)I, n_ptr, kin, ranges,
+                 (const uint32_t *)(geom + L.g_ticket) + 8, host_late, tag);
     KERNEL_CHECK(s, debug, "tile_ranges");
     return DAS3R_OK;
 }
