@@ -31,8 +31,8 @@ WORKLOAD_DESC = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default=os.environ.get("DAS3R_BENCH_WORKLOAD", "c2"), choices=sorted(WORKLOAD_DESC))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
