@@ -142,7 +142,9 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     xyh[(size_t)idx * SPLAT_REC] = xy_out;            // three fields of the Gaussian's 64-byte record
     conic_opacity[(size_t)idx * SPLAT_REC] = co_out;
     rgbd[(size_t)idx * SPLAT_REC] = rgbd_out;
-    rgbd[(size_t)idx * SPLAT_REC + 1] = make_float4(0.f, 0.f, 0.f, 0.f);   // pad: the whole 64-byte line is written (no partial-line write-back)
+    // fourth float4 of the record: (radius, tiles_touched) for the scan/emit kernel, which walks the splats in depth order and
+    // would otherwise pay three random cache lines per splat (record, radii[], tiles_touched[]); the whole line is written
+    rgbd[(size_t)idx * SPLAT_REC + 1] = make_float4(__int_as_float(radius_out), __uint_as_float(tiles_out), 0.f, 0.f);
     clamped[idx] = clamp_out;
 }
 

@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
         const int r = base + k * 256 + tid;
-        v[k] = r < P ? tiles_touched[g[k]] : 0u;
+        v[k] = r < P ? __float_as_uint(xyh[(size_t)g[k] * SPLAT_REC + 3].y) : 0u;   // tiles_touched, from the splat's 64-byte record
         sum += v[k];
     }
     uint32_t total;
@@ -97,8 +97,9 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
             off_by_gid[g[k]] = o;   // first emission slot of splat g (its instances are emitted contiguously)
             if (EMIT && v[k] != 0u) {
                 const float4 p = xyh[(size_t)g[k] * SPLAT_REC];
+                const int radius = __float_as_int(xyh[(size_t)g[k] * SPLAT_REC + 3].x);
                 int rminx, rminy, rmaxx, rmaxy;
-                binned_rect(p, radii[g[k]], tiles_x, tiles_y, tight_rect != 0, rminx, rminy, rmaxx, rmaxy);
+                binned_rect(p, radius, tiles_x, tiles_y, tight_rect != 0, rminx, rminy, rmaxx, rmaxy);
                 for (int y = rminy; y < rmaxy; y++)
                     for (int x = rminx; x < rmaxx; x++) {
                         if (o < cap) {   // cap < num_rendered only when the capacity hint was too small (the binning is then redone)
@@ -158,7 +159,8 @@ size_t scan_status_bytes(int P) {
 int launch_scan(int P, char *geom, const Layout &L, uint32_t *host_out, uint32_t tag, bool debug, hipStream_t s) {
     const int nblocks = scan_blocks(P);
 #define GO(IT)                                                                                                               \
-    DAS3R_LAUNCH((scan_emit_kernel<false, IT>), dim3(nblocks), dim3(256), 0, s, SCAN_COMMON, 0, 0, (const float4 *)nullptr,    \
+    DAS3R_LAUNCH((scan_emit_kernel<false, IT>), dim3(nblocks), dim3(256), 0, s, SCAN_COMMON, 0, 0,                            \
+                 (const float4 *)(geom + L.pub.xy),                                                                           \
                  (const int32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (uint32_t *)nullptr, 0, 0)
     switch (scan_items(P)) { case 1: GO(1); break; case 2: GO(2); break; case 4: GO(4); break; case 8: GO(8); break; default: GO(16); }
 #undef GO
