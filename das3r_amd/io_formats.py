@@ -1,0 +1,296 @@
+"""On-disk formats either side of the hot path, restated so that the per-sequence farm runs without
+plyfile / evo / open3d.  Host-side, numpy only (PIL for the PNG frames).
+
+Input side — what DAS3R's preprocessing leaves in a sequence directory (/root/reference/utils/rearrange.py:44-133) and its
+loader reads back (/root/reference/scene/dataset_readers.py:107-227, scene/colmap_loader.py:43-66,156-178,244-272):
+    images/frame_%04d.png   sparse/0/cameras.txt   sparse/0/images.txt   pred_traj.txt (TUM)   pred_intrinsics.txt
+    depth_maps/frame_%04d.npy   confidence_maps/conf_%04d.npy   dyna_avg/dyna_avg_%04d.npy   dynamic_masks/dynamic_mask_%04d.png
+Output side — the extended 3DGS PLY (/root/reference/scene/gaussian_model.py:326-364, read back at :371-418) and the optimised
+poses pose/pose_N.npy (/root/reference/train_gui.py:467-480).
+Pinned by tests/golden/ref_formats.npz (reference colmap_loader / pose_utils run on seeded inputs) and round trips."""
+import os
+
+import numpy as np
+
+
+# ---- quaternions / rotations ------------------------------------------------------------------------------------------
+def qvec2rotmat(q):
+    """COLMAP convention, q = (w, x, y, z) (scene/colmap_loader.py:43-53)."""
+    w, x, y, z = (float(v) for v in q)
+    return np.array([[1 - 2 * y * y - 2 * z * z, 2 * x * y - 2 * w * z, 2 * z * x + 2 * w * y],
+                     [2 * x * y + 2 * w * z, 1 - 2 * x * x - 2 * z * z, 2 * y * z - 2 * w * x],
+                     [2 * z * x - 2 * w * y, 2 * y * z + 2 * w * x, 1 - 2 * x * x - 2 * y * y]])
+
+
+def rotmat2qvec(R):
+    """Largest-eigenvector method of COLMAP's read_write_model (scene/colmap_loader.py:55-66); w >= 0."""
+    Rxx, Ryx, Rzx, Rxy, Ryy, Rzy, Rxz, Ryz, Rzz = np.asarray(R, dtype=np.float64).flat
+    K = np.array([[Rxx - Ryy - Rzz, 0, 0, 0], [Ryx + Rxy, Ryy - Rxx - Rzz, 0, 0], [Rzx + Rxz, Rzy + Ryz, Rzz - Rxx - Ryy, 0],
+                  [Ryz - Rzy, Rzx - Rxz, Rxy - Ryx, Rxx + Ryy + Rzz]]) / 3.0
+    vals, vecs = np.linalg.eigh(K)
+    q = vecs[[3, 0, 1, 2], np.argmax(vals)]
+    return -q if q[0] < 0 else q
+
+
+def rotation_to_quat_wxyz(R):
+    """Branching trace method used when the preprocessing writes images.txt (utils/rearrange.py:314-352) -> (w, x, y, z)."""
+    m = np.asarray(R, dtype=np.float64)
+    tr = m[0, 0] + m[1, 1] + m[2, 2]
+    if tr > 0:
+        s = 0.5 / np.sqrt(tr + 1.0)
+        return np.array([0.25 / s, (m[2, 1] - m[1, 2]) * s, (m[0, 2] - m[2, 0]) * s, (m[1, 0] - m[0, 1]) * s])
+    if m[0, 0] > m[1, 1] and m[0, 0] > m[2, 2]:
+        s = np.sqrt(1.0 + m[0, 0] - m[1, 1] - m[2, 2]) * 2
+        return np.array([(m[2, 1] - m[1, 2]) / s, 0.25 * s, (m[0, 1] + m[1, 0]) / s, (m[0, 2] + m[2, 0]) / s])
+    if m[1, 1] > m[2, 2]:
+        s = np.sqrt(1.0 + m[1, 1] - m[0, 0] - m[2, 2]) * 2
+        return np.array([(m[0, 2] - m[2, 0]) / s, (m[0, 1] + m[1, 0]) / s, 0.25 * s, (m[1, 2] + m[2, 1]) / s])
+    s = np.sqrt(1.0 + m[2, 2] - m[0, 0] - m[1, 1]) * 2
+    return np.array([(m[1, 0] - m[0, 1]) / s, (m[0, 2] + m[2, 0]) / s, (m[1, 2] + m[2, 1]) / s, 0.25 * s])
+
+
+def matrix_to_quat_wxyz(R):
+    """pytorch3d's matrix_to_quaternion as used for the trainable pose tensors (utils/pose_utils.py:117-181 rotation2quad):
+    candidates from the four |q_i|, the best-conditioned one is kept.  R: (..., 3, 3) -> (..., 4), real part first."""
+    m = np.asarray(R, dtype=np.float64)
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = [m[..., i, j] for i in range(3) for j in range(3)]
+    q_abs = np.sqrt(np.maximum(np.stack([1 + m00 + m11 + m22, 1 + m00 - m11 - m22, 1 - m00 + m11 - m22, 1 - m00 - m11 + m22], -1), 0.0))
+    cand = np.stack([np.stack([q_abs[..., 0] ** 2, m21 - m12, m02 - m20, m10 - m01], -1),
+                     np.stack([m21 - m12, q_abs[..., 1] ** 2, m10 + m01, m02 + m20], -1),
+                     np.stack([m02 - m20, m10 + m01, q_abs[..., 2] ** 2, m12 + m21], -1),
+                     np.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[..., 3] ** 2], -1)], -2)
+    cand = cand / (2.0 * np.maximum(q_abs[..., None], 0.1))
+    best = np.argmax(q_abs, -1)
+    return np.take_along_axis(cand, best[..., None, None], -2)[..., 0, :]
+
+
+# ---- pred_traj.txt / pred_intrinsics.txt --------------------------------------------------------------------------------
+def read_tum_trajectory(path):
+    """TUM trajectory: `timestamp tx ty tz qx qy qz qw` per line, '#' comments -> (timestamps, xyz[N,3], quat_wxyz[N,4])."""
+    rows = [ln.split() for ln in open(path) if ln.strip() and not ln.lstrip().startswith("#")]
+    a = np.array(rows, dtype=np.float64).reshape(-1, 8)
+    return a[:, 0], a[:, 1:4], a[:, [7, 4, 5, 6]]
+
+
+def write_tum_trajectory(path, timestamps, xyz, quat_wxyz):
+    q = np.asarray(quat_wxyz)
+    with open(path, "w") as f:
+        for t, p, r in zip(timestamps, xyz, q):
+            f.write(" ".join(repr(float(v)) for v in (t, p[0], p[1], p[2], r[1], r[2], r[3], r[0])) + "\n")
+
+
+def tumpose_to_c2w(pose7):
+    """(x, y, z, qw, qx, qy, qz) -> 4x4 camera-to-world exactly as DAS3R builds `original_pose` (utils/rearrange.py:251-273,
+    scene/dataset_readers.py:119-123): the reference hands (qx, qy, qz, qw) to a real-part-FIRST quaternion_to_matrix, i.e. the
+    rotation is that of the quaternion (real = qx, i = qy, j = qz, k = qw).  Kept as is: the Gaussians are initialised from it."""
+    x, y, z, qw, qx, qy, qz = (float(v) for v in pose7)
+    r, i, j, k = qx, qy, qz, qw
+    two_s = 2.0 / (r * r + i * i + j * j + k * k)
+    R = np.array([[1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r)],
+                  [two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r)],
+                  [two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)]])
+    c2w = np.eye(4)
+    c2w[:3, :3] = R
+    c2w[:3, 3] = (x, y, z)
+    return c2w
+
+
+def read_pred_intrinsics(path):
+    """One flattened 3x3 K per frame and line (utils/rearrange.py:69-70)."""
+    return np.loadtxt(path, dtype=np.float32).reshape(-1, 3, 3)
+
+
+# ---- COLMAP text model --------------------------------------------------------------------------------------------------
+def read_colmap_cameras_text(path):
+    """-> {camera_id: dict(model, width, height, params)}; PINHOLE only, like scene/colmap_loader.py:156-178."""
+    cams = {}
+    for ln in open(path):
+        ln = ln.strip()
+        if not ln or ln[0] == "#":
+            continue
+        e = ln.split()
+        if e[1] != "PINHOLE":
+            raise ValueError("While the loader support other types, the rest of the code assumes PINHOLE")
+        cams[int(e[0])] = dict(model=e[1], width=int(e[2]), height=int(e[3]), params=np.array([float(v) for v in e[4:]]))
+    return cams
+
+
+def read_colmap_images_text(path):
+    """-> {image_id: dict(qvec (w,x,y,z), tvec, camera_id, name)}; every image line is followed by its (possibly empty)
+    points2D line (scene/colmap_loader.py:244-272)."""
+    images = {}
+    with open(path) as f:
+        while True:
+            ln = f.readline()
+            if not ln:
+                break
+            ln = ln.strip()
+            if not ln or ln[0] == "#":
+                continue
+            e = ln.split()
+            images[int(e[0])] = dict(qvec=np.array([float(v) for v in e[1:5]]), tvec=np.array([float(v) for v in e[5:8]]),
+                                     camera_id=int(e[8]), name=e[9])
+            f.readline()   # points2D
+    return images
+
+
+def write_colmap_cameras_text(path, ori_size, intrinsics):
+    """utils/rearrange.py:286-295: one PINHOLE camera per frame, ids from 1; the principal point is moved to the image centre
+    and BOTH focals are rescaled by width/2 / cx (sic)."""
+    width, height = ori_size
+    with open(path, "w") as f:
+        for i, K in enumerate(intrinsics, 1):
+            sx = width / 2 / K[0, 2]
+            f.write(f"{i} PINHOLE {width} {height} {K[0, 0] * sx} {K[1, 1] * sx} {width / 2} {height / 2}\n")
+
+
+def write_colmap_images_text(path, poses_c2w, names):
+    """utils/rearrange.py:275-284: world-to-camera (inverse of the given camera-to-world) as `id qw qx qy qz tx ty tz id name`
+    followed by an empty points2D line."""
+    with open(path, "w") as f:
+        for i, c2w in enumerate(poses_c2w, 1):
+            w2c = np.linalg.inv(c2w)
+            q, t = rotation_to_quat_wxyz(w2c[:3, :3]), w2c[:3, 3]
+            f.write(f"{i} {q[0]} {q[1]} {q[2]} {q[3]} {t[0]} {t[1]} {t[2]} {i} {names[i - 1]}\n\n")
+
+
+# ---- sequence directory -> tensors of SplatModel.create_from_frames -------------------------------------------------------
+def load_sequence(seq_dir, device="cpu"):
+    """Read a preprocessed DAS3R sequence directory into the layout das3r_amd.model.SplatModel.create_from_frames takes:
+    images [F,3,H,W] in [0,1], depths / confs / dyna_avg [F,H,W], K [F,3,3] (focals of cameras.txt, principal point at the
+    image centre: scene/gaussian_model.py:587-596), cam2world [F,4,4] (tumpose_to_c2w of pred_traj.txt), w2c_pose7 [F,7]
+    (quaternion via matrix_to_quat_wxyz of the images.txt rotation + tvec: scene/gaussian_model.py:149-161), plus names and the
+    optional predicted dynamic masks.  Frames are ordered by COLMAP image id."""
+    import torch
+    from PIL import Image
+    cams = read_colmap_cameras_text(os.path.join(seq_dir, "sparse/0/cameras.txt"))
+    imgs = read_colmap_images_text(os.path.join(seq_dir, "sparse/0/images.txt"))
+    _, xyz, quat = read_tum_trajectory(os.path.join(seq_dir, "pred_traj.txt"))
+    out = dict(images=[], depths=[], confs=[], dyna_avg=[], K=[], cam2world=[], w2c_pose7=[], names=[], dynamic_masks=[])
+    for iid in sorted(imgs):
+        im, cam = imgs[iid], cams[imgs[iid]["camera_id"]]
+        name = os.path.basename(im["name"])
+        idx = name.split(".")[0].split("_")[-1]
+        rgb = np.asarray(Image.open(os.path.join(seq_dir, "images", name)).convert("RGB"), dtype=np.float32) / 255.0
+        out["images"].append(rgb.transpose(2, 0, 1))
+        out["depths"].append(np.load(os.path.join(seq_dir, "depth_maps", f"frame_{idx}.npy")).astype(np.float32))
+        out["confs"].append(np.load(os.path.join(seq_dir, "confidence_maps", f"conf_{idx}.npy")).astype(np.float32))
+        out["dyna_avg"].append(np.load(os.path.join(seq_dir, "dyna_avg", f"dyna_avg_{idx}.npy")).astype(np.float32))
+        fx, fy = cam["params"][0], cam["params"][1]
+        out["K"].append(np.array([[fx, 0, cam["width"] / 2], [0, fy, cam["height"] / 2], [0, 0, 1]], dtype=np.float32))
+        out["cam2world"].append(tumpose_to_c2w(np.concatenate([xyz[int(idx)], quat[int(idx)]])).astype(np.float32))
+        Rw2c = qvec2rotmat(im["qvec"])
+        out["w2c_pose7"].append(np.concatenate([matrix_to_quat_wxyz(Rw2c), im["tvec"]]).astype(np.float32))
+        out["names"].append(name)
+        mpath = os.path.join(seq_dir, "dynamic_masks", f"dynamic_mask_{idx}.png")
+        out["dynamic_masks"].append((np.asarray(Image.open(mpath)) / 255.0 > 0.5) if os.path.exists(mpath) else None)
+    res = {k: torch.from_numpy(np.stack(v)).to(device) for k, v in out.items() if k not in ("names", "dynamic_masks")}
+    res["names"], res["dynamic_masks"] = out["names"], out["dynamic_masks"]
+    res["W"], res["H"], res["focal"] = int(res["images"].shape[3]), int(res["images"].shape[2]), float(res["K"][0, 0, 0])
+    return res
+
+
+# ---- extended 3DGS PLY ----------------------------------------------------------------------------------------------------
+def ply_attribute_names(n_dc, n_rest, n_scale=3, n_rot=4):
+    """Property order of the reference's save_ply (scene/gaussian_model.py:326-341)."""
+    return (["x", "y", "z", "nx", "ny", "nz"] + [f"f_dc_{i}" for i in range(n_dc)] + [f"f_rest_{i}" for i in range(n_rest)] +
+            ["opacity_ori", "opacity", "conf_static"] + [f"scale_{i}" for i in range(n_scale)] + [f"rot_{i}" for i in range(n_rot)])
+
+
+def save_gaussians_ply(path, xyz, features_dc, features_rest, opacity_raw, scaling, rotation, conf_static_per_gaussian):
+    """Write what GaussianModel.save_ply writes (scene/gaussian_model.py:343-364), binary little-endian float32, one `vertex`
+    element: features as [P,K,3] tensors are stored channel-major (transpose(1,2).flatten), `opacity_ori` is the raw logit,
+    `opacity` = inverse_sigmoid(sigmoid(opacity_ori) * conf_static), normals are zero."""
+    to = lambda t: np.asarray(t.detach().cpu().numpy() if hasattr(t, "detach") else t, dtype=np.float32)
+    xyz, opacity_raw, scaling, rotation = to(xyz), to(opacity_raw).reshape(-1, 1), to(scaling), to(rotation)
+    conf = to(conf_static_per_gaussian).reshape(-1, 1)
+    f_dc = to(features_dc).transpose(0, 2, 1).reshape(xyz.shape[0], -1)
+    f_rest = to(features_rest).transpose(0, 2, 1).reshape(xyz.shape[0], -1)
+    sig = 1.0 / (1.0 + np.exp(-opacity_raw.astype(np.float32)))
+    o = (sig * conf).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        opacity = np.log(o / (1 - o)).astype(np.float32)
+    table = np.concatenate([xyz, np.zeros_like(xyz), f_dc, f_rest, opacity_raw, opacity, conf, scaling, rotation], axis=1).astype("<f4")
+    names = ply_attribute_names(f_dc.shape[1], f_rest.shape[1], scaling.shape[1], rotation.shape[1])
+    assert table.shape[1] == len(names)
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    header = "ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % xyz.shape[0]
+    header += "".join(f"property float {n}\n" for n in names) + "end_header\n"
+    with open(path, "wb") as f:
+        f.write(header.encode("ascii"))
+        f.write(np.ascontiguousarray(table).tobytes())
+
+
+def read_ply_vertices(path):
+    """Minimal PLY reader for single-element `vertex` files with scalar properties (binary little-endian or ascii) ->
+    {property name: 1-D numpy array}."""
+    types = {"float": "<f4", "float32": "<f4", "double": "<f8", "float64": "<f8", "uchar": "u1", "uint8": "u1", "char": "i1",
+             "int8": "i1", "short": "<i2", "int16": "<i2", "ushort": "<u2", "uint16": "<u2", "int": "<i4", "int32": "<i4",
+             "uint": "<u4", "uint32": "<u4"}
+    with open(path, "rb") as f:
+        if f.readline().strip() != b"ply":
+            raise ValueError("not a PLY file")
+        fmt, n, props = None, 0, []
+        while True:
+            ln = f.readline()
+            if not ln:
+                raise ValueError("unterminated PLY header")
+            tok = ln.decode("ascii").split()
+            if not tok or tok[0] == "comment":
+                continue
+            if tok[0] == "format":
+                fmt = tok[1]
+            elif tok[0] == "element":
+                if tok[1] != "vertex" or props:
+                    raise ValueError("only single-element vertex PLY files are supported")
+                n = int(tok[2])
+            elif tok[0] == "property":
+                if tok[1] == "list":
+                    raise ValueError("list properties are not supported")
+                props.append((tok[2], types[tok[1]]))
+            elif tok[0] == "end_header":
+                break
+        dt = np.dtype(props)
+        if fmt == "binary_little_endian":
+            data = np.frombuffer(f.read(n * dt.itemsize), dtype=dt, count=n)
+        elif fmt == "ascii":
+            data = np.loadtxt(f, dtype=np.float64, ndmin=2)[:n]
+            return {name: data[:, i].astype(t) for i, (name, t) in enumerate(props)}
+        else:
+            raise ValueError(f"unsupported PLY format {fmt}")
+    return {name: np.array(data[name]) for name, _ in props}
+
+
+def load_gaussians_ply(path, max_sh_degree=3):
+    """Arrays in the layout GaussianModel.load_ply builds (scene/gaussian_model.py:371-418): xyz [P,3], features_dc [P,1,3],
+    features_rest [P,K-1,3], opacity = `opacity_ori` (the reference renders with it), conf_static [P,1], scaling, rotation."""
+    v = read_ply_vertices(path)
+    P = v["x"].shape[0]
+    rest_names = sorted([k for k in v if k.startswith("f_rest_")], key=lambda s: int(s.split("_")[-1]))
+    if len(rest_names) != 3 * (max_sh_degree + 1) ** 2 - 3:
+        raise ValueError("f_rest_* count does not match the SH degree")
+    col = lambda names: np.stack([v[k] for k in names], 1).astype(np.float32)
+    f_dc = col(["f_dc_0", "f_dc_1", "f_dc_2"]).reshape(P, 3, 1).transpose(0, 2, 1)
+    f_rest = col(rest_names).reshape(P, 3, (max_sh_degree + 1) ** 2 - 1).transpose(0, 2, 1)
+    scale_names = sorted([k for k in v if k.startswith("scale_")], key=lambda s: int(s.split("_")[-1]))
+    rot_names = sorted([k for k in v if k.startswith("rot")], key=lambda s: int(s.split("_")[-1]))
+    return dict(xyz=col(["x", "y", "z"]), features_dc=np.ascontiguousarray(f_dc), features_rest=np.ascontiguousarray(f_rest),
+                opacity=v["opacity_ori"].astype(np.float32)[:, None], opacity_with_conf=v["opacity"].astype(np.float32)[:, None],
+                conf_static=v["conf_static"].astype(np.float32)[:, None], scaling=col(scale_names), rotation=col(rot_names))
+
+
+def save_model_ply(path, model):
+    """GaussianModel.save_ply for das3r_amd.model.SplatModel."""
+    conf = model._conf_static.reshape(-1, 1)[model.aggregated_mask]
+    save_gaussians_ply(path, model._xyz, model._features_dc, model._features_rest, model._opacity, model._scaling, model._rotation, conf)
+
+
+def save_poses_npy(path, pose7_by_colmap_id):
+    """train_gui.py:467-480 save_pose: the optimised (quat, t) tensors turned into 4x4 world-to-camera matrices, ordered by
+    COLMAP image id, as one [N,4,4] array."""
+    import torch
+    from .camera import camera_from_tensor
+    mats = torch.stack([camera_from_tensor(p) for p in pose7_by_colmap_id]).detach().cpu().numpy()
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    np.save(path, mats)
+    return mats

@@ -19,8 +19,8 @@ from .model import OptimParams, SplatModel
 from .render import das3r_render
 
 
-def make_camera(uid, image, focal, W, H, device):
-    fovx, fovy = focal2fov(focal, W), focal2fov(focal, H)
+def make_camera(uid, image, focal, W, H, device, focal_y=None):
+    fovx, fovy = focal2fov(focal, W), focal2fov(focal if focal_y is None else focal_y, H)
     return SimpleNamespace(uid=uid, FoVx=fovx, FoVy=fovy, image_width=W, image_height=H, original_image=image,
                            projection_matrix=projection_matrix(0.01, 100.0, fovx, fovy).transpose(0, 1).to(device))
 
@@ -63,7 +63,7 @@ def train_step(model: SplatModel, cam, opt: OptimParams, iteration, pipe, backgr
     return loss.detach(), psnr_frame.detach(), pkg
 
 
-def train(model, cameras, opt: OptimParams, iterations, pipe=None, background=None, seed=0, log_every=0):
+def train(model, cameras, opt: OptimParams, iterations, pipe=None, background=None, seed=0, log_every=0, fused=False):
     """Random camera without replacement per epoch (train_gui.py:546-555).  Returns dict(loss, psnr, iters_per_s)."""
     pipe = pipe or SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
     dev = model.get_xyz.device
@@ -77,7 +77,7 @@ def train(model, cameras, opt: OptimParams, iterations, pipe=None, background=No
         if not stack:
             stack = list(cameras)
         cam = stack.pop(rng.randint(0, len(stack) - 1))
-        loss, p, _ = train_step(model, cam, opt, it, pipe, background)
+        loss, p, _ = train_step(model, cam, opt, it, pipe, background, fused=fused)
         ema = 0.4 * float(loss) + 0.6 * ema
         last_psnr = float(p)
         if log_every and it % log_every == 0:
@@ -149,5 +149,7 @@ def build_from_sequence(seq, sh_degree=3):
     model = SplatModel(sh_degree).create_from_frames(seq["images"], seq["depths"], seq["confs"], seq["dyna_avg"], seq["K"],
                                                      seq["cam2world"], seq["w2c_pose7"])
     dev = seq["images"].device
-    cams = [make_camera(i, seq["images"][i], seq["focal"], seq["W"], seq["H"], dev) for i in range(seq["images"].shape[0])]
+    K = seq["K"]   # per-frame focals (cameras.txt: scene/dataset_readers.py:139-147); principal point at the image centre
+    cams = [make_camera(i, seq["images"][i], float(K[i, 0, 0]), seq["W"], seq["H"], dev, focal_y=float(K[i, 1, 1]))
+            for i in range(seq["images"].shape[0])]
     return model, cams
