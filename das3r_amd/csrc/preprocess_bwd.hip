@@ -71,7 +71,7 @@ __device__ __forceinline__ void sh_basis(const int D, const float x, const float
     } while (0)
 
 template <bool HAS_SH, bool HAS_COV, bool STAGE_IN, bool STAGE_OUT>
-__global__ void __launch_bounds__(256) preprocess_backward_kernel(
+__global__ void __launch_bounds__(256, 3) preprocess_backward_kernel(
     int P, int D, int M, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
     const float *__restrict__ rotations, const float *__restrict__ shs, const float *__restrict__ cov3D_precomp,
     const float *__restrict__ viewmatrix, const float *__restrict__ projmatrix, const float *__restrict__ campos, int W, int H,
