@@ -210,10 +210,13 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         saved->binning = alloc_binning(user, 256);
         return 0;
     }
-    // The tile partition can only raise its error word after the count has been copied back.  It is collected without
-    // ever blocking the host: copied to pinned memory at the end of this forward and examined at the start of the next one
-    // (debug mode waits for it right away).  Bits: 1 look-back timeout, 2 index out of range (write suppressed), 8 counts
-    // do not add up to the histogram.
+    // Host <-> device hand-offs of one forward (all through the pinned mailbox, no copies, no events):
+    //   * num_rendered (sum of tiles_touched) leaves with the preprocess kernel, five kernels before the device needs it, so
+    //     the binning buffer is always sized exactly and the host practically never waits (upstream blocks on a cudaMemcpy
+    //     in the middle of every forward);
+    //   * the binning self-check word (bit 1 look-back timeout, 2 index out of range -> write suppressed, 8 counts do not
+    //     add up to the histogram) is delivered by the last binning kernel and examined at the start of the NEXT forward
+    //     (debug mode waits for it right away).
     Mailbox *mb = nullptr;
     if ((rc = mailbox_get(&mb))) return rc;
     static thread_local uint32_t late_tag = 0;   // tag of the forward whose self-check word has not been examined yet
@@ -223,68 +226,38 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         if (__atomic_load_n(&mb->host[9], __ATOMIC_ACQUIRE) != late_tag) return DAS3R_OK;   // not there yet: look again next time
         late_tag = 0;
         const uint32_t flags = mb->host[8];
-        if (flags) { set_error("a forward's tile partition failed its self-check (flags 0x%x); its output was invalid", flags); return DAS3R_ERR_HIP; }
+        if (flags) { set_error("a forward's binning failed its self-check (flags 0x%x); its output was invalid", flags); return DAS3R_ERR_HIP; }
         return DAS3R_OK;
     };
     if ((rc = check_late(false))) return rc;
-    // hinted path: the binning buffer can be allocated up front, and its control words are zeroed by the preprocess kernel
-    // instead of a separate memset
-    bool binning_ready = false;
-    if (a->capacity_hint > 0 && use_onesweep() && a->capacity_hint <= (int64_t)0x7FFFFF00) {
-        Layout Lb;
-        compute_layout(P, a->capacity_hint, W, H, &Lb);
-        saved->binning = alloc_binning(user, Lb.pub.binning_bytes);
-        if (!saved->binning) { set_error("scratch allocation failed (binning %zu B)", Lb.pub.binning_bytes); return DAS3R_ERR_ALLOC; }
-        if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, saved->binning + Lb.b_ghist, Lb.b_ctrl_bytes, L, s))) return rc;
-        binning_ready = true;
-    } else if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, nullptr, 0, L, s))) return rc;
-    if ((rc = launch_depth_sort(P, saved->geom, L, a->debug != 0, s))) return rc;
-
-    // num_rendered comes out of the scan of tiles_touched.  Without a capacity hint the scan runs alone and the host waits
-    // for its 8-byte result (upstream does the same) before sizing the binning buffer; with a hint the scan is fused with
-    // the instance emission, everything is enqueued first and the count is only collected afterwards.
-    int64_t cap = a->capacity_hint > 0 ? a->capacity_hint : -1, I = -1;
-    bool scanned = false;
-    uint32_t count_tag = 0;
-    for (int attempt = 0; attempt < 2; attempt++) {
-        if ((cap < 0 || !use_onesweep()) && !scanned) {
-            count_tag = ++mb->seq ? mb->seq : ++mb->seq;
-            if ((rc = launch_scan(P, saved->geom, L, mb->dev, count_tag, a->debug != 0, s))) return rc;
-            scanned = true;
-        }
-        if (cap < 0) {  // exact sizing: wait for the count now
-            if ((rc = mailbox_wait(mb, 2, count_tag, s))) return rc;
-            I = (int64_t)mb->host[0];
-            cap = I;
-        }
-        if (cap > (int64_t)0x7FFFFF00) { set_error("num_rendered %lld exceeds 2^31", (long long)cap); return DAS3R_ERR_OVERFLOW; }
-        compute_layout(P, cap, W, H, &L);
-        if (!(binning_ready && attempt == 0)) {
-            saved->binning = alloc_binning(user, L.pub.binning_bytes);
-            if (!saved->binning) { set_error("scratch allocation failed (binning %zu B)", L.pub.binning_bytes); return DAS3R_ERR_ALLOC; }
-        }
-        const bool fused_scan = !scanned;
-        if (fused_scan) {   // the count leaves right behind the scan, ahead of the partition passes
-            count_tag = ++mb->seq ? mb->seq : ++mb->seq;
-            if ((rc = launch_binning_scan_emit(P, cap, out->radii, saved->geom, saved->binning, L, binning_ready && attempt == 0, mb->dev,
-                                               count_tag, a->debug != 0, s))) return rc;
-            scanned = true;
-        }
-        if (cap > 0) {
-            if ((rc = check_late(true))) return rc;   // one self-check word in flight at a time (only ever waits on a redo)
-            late_tag = ++mb->seq ? mb->seq : ++mb->seq;
-        }
-        if ((rc = launch_binning(P, cap, W, H, out->radii, saved->geom, saved->binning, saved->img, L, fused_scan, mb->dev + 8, late_tag,
-                                 a->debug != 0, s))) return rc;
-        if ((rc = launch_render_forward(a, in->colors_precomp, out->out_color, saved->geom, saved->binning, saved->img, L, s))) return rc;
-        if (I < 0) {  // hinted path: everything is enqueued; now collect the count (available since the scan finished)
-            if ((rc = mailbox_wait(mb, 2, count_tag, s))) return rc;
-            I = (int64_t)mb->host[0];
-        }
-        if (mb->host[1] != 0) { set_error("radix look-back timed out (flags 0x%x)", mb->host[1]); return DAS3R_ERR_HIP; }
-        if (I <= cap) break;
-        cap = -1;  // hint too small: lists were truncated, redo binning + render with the exact size
+    // per-thread ring of self re-arming arrival words for the count reduction of the preprocess kernel
+    static thread_local unsigned long long *arrive_ring = nullptr;
+    constexpr uint32_t ARRIVE_SLOTS = 64;
+    if (!arrive_ring) {
+        HIP_TRY(hipMalloc((void **)&arrive_ring, ARRIVE_SLOTS * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(arrive_ring, 0, ARRIVE_SLOTS * sizeof(unsigned long long)));
     }
+    const uint32_t count_tag = ++mb->seq ? mb->seq : ++mb->seq;
+    if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, nullptr, 0, L, arrive_ring + (count_tag % ARRIVE_SLOTS), mb->dev,
+                                count_tag, s))) return rc;
+    if ((rc = launch_depth_sort(P, saved->geom, L, a->debug != 0, s))) return rc;
+    if ((rc = mailbox_wait(mb, 2, count_tag, s))) return rc;    // usually there already: preprocess finished long ago
+    const int64_t I = (int64_t)mb->host[0], cap = I;
+    if (cap > (int64_t)0x7FFFFF00) { set_error("num_rendered %lld exceeds 2^31", (long long)cap); return DAS3R_ERR_OVERFLOW; }
+    compute_layout(P, cap, W, H, &L);
+    saved->binning = alloc_binning(user, L.pub.binning_bytes);
+    if (!saved->binning) { set_error("scratch allocation failed (binning %zu B)", L.pub.binning_bytes); return DAS3R_ERR_ALLOC; }
+    const bool fused_scan = use_onesweep();   // scan + emission in one kernel; the classic path scans, then emits
+    if (fused_scan) {
+        if ((rc = launch_binning_scan_emit(P, cap, out->radii, saved->geom, saved->binning, L, false, nullptr, 0, a->debug != 0, s))) return rc;
+    } else if ((rc = launch_scan(P, saved->geom, L, nullptr, 0, a->debug != 0, s))) return rc;
+    if (cap > 0) {
+        if ((rc = check_late(true))) return rc;   // one self-check word in flight at a time
+        late_tag = ++mb->seq ? mb->seq : ++mb->seq;
+    }
+    if ((rc = launch_binning(P, cap, W, H, out->radii, saved->geom, saved->binning, saved->img, L, fused_scan, mb->dev + 8, late_tag,
+                             a->debug != 0, s))) return rc;
+    if ((rc = launch_render_forward(a, in->colors_precomp, out->out_color, saved->geom, saved->binning, saved->img, L, s))) return rc;
     if (a->debug && (rc = check_late(true))) return rc;   // debug: report this forward's self-check word right away
     saved->num_rendered = I;
     saved->capacity = cap;

@@ -99,8 +99,10 @@ void compute_layout(int P, int64_t I, int W, int H, Layout *L);
 
 // ---- launchers implemented in the individual .hip files ----
 // binning_ctrl (may be null): the binning buffer's control words, zeroed by the same kernel when the buffer already exists
+// arrive: a zeroed 64-bit device word (self re-arming); host_out / tag: pinned mailbox that receives num_rendered
 int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int32_t *radii, char *geom, char *img, char *binning_ctrl,
-                      size_t binning_ctrl_bytes, const Layout &L, hipStream_t s);
+                      size_t binning_ctrl_bytes, const Layout &L, unsigned long long *arrive, uint32_t *host_out, uint32_t tag,
+                      hipStream_t s);
 int launch_mark_visible(int P, const float *means3D, const float *viewmatrix, uint8_t *present, hipStream_t s);
 int launch_depth_sort(int P, char *geom, const Layout &L, bool debug, hipStream_t s);
 // scan of tiles_touched in depth order -> offsets / off_by_gid / count (exact path: the host then reads the count)

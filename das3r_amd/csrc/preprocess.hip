@@ -21,8 +21,12 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     int tiles_x, int tiles_y, int32_t *__restrict__ radii, uint32_t *__restrict__ depth_key, float4 *__restrict__ xyh,
     float4 *__restrict__ conic_opacity, float4 *__restrict__ rgbd, uint8_t *__restrict__ clamped,
     uint32_t *__restrict__ tiles_touched, int tight_rect, uint32_t *__restrict__ zero_a, uint32_t zero_a_words, uint32_t *__restrict__ zero_b,
-    uint32_t zero_b_words, uint32_t *__restrict__ zero_c, uint32_t zero_c_words) {
+    uint32_t zero_b_words, uint32_t *__restrict__ zero_c, uint32_t zero_c_words, unsigned long long *__restrict__ arrive,
+    uint32_t *__restrict__ host_out, uint32_t tag) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t s_tiles;   // this workgroup's sum of tiles_touched (num_rendered is their grand total)
+    if (threadIdx.x == 0) s_tiles = 0;
+    if (!STAGE) __syncthreads();
     // this kernel runs before every consumer of the radix control words (geom side) and of the tile ranges: zero them here
     // instead of spending two memset launches
     for (uint32_t i = idx; i < zero_a_words; i += gridDim.x * blockDim.x) zero_a[i] = 0u;
@@ -146,6 +150,23 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     // would otherwise pay three random cache lines per splat (record, radii[], tiles_touched[]); the whole line is written
     rgbd[(size_t)idx * SPLAT_REC + 1] = make_float4(__int_as_float(radius_out), __uint_as_float(tiles_out), 0.f, 0.f);
     clamped[idx] = clamp_out;
+
+    // num_rendered = sum of tiles_touched does not depend on the depth order: deliver it to the host NOW, five kernels before the
+    // scan that needs it on the device, so that the host can size the binning buffer exactly without ever waiting for the sort.
+    // One 64-bit atomic per workgroup carries (workgroups done << 40 | tiles); the last arriver owns the total, re-arms the
+    // counter for its next use and writes {count, tag} to the pinned mailbox (see api.hip).
+    if (tiles_out) atomicAdd(&s_tiles, tiles_out);
+    __syncthreads();   // (waves that returned early have terminated and do not take part)
+    if (threadIdx.x == 0) {
+        const unsigned long long mine = (1ull << 40) | (unsigned long long)s_tiles;
+        const unsigned long long old = atomicAdd(arrive, mine);
+        if ((old >> 40) + 1ull == (unsigned long long)gridDim.x) {
+            const unsigned long long total = (old + mine) & ((1ull << 40) - 1ull);
+            __hip_atomic_store(arrive, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            host_out[0] = (uint32_t)(total > 0xFFFFFFFFull ? 0xFFFFFFFFull : total);
+            __hip_atomic_store(host_out + 2, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float *__restrict__ means3D,
@@ -160,7 +181,8 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float *_
 }
 
 int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int32_t *radii, char *geom, char *img, char *binning_ctrl,
-                      size_t binning_ctrl_bytes, const Layout &L, hipStream_t s) {
+                      size_t binning_ctrl_bytes, const Layout &L, unsigned long long *arrive, uint32_t *host_out, uint32_t tag,
+                      hipStream_t s) {
     const int P = a->P;
     if (P == 0) return DAS3R_OK;
     dim3 grid(div_up(P, 256)), block(256);
@@ -171,7 +193,7 @@ int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int
         a->tanfovx, a->tanfovy, L.tiles_x, L.tiles_y, radii, (uint32_t *)(geom + L.g_keyA), (float4 *)(geom + L.pub.xy),  \
         (float4 *)(geom + L.pub.conic_opacity), (float4 *)(geom + L.pub.rgbd), (uint8_t *)(geom + L.pub.clamped),         \
         (uint32_t *)(geom + L.pub.tiles_touched), use_tight_rect() ? 1 : 0, (uint32_t *)(geom + L.g_ghist), (uint32_t)(L.g_ctrl_bytes / 4),                 \
-        (uint32_t *)(img + L.pub.ranges), (uint32_t)(2 * L.ntiles), (uint32_t *)binning_ctrl, (uint32_t)(binning_ctrl_bytes / 4)
+        (uint32_t *)(img + L.pub.ranges), (uint32_t)(2 * L.ntiles), (uint32_t *)binning_ctrl, (uint32_t)(binning_ctrl_bytes / 4), arrive, host_out, tag
     const bool stage = has_sh && a->M == 16 && a->sh_degree >= 2 && ((uintptr_t)in->shs & 15) == 0 && !getenv("DAS3R_NO_SH_STAGE");
     if (has_sh && !has_cov && stage) DAS3R_LAUNCH((preprocess_kernel<true, false, true>), grid, block, 0, s, ARGS);
     else if (has_sh && has_cov && stage) DAS3R_LAUNCH((preprocess_kernel<true, true, true>), grid, block, 0, s, ARGS);

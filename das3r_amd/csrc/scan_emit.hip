@@ -123,9 +123,11 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
         count[1] = flags;
         // the host polls a pinned mailbox instead of waiting for a copy + event: count and flags first, then the tag of this
         // call with system-scope release semantics
-        host_out[0] = carry;
-        host_out[1] = flags;
-        __hip_atomic_store(host_out + 2, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (host_out) {
+            host_out[0] = carry;
+            host_out[1] = flags;
+            __hip_atomic_store(host_out + 2, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     if (EMIT) {
         __syncthreads();

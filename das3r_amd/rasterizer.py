@@ -121,16 +121,12 @@ def _stream(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-# last num_rendered per (P, W, H): lets the next forward size its binning buffer without waiting for the device
-_CAPACITY_CACHE = {}
-
-
 def _forward_impl(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp):
-    """Exact-size forward (one blocking count read-back): -> (num_rendered, color, radii, geom, binning, img)."""
-    return _forward_full(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, exact=True)[:6]
+    """-> (num_rendered, color, radii, geom, binning, img)."""
+    return _forward_full(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)[:6]
 
 
-def _forward_full(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, exact=False):
+def _forward_full(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, exact=True):
     """-> (num_rendered, color, radii, geom, binning, img, capacity)."""
     lib = _lib.load()
     device = means3D.device
@@ -156,9 +152,7 @@ def _forward_full(rs, means3D, sh, colors_precomp, opacities, scales, rotations,
     alloc = _Alloc.get(device)
     keep = []
     a = _fill_args(rs, P, M, device, keep)
-    key = (P, W, H, device.index)
-    last = _CAPACITY_CACHE.get(key)
-    a.capacity_hint = 0 if (exact or not last) else int(last * 1.25) + 4096
+    a.capacity_hint = 0   # reserved: the library sizes the binning buffer exactly (the count leaves with its first kernel)
     i = _fill_in(means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp)
     o = _lib.RasterOut()
     o.out_color, o.radii = color.data_ptr(), radii.data_ptr()
@@ -167,7 +161,6 @@ def _forward_full(rs, means3D, sh, colors_precomp, opacities, scales, rotations,
         rc = lib.das3r_raster_forward(C.byref(a), C.byref(i), C.byref(o), alloc.fns["geom"], alloc.fns["binning"],
                                       alloc.fns["img"], None, C.byref(saved), _stream(device))
     _lib.check(rc, "das3r_raster_forward")
-    _CAPACITY_CACHE[key] = int(rc)
     empty = torch.empty(0, dtype=torch.uint8, device=device)
     bufs = alloc.take()
     return (int(rc), color, radii, bufs.get("geom", empty), bufs.get("binning", empty), bufs.get("img", empty), int(saved.capacity))

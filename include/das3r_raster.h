@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DAS3R_ABI_VERSION 4
+#define DAS3R_ABI_VERSION 5
 
 typedef enum {
     DAS3R_OK = 0,
@@ -68,10 +68,8 @@ typedef struct {
     const float *campos;     /* [3]    device */
     int32_t prefiltered;
     int32_t debug;           /* !=0: synchronise + check after every kernel */
-    int64_t capacity_hint;   /* 0: size the binning buffer exactly (one blocking 4-byte read-back mid-forward, like upstream).
-                              * >0: expected upper bound of num_rendered (e.g. last call's value + 25 %): the binning buffer is
-                              * sized for it, the whole forward is enqueued without waiting, and the count is read back off the
-                              * critical path; if it turns out larger than the hint the binning + render are re-run exactly. */
+    int64_t capacity_hint;   /* reserved (ignored since ABI v5): the binning buffer is always sized exactly — num_rendered reaches the
+                              * host from the first kernel of the forward, long before the buffer is needed */
 } das3r_raster_args;
 
 /* Inputs of GaussianRasterizer.forward.  Exactly one of shs/colors_precomp and exactly one of

@@ -18,7 +18,6 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--env", action="append", default=[])
     ap.add_argument("--fwd-only", action="store_true")
-    ap.add_argument("--exact", action="store_true", help="size the binning buffer exactly (blocking count read-back)")
     args = ap.parse_args()
     from das3r_amd import GaussianRasterizationSettings, _lib
     from das3r_amd.rasterizer import _backward_impl, _forward_full
@@ -37,8 +36,7 @@ def main():
                 os.environ[k] = v
 
             def step():
-                I, color, radii, geom, binning, img, cap = _forward_full(rs, sc.means3D, sc.shs, e, sc.opacities, sc.scales, sc.rotations, e,
-                                                                         exact=args.exact)
+                I, color, radii, geom, binning, img, cap = _forward_full(rs, sc.means3D, sc.shs, e, sc.opacities, sc.scales, sc.rotations, e)
                 if not args.fwd_only:
                     _backward_impl(rs, I, sc.dL_dpix, sc.means3D, sc.shs, e, sc.opacities, sc.scales, sc.rotations, e, geom, binning, img, cap)
                 return I
