@@ -240,16 +240,17 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     const uint32_t count_tag = ++mb->seq ? mb->seq : ++mb->seq;
     if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, nullptr, 0, L, arrive_ring + (count_tag % ARRIVE_SLOTS), mb->dev,
                                 count_tag, s))) return rc;
-    if ((rc = launch_depth_sort(P, saved->geom, L, a->debug != 0, s))) return rc;
+    if ((rc = launch_depth_sort(P, saved->geom, L, 0, nullptr, 0, a->debug != 0, s))) return rc;
     if ((rc = mailbox_wait(mb, 2, count_tag, s))) return rc;    // usually there already: preprocess finished long ago
     const int64_t I = (int64_t)mb->host[0], cap = I;
     if (cap > (int64_t)0x7FFFFF00) { set_error("num_rendered %lld exceeds 2^31", (long long)cap); return DAS3R_ERR_OVERFLOW; }
     compute_layout(P, cap, W, H, &L);
     saved->binning = alloc_binning(user, L.pub.binning_bytes);
     if (!saved->binning) { set_error("scratch allocation failed (binning %zu B)", L.pub.binning_bytes); return DAS3R_ERR_ALLOC; }
+    if ((rc = launch_depth_sort(P, saved->geom, L, 1, saved->binning + L.b_ghist, L.b_ctrl_bytes, a->debug != 0, s))) return rc;
     const bool fused_scan = use_onesweep();   // scan + emission in one kernel; the classic path scans, then emits
     if (fused_scan) {
-        if ((rc = launch_binning_scan_emit(P, cap, out->radii, saved->geom, saved->binning, L, false, nullptr, 0, a->debug != 0, s))) return rc;
+        if ((rc = launch_binning_scan_emit(P, cap, out->radii, saved->geom, saved->binning, L, true, nullptr, 0, a->debug != 0, s))) return rc;
     } else if ((rc = launch_scan(P, saved->geom, L, nullptr, 0, a->debug != 0, s))) return rc;
     if (cap > 0) {
         if ((rc = check_late(true))) return rc;   // one self-check word in flight at a time

@@ -104,7 +104,9 @@ int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int
                       size_t binning_ctrl_bytes, const Layout &L, unsigned long long *arrive, uint32_t *host_out, uint32_t tag,
                       hipStream_t s);
 int launch_mark_visible(int P, const float *means3D, const float *viewmatrix, uint8_t *present, hipStream_t s);
-int launch_depth_sort(int P, char *geom, const Layout &L, bool debug, hipStream_t s);
+// part 0: everything that can be enqueued before num_rendered is known; part 1: the rest, which also zeroes the binning buffer's
+// control words (binning_ctrl may be null)
+int launch_depth_sort(int P, char *geom, const Layout &L, int part, char *binning_ctrl, size_t binning_ctrl_bytes, bool debug, hipStream_t s);
 // scan of tiles_touched in depth order -> offsets / off_by_gid / count (exact path: the host then reads the count)
 int launch_scan(int P, char *geom, const Layout &L, uint32_t *host_out, uint32_t tag, bool debug, hipStream_t s);
 // the same scan with the instance emission fused in (hinted path; sort_onesweep.hip)
@@ -114,7 +116,8 @@ size_t scan_status_bytes(int P);
 int launch_binning_scan_emit(int P, int64_t I, const int32_t *radii, char *geom, char *binning, const Layout &L, bool ctrl_zeroed,
                              uint32_t *host_out, uint32_t tag, bool debug, hipStream_t s);
 size_t onesweep_status_bytes(int64_t n, int passes);
-int launch_onesweep_depth_sort(int P, char *geom, const Layout &L, bool debug, hipStream_t s);
+int launch_onesweep_depth_sort(int P, char *geom, const Layout &L, int part, uint32_t *zero_ptr, uint32_t zero_words, bool debug,
+                               hipStream_t s);
 int launch_onesweep_partition(int64_t cap, char *geom, char *binning, const Layout &L, uint32_t **keys_final, bool debug, hipStream_t s);
 bool use_row_private(int64_t instances, int ntiles);  // forward: 4x4-block-per-row kernel for long tile lists (render_rows.hip)
 int launch_render_forward_rows(const das3r_raster_args *a, float *out_color, char *geom, char *binning, char *img, const Layout &L,

@@ -258,14 +258,15 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(uint32_t cap, const ui
 }
 
 // ---------------------------------------------------------------- host side
-int launch_depth_sort(int P, char *geom, const Layout &L, bool debug, hipStream_t s) {
+int launch_depth_sort(int P, char *geom, const Layout &L, int part, char *binning_ctrl, size_t binning_ctrl_bytes, bool debug, hipStream_t s) {
     uint32_t *keyA = (uint32_t *)(geom + L.g_keyA), *keyB = (uint32_t *)(geom + L.g_keyB);
     uint32_t *valA = (uint32_t *)(geom + L.g_valA), *valB = (uint32_t *)(geom + L.g_valB);
     uint32_t *hist = (uint32_t *)(geom + L.g_hist), *totals = (uint32_t *)(geom + L.g_totals);
     if (P == 0) return DAS3R_OK;
     // 4 passes: A -> B -> A -> B -> A ; final ranks land in valA (== pub.sorted_idx)
     int rc;
-    if (use_onesweep()) return launch_onesweep_depth_sort(P, geom, L, debug, s);
+    if (use_onesweep()) return launch_onesweep_depth_sort(P, geom, L, part, (uint32_t *)binning_ctrl, (uint32_t)(binning_ctrl_bytes / 4), debug, s);
+    if (part == 1) return DAS3R_OK;   // classic path: everything ran in part 0 (its binning does not use control words)
     if ((rc = radix_pass(keyA, nullptr, keyB, valB, P, 0, 8, hist, totals, debug, s))) return rc;
     if ((rc = radix_pass(keyB, valB, keyA, valA, P, 8, 8, hist, totals, debug, s))) return rc;
     if ((rc = radix_pass(keyA, valA, keyB, valB, P, 16, 8, hist, totals, debug, s))) return rc;
@@ -294,7 +295,7 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
     uint32_t *hist = (uint32_t *)(binning + L.b_hist), *totals = (uint32_t *)(binning + L.b_totals);
     uint32_t *gid_of = (uint32_t *)(binning + L.b_gid_of), *inv = (uint32_t *)(binning + L.b_slot);
     const bool onesweep = use_onesweep();
-    if (onesweep && !fused_scan) HIP_TRY(hipMemsetAsync(binning + L.b_ghist, 0, L.b_ctrl_bytes, s));  // digit histograms, tickets, status words
+    (void)onesweep;   // the binning control words were zeroed by the last depth pass (launch_depth_sort part 1)
     if (!fused_scan) {   // (hinted path: launch_binning_scan_emit has already emitted the instances)
     const int emit_blocks = div_up(P, 256) < 1024 ? div_up(P, 256) : 1024;
     DAS3R_LAUNCH(emit_kernel, dim3(emit_blocks), dim3(256), 0, s, P, L.tiles_x, L.tiles_y,

@@ -80,7 +80,10 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
                                                             u64 *__restrict__ group_status /*[ngroups][256]*/, int gs_log2,
                                                             uint32_t *__restrict__ ticket,
                                                             const uint32_t *__restrict__ gather_src, uint32_t *__restrict__ inv_out,
-                                                            uint32_t *__restrict__ err) {
+                                                            uint32_t *__restrict__ err, uint32_t *__restrict__ zero_ptr, uint32_t zero_words) {
+    // side duty (last depth pass only): zero the control words of the binning buffer, which did not exist yet when the
+    // preprocess kernel zeroed everything else; nothing in this kernel touches them
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < zero_words; i += gridDim.x * 256u) zero_ptr[i] = 0u;
     __shared__ uint32_t cnt[4][RADIX_SIZE];  // per-wave digit counts, then per-wave running offsets
     __shared__ uint32_t gdelta[RADIX_SIZE];
     __shared__ uint32_t sk[256 * IPL], sv[256 * IPL];  // staging: key, payload
@@ -222,14 +225,15 @@ static int onesweep_group_log2(int nblocks);
 
 static int onesweep_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t cap, const uint32_t *n_ptr,
                          int shift, int bits, const uint32_t *ghist, u64 *status, uint32_t *ticket, const uint32_t *gather_src,
-                         uint32_t *inv_out, uint32_t *err, bool debug, hipStream_t s) {
+                         uint32_t *inv_out, uint32_t *err, bool debug, hipStream_t s, uint32_t *zero_ptr = nullptr,
+                         uint32_t zero_words = 0) {
     const int ipl = sort_items_per_lane(cap);
     const int nblocks = div_up(cap, (int64_t)256 * ipl);
     const int gs_log2 = onesweep_group_log2(nblocks);
     u64 *group_status = status + (size_t)nblocks * RADIX_SIZE;
 #define PASS(IPL, FINAL)                                                                                                  \
     DAS3R_LAUNCH((onesweep_pass_kernel<IPL, FINAL>), dim3(nblocks), dim3(256), 0, s, kin, vin, kout, vout, (uint32_t)cap, n_ptr, \
-                 shift, bits, ghist, status, group_status, gs_log2, ticket, gather_src, inv_out, err)
+                 shift, bits, ghist, status, group_status, gs_log2, ticket, gather_src, inv_out, err, zero_ptr, zero_words)
     if (inv_out) {
         if (ipl == 4) PASS(4, true); else if (ipl == 8) PASS(8, true); else PASS(16, true);
     } else {
@@ -256,22 +260,27 @@ size_t onesweep_status_bytes(int64_t n, int passes) {
 }
 
 // Depth sort of the P splats: ctrl = [ghist 4x256 u32][tickets 4 u32 (+pad)][status 4 passes], zeroed by preprocess_kernel.
-int launch_onesweep_depth_sort(int P, char *geom, const Layout &L, bool debug, hipStream_t s) {
+// part: 0 = histogram + passes 0..2 (enqueued before the host knows num_rendered), 1 = pass 3, which also zeroes
+// zero_ptr[0..zero_words) — the binning buffer's control words
+int launch_onesweep_depth_sort(int P, char *geom, const Layout &L, int part, uint32_t *zero_ptr, uint32_t zero_words, bool debug,
+                               hipStream_t s) {
     uint32_t *keyA = (uint32_t *)(geom + L.g_keyA), *keyB = (uint32_t *)(geom + L.g_keyB);
     uint32_t *valA = (uint32_t *)(geom + L.g_valA), *valB = (uint32_t *)(geom + L.g_valB);
     uint32_t *ghist = (uint32_t *)(geom + L.g_ghist), *ticket = (uint32_t *)(geom + L.g_ticket);
     uint32_t *err = (uint32_t *)(geom + L.g_ticket) + 8;  // inside the zeroed control region
     u64 *status = (u64 *)(geom + L.g_status);
     const size_t per_pass = onesweep_status_bytes(P, 1) / sizeof(u64);
+    int rc;
+    if (part == 1)
+        return onesweep_pass(keyB, valB, nullptr, valA, P, nullptr, 24, 8, ghist + 768, status + 3 * per_pass, ticket + 3, nullptr, nullptr, err,
+                             debug, s, zero_ptr, zero_words);
     const int hist_blocks = div_up(P, 256) < 512 ? div_up(P, 256) : 512;
     DAS3R_LAUNCH(depth_hist_kernel, dim3(hist_blocks), dim3(256), 0, s, keyA, (uint32_t)P, ghist);
     KERNEL_CHECK(s, debug, "depth_hist");
-    int rc;
     // A -> B -> A -> B -> A ; final ranks land in valA (== pub.sorted_idx)
     if ((rc = onesweep_pass(keyA, nullptr, keyB, valB, P, nullptr, 0, 8, ghist + 0, status + 0 * per_pass, ticket + 0, nullptr, nullptr, err, debug, s))) return rc;
     if ((rc = onesweep_pass(keyB, valB, keyA, valA, P, nullptr, 8, 8, ghist + 256, status + 1 * per_pass, ticket + 1, nullptr, nullptr, err, debug, s))) return rc;
     if ((rc = onesweep_pass(keyA, valA, keyB, valB, P, nullptr, 16, 8, ghist + 512, status + 2 * per_pass, ticket + 2, nullptr, nullptr, err, debug, s))) return rc;
-    if ((rc = onesweep_pass(keyB, valB, nullptr, valA, P, nullptr, 24, 8, ghist + 768, status + 3 * per_pass, ticket + 3, nullptr, nullptr, err, debug, s))) return rc;
     return DAS3R_OK;
 }
 
