@@ -114,26 +114,17 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
     }
     __syncthreads();
 
-    // thread d owns digit d: publish this workgroup's count, look back over the earlier workgroups
+    // thread d owns digit d.  Publish this workgroup's count first, then do everything that needs only LOCAL information
+    // (ranking + staging, ~3 us); the look-back over the earlier workgroups' counts comes after it, when their words have
+    // long been published, and only the final write-out needs its result.
+    const uint32_t c0 = cnt[0][tid], c1 = cnt[1][tid], c2 = cnt[2][tid], c3 = cnt[3][tid];
+    const uint32_t total = c0 + c1 + c2 + c3;
+    granule_store(status + (size_t)b * RADIX_SIZE + tid, TAG_AGG | total);
+    const uint32_t g = ghist[tid];
+    uint32_t digit_base, lstart;
     {
-        const uint32_t c0 = cnt[0][tid], c1 = cnt[1][tid], c2 = cnt[2][tid], c3 = cnt[3][tid];
-        const uint32_t total = c0 + c1 + c2 + c3;
-        // Two-level look-back.  Workgroups are grouped GS = 2^gs_log2 at a time; the last workgroup of a group also
-        // publishes the group's total.  Every workgroup then needs (its predecessors inside its group) + (the totals of
-        // all earlier groups): <= GS - 1 + ngroups - 1 ~ 2 sqrt(nblocks) words, ALL INDEPENDENT loads (no chain of
-        // prefixes to chase), i.e. about three far-memory round trips per pass however many workgroups run at once.
-        // (The one-level chained scan degenerates when every workgroup is resident from the start — the normal case for
-        // 0.1-4 M keys on 256 CUs: nobody owns a prefix yet, so workgroup b walks over all b predecessors.)
-        const uint32_t gs_mask = (1u << gs_log2) - 1u;
-        const uint32_t grp = b >> gs_log2, r = b & gs_mask;
-        granule_store(status + (size_t)b * RADIX_SIZE + tid, TAG_AGG | total);
-        const uint32_t in_group = sum_published(status + (size_t)(b - r) * RADIX_SIZE + tid, (int)r, err);
-        if (r == gs_mask) granule_store(group_status + (size_t)grp * RADIX_SIZE + tid, TAG_AGG | (u64)(in_group + total));
-        const uint32_t excl = in_group + sum_published(group_status + tid, (int)grp, err);
-        if (b == gridDim.x - 1 && excl + total != ghist[tid]) atomicOr(err, ERR_COUNTS);   // self-check: all counts add up to the histogram
         // global: first output slot of digit d = (keys with smaller digits) + (same digit in earlier workgroups);
         // local: slot of this workgroup's first digit-d key inside its own LDS staging area (keys grouped by digit)
-        const uint32_t g = ghist[tid];
         const uint32_t incl = wave_incl_scan_u32(g), lincl = wave_incl_scan_u32(total);
         if (lane == 63) {
             ws[wave] = incl;
@@ -147,8 +138,8 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
                 wbase += ws[w];
                 lbase += ws[4 + w];
             }
-        const uint32_t lstart = lbase + lincl - total;
-        gdelta[tid] = wbase + incl - g + excl - lstart;   // destination of staged slot i holding digit d: i + gdelta[d]
+        lstart = lbase + lincl - total;
+        digit_base = wbase + incl - g;
         cnt[0][tid] = lstart;
         cnt[1][tid] = lstart + c0;
         cnt[2][tid] = lstart + c0 + c1;
@@ -187,6 +178,21 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
             sk[slot] = k[s];
             sv[slot] = out[s];
         }
+    }
+    {
+        // Two-level look-back.  Workgroups are grouped GS = 2^gs_log2 at a time; the last workgroup of a group also
+        // publishes the group's total.  Every workgroup then needs (its predecessors inside its group) + (the totals of
+        // all earlier groups): <= GS - 1 + ngroups - 1 ~ 2 sqrt(nblocks) words, ALL INDEPENDENT loads (no chain of
+        // prefixes to chase), i.e. two far-memory round trips per pass however many workgroups run at once.
+        // (The one-level chained scan degenerates when every workgroup is resident from the start — the normal case for
+        // 0.1-4 M keys on 256 CUs: nobody owns a prefix yet, so workgroup b walks over all b predecessors.)
+        const uint32_t gs_mask = (1u << gs_log2) - 1u;
+        const uint32_t grp = b >> gs_log2, r = b & gs_mask;
+        const uint32_t in_group = sum_published(status + (size_t)(b - r) * RADIX_SIZE + tid, (int)r, err);
+        if (r == gs_mask) granule_store(group_status + (size_t)grp * RADIX_SIZE + tid, TAG_AGG | (u64)(in_group + total));
+        const uint32_t excl = in_group + sum_published(group_status + tid, (int)grp, err);
+        if (b == gridDim.x - 1 && excl + total != g) atomicOr(err, ERR_COUNTS);   // self-check: all counts add up to the histogram
+        gdelta[tid] = digit_base + excl - lstart;   // destination of staged slot i holding digit d: i + gdelta[d]
     }
     __syncthreads();
 
