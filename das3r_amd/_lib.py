@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdas3r_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
@@ -49,8 +49,8 @@ class RasterLayout(C.Structure):
 # every symbol include/das3r_raster.h declares
 EXPORTS = ("das3r_raster_forward", "das3r_raster_backward", "das3r_mark_visible", "das3r_knn3_workspace_bytes",
            "das3r_knn3_mean_dist2", "das3r_raster_get_layout", "das3r_abi_version", "das3r_last_error",
-           "das3r_profile_enable", "das3r_profile_report", "das3r_pretransform_forward", "das3r_pretransform_backward",
-           "das3r_adam_step", "das3r_photometric_blocks", "das3r_photometric_forward", "das3r_photometric_backward")
+           "das3r_profile_enable", "das3r_profile_report", "das3r_pretransform_forward", "das3r_pretransform_backward", "das3r_pose_matrices", "das3r_pose_chain",
+           "das3r_adam_step", "das3r_adam_step_gated", "das3r_photometric_blocks", "das3r_photometric_forward", "das3r_photometric_backward")
 
 _lib = None
 
@@ -84,6 +84,10 @@ def load():
     L.das3r_knn3_workspace_bytes.argtypes = [C.c_int32]
     L.das3r_knn3_mean_dist2.restype = C.c_int
     L.das3r_knn3_mean_dist2.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.das3r_pose_matrices.restype = C.c_int
+    L.das3r_pose_matrices.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.das3r_pose_chain.restype = C.c_int
+    L.das3r_pose_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.das3r_pretransform_forward.restype = C.c_int
     L.das3r_pretransform_forward.argtypes = [C.c_int32] + [C.c_void_p] * 13 + [C.c_void_p]
     L.das3r_pretransform_backward.restype = C.c_int
@@ -95,6 +99,8 @@ def load():
     L.das3r_photometric_backward.restype = C.c_int
     L.das3r_photometric_backward.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p]
+    L.das3r_adam_step_gated.restype = C.c_int
+    L.das3r_adam_step_gated.argtypes = [C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
     L.das3r_adam_step.restype = C.c_int
     L.das3r_adam_step.argtypes = [C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]
     L.das3r_raster_get_layout.restype = C.c_int

@@ -29,7 +29,24 @@ struct AdamTable {
     int n;
 };
 
-__global__ void __launch_bounds__(256) adam_kernel(const AdamTable T, float beta1, float beta2, float eps) {
+// GATED: the step only happens if the device-side flag state[1] is set (adam_gate_kernel); the bias corrections then come from
+// the device-side step count state[0] and T.step_size holds the plain learning rate.
+__global__ void adam_gate_kernel(const float *__restrict__ gate, float threshold, int32_t *__restrict__ state) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool go = gate[0] > threshold;
+    state[1] = go ? 1 : 0;
+    if (go) state[0] += 1;
+}
+
+template <bool GATED>
+__global__ void __launch_bounds__(256) adam_kernel(const AdamTable T, float beta1, float beta2, float eps, const int32_t *__restrict__ state) {
+    float gate_bc1 = 1.f, gate_bc2_sqrt = 1.f;
+    if (GATED) {
+        if (state[1] == 0) return;
+        const float t = (float)state[0];
+        gate_bc1 = 1.f - powf(beta1, t);
+        gate_bc2_sqrt = sqrtf(1.f - powf(beta2, t));
+    }
     int t = 0;
 #pragma unroll 1
     while (t + 1 < T.n && (int)blockIdx.x >= T.first_chunk[t + 1]) t++;
@@ -40,7 +57,8 @@ __global__ void __launch_bounds__(256) adam_kernel(const AdamTable T, float beta
     float *__restrict__ v = T.v[t];
     const long long n = T.n_active[t];
     const int row_len = T.row_len[t], active_len = T.active_len[t];
-    const float step_size = T.step_size[t], bc2_sqrt = T.bc2_sqrt[t], step_size_tail = T.step_size_tail[t];
+    const float step_size = GATED ? T.step_size[t] / gate_bc1 : T.step_size[t], bc2_sqrt = GATED ? gate_bc2_sqrt : T.bc2_sqrt[t];
+    const float step_size_tail = GATED ? T.step_size_tail[t] / gate_bc1 : T.step_size_tail[t];
     const int head_len = T.head_len[t];
 #pragma unroll
     for (int k = 0; k < ADAM_CHUNK / 256; k++) {
@@ -66,7 +84,8 @@ using namespace das3r;
 
 // tensors: host array of n entries.  rows * row_len = numel; only the first active_len floats of every row are updated
 // (active_len == row_len: the whole tensor).  step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t).
-extern "C" int das3r_adam_step(int32_t n, const das3r_adam_tensor *tensors, float beta1, float beta2, float eps, das3r_stream_t stream) {
+static int adam_launch(int32_t n, const das3r_adam_tensor *tensors, float beta1, float beta2, float eps, const float *gate, float threshold,
+                       int32_t *state, das3r_stream_t stream) {
     if (n < 0 || n > ADAM_MAX_TENSORS || (n > 0 && !tensors)) {
         set_error("das3r_adam_step: between 0 and %d tensors per call", ADAM_MAX_TENSORS);
         return DAS3R_ERR_INVALID_ARG;
@@ -96,7 +115,26 @@ extern "C" int das3r_adam_step(int32_t n, const das3r_adam_tensor *tensors, floa
     T.n = k;
     if (chunks == 0) return DAS3R_OK;
     hipStream_t s = (hipStream_t)stream;
-    DAS3R_LAUNCH(adam_kernel, dim3(chunks), dim3(256), 0, s, T, beta1, beta2, eps);
+    if (gate) {
+        DAS3R_LAUNCH(adam_gate_kernel, dim3(1), dim3(64), 0, s, gate, threshold, state);
+        DAS3R_LAUNCH((adam_kernel<true>), dim3(chunks), dim3(256), 0, s, T, beta1, beta2, eps, (const int32_t *)state);
+    } else {
+        DAS3R_LAUNCH((adam_kernel<false>), dim3(chunks), dim3(256), 0, s, T, beta1, beta2, eps, (const int32_t *)nullptr);
+    }
     KERNEL_CHECK(s, false, "adam");
     return DAS3R_OK;
+}
+
+extern "C" int das3r_adam_step(int32_t n, const das3r_adam_tensor *tensors, float beta1, float beta2, float eps, das3r_stream_t stream) {
+    return adam_launch(n, tensors, beta1, beta2, eps, nullptr, 0.f, nullptr, stream);
+}
+
+// Conditional step decided ON THE DEVICE: the update happens iff gate[0] > threshold (DAS3R steps its camera optimizer only
+// when the frame's PSNR exceeds 26 dB, train_gui.py:584-586 — a host-side `if` on a device scalar stalls the host every
+// iteration).  state[0] = number of steps taken so far (device int32, zero-initialised by the caller, incremented here),
+// state[1] = scratch flag; tensors[i].step_size / step_size_tail hold the plain learning rates, bc2_sqrt is ignored.
+extern "C" int das3r_adam_step_gated(int32_t n, const das3r_adam_tensor *tensors, float beta1, float beta2, float eps, const float *gate,
+                                     float threshold, int32_t *state, das3r_stream_t stream) {
+    if (!gate || !state) { set_error("das3r_adam_step_gated: gate and state are required"); return DAS3R_ERR_INVALID_ARG; }
+    return adam_launch(n, tensors, beta1, beta2, eps, gate, threshold, state, stream);
 }

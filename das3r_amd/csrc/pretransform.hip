@@ -101,9 +101,64 @@ __global__ void __launch_bounds__(256) pretransform_backward_kernel(
     }
 }
 
+// pose (qw,qx,qy,qz,tx,ty,tz) -> mats[28] = R (9, row-major; rotation of the NORMALISED quaternion, like get_camera_from_tensor),
+// t (3), Lq (16, row-major; left-multiplication matrix of the RAW quaternion, like quadmultiply).  One lane.
+__global__ void pose_matrices_kernel(const float *__restrict__ pose, float *__restrict__ mats) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float w = pose[0], x = pose[1], y = pose[2], z = pose[3];
+    const float inv = 1.0f / sqrtf(w * w + x * x + y * y + z * z);
+    const float r = w * inv, i = x * inv, j = y * inv, k = z * inv;
+    const float R[9] = {1 - 2 * (j * j + k * k), 2 * (i * j - r * k), 2 * (i * k + r * j), 2 * (i * j + r * k), 1 - 2 * (i * i + k * k),
+                        2 * (j * k - r * i), 2 * (i * k - r * j), 2 * (j * k + r * i), 1 - 2 * (i * i + j * j)};
+    const float L[16] = {w, -x, -y, -z, x, w, -z, y, y, z, w, -x, z, -y, x, w};
+    for (int a = 0; a < 9; a++) mats[a] = R[a];
+    for (int a = 0; a < 3; a++) mats[9 + a] = pose[4 + a];
+    for (int a = 0; a < 16; a++) mats[12 + a] = L[a];
+}
+
+// chain rule of pose_matrices: g[28] = dL/d(R, t, Lq) -> g_pose[7].  One lane.
+__global__ void pose_chain_kernel(const float *__restrict__ pose, const float *__restrict__ g, float *__restrict__ g_pose) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float w = pose[0], x = pose[1], y = pose[2], z = pose[3];
+    const float n = sqrtf(w * w + x * x + y * y + z * z), inv = 1.0f / n;
+    const float r = w * inv, i = x * inv, j = y * inv, k = z * inv;
+    const float *G = g;          // dL/dR, row-major
+    // dL/d(normalised quaternion): entry-wise derivative of R(r, i, j, k)
+    const float dr = -2 * k * G[1] + 2 * j * G[2] + 2 * k * G[3] - 2 * i * G[5] - 2 * j * G[6] + 2 * i * G[7];
+    const float di = 2 * j * G[1] + 2 * k * G[2] + 2 * j * G[3] - 4 * i * G[4] - 2 * r * G[5] + 2 * k * G[6] + 2 * r * G[7] - 4 * i * G[8];
+    const float dj = -4 * j * G[0] + 2 * i * G[1] + 2 * r * G[2] + 2 * i * G[3] + 2 * k * G[5] - 2 * r * G[6] + 2 * k * G[7] - 4 * j * G[8];
+    const float dk = -4 * k * G[0] - 2 * r * G[1] + 2 * i * G[2] + 2 * r * G[3] - 4 * k * G[4] + 2 * j * G[5] + 2 * i * G[6] + 2 * j * G[7];
+    // through the normalisation q / |q|
+    const float dot = r * dr + i * di + j * dj + k * dk;
+    float gq[4] = {(dr - r * dot) * inv, (di - i * dot) * inv, (dj - j * dot) * inv, (dk - k * dot) * inv};
+    const float *H = g + 12;     // dL/dLq, row-major; Lq is linear in the raw quaternion
+    gq[0] += H[0] + H[5] + H[10] + H[15];
+    gq[1] += -H[1] + H[4] - H[11] + H[14];
+    gq[2] += -H[2] + H[7] + H[8] - H[13];
+    gq[3] += -H[3] - H[6] + H[9] + H[12];
+    for (int a = 0; a < 4; a++) g_pose[a] = gq[a];
+    for (int a = 0; a < 3; a++) g_pose[4 + a] = g[9 + a];
+}
+
 }  // namespace das3r
 
 using namespace das3r;
+
+extern "C" int das3r_pose_matrices(const float *pose, float *mats, das3r_stream_t stream) {
+    if (!pose || !mats) { set_error("das3r_pose_matrices: invalid argument"); return DAS3R_ERR_INVALID_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    DAS3R_LAUNCH(pose_matrices_kernel, dim3(1), dim3(64), 0, s, pose, mats);
+    KERNEL_CHECK(s, false, "pose_matrices");
+    return DAS3R_OK;
+}
+
+extern "C" int das3r_pose_chain(const float *pose, const float *g_mats, float *g_pose, das3r_stream_t stream) {
+    if (!pose || !g_mats || !g_pose) { set_error("das3r_pose_chain: invalid argument"); return DAS3R_ERR_INVALID_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    DAS3R_LAUNCH(pose_chain_kernel, dim3(1), dim3(64), 0, s, pose, g_mats, g_pose);
+    KERNEL_CHECK(s, false, "pose_chain");
+    return DAS3R_OK;
+}
 
 extern "C" int das3r_pretransform_forward(int32_t P, const float *xyz, const float *rot, const float *scaling, const float *opacity_raw,
                                           const float *conf_flat, const int64_t *mask_index, const float *R, const float *t,

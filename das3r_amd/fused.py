@@ -11,7 +11,6 @@ import math
 import torch
 
 from . import _lib
-from .camera import quat_to_rotation
 
 
 class AdamTensor(C.Structure):
@@ -28,32 +27,28 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
-def quat_left_matrix(q):
-    """4x4 matrix L with quat_multiply(q, r) == L @ r (differentiable in q)."""
-    w, x, y, z = q.unbind(-1)
-    return torch.stack([torch.stack([w, -x, -y, -z]), torch.stack([x, w, -z, y]), torch.stack([y, z, w, -x]),
-                        torch.stack([z, -y, x, w])])
-
-
 class _PreTransform(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz, rot, scaling, opacity_raw, conf, mask_index, R, t, Lq):
+    def forward(ctx, xyz, rot, scaling, opacity_raw, conf, mask_index, pose):
         lib = _lib.load()
         dev = xyz.device
         if dev.type != "cuda":
             raise RuntimeError("das3r_amd.fused.pretransform: tensors must live on a HIP device; there is no CPU path")
         xyz, rot, scaling, opacity_raw = (a.contiguous() for a in (xyz, rot, scaling, opacity_raw))
         conf_flat = conf.contiguous().view(-1)
-        R, t, Lq = R.contiguous().float(), t.contiguous().float(), Lq.contiguous().float()
+        pose = pose.contiguous().float()
         P = xyz.shape[0]
+        mats = torch.empty(28, device=dev)    # R (9) | t (3) | Lq (16), built on the device from the 7-vector pose
         means3D, rotations = torch.empty_like(xyz), torch.empty_like(rot)
         scales, opac = torch.empty_like(scaling), torch.empty(P, 1, device=dev)
         with torch.cuda.device(dev):
+            st = _stream(dev)
+            _lib.check(lib.das3r_pose_matrices(_p(pose), _p(mats), st), "das3r_pose_matrices")
             rc = lib.das3r_pretransform_forward(P, _p(xyz), _p(rot), _p(scaling), _p(opacity_raw), _p(conf_flat),
-                                                _p(mask_index) if mask_index is not None else None, _p(R), _p(t), _p(Lq),
-                                                _p(means3D), _p(rotations), _p(scales), _p(opac), _stream(dev))
+                                                _p(mask_index) if mask_index is not None else None, _p(mats), C.c_void_p(mats.data_ptr() + 36),
+                                                C.c_void_p(mats.data_ptr() + 48), _p(means3D), _p(rotations), _p(scales), _p(opac), st)
         _lib.check(rc, "das3r_pretransform_forward")
-        ctx.save_for_backward(xyz, rot, scaling, opacity_raw, conf_flat, R, Lq)
+        ctx.save_for_backward(xyz, rot, scaling, opacity_raw, conf_flat, mats, pose)
         ctx.mask_index = mask_index
         ctx.conf_shape = conf.shape
         return means3D, rotations, scales, opac
@@ -61,35 +56,34 @@ class _PreTransform(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_means3D, g_rot, g_scales, g_opac):
         lib = _lib.load()
-        xyz, rot, scaling, opacity_raw, conf_flat, R, Lq = ctx.saved_tensors
+        xyz, rot, scaling, opacity_raw, conf_flat, mats, pose = ctx.saved_tensors
         dev, P = xyz.device, xyz.shape[0]
-        z = lambda t: torch.zeros_like(t) if t is None else t.contiguous()
-        g_means3D = z(g_means3D) if g_means3D is not None else torch.zeros_like(xyz)
-        g_rot = z(g_rot) if g_rot is not None else torch.zeros_like(rot)
-        g_scales = z(g_scales) if g_scales is not None else torch.zeros_like(scaling)
-        g_opac = z(g_opac) if g_opac is not None else torch.zeros(P, 1, device=dev)
+        g_means3D = torch.zeros_like(xyz) if g_means3D is None else g_means3D.contiguous()
+        g_rot = torch.zeros_like(rot) if g_rot is None else g_rot.contiguous()
+        g_scales = torch.zeros_like(scaling) if g_scales is None else g_scales.contiguous()
+        g_opac = torch.zeros(P, 1, device=dev) if g_opac is None else g_opac.contiguous()
         g_xyz, g_rotation, g_scaling = torch.empty_like(xyz), torch.empty_like(rot), torch.empty_like(scaling)
         g_opacity_raw = torch.empty_like(opacity_raw)
         g_conf = torch.zeros_like(conf_flat)
         g_small = torch.zeros(28, device=dev)
+        g_pose = torch.empty(7, device=dev)
         mi = ctx.mask_index
         with torch.cuda.device(dev):
+            st = _stream(dev)
             rc = lib.das3r_pretransform_backward(P, _p(xyz), _p(rot), _p(scaling), _p(opacity_raw), _p(conf_flat),
-                                                 _p(mi) if mi is not None else None, _p(R), _p(Lq), _p(g_means3D), _p(g_rot), _p(g_scales),
-                                                 _p(g_opac), _p(g_xyz), _p(g_rotation), _p(g_scaling), _p(g_opacity_raw), _p(g_conf),
-                                                 _p(g_small), _stream(dev))
-        _lib.check(rc, "das3r_pretransform_backward")
-        return (g_xyz, g_rotation, g_scaling, g_opacity_raw, g_conf.view(ctx.conf_shape), None, g_small[:9].view(3, 3), g_small[9:12],
-                g_small[12:].view(4, 4))
+                                                 _p(mi) if mi is not None else None, _p(mats), C.c_void_p(mats.data_ptr() + 48), _p(g_means3D),
+                                                 _p(g_rot), _p(g_scales), _p(g_opac), _p(g_xyz), _p(g_rotation), _p(g_scaling),
+                                                 _p(g_opacity_raw), _p(g_conf), _p(g_small), st)
+            _lib.check(rc, "das3r_pretransform_backward")
+            _lib.check(lib.das3r_pose_chain(_p(pose), _p(g_small), _p(g_pose), st), "das3r_pose_chain")
+        return g_xyz, g_rotation, g_scaling, g_opacity_raw, g_conf.view(ctx.conf_shape), None, g_pose
 
 
 def pretransform(xyz, rot, scaling, opacity_raw, conf, mask_index, pose):
     """-> (means3D, rotations, scales, opacities) exactly as DAS3R's render() builds them from the raw parameters and the
-    7-vector pose (qw,qx,qy,qz,tx,ty,tz).  The pose -> (R, t, Lq) step stays in PyTorch (tiny, autograd-tracked)."""
-    R = quat_to_rotation(pose[None, :4])[0]       # normalises the quaternion, like get_camera_from_tensor
-    t = pose[4:]
-    Lq = quat_left_matrix(pose[:4])               # quadmultiply(pose[:4], .) uses the raw quaternion
-    return _PreTransform.apply(xyz, rot, scaling, opacity_raw, conf, mask_index, R, t, Lq)
+    7-vector pose (qw,qx,qy,qz,tx,ty,tz): R from the normalised quaternion (get_camera_from_tensor), quadmultiply with the raw
+    one.  Two launches each way (pose -> matrices / chain rule are one-lane kernels); no PyTorch glue."""
+    return _PreTransform.apply(xyz, rot, scaling, opacity_raw, conf, mask_index, pose)
 
 
 class FusedAdam:
@@ -109,6 +103,7 @@ class FusedAdam:
         self.betas, self.eps = betas, eps
         self.state = {}
         self.active_sh_degree = None
+        self._gate_state = None   # device int32[2] of step(gate=...): steps actually taken, scratch flag
 
     def set_active_sh_degree(self, d):
         self.active_sh_degree = d
@@ -122,7 +117,10 @@ class FusedAdam:
                     p.grad.zero_()
 
     @torch.no_grad()
-    def step(self):
+    def step(self, gate=None, threshold=0.0):
+        """gate: optional 0-dim device tensor — the step is taken iff gate > threshold, decided on the device (no host sync);
+        the bias corrections then use a device-side count of the steps actually taken, exactly as if step() had only been
+        called on those iterations."""
         lib = _lib.load()
         b1, b2 = self.betas
         entries, keep, dev = [], [], None
@@ -156,14 +154,29 @@ class FusedAdam:
                     e.rows, e.row_len, e.active_len = 1, p.numel(), p.numel()
                     if p.numel() >= 2 ** 31:
                         raise RuntimeError("FusedAdam: tensor too large")
-                e.step_size = g["lr"] / (1.0 - b1 ** t)
-                e.bc2_sqrt = math.sqrt(1.0 - b2 ** t)
+                if gate is None:
+                    e.step_size = g["lr"] / (1.0 - b1 ** t)
+                    e.bc2_sqrt = math.sqrt(1.0 - b2 ** t)
+                else:           # plain learning rates: the kernel divides by the device-side bias correction
+                    e.step_size, e.bc2_sqrt = g["lr"], 1.0
+                    if e.head_len:
+                        e.step_size_tail = g["lr_rest"]
                 entries.append(e)
         for i in range(0, len(entries), 16):
             chunk = entries[i:i + 16]
             arr = (AdamTensor * len(chunk))(*chunk)
             with torch.cuda.device(dev):
-                rc = lib.das3r_adam_step(len(chunk), arr, C.c_float(b1), C.c_float(b2), C.c_float(self.eps), _stream(dev))
+                if gate is None:
+                    rc = lib.das3r_adam_step(len(chunk), arr, C.c_float(b1), C.c_float(b2), C.c_float(self.eps), _stream(dev))
+                else:
+                    if len(entries) > 16:
+                        raise RuntimeError("FusedAdam.step(gate=...): at most 16 tensors")
+                    if self._gate_state is None:
+                        self._gate_state = torch.zeros(2, dtype=torch.int32, device=dev)
+                    gt = gate.detach().reshape(1).float().contiguous()
+                    keep.append(gt)
+                    rc = lib.das3r_adam_step_gated(len(chunk), arr, C.c_float(b1), C.c_float(b2), C.c_float(self.eps), _p(gt),
+                                                   C.c_float(threshold), _p(self._gate_state), _stream(dev))
             _lib.check(rc, "das3r_adam_step")
 
 

@@ -128,9 +128,10 @@ class SplatModel:
             from .fused import FusedAdam
             groups[2]["sh_rest"] = True
             self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
+            self.optimizer_cam = FusedAdam(cam, lr=0.0, eps=1e-15)   # stepped with a device-side PSNR gate (train.py)
         else:
             self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
-        self.optimizer_cam = torch.optim.Adam(cam, lr=0.0, eps=1e-15)
+            self.optimizer_cam = torch.optim.Adam(cam, lr=0.0, eps=1e-15)
         self._lr_xyz = expon_lr_func(opt.position_lr_init * s, opt.position_lr_final * s, lr_delay_mult=opt.position_lr_delay_mult,
                                      max_steps=opt.position_lr_max_steps)
         self._lr_cam = expon_lr_func(0.00003, 0.000003, lr_delay_mult=opt.position_lr_delay_mult, max_steps=1000)

@@ -43,7 +43,9 @@ def train_step(model: SplatModel, cam, opt: OptimParams, iteration, pipe, backgr
         with torch.no_grad():
             model.optimizer.step()
             model.optimizer.zero_grad(set_to_none=True)
-            if psnr_frame > opt.psnr_threshold:
+            if hasattr(model.optimizer_cam, "_gate_state"):   # FusedAdam: the 26 dB gate is evaluated on the device
+                model.optimizer_cam.step(gate=psnr_frame, threshold=opt.psnr_threshold)
+            elif psnr_frame > opt.psnr_threshold:
                 model.optimizer_cam.step()
             model.optimizer_cam.zero_grad(set_to_none=True)
         return loss.detach(), psnr_frame.detach(), pkg
@@ -69,7 +71,7 @@ def train(model, cameras, opt: OptimParams, iterations, pipe=None, background=No
     dev = model.get_xyz.device
     background = background if background is not None else torch.zeros(3, device=dev)
     rng = random.Random(seed)
-    stack, ema, last_psnr = [], 0.0, 0.0
+    stack, ema, last_psnr = [], torch.zeros((), device=dev), torch.zeros((), device=dev)
     if dev.type == "cuda":
         torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -78,13 +80,13 @@ def train(model, cameras, opt: OptimParams, iterations, pipe=None, background=No
             stack = list(cameras)
         cam = stack.pop(rng.randint(0, len(stack) - 1))
         loss, p, _ = train_step(model, cam, opt, it, pipe, background, fused=fused)
-        ema = 0.4 * float(loss) + 0.6 * ema
-        last_psnr = float(p)
+        ema = 0.4 * loss + 0.6 * ema          # stays on the device: a float() here would stall the host every iteration
+        last_psnr = p
         if log_every and it % log_every == 0:
-            print(f"[ITER {it}] loss {ema:.5f} psnr_frame {last_psnr:.2f}")
+            print(f"[ITER {it}] loss {float(ema):.5f} psnr_frame {float(last_psnr):.2f}")
     if dev.type == "cuda":
         torch.cuda.synchronize()
-    return dict(loss=ema, psnr=last_psnr, iters_per_s=iterations / (time.perf_counter() - t0))
+    return dict(loss=float(ema), psnr=float(last_psnr), iters_per_s=iterations / (time.perf_counter() - t0))
 
 
 def is_test_index(idx):

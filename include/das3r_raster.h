@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DAS3R_ABI_VERSION 5
+#define DAS3R_ABI_VERSION 6
 
 typedef enum {
     DAS3R_OK = 0,
@@ -131,6 +131,11 @@ int das3r_knn3_mean_dist2(int32_t P, const float *points /* [P,3] */, float *out
 
 /* ---- opt-in fused callers' work around the rasterizer (the default DAS3R path does not need them) ---- */
 
+/* pose (qw,qx,qy,qz,tx,ty,tz) -> mats[28] = R (9, rotation of the normalised quaternion: get_camera_from_tensor), t (3), Lq (16,
+ * left-multiplication matrix of the raw quaternion: quadmultiply) — the three small matrices das3r_pretransform_* take — and
+ * the chain rule back from dL/d(mats) (the g_small of das3r_pretransform_backward) to dL/d(pose). */
+int das3r_pose_matrices(const float *pose, float *mats, das3r_stream_t stream);
+int das3r_pose_chain(const float *pose, const float *g_mats, float *g_pose, das3r_stream_t stream);
 /* §8f-1: the per-Gaussian pre-transform + activations of /root/reference/gaussian_renderer/__init__.py:83-97,107 in one
  * pass: means3D = R xyz + t, rotations = Lq rot (quadmultiply(pose[:4], .) as a 4x4 matrix), scales = exp(scaling),
  * opacities = sigmoid(opacity_raw) * conf_flat[mask_index[i]] (mask_index NULL = identity).  R [3,3], t [3], Lq [4,4]:
@@ -165,6 +170,12 @@ typedef struct {
     float step_size_tail;
 } das3r_adam_tensor;
 int das3r_adam_step(int32_t n, const das3r_adam_tensor *tensors, float beta1, float beta2, float eps, das3r_stream_t stream);
+/* The same step taken iff the DEVICE scalar gate[0] > threshold (DAS3R's camera optimizer steps only when the frame PSNR exceeds
+ * 26 dB, train_gui.py:584-586; deciding on the host stalls it every iteration).  state: two device int32, zero-initialised by the
+ * caller: [0] counts the steps actually taken (bias corrections are computed from it on the device), [1] is scratch.
+ * tensors[i].step_size / step_size_tail hold the plain learning rates here; bc2_sqrt is ignored. */
+int das3r_adam_step_gated(int32_t n, const das3r_adam_tensor *tensors, float beta1, float beta2, float eps, const float *gate,
+                          float threshold, int32_t *state, das3r_stream_t stream);
 
 /* ---- fused photometric loss (opt-in) ------------------------------------------------------------------
  * DAS3R's per-iteration loss (/root/reference/train_gui.py:560-571, utils/loss_utils.py:39-66): with image = render * static,

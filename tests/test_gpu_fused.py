@@ -144,6 +144,30 @@ def test_fused_adam_single_sh_tensor_matches_two_torch_groups(degree):
     assert torch.equal(pa.detach()[:, active:, :], full[:, active:, :])
 
 
+def test_fused_adam_device_gate_matches_host_gated_torch_adam():
+    """step(gate=...) decides on the device; parameters, and the bias corrections of later steps, must equal torch.optim.Adam
+    stepped only on the iterations where the gate is open."""
+    from das3r_amd.fused import FusedAdam
+    g = torch.Generator().manual_seed(11)
+    q0, t0 = torch.randn(7, 4, generator=g).cuda(), torch.randn(7, 3, generator=g).cuda()
+    qa, ta = torch.nn.Parameter(q0.clone()), torch.nn.Parameter(t0.clone())
+    qb, tb = torch.nn.Parameter(q0.clone()), torch.nn.Parameter(t0.clone())
+    fa = FusedAdam([dict(params=[qa], lr=3e-5, name="pose_Q"), dict(params=[ta], lr=3e-5, name="pose_T")], lr=0.0, eps=1e-15)
+    tb_opt = torch.optim.Adam([dict(params=[qb], lr=3e-5), dict(params=[tb], lr=3e-5)], lr=0.0, eps=1e-15)
+    gates = [20.0, 27.5, 26.0, 31.0, 12.0, 26.01, 40.0]     # threshold 26: open on steps 1, 3, 5, 6 (strictly greater)
+    for step, gv in enumerate(gates):
+        gq, gt = torch.randn(7, 4, generator=g).cuda(), torch.randn(7, 3, generator=g).cuda()
+        qa.grad, ta.grad, qb.grad, tb.grad = gq.clone(), gt.clone(), gq.clone(), gt.clone()
+        if step == 4:
+            fa.param_groups[0]["lr"] = tb_opt.param_groups[0]["lr"] = 1e-5
+        fa.step(gate=torch.tensor(gv, device="cuda"), threshold=26.0)
+        if gv > 26.0:
+            tb_opt.step()
+    assert int(fa._gate_state[0]) == 4
+    assert float((qa - qb).abs().max()) <= 2e-6 * float(qb.abs().max()) and float((ta - tb).abs().max()) <= 2e-6 * float(tb.abs().max())
+    assert not torch.equal(qa.detach(), q0)
+
+
 def test_fused_adam_skips_params_without_grad_and_rejects_cpu():
     from das3r_amd.fused import FusedAdam
     p, q = torch.nn.Parameter(torch.ones(5).cuda()), torch.nn.Parameter(torch.ones(5).cuda())

@@ -53,8 +53,10 @@ def main():
             for it in range(1000, 1005):
                 train_step(model, cams[it % len(cams)], opt, it, pipe, bg, **kw)
             torch.cuda.synchronize()
-        rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:14]
+        rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:40]
         out["breakdown_ms"] = {r.key[:60]: round(r.device_time_total / 5 / 1e3, 3) for r in rows}
+        out["kernel_launches_per_step"] = sum(r.count for r in prof.key_averages()) / 5
+        out["device_ms_per_step"] = round(sum(r.device_time_total for r in prof.key_averages()) / 5 / 1e3, 3)
     print(json.dumps(out))
 
 
