@@ -102,11 +102,16 @@ __device__ __forceinline__ void binned_rect(const float4 xyh, const int r, const
             rmaxx = rminx;
             return;
         }
-        // pixel centres are integers; tile of pixel x is floor(x / 16)
-        const int tx0 = (int)(fmaxf(xyh.x - xyh.z, 0.f) * (1.0f / TILE_X));
-        const int ty0 = (int)(fmaxf(xyh.y - xyh.w, 0.f) * (1.0f / TILE_Y));
-        const int tx1 = (xyh.x + xyh.z < 0.f) ? 0 : (int)((xyh.x + xyh.z) * (1.0f / TILE_X)) + 1;
-        const int ty1 = (xyh.y + xyh.w < 0.f) ? 0 : (int)((xyh.y + xyh.w) * (1.0f / TILE_Y)) + 1;
+        // pixel centres are integers: the splat can only matter on the centres ceil(x - hx) .. floor(x + hx) (and likewise in y);
+        // an interval that contains no integer touches nothing.  The tile of pixel p is p >> 4.
+        const float px0 = ceilf(xyh.x - xyh.z), px1 = floorf(xyh.x + xyh.z);
+        const float py0 = ceilf(xyh.y - xyh.w), py1 = floorf(xyh.y + xyh.w);
+        if (px1 < px0 || py1 < py0 || px1 < 0.f || py1 < 0.f) {
+            rmaxx = rminx;
+            return;
+        }
+        const int tx0 = (int)fmaxf(px0, 0.f) >> 4, ty0 = (int)fmaxf(py0, 0.f) >> 4;
+        const int tx1 = ((int)fminf(px1, 1.0e6f) >> 4) + 1, ty1 = ((int)fminf(py1, 1.0e6f) >> 4) + 1;
         rminx = max(rminx, tx0);
         rminy = max(rminy, ty0);
         rmaxx = max(rminx, min(rmaxx, tx1));
