@@ -232,13 +232,13 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     if ((rc = check_late(false))) return rc;
     // per-thread ring of self re-arming arrival words for the count reduction of the preprocess kernel
     static thread_local unsigned long long *arrive_ring = nullptr;
-    constexpr uint32_t ARRIVE_SLOTS = 64;
+    constexpr uint32_t ARRIVE_SLOTS = 16, ARRIVE_WORDS = 8 + 64 * 8;   // per call: top word + 64 sub-counters, one 64-byte line each
     if (!arrive_ring) {
-        HIP_TRY(hipMalloc((void **)&arrive_ring, ARRIVE_SLOTS * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(arrive_ring, 0, ARRIVE_SLOTS * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void **)&arrive_ring, ARRIVE_SLOTS * ARRIVE_WORDS * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(arrive_ring, 0, ARRIVE_SLOTS * ARRIVE_WORDS * sizeof(unsigned long long)));
     }
     const uint32_t count_tag = ++mb->seq ? mb->seq : ++mb->seq;
-    if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, nullptr, 0, L, arrive_ring + (count_tag % ARRIVE_SLOTS), mb->dev,
+    if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, nullptr, 0, L, arrive_ring + (size_t)(count_tag % ARRIVE_SLOTS) * ARRIVE_WORDS, mb->dev,
                                 count_tag, s))) return rc;
     if ((rc = launch_depth_sort(P, saved->geom, L, 0, nullptr, 0, a->debug != 0, s))) return rc;
     if ((rc = mailbox_wait(mb, 2, count_tag, s))) return rc;    // usually there already: preprocess finished long ago

@@ -23,15 +23,15 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     uint32_t *__restrict__ tiles_touched, int tight_rect, uint32_t *__restrict__ zero_a, uint32_t zero_a_words, uint32_t *__restrict__ zero_b,
     uint32_t zero_b_words, uint32_t *__restrict__ zero_c, uint32_t zero_c_words, unsigned long long *__restrict__ arrive,
     uint32_t *__restrict__ host_out, uint32_t tag) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
     __shared__ uint32_t s_tiles;   // this workgroup's sum of tiles_touched (num_rendered is their grand total)
     if (threadIdx.x == 0) s_tiles = 0;
     if (!STAGE) __syncthreads();
     // this kernel runs before every consumer of the radix control words (geom side) and of the tile ranges: zero them here
     // instead of spending two memset launches
-    for (uint32_t i = idx; i < zero_a_words; i += gridDim.x * blockDim.x) zero_a[i] = 0u;
-    for (uint32_t i = idx; i < zero_b_words; i += gridDim.x * blockDim.x) zero_b[i] = 0u;
-    for (uint32_t i = idx; i < zero_c_words; i += gridDim.x * blockDim.x) zero_c[i] = 0u;   // binning control words (hinted path)
+    for (uint32_t i = gidx; i < zero_a_words; i += gridDim.x * blockDim.x) zero_a[i] = 0u;
+    for (uint32_t i = gidx; i < zero_b_words; i += gridDim.x * blockDim.x) zero_b[i] = 0u;
+    for (uint32_t i = gidx; i < zero_c_words; i += gridDim.x * blockDim.x) zero_c[i] = 0u;   // binning control words (hinted path)
     // STAGE (M == 16, degree >= 2): the workgroup's 256 SH rows (192 B each, contiguous) are fetched with fully coalesced
     // float4 loads — every 128-B line exactly once — and re-read per lane from LDS.  Per-lane strided row loads re-fetch
     // lines evicted from L1/L2 between the 12 loads of a row: measured 2.5x the algorithmic HBM traffic at 1M splats.
@@ -47,7 +47,8 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
         }
         __syncthreads();
     }
-    if (idx >= P) return;
+    const bool live = gidx < P;   // lanes past the end stay alive (workgroup-wide reduction below): they redo the last splat and store nothing
+    const int idx = live ? gidx : P - 1;
 
     float V[16], PM[16];
 #pragma unroll
@@ -140,6 +141,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
             }
         }
     }
+    if (live) {
     radii[idx] = radius_out;
     depth_key[idx] = key_out;
     tiles_touched[idx] = tiles_out;
@@ -150,21 +152,37 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     // would otherwise pay three random cache lines per splat (record, radii[], tiles_touched[]); the whole line is written
     rgbd[(size_t)idx * SPLAT_REC + 1] = make_float4(__int_as_float(radius_out), __uint_as_float(tiles_out), 0.f, 0.f);
     clamped[idx] = clamp_out;
+    }
 
     // num_rendered = sum of tiles_touched does not depend on the depth order: deliver it to the host NOW, five kernels before the
     // scan that needs it on the device, so that the host can size the binning buffer exactly without ever waiting for the sort.
     // One 64-bit atomic per workgroup carries (workgroups done << 40 | tiles); the last arriver owns the total, re-arms the
-    // counter for its next use and writes {count, tag} to the pinned mailbox (see api.hip).
-    if (tiles_out) atomicAdd(&s_tiles, tiles_out);
-    __syncthreads();   // (waves that returned early have terminated and do not take part)
+    // counters for their next use and writes {count, tag} to the pinned mailbox (see api.hip).
+    uint32_t wsum = live ? tiles_out : 0u;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) wsum += (uint32_t)__shfl_xor((int)wsum, o, 64);
+    if (__lane_id() == 0 && wsum) atomicAdd(&s_tiles, wsum);   // one LDS atomic per wave
+    __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned long long mine = (1ull << 40) | (unsigned long long)s_tiles;
-        const unsigned long long old = atomicAdd(arrive, mine);
-        if ((old >> 40) + 1ull == (unsigned long long)gridDim.x) {
-            const unsigned long long total = (old + mine) & ((1ull << 40) - 1ull);
-            __hip_atomic_store(arrive, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            host_out[0] = (uint32_t)(total > 0xFFFFFFFFull ? 0xFFFFFFFFull : total);
-            __hip_atomic_store(host_out + 2, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // two levels, so that thousands of workgroups do not serialise on one address: 64 sub-counters (workgroup index mod
+        // 64), whose last arrivers forward their sub-totals to the top word arrive[0]
+        constexpr unsigned long long LOW = (1ull << 40) - 1ull;
+        const unsigned r = blockIdx.x & 63u;
+        const unsigned long long expected = (gridDim.x - r + 63u) / 64u;
+        unsigned long long mine = (1ull << 40) | (unsigned long long)s_tiles;
+        unsigned long long *sub = arrive + 8 + 8 * r;   // one 64-byte line per counter
+        unsigned long long old = atomicAdd(sub, mine);
+        if ((old >> 40) + 1ull == expected) {
+            __hip_atomic_store(sub, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+            mine = (1ull << 40) | ((old + mine) & LOW);
+            old = atomicAdd(arrive, mine);
+            const unsigned long long subs = gridDim.x < 64u ? gridDim.x : 64u;
+            if ((old >> 40) + 1ull == subs) {
+                const unsigned long long total = (old + mine) & LOW;
+                __hip_atomic_store(arrive, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // re-arm
+                host_out[0] = (uint32_t)(total > 0xFFFFFFFFull ? 0xFFFFFFFFull : total);
+                __hip_atomic_store(host_out + 2, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }
