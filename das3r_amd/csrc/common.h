@@ -122,6 +122,8 @@ int launch_onesweep_partition(int64_t cap, char *geom, char *binning, const Layo
 bool use_row_private(int64_t instances, int ntiles);  // forward: 4x4-block-per-row kernel for long tile lists (render_rows.hip)
 int launch_render_forward_rows(const das3r_raster_args *a, float *out_color, char *geom, char *binning, char *img, const Layout &L,
                                hipStream_t s);
+int launch_render_backward_mfma(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
+                                float *partial, hipStream_t s);
 bool use_onesweep();  // DAS3R_SORT=classic selects the three-kernel radix passes (diagnostics / A-B)
 bool use_tight_rect();  // DAS3R_RECT=upstream bins over upstream's 3-sigma square (bit-exact list tests)
 // host_late / tag: pinned mailbox the last binning kernel copies the self-check word to (see api.hip)

@@ -148,6 +148,14 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
 
 int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
                            float *partial, hipStream_t s) {
+    {
+        // Reductions on the matrix cores (render_bwd_mfma.hip) pay off on very long tile lists of tiny splats — the DAS3R shape
+        // (one Gaussian per pixel of every frame): 2.06 -> 1.67 ms on the 5 M-splat scene — and lose on 1080p scenes with a
+        // few hundred entries per tile (0.60 -> 0.82 ms at 1 M splats).  DAS3R_RENDER_BWD=mfma / dpp forces one of them.
+        const char *er = getenv("DAS3R_RENDER_BWD");
+        const bool mfma = er ? er[0] == 'm' : (L.capacity >= (int64_t)2048 * L.ntiles && !getenv("DAS3R_BWD_REDUCE") && !getenv("DAS3R_ABLATE"));
+        if (mfma) return launch_render_backward_mfma(a, dL_dpix, geom, binning, img, L, partial, s);
+    }
     const char *e = getenv("DAS3R_BWD_REDUCE");  // "shfl" selects the ds_bpermute reference reduction (diagnostics)
     const bool use_dpp = !(e && e[0] == 's');
     const char *ea = getenv("DAS3R_ABLATE");  // perf experiments only: bit0 = no partial stores, bit2 = no cross-lane reduction

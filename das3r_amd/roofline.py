@@ -37,7 +37,8 @@ def algorithmic_bytes(P, D, M, I, W, H):
     return per_kernel, b_fwd, b_bwd
 
 
-ALIASES = {"render_forward_rows_kernel": "render_forward_kernel"}   # two implementations of the same stage (render_rows.hip)
+ALIASES = {"render_forward_rows_kernel": "render_forward_kernel",     # two implementations of each compositing stage
+           "render_backward_mfma_kernel": "render_backward_kernel"}    # (render_rows.hip, render_bwd_mfma.hip)
 
 
 def group_kernel_times(report):

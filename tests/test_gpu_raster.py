@@ -269,3 +269,19 @@ def test_forward_kernels_agree_bit_for_bit(name, monkeypatch):
     assert nq == nr and torch.equal(cq, cr) and torch.equal(rq, rr)
     for k in gq:   # the backward kernel consumes the forward's final_T / n_contrib: any difference there shows up here
         util.assert_grad_close(gr[k].cpu().numpy(), gq[k].cpu().numpy(), f"rows vs quad forward dL/d{k}", tol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["basic_deg3", "long_lists", "deep", "culled", "ragged_image"])
+def test_backward_kernels_agree(name, monkeypatch):
+    """The two backward compositing kernels (cross-lane DPP reduction of the nine per-pair sums / moments reduced on the
+    matrix cores, render_bwd_mfma.hip) against each other; each of them is also checked against the oracle when selected
+    (DAS3R_RENDER_BWD=mfma python -m pytest tests -m gpu).  fp32 tolerance: the MFMA kernel sums moments about the tile centre."""
+    sc, mode = util.scene_variant(name)
+    out = {}
+    for kind in ("dpp", "mfma"):
+        monkeypatch.setenv("DAS3R_RENDER_BWD", kind)
+        c, r, g, fn = _run_hip(sc, mode)
+        out[kind] = (c, g)
+    assert torch.equal(out["dpp"][0], out["mfma"][0])
+    for k in out["dpp"][1]:
+        util.assert_grad_close(out["mfma"][1][k].cpu().numpy(), out["dpp"][1][k].cpu().numpy(), f"mfma vs dpp backward dL/d{k}", tol=2e-5)
