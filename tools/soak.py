@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Soak test of the forward+backward path: many back-to-back steps, any library error (incl. the deferred binning self-check)
+is counted and printed in full.   python tools/soak.py --workloads c2,c4,ds --steps 3000"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workloads", default="c2,c4,ds")
+    ap.add_argument("--steps", type=int, default=2000)
+    args = ap.parse_args()
+    from das3r_amd import GaussianRasterizationSettings
+    from das3r_amd.rasterizer import _backward_impl, _forward_full
+    from das3r_amd.synth import make_workload
+    dev = torch.device("cuda:0")
+    e = torch.empty(0, device=dev)
+    for w in args.workloads.split(","):
+        sc = make_workload(w).to(dev)
+        rs = GaussianRasterizationSettings(**sc.settings_kwargs())
+        errs, counts, t0 = [], set(), time.perf_counter()
+        for it in range(args.steps):
+            try:
+                I, color, radii, geom, binning, img, cap = _forward_full(rs, sc.means3D, sc.shs, e, sc.opacities, sc.scales, sc.rotations, e)
+                counts.add(I)
+                _backward_impl(rs, I, sc.dL_dpix, sc.means3D, sc.shs, e, sc.opacities, sc.scales, sc.rotations, e, geom, binning, img, cap)
+            except RuntimeError as ex:
+                errs.append((it, str(ex)))
+        torch.cuda.synchronize()
+        print(f"{w}: {args.steps} steps in {time.perf_counter() - t0:.1f} s, num_rendered values {sorted(counts)}, errors {len(errs)}")
+        for it, msg in errs[:5]:
+            print("   step", it, msg)
+
+
+if __name__ == "__main__":
+    main()
