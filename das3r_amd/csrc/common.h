@@ -95,6 +95,15 @@ struct Layout {
     int tiles_x, tiles_y, ntiles, tbits, tile_passes;
     int chunksP, chunksI;
 };
+
+// Local depth order (short tile lists): the binning skips the global depth sort, the tile lists arrive in index order and
+// the forward compositing kernel sorts each one by (depth bits, index) itself (render_common.h: local_sort_tile) — in LDS up
+// to LOCAL_MAX entries, in global memory (slow, rare) beyond.  point_list == null: the lists are already in depth order.
+struct LocalBin {
+    uint32_t *point_list, *slot_list;   // sorted in place
+    uint32_t *keys;                     // u32[num_rendered] scratch for the lists that do not fit in LDS (the dead tile keys)
+    uint32_t *host_flag;                // pinned mailbox word raised when such a list was met
+};
 void compute_layout(int P, int64_t I, int W, int H, Layout *L);
 
 // ---- launchers implemented in the individual .hip files ----
@@ -108,29 +117,31 @@ int launch_mark_visible(int P, const float *means3D, const float *viewmatrix, ui
 // control words (binning_ctrl may be null)
 int launch_depth_sort(int P, char *geom, const Layout &L, int part, char *binning_ctrl, size_t binning_ctrl_bytes, bool debug, hipStream_t s);
 // scan of tiles_touched in depth order -> offsets / off_by_gid / count (exact path: the host then reads the count)
-int launch_scan(int P, char *geom, const Layout &L, uint32_t *host_out, uint32_t tag, bool debug, hipStream_t s);
+int launch_scan(int P, char *geom, const Layout &L, uint32_t *host_out, uint32_t tag, bool debug, hipStream_t s, bool index_order = false);
 // the same scan with the instance emission fused in (hinted path; sort_onesweep.hip)
 int launch_scan_emit(int P, int64_t cap, const int32_t *radii, char *geom, char *binning, const Layout &L, uint32_t *host_out, uint32_t tag,
-                     bool debug, hipStream_t s);
+                     bool debug, hipStream_t s, bool index_order = false);
 size_t scan_status_bytes(int P);
 int launch_binning_scan_emit(int P, int64_t I, const int32_t *radii, char *geom, char *binning, const Layout &L, bool ctrl_zeroed,
-                             uint32_t *host_out, uint32_t tag, bool debug, hipStream_t s);
+                             uint32_t *host_out, uint32_t tag, bool debug, hipStream_t s, bool index_order = false);
 size_t onesweep_status_bytes(int64_t n, int passes);
 int launch_onesweep_depth_sort(int P, char *geom, const Layout &L, int part, uint32_t *zero_ptr, uint32_t zero_words, bool debug,
                                hipStream_t s);
 int launch_onesweep_partition(int64_t cap, char *geom, char *binning, const Layout &L, uint32_t **keys_final, bool debug, hipStream_t s);
 bool use_row_private(int64_t instances, int ntiles);  // forward: 4x4-block-per-row kernel for long tile lists (render_rows.hip)
 int launch_render_forward_rows(const das3r_raster_args *a, float *out_color, char *geom, char *binning, char *img, const Layout &L,
-                               hipStream_t s);
+                               const LocalBin &lb, hipStream_t s);
 int launch_render_backward_mfma(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
                                 float *partial, hipStream_t s);
+constexpr int LOCAL_MAX = 1024;   // longest tile list the forward kernels sort in LDS
 bool use_onesweep();  // DAS3R_SORT=classic selects the three-kernel radix passes (diagnostics / A-B)
 bool use_tight_rect();  // DAS3R_RECT=upstream bins over upstream's 3-sigma square (bit-exact list tests)
 // host_late / tag: pinned mailbox the last binning kernel copies the self-check word to (see api.hip)
 int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *geom, char *binning, char *img, const Layout &L,
-                   bool fused_scan, uint32_t *host_late, uint32_t tag, bool debug, hipStream_t s);
+                   bool fused_scan, uint32_t *host_late, uint32_t tag, bool debug, hipStream_t s, uint32_t **dead_keys = nullptr);
+// lb.point_list != null: the tile lists are in index order and the kernel sorts them by depth first
 int launch_render_forward(const das3r_raster_args *a, const float *colors_precomp, float *out_color, char *geom, char *binning,
-                          char *img, const Layout &L, hipStream_t s);
+                          char *img, const Layout &L, const LocalBin &lb, hipStream_t s);
 // partial: [num_rendered, 9] per-instance sums written by the render backward, gathered by the preprocess backward
 int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
                            float *partial, hipStream_t s);

@@ -52,6 +52,82 @@ __device__ __forceinline__ bool quadrant_hit(const float4 xyh, const float cx, c
     return fabsf(xyh.x - cx) <= xyh.z + 3.5f && fabsf(xyh.y - cy) <= xyh.w + 3.5f;
 }
 
+// ---- local binning front-end (local_bin.hip) -------------------------------------------------------------------------------
+// Local depth order (common.h: LocalBin): the tile's list arrives in index order; sort it by the exact (depth bits, index)
+// key — the order the global radix path produces — in place (point_list / slot_list are read by the backward pass and the
+// tests) and keep the sorted indices in s_gid for the staging loop.  Bitonic network in its always-ascending form (first
+// step of every merge mirrors the block, the rest are plain butterflies), so n needs no padding: a comparison whose partner
+// lies beyond n is skipped.  s_key / s_slot may alias the staging area: they are dead when this returns.
+// Lists longer than LOCAL_MAX are sorted in global memory by the same network (slow; the host is told and goes back to the
+// global sort for the next forwards) and s_gid is not filled.
+__device__ __forceinline__ void local_sort_tile(const LocalBin &lb, const uint2 range, const float4 *__restrict__ rgbd,
+                                                unsigned long long *s_key /*[LOCAL_MAX]*/, uint32_t *s_slot /*[LOCAL_MAX]*/,
+                                                uint32_t *s_gid /*[LOCAL_MAX]*/, const int tid) {
+    const int n = (int)(range.y - range.x);
+    if (n <= 1) {   // (uniform)
+        if (n == 1 && tid == 0) s_gid[0] = lb.point_list[range.x];
+        __syncthreads();
+        return;
+    }
+    uint32_t *pl = lb.point_list + range.x, *sl = lb.slot_list + range.x;
+    if (n <= LOCAL_MAX) {
+        for (int i = tid; i < n; i += TILE_PIX) {
+            const uint32_t g = pl[i];
+            s_key[i] = ((unsigned long long)__float_as_uint(rgbd[(size_t)g * SPLAT_REC].w) << 32) | (unsigned long long)g;
+            s_slot[i] = sl[i];
+        }
+        __syncthreads();
+        for (int k = 2; (k >> 1) < n; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const int flip = (j == (k >> 1)) ? k - 1 : j;
+                for (int i = tid; i < n; i += TILE_PIX) {
+                    const int q = i ^ flip;
+                    if (q > i && q < n) {
+                        const unsigned long long a = s_key[i], b = s_key[q];
+                        if (a > b) {
+                            s_key[i] = b;
+                            s_key[q] = a;
+                            const uint32_t t = s_slot[i];
+                            s_slot[i] = s_slot[q];
+                            s_slot[q] = t;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        for (int i = tid; i < n; i += TILE_PIX) {
+            const uint32_t g = (uint32_t)s_key[i];
+            s_gid[i] = g;
+            pl[i] = g;
+            sl[i] = s_slot[i];
+        }
+        __syncthreads();
+        return;
+    }
+    uint32_t *dk = lb.keys + range.x;
+    if (tid == 0) __hip_atomic_store(lb.host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int i = tid; i < n; i += TILE_PIX) dk[i] = __float_as_uint(rgbd[(size_t)pl[i] * SPLAT_REC].w);
+    __syncthreads();
+    for (int k = 2; (k >> 1) < n; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int flip = (j == (k >> 1)) ? k - 1 : j;
+            for (int i = tid; i < n; i += TILE_PIX) {
+                const int q = i ^ flip;
+                if (q > i && q < n) {
+                    const uint32_t da = dk[i], db = dk[q], ga = pl[i], gb = pl[q];
+                    if (da > db || (da == db && ga > gb)) {
+                        dk[i] = db; dk[q] = da;
+                        pl[i] = gb; pl[q] = ga;
+                        const uint32_t t = sl[i];
+                        sl[i] = sl[q];
+                        sl[q] = t;
+                    }
+                }
+            }
+            __syncthreads();   // same workgroup, same CU: its write-through L1 keeps the exchanged words coherent
+        }
+}
+
 // ---- transposed wavefront reduction -------------------------------------------------------------------------------
 // Sums 8 values across the 64 lanes in 18 cross-lane ops instead of 8 x 6: every exchange step also halves the number
 // of live values per lane (gfx950 v_permlane32_swap / v_permlane16_swap, then DPP inside the 16-lane rows).

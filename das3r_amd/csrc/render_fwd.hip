@@ -9,8 +9,9 @@ __global__ void __launch_bounds__(256) render_forward_kernel(const uint2 *__rest
                                                              int W, int H, int tiles_x, int ntiles, const float4 *__restrict__ xyh,
                                                              const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
                                                              const float *__restrict__ bg, float *__restrict__ final_T,
-                                                             uint32_t *__restrict__ n_contrib, float *__restrict__ out_color) {
+                                                             uint32_t *__restrict__ n_contrib, float *__restrict__ out_color, const LocalBin lb) {
     __shared__ StagedSplat stage[TILE_PIX];
+    __shared__ uint32_t s_gid[LOCAL_MAX];   // local depth order: the tile's sorted list
     const int tile = xcd_tile(blockIdx.x, ntiles);
     if (tile < 0) return;
     const int tid = threadIdx.x, lane = __lane_id(), wave = tid >> 6;
@@ -21,6 +22,10 @@ __global__ void __launch_bounds__(256) render_forward_kernel(const uint2 *__rest
     const float pxf = (float)px, pyf = (float)py;
     const float qcx = (float)(bx * TILE_X + ((wave & 1) << 3)) + 3.5f, qcy = (float)(by * TILE_Y + ((wave >> 1) << 3)) + 3.5f;
     const uint2 range = ranges[tile];
+    const bool sorted_here = lb.point_list != nullptr && (int)(range.y - range.x) <= LOCAL_MAX;   // (uniform)
+    if (lb.point_list)   // local depth order: sort this tile's list first (keys and slots borrow the staging area)
+        local_sort_tile(lb, range, rgbd, reinterpret_cast<unsigned long long *>(stage), reinterpret_cast<uint32_t *>(stage) + 2 * LOCAL_MAX,
+                        s_gid, threadIdx.x);
     int toDo = (int)(range.y - range.x);
     const int rounds = (toDo + TILE_PIX - 1) / TILE_PIX;
 
@@ -32,7 +37,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(const uint2 *__rest
         if (__syncthreads_count(done) == TILE_PIX) break;
         const uint32_t progress = range.x + i * TILE_PIX + tid;
         if (progress < range.y) {
-            const uint32_t g = point_list[progress];
+            const uint32_t g = sorted_here ? s_gid[i * TILE_PIX + tid] : (lb.point_list ? lb.point_list[progress] : point_list[progress]);
             stage[tid].xyh = xyh[(size_t)g * SPLAT_REC];           // one 64-byte record: a single cache line per splat
             stage[tid].co = conic_opacity[(size_t)g * SPLAT_REC];
             stage[tid].rgbd = rgbd[(size_t)g * SPLAT_REC];
@@ -85,14 +90,14 @@ __global__ void __launch_bounds__(256) render_forward_kernel(const uint2 *__rest
 }
 
 int launch_render_forward(const das3r_raster_args *a, const float *colors_precomp, float *out_color, char *geom, char *binning,
-                          char *img, const Layout &L, hipStream_t s) {
+                          char *img, const Layout &L, const LocalBin &lb, hipStream_t s) {
     (void)colors_precomp;  // precomputed colours were copied into rgbd by the preprocess kernel
-    if (use_row_private(L.capacity, L.ntiles)) return launch_render_forward_rows(a, out_color, geom, binning, img, L, s);
+    if (use_row_private(L.capacity, L.ntiles)) return launch_render_forward_rows(a, out_color, geom, binning, img, L, lb, s);
     DAS3R_LAUNCH(render_forward_kernel, dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, (const uint2 *)(img + L.pub.ranges),
                  (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height, L.tiles_x, L.ntiles,
                  (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),
                  (const float4 *)(geom + L.pub.rgbd), a->bg, (float *)(img + L.pub.final_T), (uint32_t *)(img + L.pub.n_contrib),
-                 out_color);
+                 out_color, lb);
     KERNEL_CHECK(s, a->debug, "render_forward");
     return DAS3R_OK;
 }

@@ -63,8 +63,9 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
                                                                   const float4 *__restrict__ conic_opacity,
                                                                   const float4 *__restrict__ rgbd, const float *__restrict__ bg,
                                                                   float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
-                                                                  float *__restrict__ out_color) {
+                                                                  float *__restrict__ out_color, const LocalBin lb) {
     __shared__ StagedSplat stage[TILE_PIX];
+    __shared__ uint32_t s_gid[LOCAL_MAX];   // local depth order: the tile's sorted list
     __shared__ uint8_t lists[4][4][TILE_PIX];   // [wave][row][position]
     const int tile = xcd_tile(blockIdx.x, ntiles);
     if (tile < 0) return;
@@ -76,6 +77,10 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
     const float pxf = (float)px, pyf = (float)py;
     const float q0x = (float)(bx * TILE_X + ((wave & 1) << 3)), q0y = (float)(by * TILE_Y + ((wave >> 1) << 3));
     const uint2 range = ranges[tile];
+    const bool sorted_here = lb.point_list != nullptr && (int)(range.y - range.x) <= LOCAL_MAX;   // (uniform)
+    if (lb.point_list)   // local depth order: sort this tile's list first (keys and slots borrow the staging area)
+        local_sort_tile(lb, range, rgbd, reinterpret_cast<unsigned long long *>(stage), reinterpret_cast<uint32_t *>(stage) + 2 * LOCAL_MAX,
+                        s_gid, threadIdx.x);
     int toDo = (int)(range.y - range.x);
     const int rounds = (toDo + TILE_PIX - 1) / TILE_PIX;
 
@@ -87,7 +92,7 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
         if (__syncthreads_count(done) == TILE_PIX) break;
         const uint32_t progress = range.x + i * TILE_PIX + tid;
         if (progress < range.y) {
-            const uint32_t g = point_list[progress];
+            const uint32_t g = sorted_here ? s_gid[i * TILE_PIX + tid] : (lb.point_list ? lb.point_list[progress] : point_list[progress]);
             stage[tid].xyh = xyh[(size_t)g * SPLAT_REC];           // one 64-byte record: a single cache line per splat
             stage[tid].co = conic_opacity[(size_t)g * SPLAT_REC];
             stage[tid].rgbd = rgbd[(size_t)g * SPLAT_REC];
@@ -143,12 +148,12 @@ bool use_row_private(int64_t instances, int ntiles) {
 }
 
 int launch_render_forward_rows(const das3r_raster_args *a, float *out_color, char *geom, char *binning, char *img, const Layout &L,
-                               hipStream_t s) {
+                               const LocalBin &lb, hipStream_t s) {
     DAS3R_LAUNCH(render_forward_rows_kernel, dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, (const uint2 *)(img + L.pub.ranges),
                  (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height, L.tiles_x, L.ntiles,
                  (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),
                  (const float4 *)(geom + L.pub.rgbd), a->bg, (float *)(img + L.pub.final_T), (uint32_t *)(img + L.pub.n_contrib),
-                 out_color);
+                 out_color, lb);
     KERNEL_CHECK(s, a->debug, "render_forward_rows");
     return DAS3R_OK;
 }

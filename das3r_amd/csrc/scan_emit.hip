@@ -64,12 +64,14 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
         const int r = base + k * 256 + tid;
-        g[k] = r < P ? sorted_idx[r] : 0u;
+        g[k] = r < P ? (sorted_idx ? sorted_idx[r] : (uint32_t)r) : 0u;   // sorted_idx == null: index order (local depth order)
     }
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
         const int r = base + k * 256 + tid;
-        v[k] = r < P ? __float_as_uint(xyh[(size_t)g[k] * SPLAT_REC + 3].y) : 0u;   // tiles_touched, from the splat's 64-byte record
+        // tiles_touched: from the splat's 64-byte record in depth order (one random line instead of two), from the plain array
+        // in index order
+        v[k] = r < P ? (sorted_idx ? __float_as_uint(xyh[(size_t)g[k] * SPLAT_REC + 3].y) : tiles_touched[r]) : 0u;
         sum += v[k];
     }
     uint32_t total;
@@ -153,13 +155,14 @@ size_t scan_status_bytes(int P) {
 }
 
 #define SCAN_COMMON                                                                                                           \
-    P, (const uint32_t *)(geom + L.pub.sorted_idx), (const uint32_t *)(geom + L.pub.tiles_touched),                          \
+    P, order, (const uint32_t *)(geom + L.pub.tiles_touched),                          \
         (uint32_t *)(geom + L.pub.offsets), (uint32_t *)(geom + L.g_off_by_gid), (uint32_t *)(geom + L.g_count),             \
         (u64 *)(geom + L.g_scan_status), (u64 *)(geom + L.g_scan_status) + nblocks, (uint32_t *)(geom + L.g_ticket) + 16,   \
         (uint32_t *)(geom + L.g_ticket) + 8, host_out, tag
 
-int launch_scan(int P, char *geom, const Layout &L, uint32_t *host_out, uint32_t tag, bool debug, hipStream_t s) {
+int launch_scan(int P, char *geom, const Layout &L, uint32_t *host_out, uint32_t tag, bool debug, hipStream_t s, bool index_order) {
     const int nblocks = scan_blocks(P);
+    const uint32_t *order = index_order ? nullptr : (const uint32_t *)(geom + L.pub.sorted_idx);
 #define GO(IT)                                                                                                               \
     DAS3R_LAUNCH((scan_emit_kernel<false, IT>), dim3(nblocks), dim3(256), 0, s, SCAN_COMMON, 0, 0,                            \
                  (const float4 *)(geom + L.pub.xy),                                                                           \
@@ -171,8 +174,9 @@ int launch_scan(int P, char *geom, const Layout &L, uint32_t *host_out, uint32_t
 }
 
 int launch_scan_emit(int P, int64_t cap, const int32_t *radii, char *geom, char *binning, const Layout &L, uint32_t *host_out, uint32_t tag,
-                     bool debug, hipStream_t s) {
+                     bool debug, hipStream_t s, bool index_order) {
     const int nblocks = scan_blocks(P);
+    const uint32_t *order = index_order ? nullptr : (const uint32_t *)(geom + L.pub.sorted_idx);
 #define GO(IT)                                                                                                               \
     DAS3R_LAUNCH((scan_emit_kernel<true, IT>), dim3(nblocks), dim3(256), 0, s, SCAN_COMMON, L.tiles_x, L.tiles_y,              \
                  (const float4 *)(geom + L.pub.xy), radii, (uint32_t *)(binning + L.b_keyA), (uint32_t *)(binning + L.b_gid_of), \

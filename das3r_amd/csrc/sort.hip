@@ -277,15 +277,15 @@ int launch_depth_sort(int P, char *geom, const Layout &L, int part, char *binnin
 // Hinted path, first half of the binning: zero the control words, then scan + emit in one kernel.  The caller copies the
 // count back right behind it and then calls launch_binning(..., fused_scan = true) for the partition.
 int launch_binning_scan_emit(int P, int64_t I, const int32_t *radii, char *geom, char *binning, const Layout &L, bool ctrl_zeroed,
-                             uint32_t *host_out, uint32_t tag, bool debug, hipStream_t s) {
+                             uint32_t *host_out, uint32_t tag, bool debug, hipStream_t s, bool index_order) {
     if (I == 0 || P == 0) return DAS3R_OK;
     if (!ctrl_zeroed) HIP_TRY(hipMemsetAsync(binning + L.b_ghist, 0, L.b_ctrl_bytes, s));
-    return launch_scan_emit(P, I, radii, geom, binning, L, host_out, tag, debug, s);
+    return launch_scan_emit(P, I, radii, geom, binning, L, host_out, tag, debug, s, index_order);
 }
 
 // I = capacity of the binning buffer; the true instance count is read by the kernels from geom + L.g_count
 int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *geom, char *binning, char *img, const Layout &L,
-                   bool fused_scan, uint32_t *host_late, uint32_t tag, bool debug, hipStream_t s) {
+                   bool fused_scan, uint32_t *host_late, uint32_t tag, bool debug, hipStream_t s, uint32_t **dead_keys) {
     const uint32_t *n_ptr = (const uint32_t *)(geom + L.g_count);
     (void)W; (void)H;
     uint2 *ranges = (uint2 *)(img + L.pub.ranges);  // zeroed by preprocess_kernel
@@ -308,6 +308,7 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
         uint32_t *kfinal = nullptr;
         int rc1 = launch_onesweep_partition(I, geom, binning, L, &kfinal, debug, s);
         if (rc1) return rc1;
+        if (dead_keys) *dead_keys = kfinal;   // the tile keys are dead once tile_ranges_kernel has run
         DAS3R_LAUNCH(tile_ranges_kernel, dim3(div_up(I, 256)), dim3(256), 0, s, (uint32_t)I, n_ptr, kfinal, ranges,
                      (const uint32_t *)(geom + L.g_ticket) + 8, host_late, tag);
         KERNEL_CHECK(s, debug, "tile_ranges");
@@ -328,6 +329,7 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
         vout = (vout == valB) ? valA : valB;
     }
     // kin/vin now hold the partitioned (tile id, gaussian id) lists; vin == binning + pub.point_list by construction
+    if (dead_keys) *dead_keys = kin;
     DAS3R_LAUNCH(tile_ranges_kernel, dim3(div_up(I, 256)), dim3(256), 0, s, (uint32_t)I, n_ptr, kin, ranges,
                  (const uint32_t *)(geom + L.g_ticket) + 8, host_late, tag);
     KERNEL_CHECK(s, debug, "tile_ranges");

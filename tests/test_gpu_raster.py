@@ -55,13 +55,19 @@ def test_forward_backward_vs_oracle(name):
     assert float(g["means2D"][:, 2].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("name", ["basic_deg3", "ragged_image", "long_lists", "culled", "depth_ties", "world_camera"])
-def test_binning_bit_exact(name, monkeypatch):
+@pytest.mark.parametrize("binning_path", ["radix", "local"])
+@pytest.mark.parametrize("name", ["basic_deg3", "ragged_image", "long_lists", "deep", "culled", "depth_ties", "world_camera"])
+def test_binning_bit_exact(name, binning_path, monkeypatch):
     """Per-Gaussian geometry, depth order, per-tile splat lists and tile ranges are integer / exactly-rounded fp32 work:
     they must equal the oracle's bit for bit (binning over upstream's 3-sigma square: DAS3R_RECT=upstream; the default
-    opacity-aware clipped rectangle is covered by test_tight_rect_is_exact)."""
+    opacity-aware clipped rectangle is covered by test_tight_rect_is_exact) — with the global depth sort and with the local
+    depth order (lists emitted in index order and sorted by the compositing kernel: in LDS, or, "long_lists", in global
+    memory when a list has more than 1024 entries)."""
     monkeypatch.setenv("DAS3R_RECT", "upstream")
+    monkeypatch.setenv("DAS3R_BINNING", binning_path)
     from das3r_amd import _lib
+    _lib.profile_report()   # drain
+    _lib.profile_enable(True)
     sc, mode = util.scene_variant(name)
     _, ref_radii, _, S = util.run_oracle(sc, mode, backward=False)
     from das3r_amd import GaussianRasterizationSettings
@@ -74,6 +80,10 @@ def test_binning_bit_exact(name, monkeypatch):
         GaussianRasterizationSettings(**skw), kw["means3D"], kw.get("shs", e), kw.get("colors_precomp", e), kw["opacities"],
         kw.get("scales", e), kw.get("rotations", e), kw.get("cov3D_precomp", e))
     torch.cuda.synchronize()
+    _lib.profile_enable(False)
+    kernels = _lib.profile_report()
+    ran = lambda prefix: any(k.startswith(prefix) for k in kernels)
+    assert ran("depth_hist") == (binning_path == "radix"), kernels   # the local order skips the global depth sort
     assert np.array_equal(radii.cpu().numpy(), ref_radii)
     P, npix = sc.P, sc.W * sc.H
     L = _lib.layout(P, I, sc.W, sc.H)
@@ -285,3 +295,23 @@ def test_backward_kernels_agree(name, monkeypatch):
     assert torch.equal(out["dpp"][0], out["mfma"][0])
     for k in out["dpp"][1]:
         util.assert_grad_close(out["mfma"][1][k].cpu().numpy(), out["dpp"][1][k].cpu().numpy(), f"mfma vs dpp backward dL/d{k}", tol=2e-5)
+
+
+@pytest.mark.parametrize("render", ["quad", "rows"])
+@pytest.mark.parametrize("name", ["basic_deg3", "long_lists", "deep", "depth_ties", "ragged_image"])
+def test_depth_orders_agree(name, render, monkeypatch):
+    """Global depth sort vs the local depth order (tile lists sorted by the compositing kernel, api.hip): the lists are
+    identical, so image, radii and num_rendered must be too, and the gradients up to the order of the per-wave LDS adds
+    (the emission slots — rows of the backward pass's partial sums — are numbered in index instead of depth order)."""
+    sc, mode = util.scene_variant(name)
+    monkeypatch.setenv("DAS3R_RENDER", render)
+    out = {}
+    for kind in ("radix", "local"):
+        monkeypatch.setenv("DAS3R_BINNING", kind)
+        c, r, g, fn = _run_hip(sc, mode)
+        out[kind] = (c, r, g, fn.num_rendered)
+    ca, ra, ga, na = out["radix"]
+    cb, rb, gb, nb = out["local"]
+    assert na == nb and torch.equal(ca, cb) and torch.equal(ra, rb)
+    for k in ga:
+        util.assert_grad_close(gb[k].cpu().numpy(), ga[k].cpu().numpy(), f"local vs global depth order dL/d{k}", tol=1e-5)
