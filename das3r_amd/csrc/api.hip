@@ -242,49 +242,85 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     // size; the instances are emitted in index order and the compositing kernel sorts every tile's list itself (common.h:
     // LocalBin).  Chosen from the instance count of the previous forward of the same shape, confirmed with this forward's
     // count; a list that outgrows LDS is still sorted correctly (slowly) and sends the next forwards back to the global sort.
-    struct Verdict { int P, W, H; int64_t last_I; int radix_left; };
-    static thread_local Verdict verdict = {0, 0, 0, -1, 0};
-    constexpr int64_t LOCAL_AVG = 128;   // mean list length up to which the local order wins
-    if (verdict.P != P || verdict.W != W || verdict.H != H) verdict = Verdict{P, W, H, -1, 0};
+    struct Verdict { int P, W, H; int64_t last_I; int radix_left, backoff; };
+    static thread_local Verdict verdict = {0, 0, 0, -1, 0, 64};
+    constexpr int64_t LOCAL_AVG = 384;   // mean list length up to which the local order wins (measured: 1 M splats at 1080p, mean 320: -4 %)
+    if (verdict.P != P || verdict.W != W || verdict.H != H) verdict = Verdict{P, W, H, -1, 0, 64};
     if (mb->host[10]) {   // a forward met a list that did not fit in LDS
         mb->host[10] = 0;
-        verdict.radix_left = 64;
+        verdict.radix_left = verdict.backoff;   // global sort for a while; longer every time it happens again
+        if (verdict.backoff < 4096) verdict.backoff *= 2;
     }
     const char *eb = getenv("DAS3R_BINNING");   // local | radix: force one (diagnostics, tests)
     const int forced = eb ? (eb[0] == 'l' ? 1 : eb[0] == 'r' ? -1 : 0) : 0;
     bool local = use_onesweep() && (forced > 0 || (forced == 0 && verdict.radix_left == 0 && verdict.last_I <= LOCAL_AVG * L.ntiles));
     if (forced == 0 && verdict.radix_left > 0) verdict.radix_left--;
     const uint32_t count_tag = ++mb->seq ? mb->seq : ++mb->seq;
-    if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, nullptr, 0, L, arrive_ring + (size_t)(count_tag % ARRIVE_SLOTS) * ARRIVE_WORDS, mb->dev,
-                                count_tag, s))) return rc;
-    if (!local && (rc = launch_depth_sort(P, saved->geom, L, 0, nullptr, 0, a->debug != 0, s))) return rc;
-    if ((rc = mailbox_wait(mb, 2, count_tag, s))) return rc;    // usually there already: preprocess finished long ago
-    const int64_t I = (int64_t)mb->host[0], cap = I;
-    if (cap > (int64_t)0x7FFFFF00) { set_error("num_rendered %lld exceeds 2^31", (long long)cap); return DAS3R_ERR_OVERFLOW; }
-    verdict.last_I = I;
-    if (local && forced == 0 && I > LOCAL_AVG * L.ntiles) {   // the scene grew: global sort after all
-        local = false;
-        if ((rc = launch_depth_sort(P, saved->geom, L, 0, nullptr, 0, a->debug != 0, s))) return rc;
+    unsigned long long *arrive = arrive_ring + (size_t)(count_tag % ARRIVE_SLOTS) * ARRIVE_WORDS;
+    // everything behind the count: scan + emission, partition, tile ranges, compositing (L laid out for `cap`, buffer allocated)
+    auto bin_and_render = [&](int64_t cap, bool local_order, bool ctrl_zeroed) -> int {
+        int r;
+        const bool fused_scan = use_onesweep();   // scan + emission in one kernel; the classic path scans, then emits
+        if (fused_scan) {
+            if ((r = launch_binning_scan_emit(P, cap, out->radii, saved->geom, saved->binning, L, ctrl_zeroed, nullptr, 0, a->debug != 0, s, local_order))) return r;
+        } else if ((r = launch_scan(P, saved->geom, L, nullptr, 0, a->debug != 0, s))) return r;
+        if (cap > 0) {
+            if ((r = check_late(true))) return r;   // one self-check word in flight at a time
+            late_tag = ++mb->seq ? mb->seq : ++mb->seq;
+        }
+        uint32_t *dead_keys = nullptr;
+        if ((r = launch_binning(P, cap, W, H, out->radii, saved->geom, saved->binning, saved->img, L, fused_scan, mb->dev + 8, late_tag,
+                                a->debug != 0, s, &dead_keys))) return r;
+        LocalBin lb = {nullptr, nullptr, nullptr, nullptr};
+        if (local_order && cap > 0)
+            lb = LocalBin{(uint32_t *)(saved->binning + L.pub.point_list), (uint32_t *)(saved->binning + L.b_slot), dead_keys, mb->dev + 10};
+        return launch_render_forward(a, in->colors_precomp, out->out_color, saved->geom, saved->binning, saved->img, L, lb, s);
+    };
+    int64_t I, cap;
+    // Local order + a previous forward of the same shape: nothing else could be enqueued while the count is on its way, so
+    // the binning buffer is laid out for that forward's count + 25 % and the whole forward is enqueued before the host looks
+    // at the mailbox (the kernels clamp to the capacity).  Should the scene have grown past it, the binning and the
+    // compositing are redone with the exact size.  DAS3R_CAPACITY=exact switches the speculation off.
+    const char *ec = getenv("DAS3R_CAPACITY");
+    if (local && verdict.last_I >= 0 && a->capacity_hint != -1 && !(ec && ec[0] == 'e')) {
+        cap = verdict.last_I + verdict.last_I / 4 + 4096;
+        if (cap > (int64_t)0x7FFFFF00) cap = (int64_t)0x7FFFFF00;
+        compute_layout(P, cap, W, H, &L);
+        saved->binning = alloc_binning(user, L.pub.binning_bytes);
+        if (!saved->binning) { set_error("scratch allocation failed (binning %zu B)", L.pub.binning_bytes); return DAS3R_ERR_ALLOC; }
+        if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, saved->binning + L.b_ghist, L.b_ctrl_bytes, L, arrive, mb->dev,
+                                    count_tag, s))) return rc;
+        if ((rc = bin_and_render(cap, true, true))) return rc;
+        if ((rc = mailbox_wait(mb, 2, count_tag, s))) return rc;
+        I = (int64_t)mb->host[0];
+        if (I > (int64_t)0x7FFFFF00) { set_error("num_rendered %lld exceeds 2^31", (long long)I); return DAS3R_ERR_OVERFLOW; }
+        verdict.last_I = I;
+        if (I > cap) {
+            cap = I;
+            compute_layout(P, cap, W, H, &L);
+            saved->binning = alloc_binning(user, L.pub.binning_bytes);
+            if (!saved->binning) { set_error("scratch allocation failed (binning %zu B)", L.pub.binning_bytes); return DAS3R_ERR_ALLOC; }
+            HIP_TRY(hipMemsetAsync(saved->geom + L.g_ghist, 0, L.g_ctrl_bytes, s));          // tickets and look-back words of the scan
+            HIP_TRY(hipMemsetAsync(saved->img + L.pub.ranges, 0, 8 * (size_t)L.ntiles, s));
+            if ((rc = bin_and_render(cap, true, false))) return rc;
+        }
+    } else {
+        if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, nullptr, 0, L, arrive, mb->dev, count_tag, s))) return rc;
+        if (!local && (rc = launch_depth_sort(P, saved->geom, L, 0, nullptr, 0, a->debug != 0, s))) return rc;
+        if ((rc = mailbox_wait(mb, 2, count_tag, s))) return rc;    // usually there already: preprocess finished long ago
+        I = cap = (int64_t)mb->host[0];
+        if (cap > (int64_t)0x7FFFFF00) { set_error("num_rendered %lld exceeds 2^31", (long long)cap); return DAS3R_ERR_OVERFLOW; }
+        verdict.last_I = I;
+        if (local && forced == 0 && I > LOCAL_AVG * L.ntiles) {   // the scene grew: global sort after all
+            local = false;
+            if ((rc = launch_depth_sort(P, saved->geom, L, 0, nullptr, 0, a->debug != 0, s))) return rc;
+        }
+        compute_layout(P, cap, W, H, &L);
+        saved->binning = alloc_binning(user, L.pub.binning_bytes);
+        if (!saved->binning) { set_error("scratch allocation failed (binning %zu B)", L.pub.binning_bytes); return DAS3R_ERR_ALLOC; }
+        if (!local && (rc = launch_depth_sort(P, saved->geom, L, 1, saved->binning + L.b_ghist, L.b_ctrl_bytes, a->debug != 0, s))) return rc;
+        if ((rc = bin_and_render(cap, local, !local))) return rc;
     }
-    compute_layout(P, cap, W, H, &L);
-    saved->binning = alloc_binning(user, L.pub.binning_bytes);
-    if (!saved->binning) { set_error("scratch allocation failed (binning %zu B)", L.pub.binning_bytes); return DAS3R_ERR_ALLOC; }
-    if (!local && (rc = launch_depth_sort(P, saved->geom, L, 1, saved->binning + L.b_ghist, L.b_ctrl_bytes, a->debug != 0, s))) return rc;
-    const bool fused_scan = use_onesweep();   // scan + emission in one kernel; the classic path scans, then emits
-    if (fused_scan) {
-        if ((rc = launch_binning_scan_emit(P, cap, out->radii, saved->geom, saved->binning, L, !local, nullptr, 0, a->debug != 0, s, local))) return rc;
-    } else if ((rc = launch_scan(P, saved->geom, L, nullptr, 0, a->debug != 0, s))) return rc;
-    if (cap > 0) {
-        if ((rc = check_late(true))) return rc;   // one self-check word in flight at a time
-        late_tag = ++mb->seq ? mb->seq : ++mb->seq;
-    }
-    uint32_t *dead_keys = nullptr;
-    if ((rc = launch_binning(P, cap, W, H, out->radii, saved->geom, saved->binning, saved->img, L, fused_scan, mb->dev + 8, late_tag,
-                             a->debug != 0, s, &dead_keys))) return rc;
-    LocalBin lb = {nullptr, nullptr, nullptr, nullptr};
-    if (local && cap > 0)
-        lb = LocalBin{(uint32_t *)(saved->binning + L.pub.point_list), (uint32_t *)(saved->binning + L.b_slot), dead_keys, mb->dev + 10};
-    if ((rc = launch_render_forward(a, in->colors_precomp, out->out_color, saved->geom, saved->binning, saved->img, L, lb, s))) return rc;
     if (a->debug && (rc = check_late(true))) return rc;   // debug: report this forward's self-check word right away
     saved->num_rendered = I;
     saved->capacity = cap;

@@ -53,28 +53,62 @@ __device__ __forceinline__ bool quadrant_hit(const float4 xyh, const float cx, c
 }
 
 // ---- local binning front-end (local_bin.hip) -------------------------------------------------------------------------------
-// Local depth order (common.h: LocalBin): the tile's list arrives in index order; sort it by the exact (depth bits, index)
-// key — the order the global radix path produces — in place (point_list / slot_list are read by the backward pass and the
-// tests) and keep the sorted indices in s_gid for the staging loop.  Bitonic network in its always-ascending form (first
-// step of every merge mirrors the block, the rest are plain butterflies), so n needs no padding: a comparison whose partner
-// lies beyond n is skipped.  s_key / s_slot may alias the staging area: they are dead when this returns.
-// Lists longer than LOCAL_MAX are sorted in global memory by the same network (slow; the host is told and goes back to the
-// global sort for the next forwards) and s_gid is not filled.
-__device__ __forceinline__ void local_sort_tile(const LocalBin &lb, const uint2 range, const float4 *__restrict__ rgbd,
-                                                unsigned long long *s_key /*[LOCAL_MAX]*/, uint32_t *s_slot /*[LOCAL_MAX]*/,
-                                                uint32_t *s_gid /*[LOCAL_MAX]*/, const int tid) {
+// Local depth order (common.h: LocalBin): the tile's list arrives in index order; put it in the exact (depth bits, index)
+// order the global radix path produces, in place (point_list / slot_list are read by the backward pass and the tests).
+//   n <= 256   rank sort fused with the staging of the first (only) batch: every thread loads its entry's record, counts the
+//              keys below its own (n broadcast LDS reads, no barriers inside) and stores the record at that rank of `stage` —
+//              one extra barrier and no extra trip to memory compared with reading a sorted list.  Returns true.
+//   n <= 1024  bitonic network on 64-bit words (depth bits << 32 | position in the list: positions follow the index order,
+//              so this is the (depth, index) order) in its always-ascending form (first step of every merge mirrors the
+//              block, the rest are plain butterflies): n needs no padding, a comparison whose partner lies beyond n is
+//              skipped.  The sorted indices stay in s_gid for the staging loop.  The words borrow the staging area.
+//   longer     the same network over global memory (slow; the host is told and goes back to the global sort for the next
+//              forwards); s_gid is not filled.
+__device__ __forceinline__ bool local_order_tile(const LocalBin &lb, const uint2 range, const float4 *__restrict__ xyh,
+                                                 const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
+                                                 StagedSplat *stage /*[TILE_PIX]*/, uint32_t *s_gid /*[LOCAL_MAX]*/, const int tid) {
     const int n = (int)(range.y - range.x);
-    if (n <= 1) {   // (uniform)
-        if (n == 1 && tid == 0) s_gid[0] = lb.point_list[range.x];
-        __syncthreads();
-        return;
-    }
     uint32_t *pl = lb.point_list + range.x, *sl = lb.slot_list + range.x;
+    if (n <= TILE_PIX) {   // (uniform)
+        unsigned long long *s_key = reinterpret_cast<unsigned long long *>(s_gid);
+        unsigned long long key = 0;
+        uint32_t g = 0, slot = 0;
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;   // (initialised: left undefined, the compiler parks them in LDS — +13 us)
+        if (tid < n) {
+            g = pl[tid];
+            slot = sl[tid];
+            r0 = xyh[(size_t)g * SPLAT_REC];
+            r1 = conic_opacity[(size_t)g * SPLAT_REC];
+            r2 = rgbd[(size_t)g * SPLAT_REC];
+            key = ((unsigned long long)__float_as_uint(r2.w) << 32) | (unsigned long long)g;
+        }
+        if (tid < ((n + 7) & ~7)) s_key[tid] = tid < n ? key : ~0ull;   // padded to a multiple of 8 with keys that count for nobody
+        __syncthreads();
+        if (tid < n) {
+            int rank = 0;
+            for (int j = 0; j < n; j += 8) {   // 8 independent broadcast reads in flight
+                unsigned long long o[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) o[u] = s_key[j + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) rank += o[u] < key ? 1 : 0;
+            }
+            stage[rank].xyh = r0;
+            stage[rank].co = r1;
+            stage[rank].rgbd = r2;
+            pl[rank] = g;
+            sl[rank] = slot;
+        }
+        return true;   // the compositing loop's barrier publishes the batch
+    }
     if (n <= LOCAL_MAX) {
+        unsigned long long *s_key = reinterpret_cast<unsigned long long *>(stage);
+        uint32_t *s_slot = reinterpret_cast<uint32_t *>(stage) + 2 * LOCAL_MAX;
         for (int i = tid; i < n; i += TILE_PIX) {
             const uint32_t g = pl[i];
-            s_key[i] = ((unsigned long long)__float_as_uint(rgbd[(size_t)g * SPLAT_REC].w) << 32) | (unsigned long long)g;
+            s_gid[i] = g;
             s_slot[i] = sl[i];
+            s_key[i] = ((unsigned long long)__float_as_uint(rgbd[(size_t)g * SPLAT_REC].w) << 32) | (unsigned long long)i;
         }
         __syncthreads();
         for (int k = 2; (k >> 1) < n; k <<= 1)
@@ -87,22 +121,31 @@ __device__ __forceinline__ void local_sort_tile(const LocalBin &lb, const uint2 
                         if (a > b) {
                             s_key[i] = b;
                             s_key[q] = a;
-                            const uint32_t t = s_slot[i];
-                            s_slot[i] = s_slot[q];
-                            s_slot[q] = t;
                         }
                     }
                 }
                 __syncthreads();
             }
-        for (int i = tid; i < n; i += TILE_PIX) {
-            const uint32_t g = (uint32_t)s_key[i];
-            s_gid[i] = g;
-            pl[i] = g;
-            sl[i] = s_slot[i];
+        uint32_t g[LOCAL_MAX / TILE_PIX], slot[LOCAL_MAX / TILE_PIX];
+#pragma unroll
+        for (int u = 0; u < LOCAL_MAX / TILE_PIX; u++) {
+            const int i = u * TILE_PIX + tid;
+            const int from = i < n ? (int)((uint32_t)s_key[i] & (uint32_t)(LOCAL_MAX - 1)) : 0;
+            g[u] = s_gid[from];
+            slot[u] = s_slot[from];
         }
         __syncthreads();
-        return;
+#pragma unroll
+        for (int u = 0; u < LOCAL_MAX / TILE_PIX; u++) {
+            const int i = u * TILE_PIX + tid;
+            if (i < n) {
+                s_gid[i] = g[u];
+                pl[i] = g[u];
+                sl[i] = slot[u];
+            }
+        }
+        __syncthreads();
+        return false;
     }
     uint32_t *dk = lb.keys + range.x;
     if (tid == 0) __hip_atomic_store(lb.host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -126,6 +169,7 @@ __device__ __forceinline__ void local_sort_tile(const LocalBin &lb, const uint2 
             }
             __syncthreads();   // same workgroup, same CU: its write-through L1 keeps the exchanged words coherent
         }
+    return false;
 }
 
 // ---- transposed wavefront reduction -------------------------------------------------------------------------------

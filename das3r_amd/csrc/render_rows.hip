@@ -78,9 +78,8 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
     const float q0x = (float)(bx * TILE_X + ((wave & 1) << 3)), q0y = (float)(by * TILE_Y + ((wave >> 1) << 3));
     const uint2 range = ranges[tile];
     const bool sorted_here = lb.point_list != nullptr && (int)(range.y - range.x) <= LOCAL_MAX;   // (uniform)
-    if (lb.point_list)   // local depth order: sort this tile's list first (keys and slots borrow the staging area)
-        local_sort_tile(lb, range, rgbd, reinterpret_cast<unsigned long long *>(stage), reinterpret_cast<uint32_t *>(stage) + 2 * LOCAL_MAX,
-                        s_gid, threadIdx.x);
+    // local depth order: sort this tile's list first (a list of one batch is staged by the sort itself)
+    const bool prestaged = lb.point_list != nullptr && local_order_tile(lb, range, xyh, conic_opacity, rgbd, stage, s_gid, threadIdx.x);
     int toDo = (int)(range.y - range.x);
     const int rounds = (toDo + TILE_PIX - 1) / TILE_PIX;
 
@@ -91,7 +90,7 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
     for (int i = 0; i < rounds; i++, toDo -= TILE_PIX) {
         if (__syncthreads_count(done) == TILE_PIX) break;
         const uint32_t progress = range.x + i * TILE_PIX + tid;
-        if (progress < range.y) {
+        if (progress < range.y && !prestaged) {
             const uint32_t g = sorted_here ? s_gid[i * TILE_PIX + tid] : (lb.point_list ? lb.point_list[progress] : point_list[progress]);
             stage[tid].xyh = xyh[(size_t)g * SPLAT_REC];           // one 64-byte record: a single cache line per splat
             stage[tid].co = conic_opacity[(size_t)g * SPLAT_REC];

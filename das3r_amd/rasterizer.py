@@ -38,10 +38,23 @@ def _ptr(t):
     return None if t is None or t.numel() == 0 else C.c_void_p(t.data_ptr())
 
 
+_EMPTY = {}
+
+
+def _empty(device):
+    """The 'not provided' placeholder (upstream passes torch.Tensor([])): one cached empty tensor per device."""
+    t = _EMPTY.get(device)
+    if t is None:
+        t = _EMPTY[device] = torch.empty(0, dtype=torch.float32, device=device)
+    return t
+
+
 def _prep(t, device, name):
     """contiguous fp32 tensor on `device` (empty tensors mean 'not provided', as upstream)."""
     if t is None:
-        return torch.empty(0, device=device)
+        return _empty(device)
+    if t.dtype == torch.float32 and t.device == device and t.is_contiguous():   # the usual case, first
+        return t
     if t.numel() == 0:  # 'not provided' placeholders (upstream passes CPU torch.Tensor([])) and P == 0 inputs: keep the shape
         return t.to(device=device, dtype=torch.float32)
     if t.numel() and t.dtype != torch.float32:
@@ -117,17 +130,40 @@ def _fill_in(means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_p
     return i
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(device):
+    if _raw_stream is not None and device.index is not None:
+        return C.c_void_p(_raw_stream(device.index))
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+class _on_device:
+    """`with torch.cuda.device(device)` only when `device` is not already current (the context manager costs ~5 us)."""
+
+    def __init__(self, device):
+        self.ctx = None if device.index is None or torch.cuda.current_device() == device.index else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*exc)
+        return False
+
+
 def _forward_impl(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp):
-    """-> (num_rendered, color, radii, geom, binning, img)."""
-    return _forward_full(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)[:6]
+    """-> (num_rendered, color, radii, geom, binning, img), the binning buffer laid out for exactly num_rendered instances
+    (inspection helper of the tests and tools: `_lib.layout(P, num_rendered, W, H)` then describes the buffers)."""
+    return _forward_full(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, exact=True)[:6]
 
 
-def _forward_full(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, exact=True):
-    """-> (num_rendered, color, radii, geom, binning, img, capacity)."""
+def _forward_full(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, exact=False):
+    """-> (num_rendered, color, radii, geom, binning, img, capacity); capacity >= num_rendered is what the binning buffer
+    was laid out for (`_lib.layout(P, capacity, W, H)`), == num_rendered when `exact`."""
     lib = _lib.load()
     device = means3D.device
     if device.type != "cuda":
@@ -152,12 +188,12 @@ def _forward_full(rs, means3D, sh, colors_precomp, opacities, scales, rotations,
     alloc = _Alloc.get(device)
     keep = []
     a = _fill_args(rs, P, M, device, keep)
-    a.capacity_hint = 0   # reserved: the library sizes the binning buffer exactly (the count leaves with its first kernel)
+    a.capacity_hint = -1 if exact else 0   # 0: the library may lay the binning buffer out with headroom (include/das3r_raster.h)
     i = _fill_in(means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp)
     o = _lib.RasterOut()
     o.out_color, o.radii = color.data_ptr(), radii.data_ptr()
     saved = _lib.RasterSaved()
-    with torch.cuda.device(device):
+    with _on_device(device):
         rc = lib.das3r_raster_forward(C.byref(a), C.byref(i), C.byref(o), alloc.fns["geom"], alloc.fns["binning"],
                                       alloc.fns["img"], None, C.byref(saved), _stream(device))
     _lib.check(rc, "das3r_raster_forward")
@@ -174,13 +210,15 @@ def _backward_impl(rs, num_rendered, grad_out_color, means3D, sh, colors_precomp
     P = means3D.shape[0]
     M = sh.shape[1] if sh.numel() else 0
     z = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)  # fully written by the library
+    has_sh, has_cov = sh.numel() > 0, cov3Ds_precomp.numel() > 0
     g_means2D, g_opac, g_means3D = z(P, 3), z(P, 1), z(P, 3)
-    g_sh = z(P, M, 3) if M else torch.zeros(P, 0, 3, device=device)
-    g_colors = z(P, 3)
-    g_scales, g_rot, g_cov = z(P, 3), z(P, 4), z(P, 6)
+    # only the gradients this call's inputs have (the others are returned as None by the autograd function)
+    g_sh = z(P, M, 3) if has_sh else None
+    g_colors = None if has_sh else z(P, 3)
+    g_scales, g_rot = (None, None) if has_cov else (z(P, 3), z(P, 4))
+    g_cov = z(P, 6) if has_cov else None
     if P == 0:
         return g_means2D, g_colors, g_opac, g_means3D, g_cov, g_sh, g_scales, g_rot
-    has_sh, has_cov = sh.numel() > 0, cov3Ds_precomp.numel() > 0
     scratch = z(max(capacity, 1), 9)   # per-instance partial sums (rows < num_rendered are fully written by the render backward)
     keep = []
     a = _fill_args(rs, P, M, device, keep)
@@ -191,16 +229,15 @@ def _backward_impl(rs, num_rendered, grad_out_color, means3D, sh, colors_precomp
     saved.capacity = capacity
     g = _lib.RasterGrads()
     g.dL_dmeans2D, g.dL_dopacities, g.dL_dmeans3D = g_means2D.data_ptr(), g_opac.data_ptr(), g_means3D.data_ptr()
-    g.dL_dshs = _ptr(g_sh) if has_sh else None
-    g.dL_dcolors_precomp = None if has_sh else g_colors.data_ptr()
-    g.dL_dscales = None if has_cov else g_scales.data_ptr()
-    g.dL_drotations = None if has_cov else g_rot.data_ptr()
-    g.dL_dcov3D = g_cov.data_ptr() if has_cov else None
+    g.dL_dshs = _ptr(g_sh)
+    g.dL_dcolors_precomp = _ptr(g_colors)
+    g.dL_dscales, g.dL_drotations = _ptr(g_scales), _ptr(g_rot)
+    g.dL_dcov3D = _ptr(g_cov)
     g.scratch = scratch.data_ptr()
     dL = grad_out_color.contiguous()
     if dL.dtype != torch.float32:
         dL = dL.float()
-    with torch.cuda.device(device):
+    with _on_device(device):
         rc = lib.das3r_raster_backward(C.byref(a), C.byref(i), C.byref(saved), C.c_void_p(dL.data_ptr()), C.byref(g),
                                        _stream(device))
     _lib.check(rc, "das3r_raster_backward")
@@ -295,15 +332,16 @@ class GaussianRasterizer(nn.Module):
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        e = _empty(means3D.device)   # upstream: torch.Tensor([]) placeholders
         if shs is None:
-            shs = torch.Tensor([])
+            shs = e
         if colors_precomp is None:
-            colors_precomp = torch.Tensor([])
+            colors_precomp = e
         if scales is None:
-            scales = torch.Tensor([])
+            scales = e
         if rotations is None:
-            rotations = torch.Tensor([])
+            rotations = e
         if cov3D_precomp is None:
-            cov3D_precomp = torch.Tensor([])
+            cov3D_precomp = e
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                    raster_settings)

@@ -68,8 +68,11 @@ typedef struct {
     const float *campos;     /* [3]    device */
     int32_t prefiltered;
     int32_t debug;           /* !=0: synchronise + check after every kernel */
-    int64_t capacity_hint;   /* reserved (ignored since ABI v5): the binning buffer is always sized exactly — num_rendered reaches the
-                              * host from the first kernel of the forward, long before the buffer is needed */
+    int64_t capacity_hint;   /* 0: the library lays the binning buffer out as it sees fit — exactly for num_rendered (which reaches
+                              * the host from the first kernel of the forward), or, for a shape it has seen before, with headroom
+                              * over that forward's count so that nothing waits for the count (das3r_raster_saved.capacity tells
+                              * which; a scene that outgrew the headroom is redone exactly).  -1: always exactly.  Other values
+                              * are reserved. */
 } das3r_raster_args;
 
 /* Inputs of GaussianRasterizer.forward.  Exactly one of shs/colors_precomp and exactly one of
