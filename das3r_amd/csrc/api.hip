@@ -212,8 +212,8 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     }
     // Host <-> device hand-offs of one forward (all through the pinned mailbox, no copies, no events):
     //   * num_rendered (sum of tiles_touched) leaves with the preprocess kernel, five kernels before the device needs it, so
-    //     the binning buffer is always sized exactly and the host practically never waits (upstream blocks on a cudaMemcpy
-    //     in the middle of every forward);
+    //     the binning buffer is sized exactly and the host practically never waits (upstream blocks on a cudaMemcpy in the
+    //     middle of every forward); on the local-order path nothing waits for it at all (speculative capacity, below);
     //   * the binning self-check word (bit 1 look-back timeout, 2 index out of range -> write suppressed, 8 counts do not
     //     add up to the histogram) is delivered by the last binning kernel and examined at the start of the NEXT forward
     //     (debug mode waits for it right away).
@@ -237,9 +237,8 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         HIP_TRY(hipMalloc((void **)&arrive_ring, ARRIVE_SLOTS * ARRIVE_WORDS * sizeof(unsigned long long)));
         HIP_TRY(hipMemset(arrive_ring, 0, ARRIVE_SLOTS * ARRIVE_WORDS * sizeof(unsigned long long)));
     }
-    // Depth order: scenes with short tile lists (few thousand pixels' worth of splats per tile: the 100 k-splat 1080p
-    // benchmark averages 32) skip the global depth sort — five of the eleven binning launches, each latency-bound at that
-    // size; the instances are emitted in index order and the compositing kernel sorts every tile's list itself (common.h:
+    // Depth order: scenes with short tile lists (the 100 k-splat 1080p benchmark averages 32 entries per tile) skip the global
+    // depth sort — five of the eleven binning launches, each latency-bound at that size; the instances are emitted in index order and the compositing kernel sorts every tile's list itself (common.h:
     // LocalBin).  Chosen from the instance count of the previous forward of the same shape, confirmed with this forward's
     // count; a list that outgrows LDS is still sorted correctly (slowly) and sends the next forwards back to the global sort.
     struct Verdict { int P, W, H; int64_t last_I; int radix_left, backoff; };

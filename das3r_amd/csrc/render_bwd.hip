@@ -165,7 +165,8 @@ int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, cha
         L.tiles_x, L.ntiles, (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),                \
         (const float4 *)(geom + L.pub.rgbd), a->bg, (const float *)(img + L.pub.final_T),                                    \
         (const uint32_t *)(img + L.pub.n_contrib), dL_dpix, (const uint32_t *)(binning + L.b_slot), partial, ablate
-    if (use_dpp) DAS3R_LAUNCH((render_backward_kernel<true>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS);
+    static const int pad_lds = getenv("DAS3R_BWD_PAD_LDS") ? atoi(getenv("DAS3R_BWD_PAD_LDS")) : 0;   // occupancy experiments
+    if (use_dpp) DAS3R_LAUNCH((render_backward_kernel<true>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), pad_lds, s, ARGS);
     else DAS3R_LAUNCH((render_backward_kernel<false>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS);
 #undef ARGS
     KERNEL_CHECK(s, a->debug, "render_backward");

@@ -277,11 +277,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities, geomBuffer,
                               binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)   # no zero-filled 'gradient' for radii on every backward (a fill kernel per step)
         return color, radii
 
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii):
         rs = ctx.raster_settings
+        if grad_out_color is None:   # (grads are not materialised) nothing flows back
+            return (None,) * 9
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities, geomBuffer, binningBuffer,
          imgBuffer) = ctx.saved_tensors
         args = (rs, ctx.num_rendered, grad_out_color, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,

@@ -117,6 +117,52 @@ def row_private_estimate(workload):
           f"{blk_hits_total} = {blk_hits_total / old_iters:.2f} per surviving quadrant; row occupancy {blk_hits_total / (4 * new_iters):.2f}")
 
 
+def half_wave_estimate(workload):
+    """Iterations per wave if each 32-lane half (8x4 pixels) of a quadrant's wave walked its own culled list."""
+    from das3r_amd import GaussianRasterizationSettings, _lib
+    from das3r_amd.rasterizer import _forward_impl
+    from das3r_amd.synth import make_workload
+    dev = torch.device("cuda:0")
+    sc = make_workload(workload).to(dev)
+    rs = GaussianRasterizationSettings(**sc.settings_kwargs())
+    e = torch.empty(0, device=dev)
+    P = sc.P
+    I, _, _, geom, binning, img = _forward_impl(rs, sc.means3D, sc.shs, e, sc.opacities, sc.scales, sc.rotations, e)
+    L = _lib.layout(P, I, sc.W, sc.H)
+    tx, ty = (sc.W + 15) // 16, (sc.H + 15) // 16
+    tiles = tx * ty
+    rg = _view(img, L["ranges"], torch.int32, 2 * tiles).reshape(tiles, 2).long()
+    pl = _view(binning, L["point_list"], torch.int32, I).long()
+    xyh = _lib.splat_field(geom, L, "xy", P)
+    lens = rg[:, 1] - rg[:, 0]
+    tile_of = torch.repeat_interleave(torch.arange(tiles, device=dev), lens)
+    pos = torch.arange(I, device=dev) - rg[tile_of, 0]
+    batch = pos // 256
+    nb = int(batch.max()) + 1
+    bx, by = (tile_of % tx).float() * 16, (tile_of // tx).float() * 16
+    s = xyh[pl]
+    old_iters = new_iters = half_hits = 0
+    for q in range(4):
+        qx, qy = bx + 8 * (q & 1), by + 8 * (q >> 1)
+        qhit = ((s[:, 0] - (qx + 3.5)).abs() <= s[:, 2] + 3.5) & ((s[:, 1] - (qy + 3.5)).abs() <= s[:, 3] + 3.5)
+        old_iters += int(qhit.sum())
+        per_half = []
+        for h in range(2):
+            cx, cy = qx + 3.5, qy + 4 * h + 1.5
+            hit = ((s[:, 0] - cx).abs() <= s[:, 2] + 3.5) & ((s[:, 1] - cy).abs() <= s[:, 3] + 1.5)
+            half_hits += int(hit.sum())
+            cnt = torch.zeros(tiles * nb, device=dev)
+            cnt.index_add_(0, tile_of * nb + batch, hit.float())
+            per_half.append(cnt)
+        new_iters += int(torch.stack(per_half).max(0)[0].sum())
+    print(f"{workload}: iterations now {old_iters}; half-wave (8x4) {new_iters} (x{new_iters / old_iters:.2f}); surviving (splat, half) "
+          f"{half_hits} = {half_hits / old_iters:.2f} per surviving quadrant; half occupancy {half_hits / (2 * new_iters):.2f}")
+
+
+if __name__ == "__main__" and os.environ.get("HALFWAVE"):
+    for w in os.environ["HALFWAVE"].split(","):
+        half_wave_estimate(w)
+
 if __name__ == "__main__" and os.environ.get("ROWPRIV"):
     for w in os.environ["ROWPRIV"].split(","):
         row_private_estimate(w)
