@@ -7,6 +7,7 @@ Same names, argument meaning, return values and error behaviour as the module DA
 `GaussianRasterizer(nn.Module)` with `forward(...) -> (color[3,H,W], radii[P])` and `markVisible`.
 """
 import ctypes as C
+import threading
 from typing import NamedTuple
 
 import torch
@@ -74,16 +75,20 @@ def _small(t, device, n, name):
 
 class _Alloc:
     """Allocator callbacks handed to the library (upstream's resizeFunctional): torch owns the bytes.  One instance per
-    device is kept alive (building ctypes callbacks costs tens of microseconds); `take()` hands the buffers of the call that
-    just finished to the caller and forgets them."""
+    device and host thread is kept alive (building ctypes callbacks costs tens of microseconds; threads must not share one:
+    a forward on another thread would drop this thread's buffers); `take()` hands the buffers of the call that just finished
+    to the caller and forgets them."""
 
-    _per_device = {}
+    _local = threading.local()
 
     @classmethod
     def get(cls, device):
-        a = cls._per_device.get(device)
+        per_device = getattr(cls._local, "per_device", None)
+        if per_device is None:
+            per_device = cls._local.per_device = {}
+        a = per_device.get(device)
         if a is None:
-            a = cls._per_device[device] = cls(device)
+            a = per_device[device] = cls(device)
         a.bufs = {}
         return a
 

@@ -352,3 +352,53 @@ def test_speculative_capacity_is_redone_when_the_scene_grows(monkeypatch):
             continue
         util.assert_grad_close(b.cpu().numpy(), a.cpu().numpy(), f"redone forward, grad {k}", tol=1e-5)
         util.assert_grad_close(b2.cpu().numpy(), a.cpu().numpy(), f"speculative forward, grad {k}", tol=1e-5)
+
+
+def test_two_host_threads_render_concurrently():
+    """The library's per-call state (host mailbox, arrival counters, the last shape's count) is thread_local: two host threads,
+    each on its own stream and its own scene, interleave hundreds of forwards + backwards and must reproduce the images and
+    gradients they get when they run alone."""
+    import threading
+    from das3r_amd import GaussianRasterizationSettings, rasterizer
+    dev = _dev()
+    jobs = []
+    for name in ("basic_deg3", "long_lists"):
+        sc, mode = util.scene_variant(name)
+        scd = sc.to(dev)
+        rs = GaussianRasterizationSettings(**scd.settings_kwargs())
+        jobs.append((scd, rs))
+    e = torch.empty(0, device=dev)
+
+    def run(scd, rs):
+        I, c, r, g, b, i, cap = rasterizer._forward_full(rs, scd.means3D, scd.shs, e, scd.opacities, scd.scales, scd.rotations, e)
+        grads = rasterizer._backward_impl(rs, I, scd.dL_dpix, scd.means3D, scd.shs, e, scd.opacities, scd.scales, scd.rotations, e, g, b, i, cap)
+        return I, c, grads
+
+    ref = [run(*j) for j in jobs]
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(k):
+        try:
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream):
+                for _ in range(150):
+                    I, c, grads = run(*jobs[k])
+                    if I != ref[k][0]:
+                        errors.append((k, "count", I))
+                        return
+                stream.synchronize()
+                if not torch.equal(c, ref[k][1]):
+                    errors.append((k, "image"))
+                for a, b in zip(grads, ref[k][2]):
+                    if a is not None:
+                        util.assert_grad_close(a.cpu().numpy(), b.cpu().numpy(), "concurrent render", tol=1e-5)
+        except Exception as ex:   # noqa: BLE001 - reported below
+            errors.append((k, repr(ex)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
