@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "common.h"
+#include <algorithm>
 
 namespace das3r {
 
@@ -241,10 +242,10 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     // depth sort — five of the eleven binning launches, each latency-bound at that size; the instances are emitted in index order and the compositing kernel sorts every tile's list itself (common.h:
     // LocalBin).  Chosen from the instance count of the previous forward of the same shape, confirmed with this forward's
     // count; a list that outgrows LDS is still sorted correctly (slowly) and sends the next forwards back to the global sort.
-    struct Verdict { int P, W, H; int64_t last_I; int radix_left, backoff; };
-    static thread_local Verdict verdict = {0, 0, 0, -1, 0, 64};
+    struct Verdict { int P, W, H; int64_t last_I, peak_I; int radix_left, backoff; };
+    static thread_local Verdict verdict = {0, 0, 0, -1, 0, 0, 64};
     constexpr int64_t LOCAL_AVG = 384;   // mean list length up to which the local order wins (measured: 1 M splats at 1080p, mean 320: -4 %)
-    if (verdict.P != P || verdict.W != W || verdict.H != H) verdict = Verdict{P, W, H, -1, 0, 64};
+    if (verdict.P != P || verdict.W != W || verdict.H != H) verdict = Verdict{P, W, H, -1, 0, 0, 64};
     if (mb->host[10]) {   // a forward met a list that did not fit in LDS
         mb->host[10] = 0;
         verdict.radix_left = verdict.backoff;   // global sort for a while; longer every time it happens again
@@ -282,7 +283,9 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     // compositing are redone with the exact size.  DAS3R_CAPACITY=exact switches the speculation off.
     const char *ec = getenv("DAS3R_CAPACITY");
     if (local && verdict.last_I >= 0 && a->capacity_hint != -1 && !(ec && ec[0] == 'e')) {
-        cap = verdict.last_I + verdict.last_I / 4 + 4096;
+        // headroom: 25 % over the last count, 5 % over the (slowly forgotten) largest one — a camera that moves between views
+        // of different density overflows rarely
+        cap = std::max(verdict.last_I + verdict.last_I / 4, verdict.peak_I + verdict.peak_I / 20) + 4096;
         if (cap > (int64_t)0x7FFFFF00) cap = (int64_t)0x7FFFFF00;
         compute_layout(P, cap, W, H, &L);
         saved->binning = alloc_binning(user, L.pub.binning_bytes);
@@ -294,6 +297,7 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         I = (int64_t)mb->host[0];
         if (I > (int64_t)0x7FFFFF00) { set_error("num_rendered %lld exceeds 2^31", (long long)I); return DAS3R_ERR_OVERFLOW; }
         verdict.last_I = I;
+        verdict.peak_I = std::max(I, verdict.peak_I - verdict.peak_I / 1024);
         if (I > cap) {
             cap = I;
             compute_layout(P, cap, W, H, &L);
@@ -310,6 +314,7 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         I = cap = (int64_t)mb->host[0];
         if (cap > (int64_t)0x7FFFFF00) { set_error("num_rendered %lld exceeds 2^31", (long long)cap); return DAS3R_ERR_OVERFLOW; }
         verdict.last_I = I;
+        verdict.peak_I = std::max(I, verdict.peak_I - verdict.peak_I / 1024);
         if (local && forced == 0 && I > LOCAL_AVG * L.ntiles) {   // the scene grew: global sort after all
             local = false;
             if ((rc = launch_depth_sort(P, saved->geom, L, 0, nullptr, 0, a->debug != 0, s))) return rc;

@@ -336,17 +336,21 @@ def test_speculative_capacity_is_redone_when_the_scene_grows(monkeypatch):
         grads = rasterizer._backward_impl(rs, I, scd.dL_dpix, scd.means3D, scd.shs, e, scd.opacities, scd.scales, scd.rotations, e, g, b, i, cap)
         return I, cap, c, r, grads
 
+    other, _ = util.scene_variant("basic_deg3")      # another shape: the library forgets what it knew about this one
+    od = other.to(dev)
+    rasterizer._forward_full(GaussianRasterizationSettings(**od.settings_kwargs()), od.means3D, od.shs, e, od.opacities, od.scales,
+                             od.rotations, e)
+    I_small, cap_small, *_ = run(0.15)  # first forward of the shape: sized exactly
+    assert cap_small == I_small
+    I, cap, c, r, g = run(1.0)          # speculates with I_small's capacity, overflows, redoes
+    assert (I_small + I_small // 4 + 4096) < I, "the test scene must outgrow the speculative capacity"
+    assert cap == I
+    I2, cap2, c2, r2, g2 = run(1.0)     # speculates with headroom, fits
+    assert I2 == I and cap2 > I
     monkeypatch.setenv("DAS3R_CAPACITY", "exact")
     I_ref, cap_ref, c_ref, r_ref, g_ref = run(1.0)
-    assert cap_ref == I_ref
-    monkeypatch.delenv("DAS3R_CAPACITY")
-    I_small, cap_small, *_ = run(0.15)
-    assert (I_small + I_small // 4 + 4096) < I_ref, "the test scene must outgrow the speculative capacity"
-    I, cap, c, r, g = run(1.0)          # speculates with I_small's capacity, overflows, redoes
-    assert I == I_ref and cap == I_ref
-    assert torch.equal(c, c_ref) and torch.equal(r, r_ref)
-    I2, cap2, c2, r2, g2 = run(1.0)     # speculates with headroom, fits
-    assert I2 == I_ref and cap2 > I_ref and torch.equal(c2, c_ref)
+    assert cap_ref == I_ref == I
+    assert torch.equal(c, c_ref) and torch.equal(r, r_ref) and torch.equal(c2, c_ref)
     for k, (a, b, b2) in enumerate(zip(g_ref, g, g2)):
         if a is None:
             continue
@@ -402,3 +406,41 @@ def test_two_host_threads_render_concurrently():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 63, 64, 65, 255, 256, 257, 300, 511, 512, 513, 1000, 1023, 1024, 1025, 1700])
+def test_local_order_at_every_list_length(P, monkeypatch):
+    """One 16x16 image = one tile whose list has exactly P entries (every splat visible, inside, many exact depth ties): the
+    compositing kernel's own sort — rank sort up to 256 entries, LDS bitonic network up to 1024, global-memory network beyond —
+    must produce the list of the global radix sort, bit for bit, at and around every switch-over."""
+    from das3r_amd import GaussianRasterizationSettings, _lib
+    from das3r_amd.rasterizer import _forward_impl
+    from das3r_amd.synth import make_scene
+    dev = _dev()
+    sc = make_scene(P=P, W=16, H=16, focal=20.0, sh_degree=1, seed=100 + P, s_px=(1.0, 2.5), opacity=0.6)
+    g = torch.Generator(device="cpu").manual_seed(P)
+    z = torch.rand(P, generator=g) * 4.0 + 1.0
+    z[::5] = 2.0                                   # exact depth ties: the order falls back to the splat index
+    u = torch.rand(P, 2, generator=g) - 0.5        # well inside the image
+    sc.means3D[:, 2] = z
+    sc.means3D[:, 0] = z * sc.tanfovx * u[:, 0]
+    sc.means3D[:, 1] = z * sc.tanfovy * u[:, 1]
+    scd = sc.to(dev)
+    rs = GaussianRasterizationSettings(**scd.settings_kwargs())
+    e = torch.empty(0, device=dev)
+    out = {}
+    for kind in ("radix", "local"):
+        monkeypatch.setenv("DAS3R_BINNING", kind)
+        I, color, radii, geom, binning, img = _forward_impl(rs, scd.means3D, scd.shs, e, scd.opacities, scd.scales, scd.rotations, e)
+        torch.cuda.synchronize()
+        L = _lib.layout(P, I, 16, 16)
+        pl = _view(binning, L["point_list"], torch.int32, I).cpu().numpy()
+        rg = _view(img, L["ranges"], torch.int32, 2).cpu().numpy()
+        out[kind] = (I, pl, rg, color.cpu(), radii.cpu())
+    (Ia, pla, rga, ca, ra), (Ib, plb, rgb_, cb, rb) = out["radix"], out["local"]
+    assert Ia == Ib == P and tuple(rga) == tuple(rgb_) == (0, P)
+    depth = scd.means3D[:, 2].cpu().numpy().view(np.uint32)
+    expect = np.lexsort((np.arange(P), depth))     # (depth bits, index) order, computed independently
+    assert np.array_equal(pla, expect), "global sort"
+    assert np.array_equal(plb, expect), "local order"
+    assert torch.equal(ca, cb) and torch.equal(ra, rb)

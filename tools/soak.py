@@ -15,6 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workloads", default="c2,c4,ds")
     ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--jitter", action="store_true", help="vary the scale modifier from step to step (num_rendered jumps: the speculative binning capacity overflows now and then) and check every image against an exact-capacity reference")
     args = ap.parse_args()
     from das3r_amd import GaussianRasterizationSettings
     from das3r_amd.rasterizer import _backward_impl, _forward_full
@@ -26,6 +27,25 @@ def main():
         rs = GaussianRasterizationSettings(**sc.settings_kwargs())
         errs, counts, t0 = [], set(), time.perf_counter()
         ref_color, mismatches = None, 0
+        if args.jitter:
+            mods = [0.6, 0.8, 1.0, 1.3, 1.7]
+            refs = {}
+            for m in mods:
+                r = _forward_full(rs._replace(scale_modifier=m), sc.means3D, sc.shs, e, sc.opacities, sc.scales, sc.rotations, e, exact=True)
+                refs[m] = (r[0], r[1].clone())
+            gen = torch.Generator().manual_seed(1)
+            redone = 0
+            for it in range(args.steps):
+                m = mods[int(torch.randint(len(mods), (1,), generator=gen))]
+                I, color, radii, geom, binning, img, cap = _forward_full(rs._replace(scale_modifier=m), sc.means3D, sc.shs, e, sc.opacities, sc.scales, sc.rotations, e)
+                _backward_impl(rs._replace(scale_modifier=m), I, sc.dL_dpix, sc.means3D, sc.shs, e, sc.opacities, sc.scales, sc.rotations, e, geom, binning, img, cap)
+                redone += cap == I
+                if I != refs[m][0] or not torch.equal(color, refs[m][1]):
+                    mismatches += 1
+            torch.cuda.synchronize()
+            print(f"{w} jitter: {args.steps} steps in {time.perf_counter() - t0:.1f} s, counts {sorted(v[0] for v in refs.values())}, "
+                  f"exactly sized (first / redone) {redone}, mismatches {mismatches}")
+            continue
         for it in range(args.steps):
             try:
                 I, color, radii, geom, binning, img, cap = _forward_full(rs, sc.means3D, sc.shs, e, sc.opacities, sc.scales, sc.rotations, e)
