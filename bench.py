@@ -40,6 +40,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    from das3r_amd.hostpin import pin_to_ccx, unpin
+    from das3r_amd.synth import WORKLOADS, make_scene
+    cfg = dict(WORKLOADS[args.workload])
+    cfg["seed"] = cfg["seed"] + 1000 * rank  # every rank = a different "sequence"
+    sc_cpu = make_scene(**cfg)                # on the host, before the pin: torch's CPU thread pool keeps the full mask
+    pinned = pin_to_ccx(local_rank)           # before the first HIP call: the runtime's threads inherit the mask
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -52,11 +58,7 @@ def main():
 
     from das3r_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib
     from das3r_amd.roofline import HBM_PEAK_GBS, algorithmic_bytes, group_kernel_times
-    from das3r_amd.synth import WORKLOADS, make_scene
 
-    cfg = dict(WORKLOADS[args.workload])
-    cfg["seed"] = cfg["seed"] + 1000 * rank  # every rank = a different "sequence"
-    sc_cpu = make_scene(**cfg)
     sc = sc_cpu.to(dev)
     rs = GaussianRasterizationSettings(**sc.settings_kwargs())
     rast = GaussianRasterizer(rs)
@@ -142,6 +144,7 @@ def main():
 
     # ---- CPU baseline: the oracle (plain C + OpenMP restatement) on the host cores, same scene, rank 0, N=1 only
     cpu_baseline = None
+    unpin(pinned)   # the CPU baseline below uses every host core
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import c_oracle
         o = c_oracle.RasterOracle(**sc_cpu.settings_kwargs())
@@ -168,7 +171,9 @@ def main():
                "config": {"workload": WORKLOAD_DESC[args.workload], "name": args.workload, "splats_per_gpu": sc.P,
                           "image": [sc.W, sc.H], "sh_degree": sc.sh_degree, "num_rendered": I,
                           "api": "GaussianRasterizer.forward + autograd backward (drop-in surface)",
-                          "parallelism": f"{world} independent scenes, one per GPU"},
+                          "parallelism": f"{world} independent scenes, one per GPU",
+                          "host_cpus": (f"pinned to CPUs {pinned[1][0]}-{pinned[1][-1]} (one core complex per rank)" if pinned
+                                        else "not pinned")},
                "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels_json}
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -109,6 +109,8 @@ def main():
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    from .hostpin import pin_to_ccx
+    pin_to_ccx(local)   # one core complex per rank (hostpin.py), before the first HIP call
     use_gpu = torch.cuda.is_available()
     device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
     if use_gpu:

@@ -120,3 +120,30 @@ def test_missing_library_is_a_hard_error(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_host_pinning_round_trip(monkeypatch):
+    """das3r_amd.hostpin: a worker is pinned to (at most) eight of the CPUs it was allowed, different ranks get different
+    core complexes when there are enough of them, the previous mask comes back, and DAS3R_PIN=0 switches it off."""
+    import os
+    from das3r_amd.hostpin import pin_to_ccx, unpin
+    if not hasattr(os, "sched_getaffinity"):
+        pytest.skip("no sched_setaffinity on this platform")
+    before = sorted(os.sched_getaffinity(0))
+    try:
+        p0 = pin_to_ccx(0)
+        if p0 is None:
+            assert len(before) < 8
+            return
+        assert p0[0] == before and len(p0[1]) == 8 and set(p0[1]) <= set(before)
+        assert sorted(os.sched_getaffinity(0)) == p0[1]
+        unpin(p0)
+        assert sorted(os.sched_getaffinity(0)) == before
+        p1 = pin_to_ccx(1)
+        unpin(p1)
+        if len(before) >= 32:
+            assert set(p1[1]).isdisjoint(p0[1])
+        monkeypatch.setenv("DAS3R_PIN", "0")
+        assert pin_to_ccx(0) is None and sorted(os.sched_getaffinity(0)) == before
+    finally:
+        os.sched_setaffinity(0, before)
