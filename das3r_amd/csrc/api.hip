@@ -271,9 +271,13 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         uint32_t *dead_keys = nullptr;
         if ((r = launch_binning(P, cap, W, H, out->radii, saved->geom, saved->binning, saved->img, L, fused_scan, mb->dev + 8, late_tag,
                                 a->debug != 0, s, &dead_keys))) return r;
-        LocalBin lb = {nullptr, nullptr, nullptr, nullptr};
-        if (local_order && cap > 0)
-            lb = LocalBin{(uint32_t *)(saved->binning + L.pub.point_list), (uint32_t *)(saved->binning + L.b_slot), dead_keys, mb->dev + 10};
+        LocalBin lb = {nullptr, nullptr, nullptr, nullptr, (uint32_t)(P - 1), (uint32_t)cap};
+        if (local_order && cap > 0) {
+            lb.point_list = (uint32_t *)(saved->binning + L.pub.point_list);
+            lb.slot_list = (uint32_t *)(saved->binning + L.b_slot);
+            lb.keys = dead_keys;
+            lb.host_flag = mb->dev + 10;
+        }
         return launch_render_forward(a, in->colors_precomp, out->out_color, saved->geom, saved->binning, saved->img, L, lb, s);
     };
     int64_t I, cap;

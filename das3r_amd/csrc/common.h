@@ -103,6 +103,7 @@ struct LocalBin {
     uint32_t *point_list, *slot_list;   // sorted in place
     uint32_t *keys;                     // u32[num_rendered] scratch for the lists that do not fit in LDS (the dead tile keys)
     uint32_t *host_flag;                // pinned mailbox word raised when such a list was met
+    uint32_t last_g, cap;               // P - 1 and the instances the lists hold: bounds for safe_index / safe_range (always set)
 };
 void compute_layout(int P, int64_t I, int W, int H, Layout *L);
 

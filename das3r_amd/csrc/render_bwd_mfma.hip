@@ -33,7 +33,8 @@ __global__ void __launch_bounds__(256) render_backward_mfma_kernel(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int tiles_x, int ntiles,
     const float4 *__restrict__ xyh, const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
     const float *__restrict__ bg, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
-    const float *__restrict__ dL_dpix, const uint32_t *__restrict__ slot_list, float *__restrict__ partial /*[I,9]*/) {
+    const float *__restrict__ dL_dpix, const uint32_t *__restrict__ slot_list, float *__restrict__ partial /*[I,9]*/,
+    uint32_t last_g, uint32_t cap /*bounds of the list contents: render_common.h safe_range*/) {
     __shared__ StagedSplat stage[MB];
     __shared__ uint32_t s_slot[MB];
     __shared__ float acc[MB * NACC];
@@ -54,7 +55,7 @@ __global__ void __launch_bounds__(256) render_backward_mfma_kernel(
     const float pxf = (float)px, pyf = (float)py;
     const float qcx = (float)(bx * TILE_X + ((wave & 1) << 3)) + 3.5f, qcy = (float)(by * TILE_Y + ((wave >> 1) << 3)) + 3.5f;
     const float tcx = (float)(bx * TILE_X) + 7.5f, tcy = (float)(by * TILE_Y) + 7.5f;   // tile centre
-    const uint2 range = ranges[tile];
+    const uint2 range = safe_range(ranges[tile], cap);
     const size_t pix = (size_t)py * W + px, plane = (size_t)H * W;
 
     const float T_final = inside ? final_T[pix] : 0.f;
@@ -100,14 +101,14 @@ __global__ void __launch_bounds__(256) render_backward_mfma_kernel(
     for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
     if (lane == 0) s_max[wave] = mx;
     __syncthreads();
-    const uint32_t max_contrib = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    const uint32_t max_contrib = min(max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])), range.y - range.x);
     const int rounds = ((int)max_contrib + MB - 1) / MB;
     {   // list entries beyond max_contrib receive no gradient from this tile: their partial rows are zero
         const uint32_t len = range.y - range.x;
         const uint32_t ntail = (len - max_contrib) * NACC;
         for (uint32_t f = tid; f < ntail; f += TILE_PIX) {
             const uint32_t t = f / NACC, q = f - t * NACC;
-            partial[(size_t)slot_list[range.x + max_contrib + t] * NACC + q] = 0.f;
+            partial[(size_t)min(slot_list[range.x + max_contrib + t], cap - 1u) * NACC + q] = 0.f;
         }
     }
 
@@ -162,8 +163,8 @@ __global__ void __launch_bounds__(256) render_backward_mfma_kernel(
         // stage the batch in reverse list order; entry j holds list position (max_contrib - 1 - done_before - j)
         if (tid < n) {
             const uint32_t pos = range.x + max_contrib - 1 - done_before - tid;
-            const uint32_t g = point_list[pos];
-            s_slot[tid] = slot_list[pos];
+            const uint32_t g = min(point_list[pos], last_g);
+            s_slot[tid] = min(slot_list[pos], cap - 1u);
             stage[tid].xyh = xyh[(size_t)g * SPLAT_REC];
             stage[tid].co = conic_opacity[(size_t)g * SPLAT_REC];
             stage[tid].rgbd = rgbd[(size_t)g * SPLAT_REC];
@@ -254,7 +255,8 @@ int launch_render_backward_mfma(const das3r_raster_args *a, const float *dL_dpix
                  (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height, L.tiles_x, L.ntiles,
                  (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),
                  (const float4 *)(geom + L.pub.rgbd), a->bg, (const float *)(img + L.pub.final_T),
-                 (const uint32_t *)(img + L.pub.n_contrib), dL_dpix, (const uint32_t *)(binning + L.b_slot), partial);
+                 (const uint32_t *)(img + L.pub.n_contrib), dL_dpix, (const uint32_t *)(binning + L.b_slot), partial,
+                 (uint32_t)(a->P - 1), (uint32_t)L.capacity);
     KERNEL_CHECK(s, a->debug, "render_backward_mfma");
     return DAS3R_OK;
 }

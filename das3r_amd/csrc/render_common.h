@@ -46,6 +46,14 @@ __device__ __forceinline__ bool pair_alpha(const float x, const float y, const f
     return (!(power > 0.0f)) & (alpha >= (1.0f / 255.0f));
 }
 
+// A failed binning (look-back timeout: reported through the self-check word, api.hip) may leave garbage in the tile lists.
+// Every index read from them is kept in bounds, so that the failure surfaces as the error it is and not as a memory fault.
+__device__ __forceinline__ uint2 safe_range(uint2 r, const uint32_t cap) {
+    r.y = min(r.y, cap);
+    r.x = min(r.x, r.y);
+    return r;
+}
+
 // Conservative quadrant test: can the splat reach alpha >= 1/255 on any pixel centre of the 8x8 block centred at
 // (cx, cy)?  (hx, hy) already carry their safety margin (preprocess.hip).
 __device__ __forceinline__ bool quadrant_hit(const float4 xyh, const float cx, const float cy) {
@@ -75,7 +83,7 @@ __device__ __forceinline__ bool local_order_tile(const LocalBin &lb, const uint2
         uint32_t g = 0, slot = 0;
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;   // (initialised: left undefined, the compiler parks them in LDS — +13 us)
         if (tid < n) {
-            g = pl[tid];
+            g = min(pl[tid], lb.last_g);
             slot = sl[tid];
             r0 = xyh[(size_t)g * SPLAT_REC];
             r1 = conic_opacity[(size_t)g * SPLAT_REC];
@@ -105,18 +113,29 @@ __device__ __forceinline__ bool local_order_tile(const LocalBin &lb, const uint2
         unsigned long long *s_key = reinterpret_cast<unsigned long long *>(stage);
         uint32_t *s_slot = reinterpret_cast<uint32_t *>(stage) + 2 * LOCAL_MAX;
         for (int i = tid; i < n; i += TILE_PIX) {
-            const uint32_t g = pl[i];
+            const uint32_t g = min(pl[i], lb.last_g);
             s_gid[i] = g;
             s_slot[i] = sl[i];
             s_key[i] = ((unsigned long long)__float_as_uint(rgbd[(size_t)g * SPLAT_REC].w) << 32) | (unsigned long long)i;
         }
         __syncthreads();
-        for (int k = 2; (k >> 1) < n; k <<= 1)
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                const int flip = (j == (k >> 1)) ? k - 1 : j;
-                for (int i = tid; i < n; i += TILE_PIX) {
-                    const int q = i ^ flip;
-                    if (q > i && q < n) {
+        // One thread per comparison (not per element: half of those would only find that their partner is the lower one).
+        // Comparison pr touches words of the 128-word chunk pr / 64 only as long as the partner distance stays below 128, and
+        // the comparisons 64 w .. 64 w + 63 (+ 256) belong to wave w: those steps — 42 of the 45 for 512 words — need no
+        // workgroup barrier, LDS executes a wave's accesses in order.
+        int N = 2 * TILE_PIX;
+        while (N < n) N <<= 1;
+        bool wide_before = false;   // (the barrier behind the loads above covers the first step)
+        for (int lk = 1; (1 << (lk - 1)) < n; lk++)
+            for (int lj = lk - 1; lj >= 0; lj--) {
+                const bool wide = lj > 6;   // words of another wave's chunk
+                if (wide || wide_before) __syncthreads();
+                else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                wide_before = wide;
+                for (int pr = tid; pr < (N >> 1); pr += TILE_PIX) {
+                    const int i = ((pr >> lj) << (lj + 1)) | (pr & ((1 << lj) - 1));   // bit lj of i is clear
+                    const int q = (lj == lk - 1) ? (i ^ ((2 << lj) - 1)) : (i | (1 << lj));   // mirror in the block / butterfly
+                    if (q < n) {
                         const unsigned long long a = s_key[i], b = s_key[q];
                         if (a > b) {
                             s_key[i] = b;
@@ -124,8 +143,8 @@ __device__ __forceinline__ bool local_order_tile(const LocalBin &lb, const uint2
                         }
                     }
                 }
-                __syncthreads();
             }
+        __syncthreads();
         uint32_t g[LOCAL_MAX / TILE_PIX], slot[LOCAL_MAX / TILE_PIX];
 #pragma unroll
         for (int u = 0; u < LOCAL_MAX / TILE_PIX; u++) {
@@ -149,7 +168,7 @@ __device__ __forceinline__ bool local_order_tile(const LocalBin &lb, const uint2
     }
     uint32_t *dk = lb.keys + range.x;
     if (tid == 0) __hip_atomic_store(lb.host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    for (int i = tid; i < n; i += TILE_PIX) dk[i] = __float_as_uint(rgbd[(size_t)pl[i] * SPLAT_REC].w);
+    for (int i = tid; i < n; i += TILE_PIX) dk[i] = __float_as_uint(rgbd[(size_t)min(pl[i], lb.last_g) * SPLAT_REC].w);
     __syncthreads();
     for (int k = 2; (k >> 1) < n; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {

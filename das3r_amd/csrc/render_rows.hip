@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
     const float q0x = (float)(bx * TILE_X + ((wave & 1) << 3)), q0y = (float)(by * TILE_Y + ((wave >> 1) << 3));
-    const uint2 range = ranges[tile];
+    const uint2 range = safe_range(ranges[tile], lb.cap);
     const bool sorted_here = lb.point_list != nullptr && (int)(range.y - range.x) <= LOCAL_MAX;   // (uniform)
     // local depth order: sort this tile's list first (a list of one batch is staged by the sort itself)
     const bool prestaged = lb.point_list != nullptr && local_order_tile(lb, range, xyh, conic_opacity, rgbd, stage, s_gid, threadIdx.x);
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
         if (__syncthreads_count(done) == TILE_PIX) break;
         const uint32_t progress = range.x + i * TILE_PIX + tid;
         if (progress < range.y && !prestaged) {
-            const uint32_t g = sorted_here ? s_gid[i * TILE_PIX + tid] : (lb.point_list ? lb.point_list[progress] : point_list[progress]);
+            const uint32_t g = min(sorted_here ? s_gid[i * TILE_PIX + tid] : (lb.point_list ? lb.point_list[progress] : point_list[progress]), lb.last_g);
             stage[tid].xyh = xyh[(size_t)g * SPLAT_REC];           // one 64-byte record: a single cache line per splat
             stage[tid].co = conic_opacity[(size_t)g * SPLAT_REC];
             stage[tid].rgbd = rgbd[(size_t)g * SPLAT_REC];
