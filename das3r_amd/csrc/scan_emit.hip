@@ -51,7 +51,10 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
     __shared__ uint32_t s_block, s_carry;
     __shared__ uint32_t h[EMIT ? 4 : 1][RADIX_SIZE];
     const int tid = threadIdx.x, lane = __lane_id(), wave = tid >> 6;
-    if (tid == 0) s_block = atomicAdd(ticket, 1u);
+    // order of the chained scan: a ticket (arrival order) in general; the workgroup index when the whole grid is resident at
+    // once (ticket == null: nobody can wait for a workgroup that has not started) — the returned atomic is ~2 us of every
+    // workgroup's critical path, a tenth of this kernel at 100 k splats
+    if (tid == 0) s_block = ticket ? atomicAdd(ticket, 1u) : blockIdx.x;
     if (EMIT) {
 #pragma unroll
         for (int q = 0; q < 4; q++) h[EMIT ? q : 0][tid] = 0;
@@ -157,7 +160,8 @@ size_t scan_status_bytes(int P) {
 #define SCAN_COMMON                                                                                                           \
     P, order, (const uint32_t *)(geom + L.pub.tiles_touched),                          \
         (uint32_t *)(geom + L.pub.offsets), (uint32_t *)(geom + L.g_off_by_gid), (uint32_t *)(geom + L.g_count),             \
-        (u64 *)(geom + L.g_scan_status), (u64 *)(geom + L.g_scan_status) + nblocks, (uint32_t *)(geom + L.g_ticket) + 16,   \
+        (u64 *)(geom + L.g_scan_status), (u64 *)(geom + L.g_scan_status) + nblocks,                                    \
+        grid_is_resident(nblocks) ? (uint32_t *)nullptr : (uint32_t *)(geom + L.g_ticket) + 16,   \
         (uint32_t *)(geom + L.g_ticket) + 8, host_out, tag
 
 int launch_scan(int P, char *geom, const Layout &L, uint32_t *host_out, uint32_t tag, bool debug, hipStream_t s, bool index_order) {

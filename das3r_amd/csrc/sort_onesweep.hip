@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
     __shared__ uint32_t s_block;
     const int tid = threadIdx.x, lane = __lane_id(), wave = tid >> 6;
     const uint32_t n = n_ptr ? min(*n_ptr, cap) : cap;
-    if (tid == 0) s_block = atomicAdd(ticket, 1u);
+    if (tid == 0) s_block = ticket ? atomicAdd(ticket, 1u) : blockIdx.x;   // null: the whole grid is resident (scan_emit.hip)
 #pragma unroll
     for (int w = 0; w < 4; w++) cnt[w][tid] = 0;
     __syncthreads();
@@ -239,7 +239,8 @@ static int onesweep_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kou
     u64 *group_status = status + (size_t)nblocks * RADIX_SIZE;
 #define PASS(IPL, FINAL)                                                                                                  \
     DAS3R_LAUNCH((onesweep_pass_kernel<IPL, FINAL>), dim3(nblocks), dim3(256), 0, s, kin, vin, kout, vout, (uint32_t)cap, n_ptr, \
-                 shift, bits, ghist, status, group_status, gs_log2, ticket, gather_src, inv_out, err, zero_ptr, zero_words)
+                 shift, bits, ghist, status, group_status, gs_log2, grid_is_resident(nblocks) ? (uint32_t *)nullptr : ticket, gather_src, inv_out, \
+                 err, zero_ptr, zero_words)
     if (inv_out) {
         if (ipl == 4) PASS(4, true); else if (ipl == 8) PASS(8, true); else PASS(16, true);
     } else {
