@@ -258,11 +258,12 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     const uint32_t count_tag = ++mb->seq ? mb->seq : ++mb->seq;
     unsigned long long *arrive = arrive_ring + (size_t)(count_tag % ARRIVE_SLOTS) * ARRIVE_WORDS;
     // everything behind the count: scan + emission, partition, tile ranges, compositing (L laid out for `cap`, buffer allocated)
-    auto bin_and_render = [&](int64_t cap, bool local_order, bool ctrl_zeroed) -> int {
+    auto bin_and_render = [&](int64_t cap, bool local_order, bool ctrl_zeroed, uint32_t *count_out = nullptr, uint32_t count_out_tag = 0) -> int {
         int r;
         const bool fused_scan = use_onesweep();   // scan + emission in one kernel; the classic path scans, then emits
         if (fused_scan) {
-            if ((r = launch_binning_scan_emit(P, cap, out->radii, saved->geom, saved->binning, L, ctrl_zeroed, nullptr, 0, a->debug != 0, s, local_order))) return r;
+            if ((r = launch_binning_scan_emit(P, cap, out->radii, saved->geom, saved->binning, L, ctrl_zeroed, count_out, count_out_tag, a->debug != 0, s,
+                                              local_order))) return r;
         } else if ((r = launch_scan(P, saved->geom, L, nullptr, 0, a->debug != 0, s))) return r;
         if (cap > 0) {
             if ((r = check_late(true))) return r;   // one self-check word in flight at a time
@@ -294,9 +295,10 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         compute_layout(P, cap, W, H, &L);
         saved->binning = alloc_binning(user, L.pub.binning_bytes);
         if (!saved->binning) { set_error("scratch allocation failed (binning %zu B)", L.pub.binning_bytes); return DAS3R_ERR_ALLOC; }
-        if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, saved->binning + L.b_ghist, L.b_ctrl_bytes, L, arrive, mb->dev,
+        // (the count is not needed before the end of this call: the scan delivers it, the preprocess kernel skips its reduction)
+        if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, saved->binning + L.b_ghist, L.b_ctrl_bytes, L, nullptr, mb->dev,
                                     count_tag, s))) return rc;
-        if ((rc = bin_and_render(cap, true, true))) return rc;
+        if ((rc = bin_and_render(cap, true, true, mb->dev, count_tag))) return rc;
         if ((rc = mailbox_wait(mb, 2, count_tag, s))) return rc;
         I = (int64_t)mb->host[0];
         if (I > (int64_t)0x7FFFFF00) { set_error("num_rendered %lld exceeds 2^31", (long long)I); return DAS3R_ERR_OVERFLOW; }

@@ -158,6 +158,8 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     // scan that needs it on the device, so that the host can size the binning buffer exactly without ever waiting for the sort.
     // One 64-bit atomic per workgroup carries (workgroups done << 40 | tiles); the last arriver owns the total, re-arms the
     // counters for their next use and writes {count, tag} to the pinned mailbox (see api.hip).
+    // (arrive == null: the caller does not need the count early — speculative capacity, api.hip — and lets the scan deliver it)
+    if (arrive == nullptr) return;
     uint32_t wsum = live ? tiles_out : 0u;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) wsum += (uint32_t)__shfl_xor((int)wsum, o, 64);
