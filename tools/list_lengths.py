@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Tile-list length distribution of a workload (mean, percentiles, lists over 256 / 1024 entries: the switch-overs of the
+compositing kernel's own sort).   python tools/list_lengths.py c2,c4"""
 import sys, torch, numpy as np
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from das3r_amd import GaussianRasterizationSettings, _lib
 from das3r_amd.rasterizer import _forward_full
 from das3r_amd.synth import make_workload
