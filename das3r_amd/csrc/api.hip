@@ -242,12 +242,15 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     // depth sort — five of the eleven binning launches, each latency-bound at that size; the instances are emitted in index order and the compositing kernel sorts every tile's list itself (common.h:
     // LocalBin).  Chosen from the instance count of the previous forward of the same shape, confirmed with this forward's
     // count; a list that outgrows LDS is still sorted correctly (slowly) and sends the next forwards back to the global sort.
-    struct Verdict { int P, W, H; int64_t last_I, peak_I; int radix_left, backoff; };
-    static thread_local Verdict verdict = {0, 0, 0, -1, 0, 0, 64};
+    struct Verdict { int P, W, H; int64_t last_I, peak_I; int radix_left, backoff; uint32_t gen; };
+    static thread_local Verdict verdict = {0, 0, 0, -1, 0, 0, 64, 0};
     constexpr int64_t LOCAL_AVG = 384;   // mean list length up to which the local order wins (measured: 1 M splats at 1080p, mean 320: -4 %)
-    if (verdict.P != P || verdict.W != W || verdict.H != H) verdict = Verdict{P, W, H, -1, 0, 0, 64};
-    if (mb->host[10]) {   // a forward met a list that did not fit in LDS
-        mb->host[10] = 0;
+    const uint32_t too_long = mb->host[10];   // != 0: a forward of the shape with that generation number met a list too long for LDS
+    if (too_long) mb->host[10] = 0;
+    if (verdict.P != P || verdict.W != W || verdict.H != H) {
+        const uint32_t gen = verdict.gen + 1u ? verdict.gen + 1u : 1u;
+        verdict = Verdict{P, W, H, -1, 0, 0, 64, gen};
+    } else if (too_long == verdict.gen) {
         verdict.radix_left = verdict.backoff;   // global sort for a while; longer every time it happens again
         if (verdict.backoff < 4096) verdict.backoff *= 2;
     }
@@ -258,21 +261,24 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     const uint32_t count_tag = ++mb->seq ? mb->seq : ++mb->seq;
     unsigned long long *arrive = arrive_ring + (size_t)(count_tag % ARRIVE_SLOTS) * ARRIVE_WORDS;
     // everything behind the count: scan + emission, partition, tile ranges, compositing (L laid out for `cap`, buffer allocated)
-    auto bin_and_render = [&](int64_t cap, bool local_order, bool ctrl_zeroed, uint32_t *count_out = nullptr, uint32_t count_out_tag = 0) -> int {
+    auto bin_and_render = [&](int64_t cap, bool local_order, bool ctrl_zeroed, uint32_t *count_out = nullptr, uint32_t count_out_tag = 0,
+                              uint32_t *emit_slot = nullptr /*the preprocess kernel has emitted the instances already*/) -> int {
         int r;
         const bool fused_scan = use_onesweep();   // scan + emission in one kernel; the classic path scans, then emits
-        if (fused_scan) {
-            if ((r = launch_binning_scan_emit(P, cap, out->radii, saved->geom, saved->binning, L, ctrl_zeroed, count_out, count_out_tag, a->debug != 0, s,
-                                              local_order))) return r;
-        } else if ((r = launch_scan(P, saved->geom, L, nullptr, 0, a->debug != 0, s))) return r;
+        if (!emit_slot) {
+            if (fused_scan) {
+                if ((r = launch_binning_scan_emit(P, cap, out->radii, saved->geom, saved->binning, L, ctrl_zeroed, count_out, count_out_tag, a->debug != 0,
+                                                  s, local_order))) return r;
+            } else if ((r = launch_scan(P, saved->geom, L, nullptr, 0, a->debug != 0, s))) return r;
+        }
         if (cap > 0) {
             if ((r = check_late(true))) return r;   // one self-check word in flight at a time
             late_tag = ++mb->seq ? mb->seq : ++mb->seq;
         }
         uint32_t *dead_keys = nullptr;
         if ((r = launch_binning(P, cap, W, H, out->radii, saved->geom, saved->binning, saved->img, L, fused_scan, mb->dev + 8, late_tag,
-                                a->debug != 0, s, &dead_keys))) return r;
-        LocalBin lb = {nullptr, nullptr, nullptr, nullptr, (uint32_t)(P - 1), (uint32_t)cap};
+                                a->debug != 0, s, &dead_keys, emit_slot))) return r;
+        LocalBin lb = {nullptr, nullptr, nullptr, nullptr, verdict.gen, (uint32_t)(P - 1), (uint32_t)cap};
         if (local_order && cap > 0) {
             lb.point_list = (uint32_t *)(saved->binning + L.pub.point_list);
             lb.slot_list = (uint32_t *)(saved->binning + L.b_slot);
@@ -295,10 +301,41 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         compute_layout(P, cap, W, H, &L);
         saved->binning = alloc_binning(user, L.pub.binning_bytes);
         if (!saved->binning) { set_error("scratch allocation failed (binning %zu B)", L.pub.binning_bytes); return DAS3R_ERR_ALLOC; }
-        // (the count is not needed before the end of this call: the scan delivers it, the preprocess kernel skips its reduction)
-        if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, saved->binning + L.b_ghist, L.b_ctrl_bytes, L, nullptr, mb->dev,
-                                    count_tag, s))) return rc;
-        if ((rc = bin_and_render(cap, true, true, mb->dev, count_tag))) return rc;
+        // The count is not needed before the end of this call: the preprocess kernel skips its count reduction and the scan
+        // delivers it.  When the preprocess grid is resident as a whole (P <= 196 k) the scan and the emission run inside the
+        // preprocess kernel itself (EmitArgs, common.h) and the separate scan + emit kernel is not launched at all; their
+        // control words live in a library-owned ring slot per forward, zero at rest.  DAS3R_FUSED_EMIT=0 switches that off.
+        static thread_local char *emit_ring = nullptr;
+        static thread_local bool emit_ring_dirty = false;
+        static thread_local uint32_t emit_last_tag = 0;
+        constexpr size_t EMIT_SLOT_BYTES = sizeof(uint32_t) * EMIT_SLOT_WORDS + sizeof(unsigned long long) * EMIT_STATUS_GRANULES;
+        const char *efe = getenv("DAS3R_FUSED_EMIT");
+        const bool fused_emit = grid_is_resident(div_up(P, 256)) && !(efe && efe[0] == '0');
+        uint32_t *emit_slot = nullptr;
+        if (fused_emit) {
+            if (!emit_ring) {
+                HIP_TRY(hipMalloc((void **)&emit_ring, ARRIVE_SLOTS * EMIT_SLOT_BYTES));
+                emit_ring_dirty = true;
+            }
+            if (emit_ring_dirty || count_tag < emit_last_tag) {   // first use, an aborted forward, or the tags wrapped around
+                HIP_TRY(hipMemsetAsync(emit_ring, 0, ARRIVE_SLOTS * EMIT_SLOT_BYTES, s));
+                emit_ring_dirty = false;
+            }
+            emit_last_tag = count_tag;
+            emit_slot = (uint32_t *)(emit_ring + (size_t)(count_tag % ARRIVE_SLOTS) * EMIT_SLOT_BYTES);
+            const EmitArgs em = {(unsigned long long *)(emit_slot + EMIT_SLOT_WORDS), count_tag, emit_slot + 64, emit_slot,
+                                 (uint32_t *)(saved->binning + L.b_keyA), (uint32_t *)(saved->binning + L.b_gid_of),
+                                 (uint32_t *)(saved->geom + L.g_off_by_gid), (uint32_t)cap, L.tbits, (uint32_t *)(saved->geom + L.g_count), mb->dev};
+            emit_ring_dirty = true;   // until the last binning kernel of this forward is enqueued (it re-arms the slot)
+            if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, saved->binning + L.b_ghist, L.b_ctrl_bytes, L, nullptr, mb->dev,
+                                        count_tag, s, &em))) return rc;
+            if ((rc = bin_and_render(cap, true, true, nullptr, 0, emit_slot))) return rc;
+            emit_ring_dirty = false;
+        } else {
+            if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, saved->binning + L.b_ghist, L.b_ctrl_bytes, L, nullptr, mb->dev,
+                                        count_tag, s))) return rc;
+            if ((rc = bin_and_render(cap, true, true, mb->dev, count_tag))) return rc;
+        }
         if ((rc = mailbox_wait(mb, 2, count_tag, s))) return rc;
         I = (int64_t)mb->host[0];
         if (I > (int64_t)0x7FFFFF00) { set_error("num_rendered %lld exceeds 2^31", (long long)I); return DAS3R_ERR_OVERFLOW; }

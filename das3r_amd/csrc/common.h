@@ -102,17 +102,35 @@ struct Layout {
 struct LocalBin {
     uint32_t *point_list, *slot_list;   // sorted in place
     uint32_t *keys;                     // u32[num_rendered] scratch for the lists that do not fit in LDS (the dead tile keys)
-    uint32_t *host_flag;                // pinned mailbox word raised when such a list was met
+    uint32_t *host_flag;                // pinned mailbox word that receives flag_value when such a list was met
+    uint32_t flag_value;                // names the shape (P, W, H) this forward belongs to, never 0
     uint32_t last_g, cap;               // P - 1 and the instances the lists hold: bounds for safe_index / safe_range (always set)
 };
 void compute_layout(int P, int64_t I, int W, int H, Layout *L);
+
+// Emission fused into the preprocess kernel (speculative local-order path, grid resident: api.hip).  status == null: off.
+// The control words live in a library-owned ring slot that is zero at rest (ghist, err: re-armed by tile_ranges_kernel) or
+// versioned by the forward's tag (status granules), because nothing runs before this kernel that could zero them.
+struct EmitArgs {
+    unsigned long long *status;   // [nblocks + groups] {tag << 32 | count} granules of the chained scan
+    uint32_t tag;                 // unique per forward of this host thread, never 0
+    uint32_t *ghist;              // [4][256] tile-digit histograms
+    uint32_t *err;                // self-check word
+    uint32_t *tile_keys, *gids, *off_by_gid;
+    uint32_t cap;
+    int tbits;
+    uint32_t *count;              // device word the partition passes read the instance count from (count[1] = flags)
+    uint32_t *count_out;          // pinned host mailbox {count, flags, tag}
+};
+constexpr int EMIT_SLOT_WORDS = 64 + 4 * 256;          // err + padding, ghist: the part tile_ranges_kernel re-arms
+constexpr int EMIT_STATUS_GRANULES = 1024;             // >= resident grid + its groups
 
 // ---- launchers implemented in the individual .hip files ----
 // binning_ctrl (may be null): the binning buffer's control words, zeroed by the same kernel when the buffer already exists
 // arrive: a zeroed 64-bit device word (self re-arming); host_out / tag: pinned mailbox that receives num_rendered
 int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int32_t *radii, char *geom, char *img, char *binning_ctrl,
                       size_t binning_ctrl_bytes, const Layout &L, unsigned long long *arrive, uint32_t *host_out, uint32_t tag,
-                      hipStream_t s);
+                      hipStream_t s, const EmitArgs *emit = nullptr);
 int launch_mark_visible(int P, const float *means3D, const float *viewmatrix, uint8_t *present, hipStream_t s);
 // part 0: everything that can be enqueued before num_rendered is known; part 1: the rest, which also zeroes the binning buffer's
 // control words (binning_ctrl may be null)
@@ -128,7 +146,8 @@ int launch_binning_scan_emit(int P, int64_t I, const int32_t *radii, char *geom,
 size_t onesweep_status_bytes(int64_t n, int passes);
 int launch_onesweep_depth_sort(int P, char *geom, const Layout &L, int part, uint32_t *zero_ptr, uint32_t zero_words, bool debug,
                                hipStream_t s);
-int launch_onesweep_partition(int64_t cap, char *geom, char *binning, const Layout &L, uint32_t **keys_final, bool debug, hipStream_t s);
+int launch_onesweep_partition(int64_t cap, char *geom, char *binning, const Layout &L, uint32_t **keys_final, bool debug, hipStream_t s,
+                              uint32_t *ghist_override = nullptr, uint32_t *err_override = nullptr);
 bool use_row_private(int64_t instances, int ntiles);  // forward: 4x4-block-per-row kernel for long tile lists (render_rows.hip)
 int launch_render_forward_rows(const das3r_raster_args *a, float *out_color, char *geom, char *binning, char *img, const Layout &L,
                                const LocalBin &lb, hipStream_t s);
@@ -142,7 +161,8 @@ bool use_onesweep();  // DAS3R_SORT=classic selects the three-kernel radix passe
 bool use_tight_rect();  // DAS3R_RECT=upstream bins over upstream's 3-sigma square (bit-exact list tests)
 // host_late / tag: pinned mailbox the last binning kernel copies the self-check word to (see api.hip)
 int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *geom, char *binning, char *img, const Layout &L,
-                   bool fused_scan, uint32_t *host_late, uint32_t tag, bool debug, hipStream_t s, uint32_t **dead_keys = nullptr);
+                   bool fused_scan, uint32_t *host_late, uint32_t tag, bool debug, hipStream_t s, uint32_t **dead_keys = nullptr,
+                   uint32_t *emit_slot = nullptr /*fused emission: {err, pad, ghist} ring slot, re-armed by the last kernel*/);
 // lb.point_list != null: the tile lists are in index order and the kernel sorts them by depth first
 int launch_render_forward(const das3r_raster_args *a, const float *colors_precomp, float *out_color, char *geom, char *binning,
                           char *img, const Layout &L, const LocalBin &lb, hipStream_t s);

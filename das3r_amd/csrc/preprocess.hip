@@ -8,6 +8,7 @@
 // Compiled with -ffp-contract=off: all arithmetic is plain IEEE fp32 (+,-,*,/,sqrt correctly rounded), which
 // makes radii / tile rects / conics reproducible bit-for-bit by the CPU oracle.
 #include "common.h"
+#include "granule.h"
 #include "splat_math.h"
 
 namespace das3r {
@@ -22,7 +23,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     float4 *__restrict__ conic_opacity, float4 *__restrict__ rgbd, uint8_t *__restrict__ clamped,
     uint32_t *__restrict__ tiles_touched, int tight_rect, uint32_t *__restrict__ zero_a, uint32_t zero_a_words, uint32_t *__restrict__ zero_b,
     uint32_t zero_b_words, uint32_t *__restrict__ zero_c, uint32_t zero_c_words, unsigned long long *__restrict__ arrive,
-    uint32_t *__restrict__ host_out, uint32_t tag) {
+    uint32_t *__restrict__ host_out, uint32_t tag, const EmitArgs em) {
     const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
     __shared__ uint32_t s_tiles;   // this workgroup's sum of tiles_touched (num_rendered is their grand total)
     if (threadIdx.x == 0) s_tiles = 0;
@@ -64,6 +65,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     float4 xy_out = make_float4(0.f, 0.f, -1e30f, -1e30f);
     float4 co_out = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 rgbd_out = make_float4(0.f, 0.f, 0.f, 0.f);
+    int bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;   // binned tile rectangle (fused emission)
 
     const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
     const float3 p_view = xform43(p, V);
@@ -131,11 +133,9 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
                     hy = sqrtf(tau2 * c) * 1.0005f + 0.02f;
                 }
                 xy_out = make_float4(px, py, hx, hy);
-                {   // instances are binned over the clipped rectangle (radii keeps upstream's value)
-                    int bx0, by0, bx1, by1;
-                    binned_rect(xy_out, r, tiles_x, tiles_y, tight_rect != 0, bx0, by0, bx1, by1);
-                    tiles_out = (uint32_t)((bx1 - bx0) * (by1 - by0));
-                }
+                // instances are binned over the clipped rectangle (radii keeps upstream's value)
+                binned_rect(xy_out, r, tiles_x, tiles_y, tight_rect != 0, bx0, by0, bx1, by1);
+                tiles_out = (uint32_t)((bx1 - bx0) * (by1 - by0));
                 co_out = make_float4(conA, conB, conC, op);
                 rgbd_out = make_float4(col.x, col.y, col.z, p_view.z);
             }
@@ -158,6 +158,89 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     // scan that needs it on the device, so that the host can size the binning buffer exactly without ever waiting for the sort.
     // One 64-bit atomic per workgroup carries (workgroups done << 40 | tiles); the last arriver owns the total, re-arms the
     // counters for their next use and writes {count, tag} to the pinned mailbox (see api.hip).
+    // Fused emission (speculative local-order path, the whole grid resident: common.h EmitArgs): the index-order scan of
+    // tiles_touched and the (tile id, splat) instances of scan_emit.hip, without its launch, its drain and its second trip to the
+    // records — this workgroup's splats are still in registers.
+    if (em.status != nullptr) {   // (uniform)
+        __shared__ uint32_t ws[4], s_carry;
+        __shared__ uint32_t h[4][RADIX_SIZE];
+        const int tid = threadIdx.x, lane = __lane_id(), wave = tid >> 6;
+        const uint32_t b = blockIdx.x;
+#pragma unroll
+        for (int q = 0; q < 4; q++) h[q][tid] = 0u;
+        const uint32_t mine = live ? tiles_out : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan_256(mine, ws, &total);
+        if (wave == 0) {   // one wave publishes and looks back for the whole workgroup: own group + totals of the earlier groups
+            constexpr uint32_t GS = 64u;
+            const uint32_t grp = b / GS, r = b % GS, nblocks = gridDim.x;
+            const u64 t64 = (u64)em.tag << 32;
+            if (lane == 0) granule_store(em.status + b, t64 | total);
+            uint32_t in_group = 0, before = 0;
+            unsigned spins = 0;
+            {
+                const bool has = (uint32_t)lane < r;
+                u64 x = t64;
+                while (true) {
+                    if (has) x = granule_load(em.status + (b - r) + lane);
+                    if (__all((x >> 32) == (u64)em.tag)) break;
+                    if (++spins > SPIN_LIMIT) { if (lane == 0) atomicOr(em.err, ERR_TIMEOUT); break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                in_group = has ? (uint32_t)x : 0u;
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) in_group += (uint32_t)__shfl_xor((int)in_group, o, 64);
+            }
+            if (r == GS - 1u && lane == 0) granule_store(em.status + nblocks + grp, t64 | (u64)(in_group + total));
+            for (uint32_t p0 = 0; p0 < grp; p0 += 64u) {
+                const bool has = p0 + (uint32_t)lane < grp;
+                u64 x = t64;
+                while (true) {
+                    if (has) x = granule_load(em.status + nblocks + p0 + lane);
+                    if (__all((x >> 32) == (u64)em.tag)) break;
+                    if (++spins > SPIN_LIMIT) { if (lane == 0) atomicOr(em.err, ERR_TIMEOUT); break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                uint32_t v = has ? (uint32_t)x : 0u;
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+                before += v;
+            }
+            if (lane == 0) s_carry = in_group + before;
+        }
+        __syncthreads();
+        uint32_t o = s_carry + ex;
+        if (live) {
+            em.off_by_gid[idx] = o;   // first emission slot of the splat: its instances (and their rows of `partial`) are consecutive
+            for (int y = by0; y < by1; y++)
+                for (int x = bx0; x < bx1; x++) {
+                    if (o < em.cap) {   // (a scene that outgrew the speculative capacity is redone with the exact size)
+                        const uint32_t t = (uint32_t)(y * tiles_x + x);
+                        em.tile_keys[o] = t;
+                        em.gids[o] = (uint32_t)idx;
+                        for (int q = 0, sh = 0; sh < em.tbits; q++, sh += 8) {
+                            const int bits = (em.tbits - sh) < 8 ? (em.tbits - sh) : 8;
+                            atomicAdd(&h[q][(t >> sh) & ((1u << bits) - 1u)], 1u);
+                        }
+                    }
+                    o++;
+                }
+        }
+        if (b == gridDim.x - 1 && tid == 0) {   // the last workgroup owns the grand total
+            const uint32_t count = s_carry + total, flags = *em.err;
+            em.count[0] = count;
+            em.count[1] = flags;
+            em.count_out[0] = count;
+            em.count_out[1] = flags;
+            __hip_atomic_store(em.count_out + 2, em.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __syncthreads();
+        for (int q = 0, sh = 0; sh < em.tbits; q++, sh += 8) {
+            const uint32_t c = h[q][tid];
+            if (c) atomicAdd(&em.ghist[q * RADIX_SIZE + tid], c);
+        }
+        return;
+    }
     // (arrive == null: the caller does not need the count early — speculative capacity, api.hip — and lets the scan deliver it)
     if (arrive == nullptr) return;
     uint32_t wsum = live ? tiles_out : 0u;
@@ -202,9 +285,10 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float *_
 
 int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int32_t *radii, char *geom, char *img, char *binning_ctrl,
                       size_t binning_ctrl_bytes, const Layout &L, unsigned long long *arrive, uint32_t *host_out, uint32_t tag,
-                      hipStream_t s) {
+                      hipStream_t s, const EmitArgs *emit) {
     const int P = a->P;
     if (P == 0) return DAS3R_OK;
+    const EmitArgs em = emit ? *emit : EmitArgs{nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0, nullptr, nullptr};
     dim3 grid(div_up(P, 256)), block(256);
     const bool has_sh = in->shs != nullptr, has_cov = in->cov3D_precomp != nullptr;
 #define ARGS                                                                                                              \
@@ -213,7 +297,7 @@ int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int
         a->tanfovx, a->tanfovy, L.tiles_x, L.tiles_y, radii, (uint32_t *)(geom + L.g_keyA), (float4 *)(geom + L.pub.xy),  \
         (float4 *)(geom + L.pub.conic_opacity), (float4 *)(geom + L.pub.rgbd), (uint8_t *)(geom + L.pub.clamped),         \
         (uint32_t *)(geom + L.pub.tiles_touched), use_tight_rect() ? 1 : 0, (uint32_t *)(geom + L.g_ghist), (uint32_t)(L.g_ctrl_bytes / 4),                 \
-        (uint32_t *)(img + L.pub.ranges), (uint32_t)(2 * L.ntiles), (uint32_t *)binning_ctrl, (uint32_t)(binning_ctrl_bytes / 4), arrive, host_out, tag
+        (uint32_t *)(img + L.pub.ranges), (uint32_t)(2 * L.ntiles), (uint32_t *)binning_ctrl, (uint32_t)(binning_ctrl_bytes / 4), arrive, host_out, tag, em
     const bool stage = has_sh && a->M == 16 && a->sh_degree >= 2 && ((uintptr_t)in->shs & 15) == 0 && !getenv("DAS3R_NO_SH_STAGE");
     if (has_sh && !has_cov && stage) DAS3R_LAUNCH((preprocess_kernel<true, false, true>), grid, block, 0, s, ARGS);
     else if (has_sh && has_cov && stage) DAS3R_LAUNCH((preprocess_kernel<true, true, true>), grid, block, 0, s, ARGS);

@@ -167,7 +167,7 @@ __device__ __forceinline__ bool local_order_tile(const LocalBin &lb, const uint2
         return false;
     }
     uint32_t *dk = lb.keys + range.x;
-    if (tid == 0) __hip_atomic_store(lb.host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) __hip_atomic_store(lb.host_flag, lb.flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     for (int i = tid; i < n; i += TILE_PIX) dk[i] = __float_as_uint(rgbd[(size_t)min(pl[i], lb.last_g) * SPLAT_REC].w);
     __syncthreads();
     for (int k = 2; (k >> 1) < n; k <<= 1)

@@ -15,6 +15,7 @@
 // chunk of 64*ipl keys, keeps its 256 digit counters in LDS and ranks keys with wavefront ballots
 // (match-any over the digit bits + popcount prefix) — no block barriers in the ranking loop.
 #include "granule.h"
+#include <algorithm>
 #include "splat_math.h"
 
 namespace das3r {
@@ -237,13 +238,15 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, int tiles
 
 __global__ void __launch_bounds__(256) tile_ranges_kernel(uint32_t cap, const uint32_t *__restrict__ n_ptr,
                                                           const uint32_t *__restrict__ tile_keys, uint2 *__restrict__ ranges,
-                                                          const uint32_t *__restrict__ err, uint32_t *__restrict__ host_late, uint32_t tag) {
+                                                          uint32_t *__restrict__ err, uint32_t *__restrict__ host_late, uint32_t tag,
+                                                          uint32_t rearm_words /*fused emission: err[0 .. rearm_words) back to zero*/) {
     const uint32_t I = n_ptr ? min(*n_ptr, cap) : cap;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0 && host_late) {   // last binning kernel: hand the self-check word of this forward to the host mailbox
         host_late[0] = *err;
         __hip_atomic_store(host_late + 1, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    if (i < rearm_words) err[i] = 0u;   // (thread 0 has read err[0] just above) the ring slot is zero at rest again
     if (i >= I) return;
     const uint32_t t = tile_keys[i];
     if (i == 0) ranges[t].x = 0;
@@ -285,7 +288,7 @@ int launch_binning_scan_emit(int P, int64_t I, const int32_t *radii, char *geom,
 
 // I = capacity of the binning buffer; the true instance count is read by the kernels from geom + L.g_count
 int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *geom, char *binning, char *img, const Layout &L,
-                   bool fused_scan, uint32_t *host_late, uint32_t tag, bool debug, hipStream_t s, uint32_t **dead_keys) {
+                   bool fused_scan, uint32_t *host_late, uint32_t tag, bool debug, hipStream_t s, uint32_t **dead_keys, uint32_t *emit_slot) {
     const uint32_t *n_ptr = (const uint32_t *)(geom + L.g_count);
     (void)W; (void)H;
     uint2 *ranges = (uint2 *)(img + L.pub.ranges);  // zeroed by preprocess_kernel
@@ -306,11 +309,12 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
     }
     if (onesweep) {
         uint32_t *kfinal = nullptr;
-        int rc1 = launch_onesweep_partition(I, geom, binning, L, &kfinal, debug, s);
+        int rc1 = launch_onesweep_partition(I, geom, binning, L, &kfinal, debug, s, emit_slot ? emit_slot + 64 : nullptr, emit_slot);
         if (rc1) return rc1;
         if (dead_keys) *dead_keys = kfinal;   // the tile keys are dead once tile_ranges_kernel has run
-        DAS3R_LAUNCH(tile_ranges_kernel, dim3(div_up(I, 256)), dim3(256), 0, s, (uint32_t)I, n_ptr, kfinal, ranges,
-                     (const uint32_t *)(geom + L.g_ticket) + 8, host_late, tag);
+        const int rearm = emit_slot ? EMIT_SLOT_WORDS : 0;
+        DAS3R_LAUNCH(tile_ranges_kernel, dim3(div_up(std::max<int64_t>(I, rearm), 256)), dim3(256), 0, s, (uint32_t)I, n_ptr, kfinal, ranges,
+                     emit_slot ? emit_slot : (uint32_t *)(geom + L.g_ticket) + 8, host_late, tag, (uint32_t)rearm);
         KERNEL_CHECK(s, debug, "tile_ranges");
         return DAS3R_OK;
     }
@@ -331,7 +335,7 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
     // kin/vin now hold the partitioned (tile id, gaussian id) lists; vin == binning + pub.point_list by construction
     if (dead_keys) *dead_keys = kin;
     DAS3R_LAUNCH(tile_ranges_kernel, dim3(div_up(I, 256)), dim3(256), 0, s, (uint32_t)I, n_ptr, kin, ranges,
-                 (const uint32_t *)(geom + L.g_ticket) + 8, host_late, tag);
+                 (uint32_t *)(geom + L.g_ticket) + 8, host_late, tag, 0u);
     KERNEL_CHECK(s, debug, "tile_ranges");
     return DAS3R_OK;
 }

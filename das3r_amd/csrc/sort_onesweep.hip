@@ -293,13 +293,14 @@ int launch_onesweep_depth_sort(int P, char *geom, const Layout &L, int part, uin
 
 // Stable partition of the emitted instances by tile id.  ctrl (binning buffer) = [ghist 2x256][tickets][status], zeroed by
 // a memset before emit; emit_kernel accumulated the two digit histograms.
-int launch_onesweep_partition(int64_t cap, char *geom, char *binning, const Layout &L, uint32_t **keys_final, bool debug, hipStream_t s) {
+int launch_onesweep_partition(int64_t cap, char *geom, char *binning, const Layout &L, uint32_t **keys_final, bool debug, hipStream_t s,
+                              uint32_t *ghist_override, uint32_t *err_override) {
     const uint32_t *n_ptr = (const uint32_t *)(geom + L.g_count);
-    uint32_t *err = (uint32_t *)(geom + L.g_ticket) + 8;  // inside the zeroed control region
+    uint32_t *err = err_override ? err_override : (uint32_t *)(geom + L.g_ticket) + 8;  // inside the zeroed control region
     uint32_t *keyA = (uint32_t *)(binning + L.b_keyA), *keyB = (uint32_t *)(binning + L.b_keyB);
     uint32_t *valA = (uint32_t *)(binning + L.b_valA), *valB = (uint32_t *)(binning + L.b_valB);
     uint32_t *gid_of = (uint32_t *)(binning + L.b_gid_of), *inv = (uint32_t *)(binning + L.b_slot);
-    uint32_t *ghist = (uint32_t *)(binning + L.b_ghist), *ticket = (uint32_t *)(binning + L.b_ticket);
+    uint32_t *ghist = ghist_override ? ghist_override : (uint32_t *)(binning + L.b_ghist), *ticket = (uint32_t *)(binning + L.b_ticket);
     u64 *status = (u64 *)(binning + L.b_status);
     const size_t per_pass = onesweep_status_bytes(cap, 1) / sizeof(u64);
     uint32_t *kin = keyA, *vin = nullptr, *kout = keyB, *vout = valB;

@@ -235,9 +235,16 @@ def test_repeated_forwards_agree_and_count_is_exact():
     tt = _view(g0, L["tiles_touched"], torch.int32, sc.P)
     assert int(tt.sum()) == I0
     grads0 = rasterizer._backward_impl(rs, I0, scd.dL_dpix, scd.means3D, scd.shs, e, scd.opacities, scd.scales, scd.rotations, e, g0, b0, i0, cap0)
+    pl0 = _view(b0, L["point_list"], torch.int32, I0).clone()
     for _ in range(70):   # more calls than the arrival ring has slots
         I1, c1, r1, g1, b1, i1, cap1 = rasterizer._forward_full(*args)
         assert I1 == I0 and cap1 >= I0   # (repeated shape: the binning buffer is laid out speculatively, with headroom)
+    # the speculative forwards (scan + emission fused into the preprocess kernel when the grid is resident) build the same lists
+    L1 = _lib.layout(sc.P, cap1, sc.W, sc.H)
+    assert torch.equal(_view(b1, L1["point_list"], torch.int32, I1), pl0)
+    rg0 = _view(i0, L["ranges"], torch.int32, 2 * ((sc.W + 15) // 16) * ((sc.H + 15) // 16))
+    rg1 = _view(i1, L1["ranges"], torch.int32, rg0.numel())
+    assert torch.equal(rg0, rg1)
     assert torch.equal(c1, c0) and torch.equal(r1, r0)
     grads1 = rasterizer._backward_impl(rs, I1, scd.dL_dpix, scd.means3D, scd.shs, e, scd.opacities, scd.scales, scd.rotations, e, g1, b1, i1, cap1)
     for k, (a, b) in enumerate(zip(grads0, grads1)):   # only the order of the four per-wave LDS adds differs run to run
@@ -444,3 +451,42 @@ def test_local_order_at_every_list_length(P, monkeypatch):
     assert np.array_equal(pla, expect), "global sort"
     assert np.array_equal(plb, expect), "local order"
     assert torch.equal(ca, cb) and torch.equal(ra, rb)
+
+
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_speculative_forward_builds_the_same_lists(fused, monkeypatch):
+    """A short-list scene seen before is rendered without waiting for its count: binning buffer with headroom, the count
+    delivered by the scan, and — when the preprocess grid is resident as a whole — scan and emission inside the preprocess
+    kernel itself (DAS3R_FUSED_EMIT=0: the separate kernel).  Lists, ranges, image, radii and gradients must equal those of
+    the exactly sized forward, call after call (the control words of the fused emission live in a ring that every forward has
+    to leave zeroed)."""
+    from das3r_amd import GaussianRasterizationSettings, rasterizer, _lib
+    from das3r_amd.synth import make_scene
+    monkeypatch.setenv("DAS3R_FUSED_EMIT", fused)
+    dev = _dev()
+    sc = make_scene(P=20000, W=320, H=192, focal=250.0, sh_degree=2, seed=77, s_px=(0.7, 3.0))
+    scd = sc.to(dev)
+    rs = GaussianRasterizationSettings(**scd.settings_kwargs())
+    e = torch.empty(0, device=dev)
+    args = (rs, scd.means3D, scd.shs, e, scd.opacities, scd.scales, scd.rotations, e)
+    tiles = ((sc.W + 15) // 16) * ((sc.H + 15) // 16)
+    I0, c0, r0, g0, b0, i0, cap0 = rasterizer._forward_full(*args, exact=True)
+    assert cap0 == I0 and 0 < I0 <= 384 * tiles, "the scene must take the local depth order"
+    L0 = _lib.layout(sc.P, cap0, sc.W, sc.H)
+    pl0 = _view(b0, L0["point_list"], torch.int32, I0).clone()
+    rg0 = _view(i0, L0["ranges"], torch.int32, 2 * tiles).clone()
+    grads0 = rasterizer._backward_impl(rs, I0, scd.dL_dpix, *args[1:], g0, b0, i0, cap0)
+    for it in range(40):
+        I1, c1, r1, g1, b1, i1, cap1 = rasterizer._forward_full(*args)
+        assert I1 == I0 and cap1 > I0, "speculative capacity expected"
+        if it % 13 == 0 or it == 39:
+            L1 = _lib.layout(sc.P, cap1, sc.W, sc.H)
+            assert torch.equal(_view(b1, L1["point_list"], torch.int32, I1), pl0), it
+            assert torch.equal(_view(i1, L1["ranges"], torch.int32, 2 * tiles), rg0), it
+            assert torch.equal(c1, c0) and torch.equal(r1, r0), it
+            tt = _view(g1, L1["tiles_touched"], torch.int32, sc.P)
+            assert int(tt.sum()) == I1
+    grads1 = rasterizer._backward_impl(rs, I1, scd.dL_dpix, *args[1:], g1, b1, i1, cap1)
+    for a, b in zip(grads0, grads1):
+        if a is not None:
+            util.assert_grad_close(b.cpu().numpy(), a.cpu().numpy(), "speculative forward", tol=1e-5)
