@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     // float4 loads — every 128-B line exactly once — and re-read per lane from LDS.  Per-lane strided row loads re-fetch
     // lines evicted from L1/L2 between the 12 loads of a row: measured 2.5x the algorithmic HBM traffic at 1M splats.
     // Rows are padded to 13 float4 (208 B) so that the per-lane ds_read_b128 of a 16-lane group hit 16 distinct bank slots.
-    __shared__ float4 sh_lds[STAGE ? 256 * 13 : 1];
+    __shared__ float4 sh_lds[STAGE ? 256 * 13 : 256];   // (>= 4 KB: the fused emission's digit histograms reuse it)
     if (STAGE) {
         const float4 *src = reinterpret_cast<const float4 *>(shs) + (size_t)blockIdx.x * 256 * 12;
         const size_t limit = (size_t)P * 12 - (size_t)blockIdx.x * 256 * 12;  // float4s available from src
@@ -163,14 +163,15 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     // records — this workgroup's splats are still in registers.
     if (em.status != nullptr) {   // (uniform)
         __shared__ uint32_t ws[4], s_carry;
-        __shared__ uint32_t h[4][RADIX_SIZE];
+        uint32_t(*h)[RADIX_SIZE] = reinterpret_cast<uint32_t(*)[RADIX_SIZE]>(sh_lds);   // [4][256]: the SH rows are dead (4 KB more
+                                                                                        // LDS would cost a third of the occupancy)
         const int tid = threadIdx.x, lane = __lane_id(), wave = tid >> 6;
         const uint32_t b = blockIdx.x;
-#pragma unroll
-        for (int q = 0; q < 4; q++) h[q][tid] = 0u;
         const uint32_t mine = live ? tiles_out : 0u;
         uint32_t total;
-        const uint32_t ex = block_exclusive_scan_256(mine, ws, &total);
+        const uint32_t ex = block_exclusive_scan_256(mine, ws, &total);   // (its barriers: every lane is done with its SH row)
+#pragma unroll
+        for (int q = 0; q < 4; q++) h[q][tid] = 0u;                      // (published by the barrier behind the look-back)
         if (wave == 0) {   // one wave publishes and looks back for the whole workgroup: own group + totals of the earlier groups
             constexpr uint32_t GS = 64u;
             const uint32_t grp = b / GS, r = b % GS, nblocks = gridDim.x;
