@@ -37,6 +37,23 @@ void profile_end(hipStream_t s) {
     if (!g_prof.empty()) hipEventRecord(g_prof.back().stop, s);
 }
 
+// Ticket-free chained kernels wait for lower-numbered workgroups, which is only safe while the whole grid is resident at once.
+// The bound is taken from the device the call runs on (compute partitions have fewer CUs) and stays below what it holds
+// (>= 3 workgroups per CU of the heaviest of these kernels).  DAS3R_TICKETS=always switches the
+// short cut off.
+bool grid_is_resident(int nblocks) {
+    static const int limit = [] {
+        const char *e = getenv("DAS3R_TICKETS");
+        if (e && e[0] == 'a') return 0;
+        if (e && e[0] == 'n') return 1 << 30;   // (experiments only: never take a ticket)
+        if (e && e[0] >= '1' && e[0] <= '9') return atoi(e);   // (experiments only: the bound itself)
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        return cus * 2;   // the heaviest chained kernels get 3 workgroups per CU
+    }();
+    return nblocks <= limit;
+}
+
 int sort_ipl_override() {
     const char *e = getenv("DAS3R_SORT_IPL");
     const int v = e ? atoi(e) : 0;
@@ -226,7 +243,8 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         if (wait) { int r = mailbox_wait(mb, 9, late_tag, s); if (r) return r; }
         if (__atomic_load_n(&mb->host[9], __ATOMIC_ACQUIRE) != late_tag) return DAS3R_OK;   // not there yet: look again next time
         late_tag = 0;
-        const uint32_t flags = mb->host[8];
+        const uint32_t all_flags = mb->host[8], flags = all_flags & ~16u;   // bit 16: a stalled look-back was rescued (granule.h), not an error
+        if ((all_flags & 16u) && getenv("DAS3R_VERBOSE")) fprintf(stderr, "das3r: a look-back poll needed the read-modify-write path\n");
         if (flags) { set_error("a forward's binning failed its self-check (flags 0x%x); its output was invalid", flags); return DAS3R_ERR_HIP; }
         return DAS3R_OK;
     };

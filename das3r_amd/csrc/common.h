@@ -154,9 +154,9 @@ int launch_render_forward_rows(const das3r_raster_args *a, float *out_color, cha
 int launch_render_backward_mfma(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
                                 float *partial, hipStream_t s);
 constexpr int LOCAL_MAX = 1024;   // longest tile list the forward kernels sort in LDS
-// chained kernels (scan, radix passes) order their workgroups by ticket unless every workgroup of the grid is resident at once:
-// 256 CUs x >= 4 workgroups of these kernels (LDS-limited), with a margin
-inline bool grid_is_resident(int nblocks) { return nblocks <= 768; }
+// chained kernels (scan, radix passes) order their workgroups by ticket unless every workgroup of the grid is resident at once
+// (api.hip: grid_is_resident)
+bool grid_is_resident(int nblocks);
 bool use_onesweep();  // DAS3R_SORT=classic selects the three-kernel radix passes (diagnostics / A-B)
 bool use_tight_rect();  // DAS3R_RECT=upstream bins over upstream's 3-sigma square (bit-exact list tests)
 // host_late / tag: pinned mailbox the last binning kernel copies the self-check word to (see api.hip)

@@ -15,6 +15,17 @@ __device__ __forceinline__ void granule_store(u64 *p, u64 v) { __hip_atomic_stor
 __device__ __forceinline__ u64 granule_load(const u64 *p) {
     return __hip_atomic_load(const_cast<u64 *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Poll number `spins` of a hand-off word.  Once in ~1e5 forwards a poller kept reading the unpublished value of a word that had
+// long been published, until the 4 s spin limit (soak runs, a rocprofv3 run): a cached copy that agent-scope loads kept
+// hitting is the only explanation left.  After SOFT_SPINS fruitless polls (~0.1 ms) the word is therefore read with an atomic
+// read-modify-write (OR 0), which is performed where the stores land; ERR_HARD_POLL in the error word records that it was needed
+// (informational: the host does not treat it as a failure).
+constexpr unsigned SOFT_SPINS = 96;
+constexpr uint32_t ERR_HARD_POLL = 16u;
+__device__ __forceinline__ u64 granule_poll(const u64 *p, const unsigned spins) {
+    if (spins < SOFT_SPINS) return granule_load(p);
+    return __hip_atomic_fetch_or(const_cast<u64 *>(p), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
     const int lane = __lane_id();

@@ -183,8 +183,9 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
                 const bool has = (uint32_t)lane < r;
                 u64 x = t64;
                 while (true) {
-                    if (has) x = granule_load(em.status + (b - r) + lane);
+                    if (has) x = granule_poll(em.status + (b - r) + lane, spins);
                     if (__all((x >> 32) == (u64)em.tag)) break;
+                    if (spins == SOFT_SPINS && lane == 0) atomicOr(em.err, ERR_HARD_POLL);
                     if (++spins > SPIN_LIMIT) { if (lane == 0) atomicOr(em.err, ERR_TIMEOUT); break; }
                     __builtin_amdgcn_s_sleep(2);
                 }
@@ -197,8 +198,9 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
                 const bool has = p0 + (uint32_t)lane < grp;
                 u64 x = t64;
                 while (true) {
-                    if (has) x = granule_load(em.status + nblocks + p0 + lane);
+                    if (has) x = granule_poll(em.status + nblocks + p0 + lane, spins);
                     if (__all((x >> 32) == (u64)em.tag)) break;
+                    if (spins == SOFT_SPINS && lane == 0) atomicOr(em.err, ERR_HARD_POLL);
                     if (++spins > SPIN_LIMIT) { if (lane == 0) atomicOr(em.err, ERR_TIMEOUT); break; }
                     __builtin_amdgcn_s_sleep(2);
                 }

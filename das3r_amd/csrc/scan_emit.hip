@@ -23,8 +23,9 @@ __device__ __forceinline__ uint32_t wave_sum_published(const u64 *g, const int c
         const bool mine = p + lane < count;
         u64 x = TAG_AGG;
         while (true) {
-            if (mine) x = granule_load(g + p + lane);
+            if (mine) x = granule_poll(g + p + lane, spins);
             if (__all((x & TAG_MASK) != 0)) break;   // wave-uniform exit: every lane's word is published
+            if (spins == SOFT_SPINS && lane == 0) atomicOr(err, ERR_HARD_POLL);
             if (++spins > SPIN_LIMIT) {
                 if (lane == 0) atomicOr(err, ERR_TIMEOUT);
                 break;

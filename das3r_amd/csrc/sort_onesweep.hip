@@ -31,10 +31,11 @@ __device__ __forceinline__ uint32_t sum_published(const u64 *col, const int coun
         while (true) {
             bool ok = true;
 #pragma unroll
-            for (int j = 0; j < LB; j++) x[j] = (p + j < count) ? granule_load(col + (size_t)(p + j) * RADIX_SIZE) : TAG_AGG;
+            for (int j = 0; j < LB; j++) x[j] = (p + j < count) ? granule_poll(col + (size_t)(p + j) * RADIX_SIZE, spins) : TAG_AGG;
 #pragma unroll
             for (int j = 0; j < LB; j++) ok &= (x[j] & TAG_MASK) != 0;
             if (ok) break;
+            if (spins == SOFT_SPINS) atomicOr(err, ERR_HARD_POLL);
             if (++spins > SPIN_LIMIT) {  // a predecessor never published: give up loudly instead of hanging
                 atomicOr(err, ERR_TIMEOUT);
                 return sum;
