@@ -258,8 +258,9 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     }
     // Depth order: scenes with short tile lists (the 100 k-splat 1080p benchmark averages 32 entries per tile) skip the global
     // depth sort — five of the eleven binning launches, each latency-bound at that size; the instances are emitted in index
-    // order and the compositing kernel sorts every tile's list itself (common.h: LocalBin).  Chosen from the instance count of the previous forward of the same shape, confirmed with this forward's
-    // count; a list that outgrows LDS is still sorted correctly (slowly) and sends the next forwards back to the global sort.
+    // order and the compositing kernel sorts every tile's list itself (common.h: LocalBin).  Chosen from the instance count
+    // of the previous forward of the same shape, confirmed with this forward's count; a list that outgrows LDS is still sorted
+    // correctly (slowly) and sends the next forwards back to the global sort.
     struct Verdict { int P, W, H; int64_t last_I, peak_I; int radix_left, backoff; uint32_t gen; };
     static thread_local Verdict verdict = {0, 0, 0, -1, 0, 0, 64, 0};
     constexpr int64_t LOCAL_AVG = 384;   // mean list length up to which the local order wins (measured: 1 M splats at 1080p, mean 320: -4 %)
