@@ -177,16 +177,33 @@ struct Mailbox {
     uint32_t *dev = nullptr;
     uint32_t seq = 0;
 };
-static int mailbox_get(Mailbox **out) {
-    static thread_local Mailbox mb;
-    if (!mb.host) {
+// Everything the library remembers between calls, per host thread and per device (a thread that renders on two GPUs gets two
+// of these; nothing is shared between threads: any number of them may render concurrently, each on its own stream).
+struct Verdict { int P, W, H; int64_t last_I, peak_I; int radix_left, backoff; uint32_t gen; };
+struct PerDevice {
+    Mailbox mb;
+    uint32_t late_tag = 0;                          // tag of the forward whose self-check word has not been examined yet
+    unsigned long long *arrive_ring = nullptr;      // self re-arming arrival words of the preprocess kernel's count reduction
+    Verdict verdict = {0, 0, 0, -1, 0, 0, 64, 0};  // what the last forward of the current shape (P, W, H) taught us
+    char *emit_ring = nullptr;                      // control words of the emission fused into the preprocess kernel
+    bool emit_ring_dirty = false;
+    uint32_t emit_last_tag = 0;
+};
+constexpr int MAX_DEVICES = 64;
+static int per_device(PerDevice **out) {
+    static thread_local PerDevice state[MAX_DEVICES];
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEVICES) { set_error("device ordinal %d not supported", dev); return DAS3R_ERR_INVALID_ARG; }
+    PerDevice &T = state[dev];
+    if (!T.mb.host) {
         uint32_t *h = nullptr;
         HIP_TRY(hipHostMalloc((void **)&h, 64, hipHostMallocMapped));
         memset(h, 0, 64);
-        HIP_TRY(hipHostGetDevicePointer((void **)&mb.dev, h, 0));
-        mb.host = h;
+        HIP_TRY(hipHostGetDevicePointer((void **)&T.mb.dev, h, 0));
+        T.mb.host = h;
     }
-    *out = &mb;
+    *out = &T;
     return DAS3R_OK;
 }
 // spin until word `idx` carries `tag` (bounded: falls back to a stream synchronise, then gives up loudly)
@@ -235,9 +252,10 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     //   * the binning self-check word (bit 1 look-back timeout, 2 index out of range -> write suppressed, 8 counts do not
     //     add up to the histogram) is delivered by the last binning kernel and examined at the start of the NEXT forward
     //     (debug mode waits for it right away).
-    Mailbox *mb = nullptr;
-    if ((rc = mailbox_get(&mb))) return rc;
-    static thread_local uint32_t late_tag = 0;   // tag of the forward whose self-check word has not been examined yet
+    PerDevice *T = nullptr;
+    if ((rc = per_device(&T))) return rc;
+    Mailbox *mb = &T->mb;
+    uint32_t &late_tag = T->late_tag;
     auto check_late = [&](bool wait) -> int {
         if (!late_tag) return DAS3R_OK;
         if (wait) { int r = mailbox_wait(mb, 9, late_tag, s); if (r) return r; }
@@ -250,7 +268,7 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     };
     if ((rc = check_late(false))) return rc;
     // per-thread ring of self re-arming arrival words for the count reduction of the preprocess kernel
-    static thread_local unsigned long long *arrive_ring = nullptr;
+    unsigned long long *&arrive_ring = T->arrive_ring;
     constexpr uint32_t ARRIVE_SLOTS = 16, ARRIVE_WORDS = 8 + 64 * 8;   // per call: top word + 64 sub-counters, one 64-byte line each
     if (!arrive_ring) {
         HIP_TRY(hipMalloc((void **)&arrive_ring, ARRIVE_SLOTS * ARRIVE_WORDS * sizeof(unsigned long long)));
@@ -261,8 +279,7 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     // order and the compositing kernel sorts every tile's list itself (common.h: LocalBin).  Chosen from the instance count
     // of the previous forward of the same shape, confirmed with this forward's count; a list that outgrows LDS is still sorted
     // correctly (slowly) and sends the next forwards back to the global sort.
-    struct Verdict { int P, W, H; int64_t last_I, peak_I; int radix_left, backoff; uint32_t gen; };
-    static thread_local Verdict verdict = {0, 0, 0, -1, 0, 0, 64, 0};
+    Verdict &verdict = T->verdict;
     constexpr int64_t LOCAL_AVG = 384;   // mean list length up to which the local order wins (measured: 1 M splats at 1080p, mean 320: -4 %)
     const uint32_t too_long = mb->host[10];   // != 0: a forward of the shape with that generation number met a list too long for LDS
     if (too_long) mb->host[10] = 0;
@@ -324,9 +341,9 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         // delivers it.  When the preprocess grid is resident as a whole (P <= 196 k) the scan and the emission run inside the
         // preprocess kernel itself (EmitArgs, common.h) and the separate scan + emit kernel is not launched at all; their
         // control words live in a library-owned ring slot per forward, zero at rest.  DAS3R_FUSED_EMIT=0 switches that off.
-        static thread_local char *emit_ring = nullptr;
-        static thread_local bool emit_ring_dirty = false;
-        static thread_local uint32_t emit_last_tag = 0;
+        char *&emit_ring = T->emit_ring;
+        bool &emit_ring_dirty = T->emit_ring_dirty;
+        uint32_t &emit_last_tag = T->emit_last_tag;
         constexpr size_t EMIT_SLOT_BYTES = sizeof(uint32_t) * EMIT_SLOT_WORDS + sizeof(unsigned long long) * EMIT_STATUS_GRANULES;
         const char *efe = getenv("DAS3R_FUSED_EMIT");
         const bool fused_emit = grid_is_resident(div_up(P, 256)) && !(efe && efe[0] == '0');
