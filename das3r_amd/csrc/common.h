@@ -192,6 +192,14 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     v = dpp_step<0x143, 0xc>(v);  // row_bcast31 into rows 2,3
     return v;
 }
+// Sum inside each 16-lane row: lane 15 of every row ends up with its row's total (the first four steps of the above).
+__device__ __forceinline__ float row_sum_to_lane15(float v) {
+    v = dpp_step<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_step<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_step<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_step<0x118, 0xf>(v);  // row_shr:8
+    return v;
+}
 // Portable (ds_bpermute based) full-wave sum; every lane gets the result.  Reference for the DPP path.
 __device__ __forceinline__ float wave_sum_shfl(float v) {
 #pragma unroll

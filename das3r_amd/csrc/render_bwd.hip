@@ -74,8 +74,10 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
     ReplayState st = {T_final, 0.f};
     const float tfbg = T_final * bg_dot_dpixel;
     // which accumulator this lane feeds after the cross-lane reduction
-    const bool writer = USE_DPP ? (((lane & 7) == 0) || lane == 63) : (lane < NACC);
-    const int widx = USE_DPP ? (lane == 63 ? 8 : (lane >> 3)) : lane;
+    // DPP path: lanes 0, 8, .., 56 hold the wave totals of sums 0..7, lane 15 of every row its ROW's total of the ninth — the four
+    // rows meet in the LDS add like the four waves do (two broadcast steps, six instructions, less on the vector ALU)
+    const bool writer = USE_DPP ? (((lane & 7) == 0) || ((lane & 15) == 15)) : (lane < NACC);
+    const int widx = USE_DPP ? ((lane & 15) == 15 ? 8 : (lane >> 3)) : lane;
 
     for (int i = 0; i < rounds; i++) {
         const int done_before = i * TILE_PIX;
@@ -119,8 +121,8 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
                     out = v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] + v[8];
                 } else if (USE_DPP) {
                     const float r8 = wave_reduce8_transposed(v, lane);   // lane l: total of v[l >> 3]
-                    const float r1 = wave_sum_to_lane63(v[8]);           // lane 63: total of v[8]
-                    out = lane == 63 ? r1 : r8;
+                    const float r1 = row_sum_to_lane15(v[8]);            // lane 15 of every row: that row's total of v[8]
+                    out = (lane & 15) == 15 ? r1 : r8;
                 } else {
                     // reference reduction (ds_bpermute butterflies): every lane gets every total
                     float tot[NACC];
