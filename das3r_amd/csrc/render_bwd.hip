@@ -78,6 +78,7 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
     // rows meet in the LDS add like the four waves do (two broadcast steps, six instructions, less on the vector ALU)
     const bool writer = USE_DPP ? (((lane & 7) == 0) || ((lane & 15) == 15)) : (lane < NACC);
     const int widx = USE_DPP ? ((lane & 15) == 15 ? 8 : (lane >> 3)) : lane;
+    const unsigned widx4 = (unsigned)widx * 4u;
 
     for (int i = 0; i < rounds; i++) {
         const int done_before = i * TILE_PIX;
@@ -132,8 +133,10 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
 #pragma unroll
                     for (int q = 0; q < NACC; q++) out = lane == q ? tot[q] : out;
                 }
-                if (ablate & 8) { if (writer) acc[j * NACC + widx] = out; }   // timing experiment: plain store instead of the atomic
-                else if (writer) atomicAdd(&acc[j * NACC + widx], out);  // divergent addresses: one ds_add_f32 for the whole wave
+                // (address: one full-rate 24-bit multiply-add; the compiler's choice for j * 9 + widx is a quarter-rate v_mad_u64_u32)
+                float *const slot = reinterpret_cast<float *>(reinterpret_cast<char *>(acc) + __umul24((unsigned)j, NACC * 4u) + widx4);
+                if (ablate & 8) { if (writer) *slot = out; }   // timing experiment: plain store instead of the atomic
+                else if (writer) atomicAdd(slot, out);  // divergent addresses: one ds_add_f32 for the whole wave
             }
         }
         __syncthreads();
