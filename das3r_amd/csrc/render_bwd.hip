@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
                 if (__ballot(active) == 0ull) continue;  // wave-uniform skip
                 const float4 c = stage[j].rgbd;
                 float v[NACC];
-                replay_pair(active, alpha, G, dx, dy, co, c, dLp0, dLp1, dLp2, tfbg, ddelx_dx, ddely_dy, st, v);
+                replay_pair_moments(active, alpha, G, dx, dy, c, dLp0, dLp1, dLp2, tfbg, st, v);   // geometry sums as raw moments
                 float out;
                 if (ablate & 4) {  // experiment: no cross-lane traffic, heavy arithmetic kept alive
                     out = v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] + v[8];
@@ -139,6 +139,8 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
                 else if (writer) atomicAdd(slot, out);  // divergent addresses: one ds_add_f32 for the whole wave
             }
         }
+        __syncthreads();
+        if (tid < n) moments_to_sums(&acc[tid * NACC], stage[tid].co, ddelx_dx, ddely_dy);   // once per (tile, splat), not per pair
         __syncthreads();
         // every staged entry's 9 sums go to the row of its emission slot: a splat's rows are then contiguous for the
         // per-Gaussian backward kernel (36-byte row stores, 9 lanes each)
