@@ -128,8 +128,10 @@ def main():
         achieved = per_kernel[dom] / (dom_ms * 1e-3) / 1e9
         total_ms = sum(v["ms_per_step"] for v in kernels_json.values())
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", f"pmc_{args.workload}.json")
-        if os.path.exists(pmc_path):  # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_summary.py)
+        import glob
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc_{args.workload}.json")))   # latest round
+        pmc_path = pmc_files[-1] if pmc_files else ""
+        if pmc_path:  # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_summary.py)
             try:
                 traffic = json.load(open(pmc_path)).get(dom, {}).get("hbm_bytes_per_launch")
             except Exception:  # noqa: BLE001

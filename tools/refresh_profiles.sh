@@ -15,8 +15,8 @@ for w in c2 c4; do
 done
 cd $R
 for w in c2 c4; do
-  bash tools/pmc_collect.sh $w gpurun_out/pmc_$w > $OUT/pmc_$w.txt 2>&1
-  python tools/pmc_summary.py gpurun_out/pmc_$w --json $OUT/pmc_$w.json > /dev/null
+  bash tools/pmc_collect.sh $w gpurun_out/pmc_$w > $OUT/${RN}_pmc_$w.txt 2>&1
+  python tools/pmc_summary.py gpurun_out/pmc_$w --json $OUT/${RN}_pmc_$w.json > /dev/null
 done
 python tools/train_bench.py --breakdown 2>/dev/null | tail -1 > $OUT/${RN}_train_step_unfused.json
 python tools/train_bench.py --fused-adam --fused-loss --fused-pre --breakdown 2>/dev/null | tail -1 > $OUT/${RN}_train_step_fused.json
