@@ -1,185 +1,378 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the rasterizer hot path (forward + backward through the drop-in GaussianRasterizer API) on
-synthetic random-splat scenes at 1080p, with the roofline of the dominant kernel and the CPU oracle timed beside it.
+synthetic random-splat scenes, with the roofline of the dominant kernel and the CPU oracle timed beside it.
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload c2|c4|ds|c1]
+    python bench.py [--gpus N --steps K --warmup W] [--workload c4|c2|ds|c1|c4d] [--no-extras] [--no-cpu-baseline]
 
-A step = one forward + one backward of one scene (inputs resident in HBM).  With N > 1 (launched by torch.distributed.run,
-one rank per GPU) every rank renders its OWN scene — independent sequences farmed across the node, no data-path
-collective; RCCL is used only for the barrier and the max-over-ranks time — hence "scaling": "weak".
-Prints ONE JSON line on rank 0.
+Default workload: c4 = BASELINE.json configs[3] (1 M splats at 1080p), the configuration north_star's roofline target is
+stated on.  A step = one forward + one backward of one scene (inputs resident in HBM).  With N > 1 every rank renders its OWN
+scene — independent sequences farmed across the node, no data-path collective; RCCL is used only for the
+barrier and the max-over-ranks time — hence "scaling": "weak".  `--gpus N` without a torch.distributed environment starts
+the N ranks itself (re-executes under `python -m torch.distributed.run --nproc-per-node N`); under torchrun it checks that
+WORLD_SIZE == N.  Prints ONE JSON line on rank 0.
+
+Extra keys beside the contract's: `roofline`, `cpu_baseline`, `kernels` (per-kernel time and algorithmic GB/s), `extras`
+(N = 1 only, skipped with --no-extras: the other BASELINE shapes c2 / ds / c1, c4 with the densification stress, and
+train-step ms of the DAS3R-shaped optimisation step, fused and unfused), `train_step_ms` + `scenes_per_hour` (every N: the
+farm's unit of work is a 4000-iteration optimisation of one sequence, scripts/testing_psnr_davis.sh:35-59).
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 WORKLOAD_DESC = {
     "c1": "10k random splats, 256x256, SH degree 0, forward+backward (BASELINE.json configs[0] shape)",
     "c2": "100k random splats, 1920x1080, SH degree 3, forward+backward (BASELINE.json configs[1])",
-    "c4": "1M random splats, 1920x1080, SH degree 3, forward+backward (BASELINE.json configs[3], no densification)",
+    "c4": "1M random splats, 1920x1080, SH degree 3, forward+backward (BASELINE.json configs[3], constant P)",
+    "c4d": "1M -> 1.3M random splats (clone/split of the top-gradient 5 % every 100 steps), 1920x1080, SH degree 3, "
+           "forward+backward (BASELINE.json configs[3] with its densification stress, SURVEY.md §8d)",
     "ds": "5M random splats, 512x208, SH degree 0, forward+backward (shape of real DAS3R Sintel training)",
 }
+ITERS_PER_SCENE = 4000   # BASELINE.json configs[2] / [4]: one sequence = 4000 optimisation iterations
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--workload", default=os.environ.get("DAS3R_BENCH_WORKLOAD", "c2"), choices=sorted(WORKLOAD_DESC))
+    ap.add_argument("--workload", default=os.environ.get("DAS3R_BENCH_WORKLOAD", "c4"), choices=sorted(WORKLOAD_DESC))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--stub", action="store_true",
+                    help="CPU dry run of the launch / barrier / reduction logic with a stand-in step (gloo; tests/test_bench_launch.py)")
+    return ap.parse_args(argv)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    from das3r_amd.hostpin import pin_to_ccx, unpin
-    from das3r_amd.synth import WORKLOADS, make_scene
-    cfg = dict(WORKLOADS[args.workload])
-    cfg["seed"] = cfg["seed"] + 1000 * rank  # every rank = a different "sequence"
-    sc_cpu = make_scene(**cfg)                # on the host, before the pin: torch's CPU thread pool keeps the full mask
-    pinned = pin_to_ccx(local_rank)           # before the first HIP call: the runtime's threads inherit the mask
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
 
-    from das3r_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` with no torch.distributed environment: become N ranks (one per GPU)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+class Ranks:
+    """Rank bookkeeping, barrier and max-over-ranks (RCCL on GPUs, gloo in the stub run)."""
+
+    def __init__(self, args):
+        import torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}: launch with --nproc-per-node {args.gpus} "
+                             f"(or without torchrun: bench.py starts the ranks itself)")
+        self.stub = args.stub
+        self.dist = None
+        if self.stub:
+            self.dev = torch.device("cpu")
+        else:
+            if not torch.cuda.is_available():
+                raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+            if self.local_rank >= torch.cuda.device_count():
+                raise SystemExit(f"bench.py: rank {self.rank} has no GPU (local rank {self.local_rank}, {torch.cuda.device_count()} visible)")
+            torch.cuda.set_device(self.local_rank)
+            self.dev = torch.device("cuda", self.local_rank)
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.stub:
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl", device_id=self.dev)
+            self.dist = dist
+            assert dist.get_world_size() == args.gpus
+
+    def sync(self):
+        import torch
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize()
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        self.sync()
+
+    def max_over_ranks(self, x):
+        import torch
+        if self.dist is None:
+            return float(x)
+        t = torch.tensor([x], device=self.dev, dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(self, step, steps, warmup):
+        """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides; MAX over ranks.  -> seconds"""
+        for _ in range(warmup):
+            step()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.sync()
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+class RasterJob:
+    """One scene on one GPU: step() = forward + backward through the drop-in autograd surface."""
+
+    def __init__(self, name, dev, seed_offset=0):
+        import torch
+        from das3r_amd import GaussianRasterizationSettings
+        from das3r_amd.densify import GrowthSchedule
+        from das3r_amd.synth import WORKLOADS, make_scene
+        self.name = name
+        cfg = dict(WORKLOADS["c4" if name == "c4d" else name])
+        cfg["seed"] = cfg["seed"] + seed_offset   # every rank = a different "sequence"
+        self.sc_cpu = make_scene(**cfg)           # on the host, before the pin: torch's CPU thread pool keeps the full mask
+        self.dev = dev
+        self.growth = GrowthSchedule(self.sc_cpu.P) if name == "c4d" else None
+        self.gen = torch.Generator().manual_seed(1234 + seed_offset)
+        self.events = []
+        self._rs_cls = GaussianRasterizationSettings
+        self.steps_done = 0
+
+    def upload(self):
+        import torch
+        from das3r_amd import GaussianRasterizer
+        self.sc = self.sc_cpu.to(self.dev)
+        self.rast = GaussianRasterizer(self._rs_cls(**self.sc.settings_kwargs()))
+        self._set_leaves({k: getattr(self.sc, k) for k in ("means3D", "opacities", "shs", "scales", "rotations")})
+        self.dL = self.sc.dL_dpix
+        self.num_rendered = None
+        self._torch = torch
+
+    def _set_leaves(self, tensors):
+        torch = __import__("torch")
+        self.leaves = {k: v.detach().clone().requires_grad_() for k, v in tensors.items()}
+        self.means2D = torch.zeros(self.leaves["means3D"].shape[0], 3, device=self.dev, requires_grad=True)
+        self.all_leaves = list(self.leaves.values()) + [self.means2D]
+
+    @property
+    def P(self):
+        return self.leaves["means3D"].shape[0]
+
+    def step(self):
+        L = self.leaves
+        if self.growth is not None and self.growth.due(self.steps_done, self.P):   # uses the gradients of the previous step
+            from das3r_amd.densify import grow_top_gradient
+            with self._torch.no_grad():
+                grown = grow_top_gradient({k: v.detach() for k, v in L.items()}, self.means2D.grad, self.growth.frac_for(self.P), self.gen)
+            self._set_leaves(grown)
+            L = self.leaves
+            self.events.append((self.steps_done, self.P))
+        for t in self.all_leaves:
+            t.grad = None
+        color, radii = self.rast(means3D=L["means3D"], means2D=self.means2D, opacities=L["opacities"], shs=L["shs"], scales=L["scales"],
+                                 rotations=L["rotations"])
+        color.backward(self.dL)
+        self.num_rendered = int(color.grad_fn.num_rendered)
+        self.steps_done += 1
+        return color
+
+
+def kernel_table(job, steps):
+    """The same K steps again with every kernel launch bracketed by HIP events on its launch stream (das3r_profile_*), kept apart
+    from the timed region so that `value` is not perturbed.  -> (kernels dict, roofline dict)"""
+    import glob
+    import torch
+    from das3r_amd import _lib
     from das3r_amd.roofline import HBM_PEAK_GBS, algorithmic_bytes, group_kernel_times
+    sc = job.sc
+    _lib.profile_enable(True)
+    for _ in range(steps):
+        job.step()
+    torch.cuda.synchronize()
+    rep = _lib.profile_report()
+    _lib.profile_enable(False)
+    I = job.num_rendered
+    per_kernel, b_fwd, b_bwd = algorithmic_bytes(job.P, sc.sh_degree, sc.shs.shape[1], I, sc.W, sc.H)
+    kernels = {}
+    for name, (n, ms) in sorted(group_kernel_times(rep).items(), key=lambda kv: -kv[1][1]):
+        avg_ms = ms / steps   # per step (the 'binning' entry = all its launches)
+        ent = {"ms_per_step": round(avg_ms, 5), "launches_per_step": n / steps}
+        if name in per_kernel:
+            ent["alg_bytes"] = per_kernel[name]
+            ent["GBps"] = round(per_kernel[name] / (avg_ms * 1e-3) / 1e9, 2)
+            ent["frac_of_peak"] = round(ent["GBps"] / HBM_PEAK_GBS, 5)
+        kernels[name] = ent
+    # dominant KERNEL = the single kernel with the largest time per step (the 'binning' entry is a group of small launches)
+    dom = next(k for k in kernels if k in per_kernel and k != "binning")
+    dom_ms = kernels[dom]["ms_per_step"]
+    achieved = per_kernel[dom] / (dom_ms * 1e-3) / 1e9
+    total_ms = sum(v["ms_per_step"] for v in kernels.values())
+    # HBM bytes per launch: NOT measured in this run — PMC counters need their own rocprofv3 --pmc passes (tools/pmc_collect.sh);
+    # the committed summary of the latest round is quoted, with its source
+    traffic, traffic_source = None, None
+    wname = "c4" if job.name == "c4d" else job.name
+    pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc_{wname}.json")))
+    if pmc:
+        try:
+            ent = json.load(open(pmc[-1]))
+            rec = ent.get(dom) or ent.get({"render_backward_kernel": "render_backward_scan_kernel"}.get(dom, dom)) or {}
+            traffic = rec.get("hbm_bytes_per_launch")
+            if traffic is not None:
+                traffic_source = (f"{os.path.relpath(pmc[-1], ROOT)} (separate rocprofv3 --pmc passes of the same workload, committed; "
+                                  f"FETCH_SIZE doubled per MI355X_MICROARCH.md) — not collected by this run")
+        except Exception:  # noqa: BLE001
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                "alg_bytes_per_launch": per_kernel[dom], "avg_launch_ms": round(dom_ms, 5),
+                "pipeline": {"alg_bytes_fwd_bwd": b_fwd + b_bwd, "kernel_ms_per_step": round(total_ms, 5),
+                             "GBps": round((b_fwd + b_bwd) / (total_ms * 1e-3) / 1e9, 2),
+                             "frac": round((b_fwd + b_bwd) / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                "how": "HIP events around every launch on the launch stream, separate instrumented pass of the same K steps"}
+    return kernels, roofline
 
-    sc = sc_cpu.to(dev)
-    rs = GaussianRasterizationSettings(**sc.settings_kwargs())
-    rast = GaussianRasterizer(rs)
-    leaves = {k: getattr(sc, k).clone().requires_grad_() for k in ("means3D", "opacities", "shs", "scales", "rotations")}
-    means2D = torch.zeros(sc.P, 3, device=dev, requires_grad=True)
-    dL = sc.dL_dpix
-    all_leaves = list(leaves.values()) + [means2D]
-    state = {}
+
+def cpu_baseline_of(sc_cpu, name, budget_s=20.0):
+    """The oracle (plain C + OpenMP restatement of the reference algorithm) on the host cores, same scene; rank 0, N = 1 only."""
+    from oracle import c_oracle
+    o = c_oracle.RasterOracle(**sc_cpu.settings_kwargs())
+    np_in = dict(shs=sc_cpu.shs.numpy(), scales=sc_cpu.scales.numpy(), rotations=sc_cpu.rotations.numpy())
+    times, t_start = [], time.perf_counter()
+    while len(times) < 3 and (time.perf_counter() - t_start) < budget_s:
+        t1 = time.perf_counter()
+        o.forward(sc_cpu.means3D.numpy(), sc_cpu.opacities.numpy(), **np_in)
+        o.backward(sc_cpu.dL_dpix.numpy())
+        times.append(time.perf_counter() - t1)
+    o.free()
+    best = min(times)
+    return {"value": round(sc_cpu.P / best / 1e6, 4), "unit": "Msplats/s", "cores": c_oracle.max_threads(), "kind": "port",
+            "sample": f"whole {name} scene ({sc_cpu.P} splats, {sc_cpu.W}x{sc_cpu.H}), fwd+bwd, best of {len(times)} runs, "
+                      f"{best * 1e3:.1f} ms per fwd+bwd", "ms_per_step": round(best * 1e3, 2)}
+
+
+def train_step_timer(dev, fused, frames=20, W=512, H=208):
+    """-> (step callable, splats): the DAS3R-shaped optimisation step (render + masked L1/SSIM loss + backward + both Adam steps,
+    train_gui.py:542-589) on a synthetic sequence with one Gaussian per pixel of every frame."""
+    import torch
+    from types import SimpleNamespace
+    from das3r_amd.model import OptimParams
+    from das3r_amd.train import build_from_sequence, synthetic_sequence, train_step
+    seq = synthetic_sequence(frames=frames, W=W, H=H, focal=600.0, n_splats=20000, seed=0, device=str(dev))
+    model, cams = build_from_sequence(seq)
+    opt = OptimParams(iterations=ITERS_PER_SCENE)
+    model.training_setup(opt, fused=fused)
+    pipe = SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
+    bg = torch.zeros(3, device=dev)
+    it = [0]
 
     def step():
-        for t in all_leaves:
-            t.grad = None
-        color, radii = rast(means3D=leaves["means3D"], means2D=means2D, opacities=leaves["opacities"], shs=leaves["shs"],
-                            scales=leaves["scales"], rotations=leaves["rotations"])
-        color.backward(dL)
-        state["num_rendered"] = color.grad_fn.num_rendered if hasattr(color.grad_fn, "num_rendered") else None
-        return color, radii
+        it[0] += 1
+        train_step(model, cams[it[0] % len(cams)], opt, it[0], pipe, bg, fused=fused)
+    return step, int(model.get_xyz.shape[0])
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
-    step()          # initialisation: first call loads the code objects, sizes torch's caching allocator and seeds the
-    barrier()       # capacity cache of the sync-free forward (not a bench step)
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args)   # does not return
+    import torch
+    rk = Ranks(args)
+    out = None
+    if args.stub:   # the launch contract without a GPU: N gloo ranks, stand-in step, the same timing protocol
+        x = torch.zeros(1024)
+
+        def step():
+            x.add_(1.0)
+        elapsed = rk.timed(step, args.steps, args.warmup)
+        if rk.rank == 0:
+            out = {"metric": "stub steps/s (launch-logic dry run, no GPU work)", "value": round(rk.world * args.steps / elapsed, 3),
+                   "unit": "steps/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
+                   "ms_per_step": round(elapsed / args.steps * 1e3, 6), "higher_is_better": True, "scaling": "weak",
+                   "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": "stub"}}
+            print(json.dumps(out), flush=True)
+        rk.close()
+        return
+
+    from das3r_amd.hostpin import pin_to_ccx, unpin
+    job = RasterJob(args.workload, rk.dev, seed_offset=1000 * rk.rank)
+    pinned = pin_to_ccx(rk.local_rank)            # before the first HIP call: the runtime's threads inherit the mask
+    job.upload()
+    job.step()          # initialisation: first call loads the code objects, sizes torch's caching allocator and seeds the
+    rk.barrier()        # capacity cache of the sync-free forward (not a bench step)
+    elapsed = rk.timed(job.step, args.steps, args.warmup)
     ms_per_step = elapsed / args.steps * 1e3
-    msplats = world * sc.P / (elapsed / args.steps) / 1e6
+    P_report = job.sc_cpu.P                        # (c4d: P grows; the rate is quoted on the initial P, the growth is in config)
+    msplats = rk.world * P_report / (elapsed / args.steps) / 1e6
 
-    # ---- roofline of the dominant kernel: the same K steps again, every kernel launch bracketed by HIP events on its
-    # launch stream (instrumented pass kept apart from the timed region so that `value` is not perturbed by the events)
-    roofline, kernels_json, I = None, None, None
-    if rank == 0:
-        _lib.profile_enable(True)
-        for _ in range(args.steps):
-            color, _ = step()
-        torch.cuda.synchronize()
-        rep = _lib.profile_report()
-        _lib.profile_enable(False)
-        I = int(color.grad_fn.num_rendered)
-        per_kernel, b_fwd, b_bwd = algorithmic_bytes(sc.P, sc.sh_degree, sc.shs.shape[1], I, sc.W, sc.H)
-        grouped = group_kernel_times(rep)
-        kernels_json = {}
-        for name, (n, ms) in sorted(grouped.items(), key=lambda kv: -kv[1][1]):
-            avg_ms = ms / args.steps  # per step (a 'binning' step = all its launches)
-            ent = {"ms_per_step": round(avg_ms, 5), "launches_per_step": n / args.steps}
-            if name in per_kernel:
-                ent["alg_bytes"] = per_kernel[name]
-                ent["GBps"] = round(per_kernel[name] / (avg_ms * 1e-3) / 1e9, 2)
-            kernels_json[name] = ent
-        # dominant KERNEL = the single kernel with the largest time per step (the 'binning' entry is a group of ~20 small
-        # launches and is reported in `kernels`, not as a roofline kernel)
-        dom = next(k for k in kernels_json if k in per_kernel and k != "binning")
-        dom_ms = kernels_json[dom]["ms_per_step"]
-        achieved = per_kernel[dom] / (dom_ms * 1e-3) / 1e9
-        total_ms = sum(v["ms_per_step"] for v in kernels_json.values())
-        traffic = None
-        import glob
-        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc_{args.workload}.json")))   # latest round
-        pmc_path = pmc_files[-1] if pmc_files else ""
-        if pmc_path:  # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_summary.py)
-            try:
-                traffic = json.load(open(pmc_path)).get(dom, {}).get("hbm_bytes_per_launch")
-            except Exception:  # noqa: BLE001
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "alg_bytes_per_launch": per_kernel[dom],
-                    "avg_launch_ms": round(dom_ms, 5),
-                    "pipeline": {"alg_bytes_fwd_bwd": b_fwd + b_bwd, "kernel_ms_per_step": round(total_ms, 5),
-                                 "GBps": round((b_fwd + b_bwd) / (total_ms * 1e-3) / 1e9, 2),
-                                 "frac": round((b_fwd + b_bwd) / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
-                    "how": "HIP events around every launch on the launch stream, separate instrumented pass of the same K steps"}
+    kernels, roofline = (None, None)
+    if rk.rank == 0:
+        kernels, roofline = kernel_table(job, args.steps)
 
-    # ---- CPU baseline: the oracle (plain C + OpenMP restatement) on the host cores, same scene, rank 0, N=1 only
-    cpu_baseline = None
+    # ---- train-step ms (fused §8f path) on every rank under the same protocol -> scenes/hour of the farm
+    ts_step, ts_splats = train_step_timer(rk.dev, fused=True)
+    ts_iters = max(20, min(100, args.steps))
+    ts_ms = rk.timed(ts_step, ts_iters, 10) / ts_iters * 1e3
+    train = {"fused": round(ts_ms, 4), "splats": ts_splats, "frames": 20, "image": [512, 208], "iters": ts_iters,
+             "what": "render + masked L1/SSIM loss + backward + both Adam steps (train_gui.py:542-589 counterpart), opt-in fused kernels"}
+    scenes_per_hour = rk.world * 3600e3 / (ITERS_PER_SCENE * ts_ms)
+    del ts_step
+
+    extras, cpu_baseline = None, None
     unpin(pinned)   # the CPU baseline below uses every host core
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import c_oracle
-        o = c_oracle.RasterOracle(**sc_cpu.settings_kwargs())
-        np_in = dict(shs=sc_cpu.shs.numpy(), scales=sc_cpu.scales.numpy(), rotations=sc_cpu.rotations.numpy())
-        times = []
-        t_budget = time.perf_counter()
-        while len(times) < 3 and (time.perf_counter() - t_budget) < 20.0:
-            t1 = time.perf_counter()
-            o.forward(sc_cpu.means3D.numpy(), sc_cpu.opacities.numpy(), **np_in)
-            o.backward(sc_cpu.dL_dpix.numpy())
-            times.append(time.perf_counter() - t1)
-        best = min(times)
-        cpu_baseline = {"value": round(sc.P / best / 1e6, 4), "unit": "Msplats/s", "cores": c_oracle.max_threads(), "kind": "port",
-                        "sample": f"whole {args.workload} scene ({sc.P} splats, {sc.W}x{sc.H}), fwd+bwd, best of {len(times)} runs, "
-                                  f"{best * 1e3:.1f} ms per fwd+bwd",
-                        "ms_per_step": round(best * 1e3, 2)}
-        o.free()
+    if rk.rank == 0 and rk.world == 1:
+        if not args.no_cpu_baseline:
+            cpu_baseline = cpu_baseline_of(job.sc_cpu, args.workload if args.workload != "c4d" else "c4")
+        if not args.no_extras:
+            repin = pin_to_ccx(rk.local_rank)
+            extras = {}
+            us_step, _ = train_step_timer(rk.dev, fused=False)
+            train["unfused"] = round(rk.timed(us_step, 30, 5) / 30 * 1e3, 4)
+            del us_step
+            for w, k in (("c2", 200), ("ds", 50), ("c1", 200), ("c4d", 700), ("c4", 200)):
+                if w == args.workload:
+                    continue
+                torch.cuda.empty_cache()
+                j = RasterJob(w, rk.dev)
+                j.upload()
+                j.step()
+                t = rk.timed(j.step, k, 20) / k
+                kt, rf = kernel_table(j, min(k, 50)) if w != "c4d" else (None, None)
+                ent = {"workload": WORKLOAD_DESC[w], "ms_per_step": round(t * 1e3, 4), "Msplats_per_s": round(j.sc_cpu.P / t / 1e6, 2),
+                       "steps": k, "num_rendered": j.num_rendered}
+                if rf:
+                    ent["roofline"] = {kk: rf[kk] for kk in ("kernel", "achieved", "frac", "avg_launch_ms", "pipeline")}
+                    ent["kernel_ms"] = {kk: v["ms_per_step"] for kk, v in kt.items()}
+                if w == "c4d":
+                    ent["growth"] = {"P_final": j.P, "events": len(j.events), "every": 100, "fraction": 0.05}
+                extras[w] = ent
+                del j
+            unpin(repin)
 
-    if rank == 0:
+    if rk.rank == 0:
+        sc = job.sc
         out = {"metric": "render fwd+bwd Msplats/s at 1080p" if sc.W == 1920 else f"render fwd+bwd Msplats/s at {sc.W}x{sc.H}",
-               "value": round(msplats, 3), "unit": "Msplats/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "value": round(msplats, 3), "unit": "Msplats/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
-               "config": {"workload": WORKLOAD_DESC[args.workload], "name": args.workload, "splats_per_gpu": sc.P,
-                          "image": [sc.W, sc.H], "sh_degree": sc.sh_degree, "num_rendered": I,
+               "config": {"workload": WORKLOAD_DESC[args.workload], "name": args.workload, "splats_per_gpu": P_report,
+                          "splats_per_gpu_final": job.P, "image": [sc.W, sc.H], "sh_degree": sc.sh_degree, "num_rendered": job.num_rendered,
                           "api": "GaussianRasterizer.forward + autograd backward (drop-in surface)",
-                          "parallelism": f"{world} independent scenes, one per GPU",
+                          "parallelism": f"{rk.world} independent scenes, one per GPU",
                           "host_cpus": (f"pinned to CPUs {pinned[1][0]}-{pinned[1][-1]} (one core complex per rank)" if pinned
                                         else "not pinned")},
-               "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels_json}
+               "train_step_ms": train, "scenes_per_hour": round(scenes_per_hour, 2),
+               "scenes_per_hour_def": f"N GPUs x 3600 s / ({ITERS_PER_SCENE} iterations x train_step_ms.fused, max over ranks)",
+               "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels, "extras": extras}
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    rk.close()
 
 
 if __name__ == "__main__":

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdas3r_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
@@ -31,7 +31,8 @@ class RasterOut(C.Structure):
 
 
 class RasterSaved(C.Structure):
-    _fields_ = [("geom", C.c_void_p), ("binning", C.c_void_p), ("img", C.c_void_p), ("num_rendered", C.c_int64), ("capacity", C.c_int64)]
+    _fields_ = [("geom", C.c_void_p), ("binning", C.c_void_p), ("img", C.c_void_p), ("num_rendered", C.c_int64), ("capacity", C.c_int64),
+                ("check_word", C.c_void_p), ("check_tag", C.c_uint32)]
 
 
 class RasterGrads(C.Structure):
@@ -47,8 +48,8 @@ class RasterLayout(C.Structure):
 
 
 # every symbol include/das3r_raster.h declares
-EXPORTS = ("das3r_raster_forward", "das3r_raster_backward", "das3r_mark_visible", "das3r_knn3_workspace_bytes",
-           "das3r_knn3_mean_dist2", "das3r_raster_get_layout", "das3r_abi_version", "das3r_last_error",
+EXPORTS = ("das3r_raster_forward", "das3r_raster_backward", "das3r_raster_check", "das3r_mark_visible", "das3r_knn3_workspace_bytes",
+           "das3r_knn3_mean_dist2", "das3r_raster_get_layout", "das3r_abi_version", "das3r_last_error", "das3r_reload_switches", "das3r_get_stats",
            "das3r_profile_enable", "das3r_profile_report", "das3r_pretransform_forward", "das3r_pretransform_backward", "das3r_pose_matrices", "das3r_pose_chain",
            "das3r_adam_step", "das3r_adam_step_gated", "das3r_photometric_blocks", "das3r_photometric_forward", "das3r_photometric_backward")
 
@@ -78,6 +79,8 @@ def load():
     L.das3r_raster_backward.restype = C.c_int
     L.das3r_raster_backward.argtypes = [C.POINTER(RasterArgs), C.POINTER(RasterIn), C.POINTER(RasterSaved), C.c_void_p,
                                         C.POINTER(RasterGrads), C.c_void_p]
+    L.das3r_raster_check.restype = C.c_int
+    L.das3r_raster_check.argtypes = [C.POINTER(RasterSaved), C.c_void_p]
     L.das3r_mark_visible.restype = C.c_int
     L.das3r_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.das3r_knn3_workspace_bytes.restype = C.c_size_t
@@ -107,6 +110,24 @@ def load():
     L.das3r_raster_get_layout.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(RasterLayout)]
     _lib = L
     return L
+
+
+def reload_switches():
+    """Have the library read its DAS3R_* experiment switches from the environment again (it reads them once, at first use)."""
+    L = load()
+    L.das3r_reload_switches.restype = None
+    L.das3r_reload_switches.argtypes = []
+    L.das3r_reload_switches()
+
+
+def stats():
+    """-> dict(forwards, checks_examined, rescued_polls, failed_checks): the library's process-wide counters."""
+    L = load()
+    out = (C.c_uint64 * 4)()
+    L.das3r_get_stats.restype = None
+    L.das3r_get_stats.argtypes = [C.POINTER(C.c_uint64)]
+    L.das3r_get_stats(out)
+    return dict(forwards=int(out[0]), checks_examined=int(out[1]), rescued_polls=int(out[2]), failed_checks=int(out[3]))
 
 
 def profile_enable(on):

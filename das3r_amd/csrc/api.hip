@@ -37,38 +37,59 @@ void profile_end(hipStream_t s) {
     if (!g_prof.empty()) hipEventRecord(g_prof.back().stop, s);
 }
 
+static Switches g_sw;
+static bool g_sw_loaded = false;
+static void load_switches() {
+    Switches w;
+    memset(&w, 0, sizeof(w));
+    auto env = [](const char *k) -> const char * { const char *e = getenv(k); return (e && e[0]) ? e : nullptr; };
+    const char *e;
+    if ((e = env("DAS3R_SORT_IPL"))) { const int v = atoi(e); w.sort_ipl = (v == 4 || v == 8 || v == 16) ? v : 0; }
+    w.sort_classic = (e = env("DAS3R_SORT")) && e[0] == 'c';
+    w.rect_upstream = (e = env("DAS3R_RECT")) && e[0] == 'u';
+    w.verbose = env("DAS3R_VERBOSE") != nullptr;
+    if ((e = env("DAS3R_BINNING"))) w.binning = e[0] == 'l' ? 1 : (e[0] == 'r' ? -1 : 0);
+    w.capacity_exact = (e = env("DAS3R_CAPACITY")) && e[0] == 'e';
+    w.fused_emit_off = (e = env("DAS3R_FUSED_EMIT")) && e[0] == '0';
+    w.no_sh_stage = getenv("DAS3R_NO_SH_STAGE") != nullptr;
+    if ((e = env("DAS3R_RENDER"))) w.render_fwd = e[0] == 'q' ? 1 : (e[0] == 'r' ? 2 : 0);
+    if ((e = env("DAS3R_RENDER_BWD"))) w.render_bwd = e[0] == 'd' ? 1 : (e[0] == 'm' ? 2 : (e[0] == 's' ? (strstr(e, "128") ? 4 : 3) : 0));
+    if ((e = env("DAS3R_BWD_REDUCE"))) { w.bwd_reduce_set = true; w.bwd_reduce_shfl = e[0] == 's'; }
+    if ((e = env("DAS3R_ABLATE"))) { w.ablate_set = true; w.ablate = atoi(e); }
+    w.tickets = -1;
+    if ((e = env("DAS3R_TICKETS"))) w.tickets = e[0] == 'a' ? 0 : (e[0] == 'n' ? 1 << 30 : ((e[0] >= '1' && e[0] <= '9') ? atoi(e) : -1));
+    if ((e = env("DAS3R_BWD_PAD_LDS"))) w.bwd_pad_lds = atoi(e);
+    if ((e = env("DAS3R_FWD_PAD_LDS"))) w.fwd_pad_lds = atoi(e);
+    if ((e = env("DAS3R_INJECT_FAULT"))) w.inject_fault = atoi(e);
+    g_sw = w;
+    __atomic_store_n(&g_sw_loaded, true, __ATOMIC_RELEASE);
+}
+const Switches &switches() {
+    if (!__atomic_load_n(&g_sw_loaded, __ATOMIC_ACQUIRE)) load_switches();
+    return g_sw;
+}
+
 // Ticket-free chained kernels wait for lower-numbered workgroups, which is only safe while the whole grid is resident at once.
 // The bound is taken from the device the call runs on (compute partitions have fewer CUs) and stays below what it holds
-// (>= 3 workgroups per CU of the heaviest of these kernels).  DAS3R_TICKETS=always switches the
-// short cut off.
+// (>= 3 workgroups per CU of the heaviest of these kernels).  DAS3R_TICKETS=always switches the short cut off.
 bool grid_is_resident(int nblocks) {
-    static const int limit = [] {
-        const char *e = getenv("DAS3R_TICKETS");
-        if (e && e[0] == 'a') return 0;
-        if (e && e[0] == 'n') return 1 << 30;   // (experiments only: never take a ticket)
-        if (e && e[0] >= '1' && e[0] <= '9') return atoi(e);   // (experiments only: the bound itself)
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        return cus * 2;   // the heaviest chained kernels get 3 workgroups per CU
-    }();
-    return nblocks <= limit;
+    const int forced = switches().tickets;
+    if (forced >= 0) return nblocks <= forced;
+    static thread_local int cached_dev = -1, cached_limit = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (dev != cached_dev) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+        cached_dev = dev;
+        cached_limit = cus * 2;   // the heaviest chained kernels get 3 workgroups per CU
+    }
+    return nblocks <= cached_limit;
 }
 
-int sort_ipl_override() {
-    const char *e = getenv("DAS3R_SORT_IPL");
-    const int v = e ? atoi(e) : 0;
-    return (v == 4 || v == 8 || v == 16) ? v : 0;
-}
-
-bool use_onesweep() {
-    const char *e = getenv("DAS3R_SORT");  // "classic" = histogram + row scan + scatter per digit
-    return !(e && e[0] == 'c');
-}
-
-bool use_tight_rect() {
-    const char *e = getenv("DAS3R_RECT");
-    return !(e && e[0] == 'u');
-}
+int sort_ipl_override() { return switches().sort_ipl; }
+bool use_onesweep() { return !switches().sort_classic; }
+bool use_tight_rect() { return !switches().rect_upstream; }
 
 void compute_layout(int P, int64_t I, int W, int H, Layout *L) {
     memset(L, 0, sizeof(*L));
@@ -158,6 +179,7 @@ static int validate(const das3r_raster_args *a, const das3r_raster_in *in) {
 using namespace das3r;
 
 extern "C" int das3r_abi_version(void) { return DAS3R_ABI_VERSION; }
+extern "C" void das3r_reload_switches(void) { load_switches(); }
 extern "C" const char *das3r_last_error(void) { return g_err; }
 
 extern "C" int das3r_raster_get_layout(int32_t P, int64_t num_rendered, int32_t W, int32_t H, das3r_raster_layout *out) {
@@ -168,10 +190,11 @@ extern "C" int das3r_raster_get_layout(int32_t P, int64_t num_rendered, int32_t 
     return DAS3R_OK;
 }
 
-// Host mailbox: a pinned, device-visible 64-byte block per host thread.  The scan kernel stores {count, flags} and then the
-// tag of the call (system-scope release) into words 0..2; the last binning kernel stores {self-check word, tag} into words
-// 8..9.  The host polls the tag — no D2H copy kernel, no event, no parked thread (hipEventSynchronize's wake-up alone cost
-// ~100 us per forward, a third of a 100 k-splat step).
+// Host mailbox: a pinned, device-visible block per host thread and device.  The scan kernel stores {count, flags} and then the
+// tag of the call (system-scope release) into words 0..2; word 10 is raised by a compositing kernel that met a tile list too
+// long for its LDS sort; the last binning kernel of a forward stores {self-check word, tag} into one of CHECK_SLOTS two-word
+// slots from word 16 on (slot = tag % CHECK_SLOTS).  The host polls the tags — no D2H copy kernel, no event, no parked thread
+// (hipEventSynchronize's wake-up alone cost ~100 us per forward, a third of a 100 k-splat step).
 struct Mailbox {
     volatile uint32_t *host = nullptr;
     uint32_t *dev = nullptr;
@@ -179,10 +202,11 @@ struct Mailbox {
 };
 // Everything the library remembers between calls, per host thread and per device (a thread that renders on two GPUs gets two
 // of these; nothing is shared between threads: any number of them may render concurrently, each on its own stream).
+constexpr uint32_t CHECK_SLOTS = 16, CHECK_WORD0 = 16, MAILBOX_BYTES = 4 * (CHECK_WORD0 + 2 * CHECK_SLOTS);
 struct Verdict { int P, W, H; int64_t last_I, peak_I; int radix_left, backoff; uint32_t gen; };
 struct PerDevice {
     Mailbox mb;
-    uint32_t late_tag = 0;                          // tag of the forward whose self-check word has not been examined yet
+    uint32_t pending[CHECK_SLOTS] = {};             // per slot: tag of the forward whose self-check word has not been examined yet
     unsigned long long *arrive_ring = nullptr;      // self re-arming arrival words of the preprocess kernel's count reduction
     Verdict verdict = {0, 0, 0, -1, 0, 0, 64, 0};  // what the last forward of the current shape (P, W, H) taught us
     char *emit_ring = nullptr;                      // control words of the emission fused into the preprocess kernel
@@ -198,8 +222,8 @@ static int per_device(PerDevice **out) {
     PerDevice &T = state[dev];
     if (!T.mb.host) {
         uint32_t *h = nullptr;
-        HIP_TRY(hipHostMalloc((void **)&h, 64, hipHostMallocMapped));
-        memset(h, 0, 64);
+        HIP_TRY(hipHostMalloc((void **)&h, MAILBOX_BYTES, hipHostMallocMapped));
+        memset(h, 0, MAILBOX_BYTES);
         HIP_TRY(hipHostGetDevicePointer((void **)&T.mb.dev, h, 0));
         T.mb.host = h;
     }
@@ -219,10 +243,53 @@ static int mailbox_wait(Mailbox *mb, int idx, uint32_t tag, hipStream_t s) {
     return DAS3R_ERR_HIP;
 }
 
+// Examine the self-check word a forward's last binning kernel left in `slot` = {flags, tag} of a host mailbox (bit 1 look-back
+// timeout, 2 index out of range -> write suppressed, 8 counts do not add up to the histogram; 16 = a stalled look-back was rescued,
+// granule.h: informational).  wait: spin (bounded) until the word of `tag` is there.  Returns 1 when the slot does not hold
+// `tag`'s word (not there yet, or — after CHECK_SLOTS later forwards, each of which examines the slot before reusing it — gone).
+static unsigned long long g_stats[4] = {0, 0, 0, 0};   // forwards, self-check words examined, rescued look-back polls, failed self-checks
+static void stat_add(int i) { __atomic_fetch_add(&g_stats[i], 1ull, __ATOMIC_RELAXED); }
+static int examine_check_slot(volatile uint32_t *slot, uint32_t tag, bool wait, hipStream_t s) {
+    uint32_t seen = __atomic_load_n(&slot[1], __ATOMIC_ACQUIRE);
+    if (seen != tag && wait) {
+        for (long spins = 0; spins < 200000000L && seen != tag; spins++) {
+            __builtin_ia32_pause();
+            seen = __atomic_load_n(&slot[1], __ATOMIC_ACQUIRE);
+            if ((spins & 0xFFFFF) == 0xFFFFF && hipStreamQuery(s) != hipErrorNotReady) break;   // stream drained (or failed): stop spinning
+        }
+        if (seen != tag) {
+            HIP_TRY(hipStreamSynchronize(s));
+            seen = __atomic_load_n(&slot[1], __ATOMIC_ACQUIRE);
+        }
+    }
+    if (seen != tag) return 1;
+    const uint32_t all_flags = slot[0], flags = all_flags & ~16u;
+    stat_add(1);
+    if (all_flags & 16u) stat_add(2);
+    if (flags) stat_add(3);
+    if ((all_flags & 16u) && switches().verbose) fprintf(stderr, "das3r: a look-back poll needed the read-modify-write path\n");
+    if (flags) { set_error("a forward's binning failed its self-check (flags 0x%x); its output is invalid", flags); return DAS3R_ERR_HIP; }
+    return DAS3R_OK;
+}
+
+// The self-check of the forward that produced `saved`, for callers that want it BEFORE they consume the image (the forward
+// itself returns as soon as everything is enqueued; das3r_raster_backward runs this first).  Waits, bounded, for the word.
+extern "C" int das3r_raster_check(const das3r_raster_saved *saved, das3r_stream_t stream) {
+    if (!saved) { set_error("das3r_raster_check: null saved state"); return DAS3R_ERR_INVALID_ARG; }
+    if (!saved->check_word || !saved->check_tag) return DAS3R_OK;   // P == 0, nothing rendered, or a caller that dropped the ticket
+    const int r = examine_check_slot((volatile uint32_t *)saved->check_word, saved->check_tag, true, (hipStream_t)stream);
+    return r < 0 ? r : DAS3R_OK;
+}
+
+extern "C" void das3r_get_stats(uint64_t out[4]) {
+    for (int i = 0; i < 4; i++) out[i] = (uint64_t)__atomic_load_n(&g_stats[i], __ATOMIC_RELAXED);
+}
+
 extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_raster_in *in, const das3r_raster_out *out,
                                         das3r_alloc_fn alloc_geom, das3r_alloc_fn alloc_binning, das3r_alloc_fn alloc_img,
                                         void *user, das3r_raster_saved *saved, das3r_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
+    stat_add(0);
     int rc = validate(a, in);
     if (rc) return rc;
     if (!out || !out->out_color || (a->P > 0 && !out->radii) || !alloc_geom || !alloc_binning || !alloc_img || !saved) {
@@ -237,6 +304,8 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     saved->binning = nullptr;
     saved->num_rendered = 0;
     saved->capacity = 0;
+    saved->check_word = nullptr;
+    saved->check_tag = 0;
     if (!saved->geom || !saved->img) { set_error("scratch allocation failed (geom %zu B, img %zu B)", L.pub.geom_bytes, L.pub.img_bytes); return DAS3R_ERR_ALLOC; }
     if (P == 0) {
         // upstream:rasterize_points.cu skips the rasterizer when P == 0: the image stays zero (background NOT applied)
@@ -249,24 +318,23 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     //   * num_rendered (sum of tiles_touched) leaves with the preprocess kernel, five kernels before the device needs it, so
     //     the binning buffer is sized exactly and the host practically never waits (upstream blocks on a cudaMemcpy in the
     //     middle of every forward); on the local-order path nothing waits for it at all (speculative capacity, below);
-    //   * the binning self-check word (bit 1 look-back timeout, 2 index out of range -> write suppressed, 8 counts do not
-    //     add up to the histogram) is delivered by the last binning kernel and examined at the start of the NEXT forward
-    //     (debug mode waits for it right away).
+    //   * the binning self-check word is delivered by the last binning kernel into a slot of the mailbox; saved->check_word /
+    //     check_tag name it.  It is examined by das3r_raster_backward (before anything is launched) and das3r_raster_check, which
+    //     wait for it, and — for callers that use neither — without waiting at the start of this thread's later forwards;
+    //     debug mode waits for it before returning.
     PerDevice *T = nullptr;
     if ((rc = per_device(&T))) return rc;
     Mailbox *mb = &T->mb;
-    uint32_t &late_tag = T->late_tag;
-    auto check_late = [&](bool wait) -> int {
-        if (!late_tag) return DAS3R_OK;
-        if (wait) { int r = mailbox_wait(mb, 9, late_tag, s); if (r) return r; }
-        if (__atomic_load_n(&mb->host[9], __ATOMIC_ACQUIRE) != late_tag) return DAS3R_OK;   // not there yet: look again next time
-        late_tag = 0;
-        const uint32_t all_flags = mb->host[8], flags = all_flags & ~16u;   // bit 16: a stalled look-back was rescued (granule.h), not an error
-        if ((all_flags & 16u) && getenv("DAS3R_VERBOSE")) fprintf(stderr, "das3r: a look-back poll needed the read-modify-write path\n");
-        if (flags) { set_error("a forward's binning failed its self-check (flags 0x%x); its output was invalid", flags); return DAS3R_ERR_HIP; }
-        return DAS3R_OK;
+    auto check_slot = [&](uint32_t i, bool wait) -> int {
+        if (!T->pending[i]) return DAS3R_OK;
+        const int r = examine_check_slot(mb->host + CHECK_WORD0 + 2 * i, T->pending[i], wait, s);
+        if (r == 1) return DAS3R_OK;   // not there yet: look again next time
+        T->pending[i] = 0;
+        return r;
     };
-    if ((rc = check_late(false))) return rc;
+    for (uint32_t i = 0; i < CHECK_SLOTS; i++)
+        if ((rc = check_slot(i, false))) return rc;
+    uint32_t late_tag = 0;
     // per-thread ring of self re-arming arrival words for the count reduction of the preprocess kernel
     unsigned long long *&arrive_ring = T->arrive_ring;
     constexpr uint32_t ARRIVE_SLOTS = 16, ARRIVE_WORDS = 8 + 64 * 8;   // per call: top word + 64 sub-counters, one 64-byte line each
@@ -290,8 +358,7 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         verdict.radix_left = verdict.backoff;   // global sort for a while; longer every time it happens again
         if (verdict.backoff < 4096) verdict.backoff *= 2;
     }
-    const char *eb = getenv("DAS3R_BINNING");   // local | radix: force one (diagnostics, tests)
-    const int forced = eb ? (eb[0] == 'l' ? 1 : eb[0] == 'r' ? -1 : 0) : 0;
+    const int forced = switches().binning;   // DAS3R_BINNING=local | radix: force one (diagnostics, tests)
     bool local = use_onesweep() && (forced > 0 || (forced == 0 && verdict.radix_left == 0 && verdict.last_I <= LOCAL_AVG * L.ntiles));
     if (forced == 0 && verdict.radix_left > 0) verdict.radix_left--;
     const uint32_t count_tag = ++mb->seq ? mb->seq : ++mb->seq;
@@ -307,12 +374,18 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
                                                   s, local_order))) return r;
             } else if ((r = launch_scan(P, saved->geom, L, nullptr, 0, a->debug != 0, s))) return r;
         }
+        uint32_t *host_late = nullptr;
         if (cap > 0) {
-            if ((r = check_late(true))) return r;   // one self-check word in flight at a time
             late_tag = ++mb->seq ? mb->seq : ++mb->seq;
+            const uint32_t slot = late_tag % CHECK_SLOTS;
+            if ((r = check_slot(slot, true))) return r;   // (the forward that used the slot CHECK_SLOTS forwards ago)
+            T->pending[slot] = late_tag;
+            host_late = mb->dev + CHECK_WORD0 + 2 * slot;
+            saved->check_word = (void *)(mb->host + CHECK_WORD0 + 2 * slot);
+            saved->check_tag = late_tag;
         }
         uint32_t *dead_keys = nullptr;
-        if ((r = launch_binning(P, cap, W, H, out->radii, saved->geom, saved->binning, saved->img, L, fused_scan, mb->dev + 8, late_tag,
+        if ((r = launch_binning(P, cap, W, H, out->radii, saved->geom, saved->binning, saved->img, L, fused_scan, host_late, late_tag,
                                 a->debug != 0, s, &dead_keys, emit_slot))) return r;
         LocalBin lb = {nullptr, nullptr, nullptr, nullptr, verdict.gen, (uint32_t)(P - 1), (uint32_t)cap};
         if (local_order && cap > 0) {
@@ -328,8 +401,7 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     // the binning buffer is laid out for that forward's count + 25 % and the whole forward is enqueued before the host looks
     // at the mailbox (the kernels clamp to the capacity).  Should the scene have grown past it, the binning and the
     // compositing are redone with the exact size.  DAS3R_CAPACITY=exact switches the speculation off.
-    const char *ec = getenv("DAS3R_CAPACITY");
-    if (local && verdict.last_I >= 0 && a->capacity_hint != -1 && !(ec && ec[0] == 'e')) {
+    if (local && verdict.last_I >= 0 && a->capacity_hint != -1 && !switches().capacity_exact) {
         // headroom: 25 % over the last count, 5 % over the (slowly forgotten) largest one — a camera that moves between views
         // of different density overflows rarely
         cap = std::max(verdict.last_I + verdict.last_I / 4, verdict.peak_I + verdict.peak_I / 20) + 4096;
@@ -345,8 +417,7 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         bool &emit_ring_dirty = T->emit_ring_dirty;
         uint32_t &emit_last_tag = T->emit_last_tag;
         constexpr size_t EMIT_SLOT_BYTES = sizeof(uint32_t) * EMIT_SLOT_WORDS + sizeof(unsigned long long) * EMIT_STATUS_GRANULES;
-        const char *efe = getenv("DAS3R_FUSED_EMIT");
-        const bool fused_emit = grid_is_resident(div_up(P, 256)) && !(efe && efe[0] == '0');
+        const bool fused_emit = grid_is_resident(div_up(P, 256)) && !switches().fused_emit_off;
         uint32_t *emit_slot = nullptr;
         if (fused_emit) {
             if (!emit_ring) {
@@ -404,7 +475,7 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         if (!local && (rc = launch_depth_sort(P, saved->geom, L, 1, saved->binning + L.b_ghist, L.b_ctrl_bytes, a->debug != 0, s))) return rc;
         if ((rc = bin_and_render(cap, local, !local))) return rc;
     }
-    if (a->debug && (rc = check_late(true))) return rc;   // debug: report this forward's self-check word right away
+    if (a->debug && late_tag && (rc = check_slot(late_tag % CHECK_SLOTS, true))) return rc;   // debug: report this forward's self-check word right away
     saved->num_rendered = I;
     saved->capacity = cap;
     return I;
@@ -427,6 +498,8 @@ extern "C" int das3r_raster_backward(const das3r_raster_args *a, const das3r_ras
         set_error("das3r_raster_backward: gradient buffer missing for a provided input");
         return DAS3R_ERR_INVALID_ARG;
     }
+    // the forward's binning self-check first: nothing is launched on the strength of an invalid image / list
+    if ((rc = das3r_raster_check(saved, stream))) return rc;
     Layout L;
     compute_layout(P, saved->capacity > 0 ? saved->capacity : saved->num_rendered, a->image_width, a->image_height, &L);
     // scratch = per-instance partial sums [num_rendered, 9]; no accumulator needs zeroing (no atomics anywhere)

@@ -16,6 +16,28 @@ namespace das3r {
 
 void set_error(const char *fmt, ...);
 
+// Experiment / diagnostic switches, read from the environment ONCE — at the first call into the library and
+// again whenever das3r_reload_switches() is called (tests and tools flip them between calls) — not on every launch.
+struct Switches {
+    int sort_ipl;          // DAS3R_SORT_IPL = 4 | 8 | 16: keys per lane of the radix passes (0: by size)
+    bool sort_classic;     // DAS3R_SORT=classic: histogram + row scan + scatter per digit instead of the one-sweep passes
+    bool rect_upstream;    // DAS3R_RECT=upstream: bin over upstream's 3-sigma square (bit-exact list tests)
+    bool verbose;          // DAS3R_VERBOSE
+    int binning;           // DAS3R_BINNING=local | radix: 1 | -1 (0: chosen per scene)
+    bool capacity_exact;   // DAS3R_CAPACITY=exact: never lay the binning buffer out speculatively
+    bool fused_emit_off;   // DAS3R_FUSED_EMIT=0
+    bool no_sh_stage;      // DAS3R_NO_SH_STAGE
+    int render_fwd;        // DAS3R_RENDER=quad | rows: 1 | 2 (0: by list length)
+    int render_bwd;        // DAS3R_RENDER_BWD=dpp | mfma | scan | scan128: 1 | 2 | 3 | 4 (0: by list length)
+    bool bwd_reduce_set, bwd_reduce_shfl;   // DAS3R_BWD_REDUCE=shfl | dpp (reference reduction of the pixel-per-lane kernel)
+    bool ablate_set;       // DAS3R_ABLATE (perf experiments on the pixel-per-lane kernel)
+    int ablate;
+    int tickets;           // DAS3R_TICKETS=always | never | <bound>: 0 | 1 << 30 | bound (-1: from the device's CU count)
+    int bwd_pad_lds, fwd_pad_lds;   // DAS3R_BWD_PAD_LDS / DAS3R_FWD_PAD_LDS: extra dynamic LDS (occupancy experiments)
+    int inject_fault;      // DAS3R_INJECT_FAULT: bits OR-ed into the binning self-check word of every forward (fault-injection tests)
+};
+const Switches &switches();
+
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
         hipError_t _e = (expr);                                                                \
@@ -153,6 +175,8 @@ int launch_render_forward_rows(const das3r_raster_args *a, float *out_color, cha
                                const LocalBin &lb, hipStream_t s);
 int launch_render_backward_mfma(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
                                 float *partial, hipStream_t s);
+int launch_render_backward_scan(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
+                                float *partial, int mb, hipStream_t s);
 constexpr int LOCAL_MAX = 1024;   // longest tile list the forward kernels sort in LDS
 // chained kernels (scan, radix passes) order their workgroups by ticket unless every workgroup of the grid is resident at once
 // (api.hip: grid_is_resident)

@@ -342,7 +342,7 @@ int launch_preprocess_backward(const das3r_raster_args *a, const das3r_raster_in
     if (P == 0) return DAS3R_OK;
     dim3 grid(div_up(P, 256)), block(256);
     const bool has_sh = in->shs != nullptr, has_cov = in->cov3D_precomp != nullptr;
-    const bool nostage = getenv("DAS3R_NO_SH_STAGE") != nullptr;
+    const bool nostage = switches().no_sh_stage;
     const bool stage_out = has_sh && a->M == 16 && ((uintptr_t)g->dL_dshs & 15) == 0 && !nostage;
     const bool stage_in = stage_out && a->sh_degree >= 2 && ((uintptr_t)in->shs & 15) == 0;
 #define ARGS                                                                                                                 \

@@ -156,25 +156,24 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
 
 int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
                            float *partial, hipStream_t s) {
-    {
-        // Reductions on the matrix cores (render_bwd_mfma.hip) pay off on very long tile lists of tiny splats — the DAS3R shape
-        // (one Gaussian per pixel of every frame): 2.06 -> 1.67 ms on the 5 M-splat scene — and lose on 1080p scenes with a
-        // few hundred entries per tile (0.60 -> 0.82 ms at 1 M splats).  DAS3R_RENDER_BWD=mfma / dpp forces one of them.
-        const char *er = getenv("DAS3R_RENDER_BWD");
-        const bool mfma = er ? er[0] == 'm' : (L.capacity >= (int64_t)2048 * L.ntiles && !getenv("DAS3R_BWD_REDUCE") && !getenv("DAS3R_ABLATE"));
-        if (mfma) return launch_render_backward_mfma(a, dL_dpix, geom, binning, img, L, partial, s);
-    }
-    const char *e = getenv("DAS3R_BWD_REDUCE");  // "shfl" selects the ds_bpermute reference reduction (diagnostics)
-    const bool use_dpp = !(e && e[0] == 's');
-    const char *ea = getenv("DAS3R_ABLATE");  // perf experiments only: bit0 = no partial stores, bit2 = no cross-lane reduction
-    const int ablate = ea ? atoi(ea) : 0;
+    // Which decomposition (DAS3R_RENDER_BWD=dpp | mfma | scan | scan128 forces one):
+    //   scan  lanes = 4 pixels x 16 splats, sums on the matrix cores, recurrences as DPP row scans (render_bwd_scan.hip)
+    //   mfma  pixel per lane + LDS-transposed slab -> matrix cores (render_bwd_mfma.hip): very long lists of tiny splats
+    //   dpp   pixel per lane, cross-lane reduction on the vector ALU (this file)
+    const Switches &sw = switches();
+    int kind = sw.render_bwd;
+    if (kind == 0) kind = (sw.bwd_reduce_set || sw.ablate_set) ? 1 : 3;
+    if (kind == 2) return launch_render_backward_mfma(a, dL_dpix, geom, binning, img, L, partial, s);
+    if (kind >= 3) return launch_render_backward_scan(a, dL_dpix, geom, binning, img, L, partial, kind == 4 ? 128 : 256, s);
+    const bool use_dpp = !sw.bwd_reduce_shfl;   // "shfl" selects the ds_bpermute reference reduction (diagnostics)
+    const int ablate = sw.ablate;               // perf experiments only: bit0 = no partial stores, bit2 = no cross-lane reduction
 #define ARGS                                                                                                                 \
     (const uint2 *)(img + L.pub.ranges), (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height,    \
         L.tiles_x, L.ntiles, (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),                \
         (const float4 *)(geom + L.pub.rgbd), a->bg, (const float *)(img + L.pub.final_T),                                    \
         (const uint32_t *)(img + L.pub.n_contrib), dL_dpix, (const uint32_t *)(binning + L.b_slot), partial, ablate, \
         (uint32_t)(a->P - 1), (uint32_t)L.capacity
-    static const int pad_lds = getenv("DAS3R_BWD_PAD_LDS") ? atoi(getenv("DAS3R_BWD_PAD_LDS")) : 0;   // occupancy experiments
+    const int pad_lds = sw.bwd_pad_lds;   // occupancy experiments
     if (use_dpp) DAS3R_LAUNCH((render_backward_kernel<true>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), pad_lds, s, ARGS);
     else DAS3R_LAUNCH((render_backward_kernel<false>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS);
 #undef ARGS

@@ -99,7 +99,7 @@ int launch_render_forward(const das3r_raster_args *a, const float *colors_precom
                           char *img, const Layout &L, const LocalBin &lb, hipStream_t s) {
     (void)colors_precomp;  // precomputed colours were copied into rgbd by the preprocess kernel
     if (use_row_private(L.capacity, L.ntiles)) return launch_render_forward_rows(a, out_color, geom, binning, img, L, lb, s);
-    static const int pad_lds = getenv("DAS3R_FWD_PAD_LDS") ? atoi(getenv("DAS3R_FWD_PAD_LDS")) : 0;   // occupancy experiments
+    const int pad_lds = switches().fwd_pad_lds;   // occupancy experiments
     DAS3R_LAUNCH(render_forward_kernel, dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), pad_lds, s, (const uint2 *)(img + L.pub.ranges),
                  (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height, L.tiles_x, L.ntiles,
                  (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),

@@ -145,9 +145,8 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
 // The row lists cost ~200 instructions per wave and batch to build: worth it once a tile's list is long.  DAS3R_RENDER=quad /
 // rows forces one of the two forward kernels (A-B runs, tests).
 bool use_row_private(int64_t instances, int ntiles) {
-    const char *e = getenv("DAS3R_RENDER");
-    if (e && e[0] == 'q') return false;
-    if (e && e[0] == 'r') return true;
+    const int forced = switches().render_fwd;
+    if (forced) return forced == 2;
     return instances >= (int64_t)128 * ntiles;
 }
 

@@ -239,11 +239,12 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, int tiles
 __global__ void __launch_bounds__(256) tile_ranges_kernel(uint32_t cap, const uint32_t *__restrict__ n_ptr,
                                                           const uint32_t *__restrict__ tile_keys, uint2 *__restrict__ ranges,
                                                           uint32_t *__restrict__ err, uint32_t *__restrict__ host_late, uint32_t tag,
-                                                          uint32_t rearm_words /*fused emission: err[0 .. rearm_words) back to zero*/) {
+                                                          uint32_t rearm_words /*fused emission: err[0 .. rearm_words) back to zero*/,
+                                                          uint32_t inject /*DAS3R_INJECT_FAULT: bits forced into the word (tests)*/) {
     const uint32_t I = n_ptr ? min(*n_ptr, cap) : cap;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0 && host_late) {   // last binning kernel: hand the self-check word of this forward to the host mailbox
-        host_late[0] = *err;
+        host_late[0] = *err | inject;
         __hip_atomic_store(host_late + 1, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (i < rearm_words) err[i] = 0u;   // (thread 0 has read err[0] just above) the ring slot is zero at rest again
@@ -314,7 +315,7 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
         if (dead_keys) *dead_keys = kfinal;   // the tile keys are dead once tile_ranges_kernel has run
         const int rearm = emit_slot ? EMIT_SLOT_WORDS : 0;
         DAS3R_LAUNCH(tile_ranges_kernel, dim3(div_up(std::max<int64_t>(I, rearm), 256)), dim3(256), 0, s, (uint32_t)I, n_ptr, kfinal, ranges,
-                     emit_slot ? emit_slot : (uint32_t *)(geom + L.g_ticket) + 8, host_late, tag, (uint32_t)rearm);
+                     emit_slot ? emit_slot : (uint32_t *)(geom + L.g_ticket) + 8, host_late, tag, (uint32_t)rearm, (uint32_t)switches().inject_fault);
         KERNEL_CHECK(s, debug, "tile_ranges");
         return DAS3R_OK;
     }
@@ -335,7 +336,7 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
     // kin/vin now hold the partitioned (tile id, gaussian id) lists; vin == binning + pub.point_list by construction
     if (dead_keys) *dead_keys = kin;
     DAS3R_LAUNCH(tile_ranges_kernel, dim3(div_up(I, 256)), dim3(256), 0, s, (uint32_t)I, n_ptr, kin, ranges,
-                 (uint32_t *)(geom + L.g_ticket) + 8, host_late, tag, 0u);
+                 (uint32_t *)(geom + L.g_ticket) + 8, host_late, tag, 0u, (uint32_t)switches().inject_fault);
     KERNEL_CHECK(s, debug, "tile_ranges");
     return DAS3R_OK;
 }

@@ -33,11 +33,18 @@ def assign(n_sequences, rank, world, costs=None):
 
 def gather_records(local_records, n_sequences, device):
     """all_gather of fixed-size records; returns an (n_sequences, len(RECORD_FIELDS)) float64 tensor on every rank, rows
-    ordered by scene id; sequences nobody reported (failed before producing a record) have ok = 0."""
+    ordered by scene id; sequences nobody reported (failed before producing a record) have ok = 0.  The per-rank buffer is
+    sized by the LARGEST number of records any rank holds (one all_reduce MAX): an LPT assignment can give a rank more than
+    ceil(n / world) sequences, and nothing is ever truncated."""
     world = dist.get_world_size() if dist.is_initialized() else 1
-    per_rank = (n_sequences + world - 1) // world
+    nloc = torch.tensor([len(local_records)], dtype=torch.int64, device=device)
+    if world > 1:
+        dist.all_reduce(nloc, op=dist.ReduceOp.MAX)
+    per_rank = max(int(nloc.item()), 1)
+    if len(local_records) > per_rank:
+        raise RuntimeError("gather_records: more local records than the agreed buffer holds")
     buf = torch.full((per_rank, len(RECORD_FIELDS)), -1.0, dtype=torch.float64, device=device)
-    for k, rec in enumerate(local_records[:per_rank]):
+    for k, rec in enumerate(local_records):
         buf[k] = torch.tensor([float(rec[f]) for f in RECORD_FIELDS], dtype=torch.float64)
     if world > 1:
         out = [torch.empty_like(buf) for _ in range(world)]
@@ -61,32 +68,33 @@ def sequence_cost(seq_dir):
     return float(sum(c["width"] * c["height"] for c in cams.values()))
 
 
-def run_sequence_job(scene_id, iterations, device, frames=6, seq_dir=None, out_dir=None, fused=False):
+def run_sequence_job(scene_id, iterations, device, frames=6, seq_dir=None, out_dir=None, fused=False, gt_mask_dir=None, dataset="sintel"):
     """One independent 'sequence': load a preprocessed DAS3R sequence directory (das3r_amd.io_formats.load_sequence) — or,
     without one, build a synthetic multi-frame scene —, optimise it with the train-step harness, report the held-out PSNR and,
     with out_dir, write what the reference writes (point_cloud/iteration_N/point_cloud.ply, pose/pose_N.npy:
     train_gui.py:467-480,523-528).  Failures are isolated per sequence (the reference's predictor farm does the same,
     pose_eval.py:209-222)."""
     from .model import OptimParams
-    from .train import build_from_sequence, is_test_index, psnr_report, synthetic_sequence, train
+    from .train import build_from_sequence, psnr_report, synthetic_sequence, train
     try:
         masks = None
         if seq_dir is not None:
             from .io_formats import load_sequence
-            seq = load_sequence(seq_dir, device=device)
-            masks = seq.get("dynamic_masks")
+            seq = load_sequence(seq_dir, device=device, gt_mask_dir=gt_mask_dir, dataset=dataset)
+            masks = seq.get("gt_dynamic_masks")   # ground-truth masks only: the report skips views without one
         else:
             seq = synthetic_sequence(frames=frames, seed=scene_id, device=device)
-        model, cams = build_from_sequence(seq)
+        # Gaussians, training poses and conf_static from the TRAINING frames only; the held-out frames ((idx + 5) % 10 == 0) give
+        # their poses and their images as ground truth (scene/__init__.py:88-93, dataset_readers.py:342-347)
+        model, train_cams, test = build_from_sequence(seq, heldout=True)
         opt = OptimParams(iterations=iterations)
         model.training_setup(opt, fused=fused)
-        test = [c for c in cams if is_test_index(c.uid)] or cams[-1:]
-        train_cams = [c for c in cams if c not in test] or cams
-        stats = train(model, train_cams, opt, iterations, seed=scene_id, fused=fused)
         dyn = None
-        if masks is not None and all(m is not None for m in masks):
-            dyn = {i: torch.from_numpy(m).to(device) for i, m in enumerate(masks)}
-        rep = psnr_report(model, test, dynamic_masks=dyn)
+        if masks is not None and any(m is not None for m in masks):   # keyed by the test camera's uid; views without a mask are skipped
+            dyn = {c.uid: (torch.from_numpy(masks[c.frame_index]).to(device) if masks[c.frame_index] is not None else None) for c in test}
+        stats = train(model, train_cams, opt, iterations, seed=scene_id, fused=fused, test_cameras=test, gt_dynamic_masks=dyn)
+        rep = psnr_report(model, test, dynamic_masks=dyn, test_poses=True, iteration=iterations, log_dir=out_dir)
+        cams = train_cams
         if out_dir is not None:
             from .io_formats import save_model_ply, save_poses_npy
             save_model_ply(os.path.join(out_dir, "point_cloud", f"iteration_{iterations}", "point_cloud.ply"), model)
@@ -106,6 +114,8 @@ def main():
     ap.add_argument("--data", default=None, help="directory whose sub-directories are preprocessed DAS3R sequences")
     ap.add_argument("--out", default=None, help="where to write <sequence>/point_cloud/... and pose/...")
     ap.add_argument("--fused", action="store_true", help="use the fused pre-transform / Adam / loss kernels")
+    ap.add_argument("--gt-dynamic-mask", default=None, help="root of the ground-truth dynamic masks, <root>/<sequence>/... (train_test_psnr.py --gt_dynamic_mask)")
+    ap.add_argument("--dataset", default="sintel", choices=("sintel", "davis"))
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -123,14 +133,20 @@ def main():
         args.sequences = len(dirs)
         mine = assign(len(dirs), rank, world, costs=[sequence_cost(os.path.join(args.data, d)) for d in dirs])
         records = [run_sequence_job(s, args.iterations, device, seq_dir=os.path.join(args.data, dirs[s]),
-                                    out_dir=os.path.join(args.out, dirs[s]) if args.out else None, fused=args.fused) for s in mine]
+                                    out_dir=os.path.join(args.out, dirs[s]) if args.out else None, fused=args.fused,
+                                    gt_mask_dir=os.path.join(args.gt_dynamic_mask, dirs[s]) if args.gt_dynamic_mask else None,
+                                    dataset=args.dataset) for s in mine]
     else:
         mine = assign(args.sequences, rank, world)
         records = [run_sequence_job(s, args.iterations, device, fused=args.fused) for s in mine]
     table = gather_records(records, args.sequences, device)
     if rank == 0:
+        from .train import latex_rows
         good = table[table[:, 5] > 0]
-        print(" & ".join(f"{p:.2f}" for p in table[:, 1].tolist()))     # the LaTeX row get_testing_psnr_davis.py prints
+        names = dirs if args.data else [f"seq_{i}" for i in range(args.sequences)]
+        head, row = latex_rows({names[int(r[0])]: float(r[1]) for r in good})   # the rows get_testing_psnr_davis.py:19-22 prints
+        print(head)
+        print(row)
         print(f"mean PSNR {good[:, 1].mean().item():.2f} over {good.shape[0]}/{args.sequences} sequences")
     if world > 1:
         dist.destroy_process_group()

@@ -127,6 +127,15 @@ class FusedAdam:
         for g in self.param_groups:
             for p in g["params"]:
                 if p.grad is None:
+                    # The higher-order SH coefficients get no gradient while the fused render hands the rasterizer the DC tensor
+                    # alone (render.py).  In the reference they receive an all-zero gradient from iteration 1, so torch.optim.Adam
+                    # counts those steps (moments stay 0): keep the same count, or the bias corrections would restart at 1 when
+                    # the degree goes up at iteration 3000 (bc2 = 0.001 instead of 0.95: ~3x smaller first updates)
+                    if g.get("sh_rest"):
+                        st = self.state.get(p)
+                        if st is None:
+                            st = self.state[p] = dict(step=0, exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p))
+                        st["step"] += 1
                     continue
                 if p.device.type != "cuda" or p.dtype != torch.float32:
                     raise RuntimeError("FusedAdam: fp32 tensors on a HIP device only (no CPU path)")

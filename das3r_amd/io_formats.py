@@ -155,18 +155,21 @@ def write_colmap_images_text(path, poses_c2w, names):
 
 
 # ---- sequence directory -> tensors of SplatModel.create_from_frames -------------------------------------------------------
-def load_sequence(seq_dir, device="cpu"):
+def load_sequence(seq_dir, device="cpu", gt_mask_dir=None, dataset="sintel"):
     """Read a preprocessed DAS3R sequence directory into the layout das3r_amd.model.SplatModel.create_from_frames takes:
     images [F,3,H,W] in [0,1], depths / confs / dyna_avg [F,H,W], K [F,3,3] (focals of cameras.txt, principal point at the
     image centre: scene/gaussian_model.py:587-596), cam2world [F,4,4] (tumpose_to_c2w of pred_traj.txt), w2c_pose7 [F,7]
     (quaternion via matrix_to_quat_wxyz of the images.txt rotation + tvec: scene/gaussian_model.py:149-161), plus names and the
-    optional predicted dynamic masks.  Frames are ordered by COLMAP image id."""
+    optional predicted dynamic masks.  Frames are ordered by COLMAP image id.  gt_mask_dir: the ground-truth dynamic masks of the
+    held-out report, <gt_mask_dir>/frame_%04d.png with a one-based index (Sintel) or %05d.png (DAVIS), thresholded at 0.5 of the
+    0..255 range (Sintel) or of the raw label value (DAVIS) — scene/dataset_readers.py:170-173,209-215; frames without a file have
+    none (the report skips them)."""
     import torch
     from PIL import Image
     cams = read_colmap_cameras_text(os.path.join(seq_dir, "sparse/0/cameras.txt"))
     imgs = read_colmap_images_text(os.path.join(seq_dir, "sparse/0/images.txt"))
     _, xyz, quat = read_tum_trajectory(os.path.join(seq_dir, "pred_traj.txt"))
-    out = dict(images=[], depths=[], confs=[], dyna_avg=[], K=[], cam2world=[], w2c_pose7=[], names=[], dynamic_masks=[])
+    out = dict(images=[], depths=[], confs=[], dyna_avg=[], K=[], cam2world=[], w2c_pose7=[], names=[], dynamic_masks=[], gt_dynamic_masks=[])
     for iid in sorted(imgs):
         im, cam = imgs[iid], cams[imgs[iid]["camera_id"]]
         name = os.path.basename(im["name"])
@@ -184,8 +187,18 @@ def load_sequence(seq_dir, device="cpu"):
         out["names"].append(name)
         mpath = os.path.join(seq_dir, "dynamic_masks", f"dynamic_mask_{idx}.png")
         out["dynamic_masks"].append((np.asarray(Image.open(mpath)) / 255.0 > 0.5) if os.path.exists(mpath) else None)
-    res = {k: torch.from_numpy(np.stack(v)).to(device) for k, v in out.items() if k not in ("names", "dynamic_masks")}
+        gpath = None
+        if gt_mask_dir is not None:
+            gpath = os.path.join(gt_mask_dir, f"frame_{int(idx) + 1:04d}.png" if dataset == "sintel" else f"{int(idx):05d}.png")
+        if gpath is not None and os.path.exists(gpath):
+            g = np.asarray(Image.open(gpath))
+            out["gt_dynamic_masks"].append((g > 0.5) if dataset == "davis" else (g / 255.0 > 0.5))
+        else:
+            out["gt_dynamic_masks"].append(None)
+    lists = ("names", "dynamic_masks", "gt_dynamic_masks")
+    res = {k: torch.from_numpy(np.stack(v)).to(device) for k, v in out.items() if k not in lists}
     res["names"], res["dynamic_masks"] = out["names"], out["dynamic_masks"]
+    res["gt_dynamic_masks"] = out["gt_dynamic_masks"] if any(m is not None for m in out["gt_dynamic_masks"]) else None
     res["W"], res["H"], res["focal"] = int(res["images"].shape[3]), int(res["images"].shape[2]), float(res["K"][0, 0, 0])
     return res
 

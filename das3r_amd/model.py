@@ -6,7 +6,12 @@ every confident pixel of every frame becomes one Gaussian, xyz = unprojected dep
 log(sqrt(clamp_min(distCUDA2(xyz), 1e-7))) repeated 3x, identity quaternions, opacity = inverse_sigmoid(1/num_frames),
 conf_static = 1 - dyna_avg with shape (frames, H, W); the two Adam optimizers (lr=0, eps=1e-15) with the reference's
 groups and LRs and the exponential schedules (:228-323; defaults /root/reference/arguments/__init__.py:73-90);
-oneupSHdegree (:199-201); pose parameters Q/T as (frames,4)/(frames,3) tensors (:149-184).
+oneupSHdegree (:199-201); pose parameters Q/T as (frames,4)/(frames,3) tensors (:149-184); the held-out views' poses
+test_Q/test_T with their own optimizer (:132-147,263-268) and the FoVx/FoVy "parameters" of the camera optimizer (:163-166,
+253-254).  The last two are INERT in the reference and therefore here: render() turns FoV into Python floats with math.tan, so
+no gradient ever reaches FoVx/FoVy (Adam skips parameters whose .grad is None and never creates state for them),
+and the test-pose pass of train_test_psnr.py steps optimizer_cam — which holds Q/T, not test_Q/test_T — so optimizer_cam_test is
+built and never stepped (C5).  They are kept so that optimizer groups, their order and their state match the reference's.
 """
 from dataclasses import dataclass
 
@@ -49,7 +54,10 @@ class SplatModel:
         self.max_sh_degree = sh_degree
         self.active_sh_degree = 0
         self.spatial_lr_scale = 1.0
-        self.optimizer = self.optimizer_cam = None
+        self.optimizer = self.optimizer_cam = self.optimizer_cam_test = None
+        self.enable_test = False
+        self.test_Q = self.test_T = None
+        self.FoVx = self.FoVy = None
 
     # ---- activations
     @property
@@ -72,8 +80,31 @@ class SplatModel:
     def get_features(self):
         return torch.cat((self._features_dc, self._features_rest), dim=1)
 
+    def get_covariance(self, scaling_modifier=1):
+        """scene/gaussian_model.py:195-196: Sigma from the WORLD-frame rotation parameter (render()'s compute_cov3D_python mode)."""
+        from .render import covariance_from_scaling_rotation
+        return covariance_from_scaling_rotation(self.get_scaling, scaling_modifier, self._rotation)
+
     def get_RT(self, idx):
         return torch.cat([self.Q[idx], self.T[idx]])
+
+    def get_RT_test(self, idx):
+        return torch.cat([self.test_Q[idx], self.test_T[idx]])
+
+    def init_test_RT_seq(self, w2c_pose7):
+        """Poses (qw,qx,qy,qz,tx,ty,tz) of the held-out views (gaussian_model.py:132-147); none -> enable_test stays False."""
+        if w2c_pose7 is None or len(w2c_pose7) == 0:
+            self.enable_test = False
+            return
+        self.enable_test = True
+        self.test_Q = w2c_pose7[:, :4].clone().contiguous().requires_grad_(True)
+        self.test_T = w2c_pose7[:, 4:].clone().contiguous().requires_grad_(True)
+
+    def init_fov(self, fovx, fovy):
+        """gaussian_model.py:163-166: the first training camera's FoV as 0-d tensors that require grad (and never get one)."""
+        dev = self._xyz.device
+        self.FoVx = torch.tensor(float(fovx), device=dev).requires_grad_(True)
+        self.FoVy = torch.tensor(float(fovy), device=dev).requires_grad_(True)
 
     def oneupSHdegree(self):
         if self.active_sh_degree < self.max_sh_degree:
@@ -124,14 +155,23 @@ class SplatModel:
             {"params": [self._conf_static], "lr": 3e-3, "name": "conf_static"},
         ]
         cam = [{"params": [self.Q], "lr": 0.00003, "name": "pose_Q"}, {"params": [self.T], "lr": 0.00003, "name": "pose_T"}]
+        if self.FoVx is not None:   # gaussian_model.py:253-254 (inert: module docstring)
+            cam += [{"params": [self.FoVx], "lr": 0.0001, "name": "fovX"}, {"params": [self.FoVy], "lr": 0.0001, "name": "fovY"}]
+        cam_test = None
+        if self.enable_test:        # gaussian_model.py:263-268 (built, never stepped: module docstring)
+            cam_test = [{"params": [self.test_Q], "lr": 0.00003, "name": "test_pose_Q"},
+                        {"params": [self.test_T], "lr": 0.00003, "name": "test_pose_T"}]
         if fused:   # opt-in: one HIP launch per step, SH coefficients swept only up to the active degree
             from .fused import FusedAdam
             groups[2]["sh_rest"] = True
             self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
-            self.optimizer_cam = FusedAdam(cam, lr=0.0, eps=1e-15)   # stepped with a device-side PSNR gate (train.py)
+            self.optimizer_cam = FusedAdam(cam[:2], lr=0.0, eps=1e-15)   # stepped with a device-side PSNR gate (train.py); the
+            #                                                                inert FoV groups have nothing to fuse
         else:
             self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
             self.optimizer_cam = torch.optim.Adam(cam, lr=0.0, eps=1e-15)
+        if cam_test is not None:
+            self.optimizer_cam_test = torch.optim.Adam(cam_test, lr=0.0, eps=1e-15)
         self._lr_xyz = expon_lr_func(opt.position_lr_init * s, opt.position_lr_final * s, lr_delay_mult=opt.position_lr_delay_mult,
                                      max_steps=opt.position_lr_max_steps)
         self._lr_cam = expon_lr_func(0.00003, 0.000003, lr_delay_mult=opt.position_lr_delay_mult, max_steps=1000)
@@ -141,8 +181,8 @@ class SplatModel:
 
     def update_learning_rate(self, iteration):
         for g in self.optimizer_cam.param_groups:
-            if g["name"] in ("pose_Q", "pose_T"):
-                g["lr"] = self._lr_cam(iteration)
+            if g["name"] in ("pose_Q", "pose_T", "test_pose_Q", "test_pose_T"):   # (the test names never occur in this optimizer:
+                g["lr"] = self._lr_cam(iteration)                                  #  gaussian_model.py:302-315 looks for them all the same)
         for g in self.optimizer.param_groups:
             if g["name"] == "xyz":
                 g["lr"] = self._lr_xyz(iteration)

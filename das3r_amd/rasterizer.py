@@ -160,6 +160,26 @@ class _on_device:
         return False
 
 
+class _Capacity(int):
+    """Instance capacity of a forward's binning buffer; also carries the forward's binning self-check ticket
+    (das3r_raster_saved.check_word / check_tag) to the backward pass and to `check_forward`."""
+    check_word = None
+    check_tag = 0
+
+
+def check_forward(capacity, device):
+    """Wait for the binning self-check of the forward that returned `capacity` (the 7th element of `_forward_full`'s result) and
+    raise RuntimeError if that forward's image is invalid — for callers that render without a backward pass (evaluation);
+    the backward pass does this itself before it launches anything (include/das3r_raster.h: das3r_raster_check)."""
+    if not getattr(capacity, "check_tag", 0):
+        return
+    saved = _lib.RasterSaved()
+    saved.check_word, saved.check_tag = capacity.check_word, capacity.check_tag
+    with _on_device(device):
+        rc = _lib.load().das3r_raster_check(C.byref(saved), _stream(device))
+    _lib.check(rc, "das3r_raster_check")
+
+
 def _forward_impl(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp):
     """-> (num_rendered, color, radii, geom, binning, img), the binning buffer laid out for exactly num_rendered instances
     (inspection helper of the tests and tools: `_lib.layout(P, num_rendered, W, H)` then describes the buffers)."""
@@ -204,11 +224,14 @@ def _forward_full(rs, means3D, sh, colors_precomp, opacities, scales, rotations,
     _lib.check(rc, "das3r_raster_forward")
     empty = torch.empty(0, dtype=torch.uint8, device=device)
     bufs = alloc.take()
-    return (int(rc), color, radii, bufs.get("geom", empty), bufs.get("binning", empty), bufs.get("img", empty), int(saved.capacity))
+    cap = _Capacity(saved.capacity)
+    cap.check_word, cap.check_tag = saved.check_word, int(saved.check_tag)
+    return (int(rc), color, radii, bufs.get("geom", empty), bufs.get("binning", empty), bufs.get("img", empty), cap)
 
 
 def _backward_impl(rs, num_rendered, grad_out_color, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                    geom, binning, img, capacity=None):
+    ticket = capacity
     capacity = int(num_rendered) if capacity is None else int(capacity)
     lib = _lib.load()
     device = means3D.device
@@ -232,6 +255,8 @@ def _backward_impl(rs, num_rendered, grad_out_color, means3D, sh, colors_precomp
     saved.geom, saved.binning, saved.img = _ptr(geom), _ptr(binning), _ptr(img)
     saved.num_rendered = int(num_rendered)
     saved.capacity = capacity
+    if getattr(ticket, "check_tag", 0):   # the forward's binning self-check is examined before the backward launches anything
+        saved.check_word, saved.check_tag = ticket.check_word, ticket.check_tag
     g = _lib.RasterGrads()
     g.dL_dmeans2D, g.dL_dopacities, g.dL_dmeans3D = g_means2D.data_ptr(), g_opac.data_ptr(), g_means3D.data_ptr()
     g.dL_dshs = _ptr(g_sh)

@@ -2,11 +2,21 @@
 SURVEY.md §8 a1).  The reference file never travels to the GPU box, so the harness carries this restatement; an
 unmodified DAS3R checkout keeps using its own render() on top of the drop-in `diff_gaussian_rasterization` package.
 
-Reproduced exactly: dummy means2D leaf that receives dL/d(mean2D) (:41-50); tanfov = tan(FoV/2) (:53-54);
-viewmatrix = I4, projmatrix = I4 @ P^T, campos = 0 (:57-61); the 12 settings (:62-78); Gaussians moved into the camera
-frame in PyTorch — means3D = (rel_w2c @ [xyz,1]^T)^T[:, :3], rotations = quadmultiply(pose[:4], _rotation) (:83-93);
-opacity = sigmoid(_opacity) * conf_static.reshape(-1,1)[aggregated_mask] (:95-97); scales = exp(_scaling) (:107);
-shs = cat(f_dc, f_rest) (:126); returned dict keys (:144-149).
+Organised around what reaches the rasterizer — `rasterizer_inputs()` builds the settings and the eight tensor arguments, the
+fused (one HIP kernel, §8f-1) and the PyTorch pre-transform being two producers of the same tuple — and pinned against the
+reference itself: tests/golden/ref_render.npz holds what the reference's render() handed to a recording rasterizer for seeded
+models in all three `pipe` modes, and tests/test_golden_render.py replays them through this file.
+
+What the reference does, kept as is (quirks included):
+  * the camera is the identity (viewmatrix = I4, projmatrix = I4 @ P^T, campos = 0, :57-61); the Gaussians are moved instead:
+    means3D = (w2c(pose) [xyz 1]^T)^T[:, :3], rotations = quadmultiply(pose[:4], _rotation) (:83-93);
+  * opacity = sigmoid(_opacity)[filtering] * conf_static.reshape(-1, 1)[aggregated_mask] (:95-97) — two different index sets,
+    consistent only for the default filtering (C4);
+  * pipe.compute_cov3D_python: cov3D_precomp = pc.get_covariance(scaling_modifier), built from the WORLD-frame _rotation
+    (normalised) while the means are in the camera frame (:103-104);
+  * pipe.convert_SHs_python: colours = clamp_min(eval_sh(active degree, features, normalise(get_xyz - camera_center)) + 0.5, 0)
+    from the WORLD-frame positions and the camera's own centre, not filtered (:112-122);
+  * a dummy means2D leaf (zeros + 0, retain_grad) that receives dL/d(mean2D) (:41-50); returned dict keys (:144-149).
 """
 import math
 
@@ -15,76 +25,119 @@ import torch
 from .camera import camera_from_tensor, quat_multiply
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
+_SH_C0 = 0.28209479177387814
+_SH_C1 = 0.4886025119029199
+_SH_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
+_SH_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+          1.445305721320277, -0.5900435899266435)
 
-def das3r_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, camera_pose=None,
-                 filtering=None, use_conf=True, fused=False):
-    """viewpoint_camera: .FoVx .FoVy .image_height .image_width .projection_matrix (4x4, already transposed);
-    pc: splat model (das3r_amd.model.SplatModel or anything with the same attributes); pipe: .debug
-    .compute_cov3D_python .convert_SHs_python; camera_pose: (7,) tensor (qw,qx,qy,qz,tx,ty,tz), may require grad."""
+
+def sh_to_rgb(degree, sh, dirs):
+    """Real spherical harmonics up to `degree` (basis and signs of /root/reference/utils/sh_utils.py:57-112, pinned by
+    tests/golden/ref_helpers.npz).  sh [..., C, (max_degree + 1)^2], dirs [..., 3] unit -> [..., C]."""
+    x, y, z = dirs[..., 0:1], dirs[..., 1:2], dirs[..., 2:3]
+    out = _SH_C0 * sh[..., 0]
+    if degree >= 1:
+        out = out - _SH_C1 * y * sh[..., 1] + _SH_C1 * z * sh[..., 2] - _SH_C1 * x * sh[..., 3]
+    if degree >= 2:
+        xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+        out = (out + _SH_C2[0] * xy * sh[..., 4] + _SH_C2[1] * yz * sh[..., 5] + _SH_C2[2] * (2.0 * zz - xx - yy) * sh[..., 6]
+               + _SH_C2[3] * xz * sh[..., 7] + _SH_C2[4] * (xx - yy) * sh[..., 8])
+    if degree >= 3:
+        out = (out + _SH_C3[0] * y * (3 * xx - yy) * sh[..., 9] + _SH_C3[1] * xy * z * sh[..., 10]
+               + _SH_C3[2] * y * (4 * zz - xx - yy) * sh[..., 11] + _SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * sh[..., 12]
+               + _SH_C3[4] * x * (4 * zz - xx - yy) * sh[..., 13] + _SH_C3[5] * z * (xx - yy) * sh[..., 14]
+               + _SH_C3[6] * x * (xx - 3 * yy) * sh[..., 15])
+    return out
+
+
+def covariance_from_scaling_rotation(scaling, scaling_modifier, rotation):
+    """pc.get_covariance of the reference (scene/gaussian_model.py:32-36 + utils/general_utils.py:62-110): Sigma = (R S)(R S)^T
+    with R from the NORMALISED quaternion, as the 6 upper-triangular entries (xx, xy, xz, yy, yz, zz)."""
+    q = rotation / rotation.norm(dim=1, keepdim=True)
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                     2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                     2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+    L = R * (scaling_modifier * scaling)[:, None, :]
+    S = L @ L.transpose(1, 2)
+    return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1)
+
+
+def _settings(cam, pc, pipe, bg_color, scaling_modifier, device):
+    ident = torch.eye(4, device=device)
+    proj = ident.unsqueeze(0).bmm(cam.projection_matrix.to(device).unsqueeze(0)).squeeze(0)
+    return GaussianRasterizationSettings(
+        image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=math.tan(float(cam.FoVx) * 0.5),
+        tanfovy=math.tan(float(cam.FoVy) * 0.5), bg=bg_color, scale_modifier=scaling_modifier, viewmatrix=ident, projmatrix=proj,
+        sh_degree=pc.active_sh_degree, campos=ident.inverse()[3, :3], prefiltered=False, debug=bool(getattr(pipe, "debug", False)))
+
+
+def rasterizer_inputs(cam, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, camera_pose=None, filtering=None,
+                      use_conf=True, fused=False):
+    """-> (GaussianRasterizationSettings, kwargs of GaussianRasterizer.forward): everything render() computes in front of the
+    rasterizer."""
     xyz = pc.get_xyz
     device = xyz.device
-    all_pass = filtering is None
-    if filtering is None:
+    everything = filtering is None
+    if everything:
         filtering = torch.ones(xyz.shape[0], dtype=torch.bool, device=device)
-    screenspace_points = torch.zeros_like(xyz[filtering], dtype=xyz.dtype, requires_grad=True, device=device) + 0
+    means2D = torch.zeros_like(xyz[filtering], dtype=xyz.dtype, requires_grad=True, device=device) + 0
     try:
-        screenspace_points.retain_grad()
+        means2D.retain_grad()
     except Exception:  # noqa: BLE001
         pass
+    settings = _settings(cam, pc, pipe, bg_color, scaling_modifier, device)
+    cov_python = bool(getattr(pipe, "compute_cov3D_python", False))
+    sh_python = bool(getattr(pipe, "convert_SHs_python", False))
 
-    tanfovx = math.tan(float(viewpoint_camera.FoVx) * 0.5)
-    tanfovy = math.tan(float(viewpoint_camera.FoVy) * 0.5)
-    w2c = torch.eye(4, device=device)
-    projmatrix = w2c.unsqueeze(0).bmm(viewpoint_camera.projection_matrix.to(device).unsqueeze(0)).squeeze(0)
-    camera_pos = w2c.inverse()[3, :3]
-    raster_settings = GaussianRasterizationSettings(
-        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width), tanfovx=tanfovx,
-        tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier, viewmatrix=w2c, projmatrix=projmatrix,
-        sh_degree=pc.active_sh_degree, campos=camera_pos, prefiltered=False, debug=bool(getattr(pipe, "debug", False)))
-    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
-
-    if fused and override_color is None and not getattr(pipe, "compute_cov3D_python", False) and use_conf and all_pass:
-        # opt-in (SURVEY.md §8f-1): the pre-transform + activations below as ONE HIP kernel (+ one for its backward)
+    if fused and override_color is None and not cov_python and not sh_python and use_conf and everything:
+        # opt-in (SURVEY.md §8f-1): pose -> camera frame, quaternion product, exp / sigmoid * conf as ONE HIP kernel each way
         from .fused import pretransform
         idx = getattr(pc, "_mask_index", None)
         if idx is None:
             idx = pc._mask_index = torch.nonzero(pc.aggregated_mask.reshape(-1), as_tuple=False).reshape(-1).contiguous()
-        means3D, rotations, scales, opacity = pretransform(pc._xyz, pc._rotation, pc._scaling, pc._opacity, pc._conf_static, idx,
-                                                           camera_pose)
-        # while the active SH degree is 0 (iterations < 3000 of DAS3R's 4000) only the DC coefficient is read: hand the
-        # rasterizer the [P, 1, 3] DC tensor itself (M = 1) instead of cat(f_dc, f_rest) — same image bit for bit, 12 instead
-        # of 192 bytes of SH per splat each way, and f_rest gets no gradient at all (Adam skips it)
+        means3D, rotations, scales, opacity = pretransform(pc._xyz, pc._rotation, pc._scaling, pc._opacity, pc._conf_static, idx, camera_pose)
+        # while the active SH degree is 0 (iterations < 3000 of DAS3R's 4000) only the DC coefficient is read: the rasterizer gets
+        # the [P, 1, 3] DC tensor itself (M = 1) instead of cat(f_dc, f_rest) — same image bit for bit, 12 instead of 192 bytes of
+        # SH per splat each way; f_rest then has no gradient (FusedAdam counts its steps all the same: fused.py)
         shs = pc._features_dc if pc.active_sh_degree == 0 else pc.get_features
-        rendered_image, radii = rasterizer(means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=None,
-                                           opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=None)
-        return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
+        return settings, dict(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None, opacities=opacity, scales=scales,
+                              rotations=rotations, cov3D_precomp=None)
 
-    rel_w2c = camera_from_tensor(camera_pose)
-    gaussians_xyz = pc._xyz.clone()[filtering]
-    gaussians_rot = pc._rotation.clone()[filtering]
-    xyz_ones = torch.ones(gaussians_xyz.shape[0], 1, device=device).float()
-    xyz_homo = torch.cat((gaussians_xyz, xyz_ones), dim=1)
-    means3D = (rel_w2c @ xyz_homo.T).T[:, :3]
-    gaussians_rot_trans = quat_multiply(camera_pose[:4], gaussians_rot)
-    means2D = screenspace_points
-
+    w2c = camera_from_tensor(camera_pose)
+    pts = pc._xyz.clone()[filtering]
+    homo = torch.cat((pts, torch.ones(pts.shape[0], 1, device=device).float()), dim=1)
+    means3D = (w2c @ homo.T).T[:, :3]
+    rot_cam = quat_multiply(camera_pose[:4], pc._rotation.clone()[filtering])
     opacity = pc.get_opacity[filtering]
     if use_conf:
         opacity = opacity * pc._conf_static.reshape(-1, 1)[pc.aggregated_mask]
-
-    scales = rotations = cov3D_precomp = None
-    if getattr(pipe, "compute_cov3D_python", False):
-        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    kw = dict(means3D=means3D, means2D=means2D, shs=None, colors_precomp=None, opacities=opacity, scales=None, rotations=None,
+              cov3D_precomp=None)
+    if cov_python:
+        kw["cov3D_precomp"] = (pc.get_covariance(scaling_modifier) if hasattr(pc, "get_covariance")
+                               else covariance_from_scaling_rotation(pc.get_scaling, scaling_modifier, pc._rotation))
     else:
-        scales = pc.get_scaling[filtering]
-        rotations = gaussians_rot_trans
-
-    shs = colors_precomp = None
-    if override_color is None:
-        shs = pc.get_features[filtering]
+        kw["scales"], kw["rotations"] = pc.get_scaling[filtering], rot_cam
+    if override_color is not None:
+        kw["colors_precomp"] = override_color
+    elif sh_python:
+        feats = pc.get_features
+        per_channel = feats.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+        away = pc.get_xyz - cam.camera_center.to(device).repeat(feats.shape[0], 1)
+        kw["colors_precomp"] = torch.clamp_min(sh_to_rgb(pc.active_sh_degree, per_channel, away / away.norm(dim=1, keepdim=True)) + 0.5, 0.0)
     else:
-        colors_precomp = override_color
+        kw["shs"] = pc.get_features[filtering]
+    return settings, kw
 
-    rendered_image, radii = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,
-                                       opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
-    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
+
+def das3r_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, camera_pose=None,
+                 filtering=None, use_conf=True, fused=False):
+    """viewpoint_camera: .FoVx .FoVy .image_height .image_width .projection_matrix (4x4, already transposed) [.camera_center for
+    pipe.convert_SHs_python]; pc: splat model (das3r_amd.model.SplatModel or anything with the same attributes); pipe: .debug
+    .compute_cov3D_python .convert_SHs_python; camera_pose: (7,) tensor (qw,qx,qy,qz,tx,ty,tz), may require grad."""
+    settings, kw = rasterizer_inputs(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, camera_pose, filtering,
+                                     use_conf, fused)
+    image, radii = GaussianRasterizer(raster_settings=settings)(**kw)
+    return {"render": image, "viewspace_points": kw["means2D"], "visibility_filter": radii > 0, "radii": radii}

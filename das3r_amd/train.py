@@ -19,9 +19,10 @@ from .model import OptimParams, SplatModel
 from .render import das3r_render
 
 
-def make_camera(uid, image, focal, W, H, device, focal_y=None):
+def make_camera(uid, image, focal, W, H, device, focal_y=None, camera_center=None):
     fovx, fovy = focal2fov(focal, W), focal2fov(focal if focal_y is None else focal_y, H)
-    return SimpleNamespace(uid=uid, FoVx=fovx, FoVy=fovy, image_width=W, image_height=H, original_image=image,
+    center = torch.zeros(3, device=device) if camera_center is None else camera_center.to(device)   # (only render()'s convert_SHs_python mode reads it)
+    return SimpleNamespace(uid=uid, FoVx=fovx, FoVy=fovy, image_width=W, image_height=H, original_image=image, camera_center=center,
                            projection_matrix=projection_matrix(0.01, 100.0, fovx, fovy).transpose(0, 1).to(device))
 
 
@@ -65,8 +66,10 @@ def train_step(model: SplatModel, cam, opt: OptimParams, iteration, pipe, backgr
     return loss.detach(), psnr_frame.detach(), pkg
 
 
-def train(model, cameras, opt: OptimParams, iterations, pipe=None, background=None, seed=0, log_every=0, fused=False):
-    """Random camera without replacement per epoch (train_gui.py:546-555).  Returns dict(loss, psnr, iters_per_s)."""
+def train(model, cameras, opt: OptimParams, iterations, pipe=None, background=None, seed=0, log_every=0, fused=False,
+          test_cameras=None, gt_dynamic_masks=None):
+    """Random camera without replacement per epoch (train_gui.py:546-555).  With test_cameras: train_test_psnr.py's loop, which
+    walks the held-out views whenever the training stack has run empty (test_pose_pass).  Returns dict(loss, psnr, iters_per_s)."""
     pipe = pipe or SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
     dev = model.get_xyz.device
     background = background if background is not None else torch.zeros(3, device=dev)
@@ -80,6 +83,8 @@ def train(model, cameras, opt: OptimParams, iterations, pipe=None, background=No
             stack = list(cameras)
         cam = stack.pop(rng.randint(0, len(stack) - 1))
         loss, p, _ = train_step(model, cam, opt, it, pipe, background, fused=fused)
+        if not stack and test_cameras and model.enable_test:
+            test_pose_pass(model, test_cameras, gt_dynamic_masks, opt, pipe, background, rng)
         ema = 0.4 * loss + 0.6 * ema          # stays on the device: a float() here would stall the host every iteration
         last_psnr = p
         if log_every and it % log_every == 0:
@@ -94,24 +99,98 @@ def is_test_index(idx):
     return (idx + 5) % 10 == 0
 
 
+def resize_mask_nearest(mask, H, W):
+    """gt_dynamic_mask as the reference's Camera stores it (scene/cameras.py:60-67): [h,w] bool/float -> float [3,H,W],
+    nearest-neighbour resized to the render size."""
+    m = mask.to(torch.float32)[None].repeat(3, 1, 1)[None]
+    return torch.nn.functional.interpolate(m, size=(H, W), mode="nearest")[0]
+
+
+def test_pose_pass(model, test_cams, gt_dynamic_masks, opt: OptimParams, pipe, background, rng):
+    """The pass over the held-out views train_test_psnr.py runs whenever the training stack runs empty (:109-147): every test
+    view, in random order, is rendered with its test pose, the loss against the ground truth under (1 - gt_dynamic_mask) is
+    back-propagated, the Gaussian optimizer's gradients are dropped WITHOUT a step, and optimizer_cam is stepped when the frame
+    PSNR exceeds the gate.  optimizer_cam holds the TRAINING poses, whose gradients are None here, so no parameter changes
+     — the pass costs time and nothing else; it is reproduced for the iterations/s of configs[4]."""
+    stack = list(test_cams)
+    while stack:
+        cam = stack.pop(rng.randint(0, len(stack) - 1))
+        pkg = das3r_render(cam, model, pipe, background, camera_pose=model.get_RT_test(cam.uid))
+        m = gt_dynamic_masks.get(cam.uid) if gt_dynamic_masks else None
+        static = 1 - resize_mask_nearest(m, cam.image_height, cam.image_width) if m is not None else 1.0
+        image, gt = pkg["render"] * static, cam.original_image * static
+        psnr_frame = psnr(image, gt).mean()
+        loss = ((1.0 - opt.lambda_dssim) * l1_loss(image, gt, reduce=False) + opt.lambda_dssim * (1.0 - ssim(image, gt, size_average=False))).mean()
+        loss.backward(retain_graph=True)
+        with torch.no_grad():
+            model.optimizer.zero_grad(set_to_none=True)
+            if psnr_frame > opt.psnr_threshold and not hasattr(model.optimizer_cam, "_gate_state"):
+                model.optimizer_cam.step()   # every gradient it owns is None: a no-op, as in the reference
+            model.optimizer_cam.zero_grad(set_to_none=True)
+            if model.test_Q.grad is not None:   # (test_Q / test_T do get gradients; nothing ever consumes them)
+                model.test_Q.grad = model.test_T.grad = None
+
+
 @torch.no_grad()
-def psnr_report(model, cameras, dynamic_masks=None, pipe=None, background=None):
-    """Mean masked PSNR / L1 over `cameras` (train_test_psnr.py:241-302): clamp the render to [0,1], mask both images with
-    (1 - gt_dynamic_mask), per-channel psnr = 20 log10(1 / sqrt(mse)) then mean."""
+def psnr_report(model, cameras, dynamic_masks=None, pipe=None, background=None, test_poses=False, iteration=None, log_dir=None,
+                name="test"):
+    """Held-out report of train_test_psnr.py:241-302.  Per view: clamp the render to [0,1], mask render and ground truth with
+    (1 - gt_dynamic_mask) — the mask nearest-resized to the render size (scene/cameras.py:60-67) —, L1 = mean |d|, PSNR = mean
+    over channels of 20 log10(1 / sqrt(mse_c)) (utils/image_utils.py:17-19), both accumulated in float64.  ONLY views that have a
+    mask count: a view without one is rendered and skipped (`lens` is incremented inside the mask branch, :262-289), so with
+    `dynamic_masks` given the averages run over the masked views; `dynamic_masks=None` is the harness's own mode for sequences
+    without ground-truth masks (every view counts, unmasked).  test_poses: use model.get_RT_test (the reference's 'test' config)
+    instead of the training poses.  log_dir: append the reference's line to <log_dir>/<name>_log.txt (:299-300).
+    -> dict(l1, psnr, views, skipped)"""
     pipe = pipe or SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
     dev = model.get_xyz.device
     background = background if background is not None else torch.zeros(3, device=dev)
-    l1s, ps = [], []
+    l1_sum = torch.zeros((), dtype=torch.float64, device=dev)
+    psnr_sum = torch.zeros((), dtype=torch.float64, device=dev)
+    lens = skipped = 0
     for cam in cameras:
-        img = torch.clamp(das3r_render(cam, model, pipe, background, camera_pose=model.get_RT(cam.uid))["render"], 0.0, 1.0)
+        pose = model.get_RT_test(cam.uid) if test_poses else model.get_RT(cam.uid)
+        img = torch.clamp(das3r_render(cam, model, pipe, background, camera_pose=pose)["render"], 0.0, 1.0)
         gt = torch.clamp(cam.original_image, 0.0, 1.0)
         if dynamic_masks is not None:
-            m = 1 - dynamic_masks[cam.uid].to(img.dtype)
-            img, gt = img * m, gt * m
-        l1s.append(float(l1_loss(img, gt)))
-        ps.append(float(psnr(img, gt).mean()))
-    n = max(len(ps), 1)
-    return dict(l1=sum(l1s) / n, psnr=sum(ps) / n, views=len(ps))
+            m = dynamic_masks.get(cam.uid) if hasattr(dynamic_masks, "get") else dynamic_masks[cam.uid]
+            if m is None:
+                skipped += 1
+                continue
+            static = 1 - resize_mask_nearest(m.to(dev), img.shape[1], img.shape[2])
+            img, gt = img * static, gt * static
+        l1_sum += l1_loss(img, gt).mean().double()
+        psnr_sum += psnr(img, gt).mean().double()
+        lens += 1
+    l1_v = float(l1_sum) / lens if lens else float("nan")     # (the reference divides by zero here when no view has a mask)
+    psnr_v = float(psnr_sum) / lens if lens else float("nan")
+    if log_dir is not None and lens:
+        import os
+        os.makedirs(log_dir, exist_ok=True)
+        with open(os.path.join(log_dir, f"{name}_log.txt"), "a") as f:
+            f.write(f"[ITER {iteration}] Evaluating {name}: L1 {l1_v} PSNR {psnr_v}\n")
+    return dict(l1=l1_v, psnr=psnr_v, views=lens, skipped=skipped)
+
+
+def scrape_test_logs(root, exp, log_name="test_log.txt"):
+    """/root/reference/scripts/get_testing_psnr_davis.py:8-17: {scene: last number of the last line of <root>/<scene>/<exp>/
+    test_log.txt}, scenes in sorted order."""
+    import os
+    out = {}
+    for scene in sorted(os.listdir(root)):
+        path = os.path.join(root, scene, exp, log_name)
+        if os.path.isdir(os.path.join(root, scene)) and os.path.exists(path):
+            with open(path) as f:
+                out[scene] = float(f.read().strip().split("\n")[-1].split()[-1])
+    return out
+
+
+def latex_rows(results):
+    """The two rows get_testing_psnr_davis.py:19-22 prints for {scene: psnr}."""
+    avg = sum(results.values()) / len(results) if results else 0
+    head = "Scene & " + " & ".join(results.keys()).replace("_", "-") + "& average"
+    row = "PSNR & " + " & ".join(f"{v:.2f}" for v in results.values()) + f" & {avg:.2f} "
+    return head, row
 
 
 def synthetic_sequence(frames=6, W=128, H=80, focal=110.0, n_splats=6000, seed=0, device="cuda"):
@@ -147,11 +226,36 @@ def synthetic_sequence(frames=6, W=128, H=80, focal=110.0, n_splats=6000, seed=0
                 w2c_pose7=torch.stack(poses7).to(dev), focal=focal, W=W, H=H)
 
 
-def build_from_sequence(seq, sh_degree=3):
-    model = SplatModel(sh_degree).create_from_frames(seq["images"], seq["depths"], seq["confs"], seq["dyna_avg"], seq["K"],
-                                                     seq["cam2world"], seq["w2c_pose7"])
+def split_sequence(seq):
+    """Held-out split of the reference (scene/dataset_readers.py:336-347, eval mode): frames with (idx + 5) % 10 == 0 are test
+    views, the others training views.  -> (train index list, test index list)"""
+    F = seq["images"].shape[0]
+    test = [i for i in range(F) if is_test_index(i)]
+    return [i for i in range(F) if not is_test_index(i)], test
+
+
+def build_from_sequence(seq, sh_degree=3, heldout=False):
+    """-> (model, cameras) from every frame, or with heldout=True -> (model, train cameras, test cameras): Gaussians, training
+    poses and conf_static come from the TRAINING frames only (the reference builds them from scene.train_cameras:
+    scene/__init__.py:88-93), the held-out frames only contribute their poses (init_test_RT_seq) and their images as ground
+    truth.  Camera uids index the model's per-frame tensors: 0..n_train-1 / 0..n_test-1."""
     dev = seq["images"].device
+    F = seq["images"].shape[0]
+    tr, te = split_sequence(seq) if heldout else (list(range(F)), [])
+    if heldout and not te:   # short sequences (< 6 frames) have no held-out view under the reference's rule
+        tr, te = list(range(F - 1)), [F - 1]
+    sel = torch.tensor(tr, device=dev)
+    model = SplatModel(sh_degree).create_from_frames(seq["images"][sel], seq["depths"][sel], seq["confs"][sel], seq["dyna_avg"][sel],
+                                                     seq["K"][sel], seq["cam2world"][sel], seq["w2c_pose7"][sel])
     K = seq["K"]   # per-frame focals (cameras.txt: scene/dataset_readers.py:139-147); principal point at the image centre
-    cams = [make_camera(i, seq["images"][i], float(K[i, 0, 0]), seq["W"], seq["H"], dev, focal_y=float(K[i, 1, 1]))
-            for i in range(seq["images"].shape[0])]
-    return model, cams
+    mk = lambda uid, i: make_camera(uid, seq["images"][i], float(K[i, 0, 0]), seq["W"], seq["H"], dev, focal_y=float(K[i, 1, 1]),
+                                    camera_center=seq["cam2world"][i][:3, 3])
+    cams = [mk(u, i) for u, i in enumerate(tr)]
+    model.init_fov(cams[0].FoVx, cams[0].FoVy)
+    if not heldout:
+        return model, cams
+    model.init_test_RT_seq(seq["w2c_pose7"][torch.tensor(te, device=dev)])
+    test_cams = [mk(u, i) for u, i in enumerate(te)]
+    for c, i in zip(test_cams, te):
+        c.frame_index = i
+    return model, cams, test_cams

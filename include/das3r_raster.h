@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DAS3R_ABI_VERSION 6
+#define DAS3R_ABI_VERSION 7
 
 typedef enum {
     DAS3R_OK = 0,
@@ -99,6 +99,8 @@ typedef struct {
     char *img;
     int64_t num_rendered;
     int64_t capacity;        /* instances the binning buffer was laid out for (>= num_rendered) */
+    void *check_word;        /* HOST address of the {flags, tag} word this forward's binning self-check is delivered to ... */
+    uint32_t check_tag;      /* ... and the tag that marks it as this forward's (0: nothing to check) */
 } das3r_raster_saved;
 
 /* Gradient outputs of backward.  Every buffer is fully written by the call (no pre-zeroing needed). */
@@ -121,6 +123,14 @@ int64_t das3r_raster_forward(const das3r_raster_args *args, const das3r_raster_i
 
 int das3r_raster_backward(const das3r_raster_args *args, const das3r_raster_in *in, const das3r_raster_saved *saved,
                           const float *dL_dpix /* [3,H,W] */, const das3r_raster_grads *grads, das3r_stream_t stream);
+
+/* das3r_raster_forward returns as soon as its kernels are enqueued.  Its binning kernels check themselves (a bounded wait on
+ * another workgroup that timed out, an index out of range, counts that do not add up) and leave one word for the host; this call
+ * waits (bounded) for that word of the forward that produced `saved` and returns DAS3R_ERR_HIP if the forward's image and lists are
+ * invalid.  das3r_raster_backward calls it before launching anything; callers that render without a backward (evaluation) call it
+ * before they use the image.  A forward with args->debug != 0 has already waited for it.  The ticket may be examined from any
+ * host thread. */
+int das3r_raster_check(const das3r_raster_saved *saved, das3r_stream_t stream);
 
 /* present[i] = (view-space z of means3D[i]) > near plane (0.001, /root/reference/README.md:41-44). */
 int das3r_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,
@@ -225,6 +235,14 @@ int das3r_raster_get_layout(int32_t P, int64_t capacity, int32_t W, int32_t H, d
  * into buf, then clears the records; returns bytes written or a negative status.  Single-threaded use (bench.py). */
 void das3r_profile_enable(int on);
 int das3r_profile_report(char *buf, size_t cap);
+
+/* The library reads its diagnostic / experiment switches (environment variables DAS3R_*) once, at the first
+ * call; a process that changes them afterwards (tests, A-B tools) calls this to have them read again. */
+void das3r_reload_switches(void);
+
+/* Process-wide counters since load: out[0] forwards, [1] binning self-check words examined by the host, [2] of those with the
+ * "a stalled look-back poll was rescued by the atomic read path" note (granule.h; informational), [3] failed self-checks. */
+void das3r_get_stats(uint64_t out[4]);
 
 int das3r_abi_version(void);
 const char *das3r_last_error(void);

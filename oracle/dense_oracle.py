@@ -44,7 +44,8 @@ def rasterize_dense(means3D, means2D, opacities, shs=None, colors_precomp=None, 
                     viewmatrix, projmatrix, sh_degree, campos, near=0.001, dtype=torch.float64):
     """Returns (color[3,H,W], radii[P], aux dict).  All tensor args may require grad."""
     H, W = int(image_height), int(image_width)
-    cast = lambda t: None if t is None else t.to(dtype)
+    dev = means3D.device   # runs wherever its inputs live (plain torch ops: on the GPU box a HIP device makes the 4000-step runs feasible)
+    cast = lambda t: None if t is None else t.to(device=dev, dtype=dtype)
     means3D, means2D, opacities = cast(means3D), cast(means2D), cast(opacities)
     shs, colors_precomp, scales, rotations, cov3D_precomp = map(cast, (shs, colors_precomp, scales, rotations, cov3D_precomp))
     V = cast(torch.as_tensor(viewmatrix)).reshape(4, 4)
@@ -53,8 +54,8 @@ def rasterize_dense(means3D, means2D, opacities, shs=None, colors_precomp=None, 
     campos = cast(torch.as_tensor(campos)).reshape(3)
     P = means3D.shape[0]
     if P == 0:
-        return torch.zeros(3, H, W, dtype=dtype), torch.zeros(0, dtype=torch.int32), {}
-    ones = torch.ones(P, 1, dtype=dtype)
+        return torch.zeros(3, H, W, dtype=dtype, device=dev), torch.zeros(0, dtype=torch.int32, device=dev), {}
+    ones = torch.ones(P, 1, dtype=dtype, device=dev)
     ph = torch.cat([means3D, ones], 1)
     p_view = ph @ V[:, :3]          # row-vector convention
     p_hom = ph @ PM
@@ -118,9 +119,8 @@ def rasterize_dense(means3D, means2D, opacities, shs=None, colors_precomp=None, 
 
     # global order (depth asc, index asc) restricted per pixel by the tile gate == upstream's per-tile order
     depth = p_view[:, 2].detach().to(torch.float32).to(dtype)   # keys are fp32 depth bits upstream
-    order = sorted(range(P), key=lambda i: (float(depth[i]), i))
-    order = torch.tensor(order, dtype=torch.long)
-    ys, xs = torch.meshgrid(torch.arange(H, dtype=dtype), torch.arange(W, dtype=dtype), indexing="ij")
+    order = torch.sort(depth, stable=True).indices                 # stable: equal depths keep index order
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=dtype, device=dev), torch.arange(W, dtype=dtype, device=dev), indexing="ij")
     pix_x, pix_y = xs.reshape(-1, 1), ys.reshape(-1, 1)            # (Npix,1)
     tile_x, tile_y = torch.floor(pix_x / 16), torch.floor(pix_y / 16)
     o = order
@@ -143,7 +143,7 @@ def rasterize_dense(means3D, means2D, opacities, shs=None, colors_precomp=None, 
     C = w @ rgb[o]                                                  # (Npix,3)
     T_final = torch.where(keep, one_m, torch.ones_like(one_m)).prod(dim=1)
     out = (C + T_final[:, None] * bg[None]).t().reshape(3, H, W)
-    n_contrib = torch.where(keep, torch.arange(1, P + 1)[None].expand_as(keep), torch.zeros_like(keep, dtype=torch.long)).max(dim=1).values
+    n_contrib = torch.where(keep, torch.arange(1, P + 1, device=dev)[None].expand_as(keep), torch.zeros_like(keep, dtype=torch.long)).max(dim=1).values
     aux = dict(order=order, keep=keep, T_final=T_final.reshape(H, W), px=px, py=py, conic=torch.stack([conA, conB, conC], 1),
                rgb=rgb, depth=p_view[:, 2], vis=vis, n_pairs=int(keep.sum()), n_contrib_global=n_contrib.reshape(H, W))
     return out, radii, aux

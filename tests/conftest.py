@@ -25,3 +25,31 @@ def hip_lib():
     subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "das3r_amd", "csrc")])
     from das3r_amd import _lib
     return _lib.load()
+
+
+@pytest.fixture(autouse=True)
+def _switches_follow_env(monkeypatch):
+    """The library reads its DAS3R_* experiment switches once and again on das3r_reload_switches() (api.hip).  Tests flip them
+    through monkeypatch.setenv / delenv: forward those to the library when it is loaded, and start every test from the
+    environment as it is (the previous test's changes have been undone by then)."""
+    from das3r_amd import _lib
+
+    def reload():
+        if _lib._lib is not None:
+            _lib.reload_switches()
+
+    reload()
+    set0, del0 = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv(name, value, prepend=None):
+        set0(name, value, prepend)
+        if name.startswith("DAS3R_"):
+            reload()
+
+    def delenv(name, raising=True):
+        del0(name, raising)
+        if name.startswith("DAS3R_"):
+            reload()
+
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    yield

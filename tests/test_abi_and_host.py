@@ -38,7 +38,8 @@ def test_abi_version_and_layout(hip_lib):
     # struct sizes seen by ctypes must match what the header lays out (plain C ABI: ints, floats, pointers)
     assert ctypes.sizeof(_lib.RasterArgs) == 5 * 4 + 3 * 4 + 4 * 8 + 2 * 4 + 8
     assert ctypes.sizeof(_lib.RasterIn) == 7 * 8 and ctypes.sizeof(_lib.RasterGrads) == 9 * 8
-    assert ctypes.sizeof(_lib.RasterSaved) == 5 * 8
+    assert ctypes.sizeof(_lib.RasterSaved) == 5 * 8 + 8 + 8   # + check_word, check_tag (padded)
+    assert hip_lib.das3r_raster_check(ctypes.byref(_lib.RasterSaved()), None) == 0   # no ticket: nothing to check
 
 
 def test_invalid_arguments_are_reported_not_thrown(hip_lib):

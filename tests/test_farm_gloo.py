@@ -68,3 +68,55 @@ def test_single_process_gather():
 def test_heldout_split_rule():
     from das3r_amd.train import is_test_index
     assert [i for i in range(40) if is_test_index(i)] == [5, 15, 25, 35]
+
+
+def _worker_skewed(rank, world, port, n_seq, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = farm.assign(n_seq, rank, world, costs=[10, 1, 1, 1, 1])
+    recs = [dict(scene_id=s, psnr=30.0 + s, l1=0.0, iters_per_s=1.0, n_splats=1, ok=1) for s in mine]
+    table = farm.gather_records(recs, n_seq, torch.device("cpu"))
+    torch.save((mine, table), os.path.join(out_dir, f"skew_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_gather_records_keeps_every_record_of_a_skewed_assignment(tmp_path):
+    """the LPT assignment can give one rank more than ceil(n / world) sequences (costs [10,1,1,1,1] over 2 ranks: one
+    rank gets four); the gather must size its buffer by the largest rank and drop nothing."""
+    n_seq, world = 5, 2
+    mp.spawn(_worker_skewed, args=(world, _free_port(), n_seq, str(tmp_path)), nprocs=world, join=True)
+    (m0, t0), (m1, t1) = torch.load(tmp_path / "skew_0.pt"), torch.load(tmp_path / "skew_1.pt")
+    assert sorted(m0 + m1) == list(range(5)) and max(len(m0), len(m1)) == 4
+    assert torch.equal(t0, t1)
+    assert t0[:, 5].tolist() == [1.0] * 5 and t0[:, 1].tolist() == [30.0, 31.0, 32.0, 33.0, 34.0]
+
+
+def test_latex_rows_and_log_scraper(tmp_path):
+    """The two rows scripts/get_testing_psnr_davis.py:19-22 prints, and its scraper (:8-17): last number of the last line."""
+    from das3r_amd.train import latex_rows, scrape_test_logs
+    for scene, lines in (("bear_1", ["[ITER 2000] Evaluating test: L1 0.02 PSNR 21.5", "[ITER 4000] Evaluating test: L1 0.01 PSNR 24.25"]),
+                         ("car-turn", ["[ITER 4000] Evaluating test: L1 0.03 PSNR 19.75"])):
+        d = tmp_path / scene / "testing_pnsr_4000"
+        d.mkdir(parents=True)
+        (d / "test_log.txt").write_text("\n".join(lines) + "\n")
+    (tmp_path / "not_a_scene.txt").write_text("x")
+    res = scrape_test_logs(str(tmp_path), "testing_pnsr_4000")
+    assert res == {"bear_1": 24.25, "car-turn": 19.75}
+    head, row = latex_rows(res)
+    assert head == "Scene & bear-1 & car-turn& average"
+    assert row == "PSNR & 24.25 & 19.75 & 22.00 "
+
+
+def test_mask_resize_is_nearest_neighbour():
+    """scene/cameras.py:60-67: the ground-truth dynamic mask is repeated to 3 channels and nearest-resized to the render size."""
+    from das3r_amd.train import resize_mask_nearest
+    m = torch.zeros(4, 6, dtype=torch.bool)
+    m[1, 2] = m[3, 5] = True
+    out = resize_mask_nearest(m, 8, 12)
+    assert out.shape == (3, 8, 12) and out.dtype == torch.float32
+    assert torch.equal(out[0], out[1]) and torch.equal(out[0], out[2])
+    assert out[0].sum() == 8 and out[0, 2:4, 4:6].sum() == 4 and out[0, 6:8, 10:12].sum() == 4
+    down = resize_mask_nearest(m, 2, 3)       # source pixel = floor(dst * scale)
+    assert down[0].tolist() == [[0.0, 0.0, 0.0], [0.0, 0.0, 0.0]]

@@ -110,3 +110,115 @@ def test_gradient_consistency_between_colour_paths_c4():
     c2, _ = rast(means3D=scd.means3D, means2D=m2, opacities=scd.opacities, colors_precomp=col, scales=scd.scales, rotations=scd.rotations)
     c2.backward(scd.dL_dpix)
     util.assert_grad_close(g_sh.cpu().numpy(), sh0.grad.cpu().numpy(), "dL/dsh[0] via both colour paths", tol=1e-4)
+
+
+def test_c1_vs_oracle():
+    """BASELINE.json configs[0]: 10k random Gaussians, 256x256, SH degree 0 — the reference's "CPU-runnable plumbing" case, here
+    run on the HIP path (forward AND backward) against the CPU oracle."""
+    sc, scd, dev, Settings, Rasterizer = _setup("c1")
+    assert (sc.P, sc.W, sc.H, sc.sh_degree) == (10_000, 256, 256, 0)
+    mode = dict(colors_precomp=False, cov3D_precomp=False, scale_modifier=1.0)
+    ref_color, ref_radii, ref_g, S = util.run_oracle(sc, mode)
+    leaves = {k: getattr(scd, k).clone().requires_grad_() for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    m2 = torch.zeros(sc.P, 3, device=dev, requires_grad=True)
+    color, radii = Rasterizer(Settings(**scd.settings_kwargs()))(means2D=m2, **leaves)
+    color.backward(scd.dL_dpix)
+    torch.cuda.synchronize()
+    assert np.array_equal(radii.cpu().numpy(), ref_radii)
+    util.assert_color_close(color.detach().cpu().numpy(), ref_color, "c1 colour")
+    for k, t in leaves.items():
+        util.assert_grad_close(t.grad.cpu().numpy(), ref_g[k], f"c1 dL/d{k}")
+        util.assert_grad_elementwise(t.grad.cpu().numpy(), ref_g[k], f"c1 dL/d{k}")
+    util.assert_grad_close(m2.grad.cpu().numpy(), ref_g["means2D"], "c1 dL/dmeans2D")
+
+
+def test_densification_growth_small_vs_oracle():
+    """The densification stress of configs[3] (das3r_amd/densify.py) at a size the oracle handles: after every growth event
+    (P changes -> the library's shape cache resets, buffers are laid out again) image, radii and gradients still equal the
+    oracle's, and a speculative-capacity forward of the grown scene equals an exactly sized one bit for bit."""
+    from das3r_amd import GaussianRasterizationSettings, GaussianRasterizer
+    from das3r_amd.densify import GrowthSchedule, grow_top_gradient
+    from das3r_amd.rasterizer import _forward_full
+    from das3r_amd.synth import Scene, make_scene
+    dev = torch.device("cuda:0")
+    sc = make_scene(P=3000, W=160, H=96, focal=120.0, sh_degree=2, seed=41)
+    mode = dict(colors_precomp=False, cov3D_precomp=False, scale_modifier=1.0)
+    tensors = {k: getattr(sc, k).to(dev) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    sched = GrowthSchedule(sc.P, every=3)
+    gen = torch.Generator().manual_seed(3)
+    rs = GaussianRasterizationSettings(**sc.to(dev).settings_kwargs())
+    e = torch.empty(0, device=dev)
+    sizes, m2grad = [], None
+    for step in range(0, 22):
+        P = tensors["means3D"].shape[0]
+        if sched.due(step, P):
+            tensors = grow_top_gradient(tensors, m2grad, sched.frac_for(P), gen)
+            P = tensors["means3D"].shape[0]
+            sizes.append(P)
+        leaves = {k: v.clone().requires_grad_() for k, v in tensors.items()}
+        m2 = torch.zeros(P, 3, device=dev, requires_grad=True)
+        color, radii = GaussianRasterizer(rs)(means2D=m2, **leaves)
+        color.backward(sc.dL_dpix.to(dev))
+        m2grad = m2.grad
+        if step % 3 in (0, 1):   # the forward right after a growth event (exact sizing) and the next one (speculative capacity)
+            cpu = Scene(**{**sc.__dict__, **{k: v.detach().cpu() for k, v in tensors.items()}})
+            ref_color, ref_radii, ref_g, S = util.run_oracle(cpu, mode)
+            assert np.array_equal(radii.cpu().numpy(), ref_radii), step
+            util.assert_color_close(color.detach().cpu().numpy(), ref_color, f"step {step} colour")
+            for k, t in leaves.items():
+                util.assert_grad_close(t.grad.cpu().numpy(), ref_g[k], f"step {step} dL/d{k}")
+            exact = _forward_full(rs, tensors["means3D"], tensors["shs"], e, tensors["opacities"], tensors["scales"], tensors["rotations"], e, exact=True)
+            assert torch.equal(exact[1], color.detach()) and exact[0] == color.grad_fn.num_rendered
+    assert sizes[0] == 3150 and sizes[-1] == 3900 and all(b > a for a, b in zip(sizes, sizes[1:])), sizes
+
+
+def test_densification_growth_c4():
+    """configs[3] "densification on" at full size: 1M -> 1.3M splats in +5 % events.  Per event: num_rendered grows with P, the
+    first forward of the new shape is laid out exactly and the following ones speculatively, both give the same image bit for
+    bit, every gradient is finite and has the new shape, and the per-tile lists stay sorted."""
+    from das3r_amd import _lib
+    from das3r_amd.densify import GrowthSchedule, grow_top_gradient
+    from das3r_amd.rasterizer import _forward_full
+    sc, scd, dev, Settings, Rasterizer = _setup("c4")
+    rs = Settings(**scd.settings_kwargs())
+    tensors = {k: getattr(scd, k) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    sched = GrowthSchedule(sc.P, every=2)
+    gen = torch.Generator().manual_seed(11)
+    e = torch.empty(0, device=dev)
+    history, m2grad, step = [], None, 0
+    while True:
+        P = tensors["means3D"].shape[0]
+        if sched.due(step, P):
+            tensors = grow_top_gradient(tensors, m2grad, sched.frac_for(P), gen)
+            P = tensors["means3D"].shape[0]
+        elif step > 0 and step % 2 == 0:
+            break   # the target has been reached
+        leaves = {k: v.clone().requires_grad_() for k, v in tensors.items()}
+        m2 = torch.zeros(P, 3, device=dev, requires_grad=True)
+        color, radii = Rasterizer(rs)(means2D=m2, **leaves)
+        color.backward(scd.dL_dpix)
+        m2grad = m2.grad
+        for k, t in leaves.items():
+            assert t.grad.shape == t.shape and bool(torch.isfinite(t.grad).all()), (step, k)
+        I = color.grad_fn.num_rendered
+        if step % 2 == 0:
+            history.append((P, I))
+        else:   # second forward of this shape: speculative capacity; must equal an exactly sized forward
+            ex = _forward_full(rs, tensors["means3D"], tensors["shs"], e, tensors["opacities"], tensors["scales"], tensors["rotations"], e, exact=True)
+            assert ex[0] == I and torch.equal(ex[1], color.detach()), step
+            if P >= sched.limit:   # the final scene: per-tile lists sorted by (depth, index)
+                L = _lib.layout(P, ex[0], sc.W, sc.H)
+                tiles = ((sc.W + 15) // 16) * ((sc.H + 15) // 16)
+                rg = _view(ex[5], L["ranges"], torch.int32, 2 * tiles).reshape(tiles, 2).long()
+                pl = _view(ex[4], L["point_list"], torch.int32, ex[0]).long()
+                depth = _lib.splat_field(ex[3], L, "rgbd", P)[:, 3]
+                lens = rg[:, 1] - rg[:, 0]
+                assert int(lens.sum()) == ex[0]
+                tile_of = torch.repeat_interleave(torch.arange(tiles, device=dev), lens)
+                d = depth[pl]
+                same = tile_of[1:] == tile_of[:-1]
+                assert bool((((d[1:] > d[:-1]) | ((d[1:] == d[:-1]) & (pl[1:] > pl[:-1]))) | ~same).all())
+        step += 1
+    Ps, Is = [h[0] for h in history], [h[1] for h in history]
+    assert Ps[0] == 1_000_000 and Ps[-1] == 1_300_000 and len(Ps) == 7, Ps
+    assert all(b > a for a, b in zip(Is, Is[1:])), Is

@@ -51,6 +51,7 @@ def test_forward_backward_vs_oracle(name):
     for k, t in g.items():
         assert t is not None, f"no gradient for {k}"
         util.assert_grad_close(t.cpu().numpy(), ref_g[gmap[k]], f"{name} dL/d{k}")
+        util.assert_grad_elementwise(t.cpu().numpy(), ref_g[gmap[k]], f"{name} dL/d{k}")
     # viewspace gradient convention: z component stays zero
     assert float(g["means2D"][:, 2].abs().max()) == 0.0
 
@@ -288,20 +289,72 @@ def test_forward_kernels_agree_bit_for_bit(name, monkeypatch):
         util.assert_grad_close(gr[k].cpu().numpy(), gq[k].cpu().numpy(), f"rows vs quad forward dL/d{k}", tol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["basic_deg3", "long_lists", "deep", "culled", "ragged_image"])
+@pytest.mark.parametrize("name", ["basic_deg3", "long_lists", "deep", "culled", "ragged_image", "deg1", "single"])
 def test_backward_kernels_agree(name, monkeypatch):
-    """The two backward compositing kernels (cross-lane DPP reduction of the nine per-pair sums / moments reduced on the
-    matrix cores, render_bwd_mfma.hip) against each other; each of them is also checked against the oracle when selected
-    (DAS3R_RENDER_BWD=mfma python -m pytest tests -m gpu).  fp32 tolerance: the MFMA kernel sums moments about the tile centre."""
+    """The backward compositing kernels against each other: pixel per lane with the cross-lane DPP reduction of the nine per-pair
+    sums (render_bwd.hip), the same with the moments reduced on the matrix cores through an LDS slab (render_bwd_mfma.hip), and
+    lanes = 4 pixels x 16 splats with DPP row scans for the recurrences (render_bwd_scan.hip, 256- and 128-entry batches).  Each
+    is also checked against the oracle when selected (the default one in every other test; DAS3R_RENDER_BWD=... python -m pytest
+    tests -m gpu for the others).  fp32 tolerance: the matrix-core kernels sum moments about the tile centre."""
     sc, mode = util.scene_variant(name)
     out = {}
-    for kind in ("dpp", "mfma"):
+    for kind in ("dpp", "mfma", "scan", "scan128"):
         monkeypatch.setenv("DAS3R_RENDER_BWD", kind)
         c, r, g, fn = _run_hip(sc, mode)
         out[kind] = (c, g)
-    assert torch.equal(out["dpp"][0], out["mfma"][0])
-    for k in out["dpp"][1]:
-        util.assert_grad_close(out["mfma"][1][k].cpu().numpy(), out["dpp"][1][k].cpu().numpy(), f"mfma vs dpp backward dL/d{k}", tol=2e-5)
+    for kind in ("mfma", "scan", "scan128"):
+        assert torch.equal(out["dpp"][0], out[kind][0])
+        for k in out["dpp"][1]:
+            util.assert_grad_close(out[kind][1][k].cpu().numpy(), out["dpp"][1][k].cpu().numpy(), f"{kind} vs dpp backward dL/d{k}", tol=2e-5)
+
+
+@pytest.mark.parametrize("kind", ["dpp", "mfma", "scan", "scan128"])
+@pytest.mark.parametrize("name", ["basic_deg3", "long_lists", "deep"])
+def test_every_backward_kernel_vs_oracle(name, kind, monkeypatch):
+    """Each backward compositing kernel on its own against the CPU oracle (the default one is covered on all variants above)."""
+    monkeypatch.setenv("DAS3R_RENDER_BWD", kind)
+    sc, mode = util.scene_variant(name)
+    _, _, ref_g, _ = util.run_oracle(sc, mode)
+    _, _, g, _ = _run_hip(sc, mode)
+    gmap = {"means3D": "means3D", "opacities": "opacities", "shs": "shs", "scales": "scales", "rotations": "rotations", "means2D": "means2D"}
+    for k, t in g.items():
+        util.assert_grad_close(t.cpu().numpy(), ref_g[gmap[k]], f"{name} [{kind}] dL/d{k}")
+
+
+def test_failed_binning_is_reported_before_the_backward_pass(monkeypatch):
+    """A forward whose binning kernels fail their self-check (here: a look-back timeout forced into the word the last binning
+    kernel hands to the host, DAS3R_INJECT_FAULT) must not get as far as a parameter update: the backward pass examines the
+    forward's word before it launches anything and raises; `check_forward` does the same for callers without a backward; a debug
+    forward raises by itself.  The next clean forward works again."""
+    from das3r_amd import GaussianRasterizationSettings, GaussianRasterizer
+    from das3r_amd.rasterizer import _forward_full, check_forward
+    dev = _dev()
+    sc, mode = util.scene_variant("basic_deg3")
+    scd = sc.to(dev)
+    rs = GaussianRasterizationSettings(**scd.settings_kwargs())
+    e = torch.empty(0, device=dev)
+
+    def fwd_bwd(settings):
+        m3 = scd.means3D.clone().requires_grad_()
+        m2 = torch.zeros(sc.P, 3, device=dev, requires_grad=True)
+        color, _ = GaussianRasterizer(settings)(means3D=m3, means2D=m2, opacities=scd.opacities, shs=scd.shs, scales=scd.scales,
+                                                rotations=scd.rotations)
+        (color * scd.dL_dpix).sum().backward()
+        return m3.grad
+
+    good = fwd_bwd(rs)
+    monkeypatch.setenv("DAS3R_INJECT_FAULT", "1")   # ERR_TIMEOUT
+    with pytest.raises(RuntimeError, match="self-check"):
+        fwd_bwd(rs)                                  # the forward returns, the backward refuses
+    out = _forward_full(rs, scd.means3D, scd.shs, e, scd.opacities, scd.scales, scd.rotations, e)
+    with pytest.raises(RuntimeError, match="self-check"):
+        check_forward(out[6], dev)                   # explicit check of a forward without a backward
+    with pytest.raises(RuntimeError, match="self-check"):
+        fwd_bwd(rs._replace(debug=True))             # debug: the forward itself waits for the word
+    monkeypatch.delenv("DAS3R_INJECT_FAULT")
+    for _ in range(20):                              # every slot of the self-check ring is examined and reused cleanly
+        again = fwd_bwd(rs)
+    assert torch.allclose(again, good, rtol=1e-4, atol=1e-9)
 
 
 @pytest.mark.parametrize("render", ["quad", "rows"])

@@ -1,0 +1,190 @@
+"""GPU parity of the optimisation step and the PSNR stand-in for BASELINE.json configs[2] / [4].
+
+The Sintel / DAVIS sequences are not available offline.  Stand-in: the SAME optimisation is run twice on the same tiny
+synthetic sequence — with the product (HIP rasterizer through das3r_amd.train.train_step, fp32) and with an independent
+float64 restatement (oracle/dense_trainer.py: dense autograd rasterizer, its own pre-transform, loss, schedules; torch.optim.Adam
+on float64 parameters) — and compared: loss and every gradient of one step, every parameter after the first Adam steps, and,
+after the reference's full schedule (4000 iterations, SH degree raised at 3000, train_gui.py:542-589), the held-out PSNR within
+the +-0.3 dB SURVEY.md C11 asks for on market_2."""
+import copy
+import math
+import os
+import random
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+PIPE = SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
+
+
+def _pair(frames, W, H, seed, heldout, iterations, fused=False, generic=False):
+    """-> (HIP model, train cams, test cams, dense trainer) initialised from the same sequence.  generic: leave DAS3R's initial
+    state (every Gaussian isotropic with an identity quaternion, where dL/d(rotation) is rounding noise around an exact zero that
+    Adam's sign-like first steps amplify) for anisotropic scales and random rotations."""
+    from das3r_amd.model import OptimParams
+    from das3r_amd.train import build_from_sequence, synthetic_sequence
+    from oracle.dense_trainer import DenseTrainer
+    seq = synthetic_sequence(frames=frames, W=W, H=H, focal=0.9 * W, n_splats=1500, seed=seed)
+    if heldout:
+        model, cams, test = build_from_sequence(copy.deepcopy(seq), heldout=True)
+    else:
+        (model, cams), test = build_from_sequence(copy.deepcopy(seq)), []
+    if generic:
+        gen = torch.Generator().manual_seed(7 + seed)
+        with torch.no_grad():
+            model._scaling += 0.4 * torch.randn(model._scaling.shape, generator=gen).cuda()
+            model._rotation.copy_(torch.nn.functional.normalize(torch.randn(model._rotation.shape, generator=gen)).cuda())
+    opt = OptimParams(iterations=iterations)
+    model.training_setup(opt, fused=fused)
+    params = dict(xyz=model._xyz, f_dc=model._features_dc, f_rest=model._features_rest, opacity=model._opacity, scaling=model._scaling,
+                  rotation=model._rotation, conf_static=model._conf_static, Q=model.Q, T=model.T, mask=model.aggregated_mask)
+    cameras = [dict(gt=c.original_image, fovx=c.FoVx, fovy=c.FoVy, proj_T=c.projection_matrix) for c in cams]
+    return model, cams, test, opt, DenseTrainer(params, cameras, iterations=iterations)
+
+
+NAMES = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity", "scaling": "_scaling",
+         "rotation": "_rotation", "conf_static": "_conf_static", "Q": "Q", "T": "T"}
+
+
+def test_one_step_loss_and_gradients_match_the_float64_restatement():
+    """Loss, frame PSNR and EVERY gradient of one iteration (render -> masked L1 + SSIM -> backward) against the float64 dense
+    restatement.  fp32 tolerance: 2e-3 of the tensor's largest gradient, and element-wise 1e-2 |ref| + 1e-4 max|ref|."""
+    from das3r_amd.losses import l1_loss, psnr, ssim
+    from das3r_amd.render import das3r_render
+    model, cams, _, opt, dense = _pair(frames=3, W=32, H=24, seed=3, heldout=False, iterations=100, generic=True)
+    bg = torch.zeros(3, device="cuda")
+    uid = 1
+    pkg = das3r_render(cams[uid], model, PIPE, bg, camera_pose=model.get_RT(uid))
+    static = model._conf_static[uid]
+    image, gt = pkg["render"] * static, cams[uid].original_image * static
+    loss = ((1.0 - opt.lambda_dssim) * l1_loss(image, gt, reduce=False) + opt.lambda_dssim * (1.0 - ssim(image, gt, size_average=False))).mean()
+    loss.backward()
+    d_loss, d_psnr, d_m2d = dense.loss_of(uid, bg.double())
+    d_loss.backward()
+    assert abs(float(loss) - float(d_loss)) <= 2e-5 * abs(float(d_loss)) + 1e-7, (float(loss), float(d_loss))
+    assert abs(float(psnr(image, gt).mean()) - float(d_psnr)) < 1e-3
+    pairs = [(k, getattr(model, NAMES[k]).grad, dense.p[k].grad) for k in NAMES] + [("means2D", pkg["viewspace_points"].grad, d_m2d.grad)]
+    for k, g, r in pairs:
+        if k == "f_rest":   # active degree 0: no gradient reaches the higher-order coefficients on either side
+            assert (g is None or float(g.abs().max()) == 0.0) and (r is None or float(r.abs().max()) == 0.0)
+            continue
+        assert g is not None and r is not None, k
+        g, r = g.double().reshape(-1), r.reshape(-1)
+        scale = float(r.abs().max())
+        assert scale > 0, k
+        assert float((g - r).abs().max()) <= 2e-3 * scale, (k, float((g - r).abs().max()) / scale)
+        bad = (g - r).abs() > 1e-2 * r.abs() + 1e-4 * scale
+        assert float(bad.double().mean()) <= 1e-3, (k, float(bad.double().mean()))
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_first_adam_steps_match_the_float64_restatement(fused):
+    """Parameters after each of the first iterations (same camera order), both for the reference's PyTorch glue around the HIP
+    rasterizer and for the opt-in fused kernels.  The first bias-corrected Adam step moves every element by lr * sign(grad)
+    (eps = 1e-15), so a gradient at fp32 noise level can land on the other side: an element may differ when its float64
+    gradient is below 1e-3 of the tensor's largest, and at most 1 % of a tensor may."""
+    model, cams, _, opt, dense = _pair(frames=3, W=32, H=24, seed=4, heldout=False, iterations=100, fused=fused, generic=True)
+    from das3r_amd.train import train_step
+    bg = torch.zeros(3, device="cuda")
+    order = [0, 2, 1, 0]
+    for it, uid in enumerate(order, start=1):
+        loss, ps, _ = train_step(model, cams[uid], opt, it, PIPE, bg, fused=fused)
+        d_loss, d_ps = dense.step(it, uid, bg.double())
+        assert abs(float(loss) - d_loss) <= 1e-3 * abs(d_loss), (it, float(loss), d_loss)
+        lrs = {g["name"]: g["lr"] for g in dense.opt.param_groups}
+        lrs.update({"Q": dense.opt_cam.param_groups[0]["lr"], "T": dense.opt_cam.param_groups[1]["lr"]})
+        for k, attr in NAMES.items():
+            if k in ("Q", "T") and d_ps <= opt.psnr_threshold:
+                continue
+            a, b = getattr(model, attr).detach().double().reshape(-1), dense.p[k].detach().reshape(-1)
+            lr = lrs[k]
+            far = (a - b).abs() > 0.1 * lr * it
+            assert float(far.double().mean()) <= 1e-2, (it, k, float(far.double().mean()))
+            if it == 1 and dense.p[k].grad is not None and bool(far.any()):
+                g = dense.p[k].grad.reshape(-1).abs()
+                assert float(g[far].max()) <= 1e-3 * float(g.max()), (k, float(g[far].max()) / float(g.max()))
+
+
+def test_full_schedule_psnr_matches_the_float64_restatement():
+    """Stand-in for configs[2] / [4]: 4000 iterations (DAS3R_STANDIN_ITERS overrides), SH degree raised at 3000, random camera
+    without replacement per epoch (train_gui.py:546-555), one held-out view ((idx + 5) % 10 == 0) built from neither its pixels
+    nor its pose.  HIP fp32 vs dense float64: final held-out PSNR within 0.3 dB, the training PSNR of the last epoch within
+    0.3 dB, early losses within 1e-3."""
+    from das3r_amd.train import psnr_report, train_step
+    iters = int(os.environ.get("DAS3R_STANDIN_ITERS", "4000"))
+    model, cams, test, opt, dense = _pair(frames=12, W=32, H=24, seed=5, heldout=True, iterations=iters)
+    assert len(cams) == 11 and len(test) == 1 and test[0].frame_index == 5
+    assert model.get_xyz.shape[0] == 11 * 32 * 24          # the held-out frame's pixels seed no Gaussians
+    bg = torch.zeros(3, device="cuda")
+    rng, stack = random.Random(0), []
+    hip_tail, dense_tail = [], []
+    for it in range(1, iters + 1):
+        if not stack:
+            stack = list(range(len(cams)))
+        uid = stack.pop(rng.randint(0, len(stack) - 1))
+        loss, ps, _ = train_step(model, cams[uid], opt, it, PIPE, bg)
+        d_loss, d_ps = dense.step(it, uid, bg.double())
+        if it <= 10:
+            assert abs(float(loss) - d_loss) <= 1e-3 * abs(d_loss), (it, float(loss), d_loss)
+        if it > iters - len(cams):
+            hip_tail.append(float(ps))
+            dense_tail.append(d_ps)
+    assert model.active_sh_degree == dense.active_deg == (1 if iters >= 3000 else 0)
+    rep = psnr_report(model, test, test_poses=True)
+    d_psnr, _ = dense.heldout_psnr(test[0].original_image, model.get_RT_test(0).detach(), 0, bg.double())
+    train_h, train_d = sum(hip_tail) / len(hip_tail), sum(dense_tail) / len(dense_tail)
+    msg = f"held-out PSNR hip {rep['psnr']:.3f} dense {d_psnr:.3f}; last-epoch train PSNR hip {train_h:.3f} dense {train_d:.3f}"
+    print(msg)
+    assert math.isfinite(rep["psnr"]) and rep["views"] == 1
+    assert abs(rep["psnr"] - d_psnr) <= 0.3, msg
+    assert abs(train_h - train_d) <= 0.3, msg
+
+
+def test_heldout_report_semantics(tmp_path):
+    """train_test_psnr.py:241-302: the mask is nearest-resized to the render size and applied to both images, only views WITH a
+    mask count, the line appended to test_log.txt has the reference's wording."""
+    from das3r_amd.losses import psnr
+    from das3r_amd.render import das3r_render
+    from das3r_amd.train import build_from_sequence, psnr_report, resize_mask_nearest, synthetic_sequence
+    seq = synthetic_sequence(frames=16, W=48, H=32, focal=44.0, n_splats=1500, seed=6)
+    model, cams, test = build_from_sequence(seq, heldout=True)
+    assert [c.frame_index for c in test] == [5, 15] and [c.uid for c in test] == [0, 1]
+    bg = torch.zeros(3, device="cuda")
+    m = torch.zeros(16, 24, dtype=torch.bool, device="cuda")     # half resolution: must be resized
+    m[4:12, 6:18] = True
+    rep = psnr_report(model, test, dynamic_masks={0: m, 1: None}, test_poses=True, iteration=4000, log_dir=str(tmp_path))
+    assert rep["views"] == 1 and rep["skipped"] == 1
+    img = das3r_render(test[0], model, PIPE, bg, camera_pose=model.get_RT_test(0))["render"].clamp(0, 1)
+    static = 1 - resize_mask_nearest(m, 32, 48)
+    want = float(psnr(img * static, test[0].original_image.clamp(0, 1) * static).mean())
+    assert abs(rep["psnr"] - want) < 1e-4
+    line = (tmp_path / "test_log.txt").read_text()
+    assert line == f"[ITER 4000] Evaluating test: L1 {rep['l1']} PSNR {rep['psnr']}\n"
+    both = psnr_report(model, test, test_poses=True)             # no masks at all: every view counts, unmasked
+    assert both["views"] == 2 and both["skipped"] == 0
+    none = psnr_report(model, test, dynamic_masks={0: None, 1: None}, test_poses=True)
+    assert none["views"] == 0 and math.isnan(none["psnr"])
+
+
+def test_optimizer_groups_mirror_the_reference():
+    """scene/gaussian_model.py:236-268: seven Gaussian groups, camera optimizer = pose_Q, pose_T, fovX, fovY (the FoV groups never
+    receive a gradient: no state is ever created for them), a test-pose optimizer that exists and is never stepped."""
+    from das3r_amd.model import OptimParams
+    from das3r_amd.train import build_from_sequence, synthetic_sequence, train_step
+    seq = synthetic_sequence(frames=12, W=32, H=24, focal=30.0, n_splats=800, seed=7)
+    model, cams, test = build_from_sequence(seq, heldout=True)
+    opt = OptimParams(iterations=50)
+    model.training_setup(opt)
+    assert [g["name"] for g in model.optimizer.param_groups] == ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "conf_static"]
+    assert [g["name"] for g in model.optimizer_cam.param_groups] == ["pose_Q", "pose_T", "fovX", "fovY"]
+    assert [g["lr"] for g in model.optimizer_cam.param_groups][2:] == [0.0001, 0.0001]
+    assert [g["name"] for g in model.optimizer_cam_test.param_groups] == ["test_pose_Q", "test_pose_T"]
+    bg = torch.zeros(3, device="cuda")
+    for it in range(1, 4):
+        train_step(model, cams[it], opt, it, PIPE, bg)
+    assert model.FoVx.grad is None and model.FoVx not in model.optimizer_cam.state and model.FoVy not in model.optimizer_cam.state
+    assert len(model.optimizer_cam_test.state) == 0
+    assert abs(float(model.FoVx) - cams[0].FoVx) < 1e-7

@@ -34,6 +34,7 @@ def main():
                 k, v = kv.split("=")
                 saved_env[k] = os.environ.get(k)
                 os.environ[k] = v
+            _lib.reload_switches()
 
             def step():
                 I, color, radii, geom, binning, img, cap = _forward_full(rs, sc.means3D, sc.shs, e, sc.opacities, sc.scales, sc.rotations, e)
@@ -66,6 +67,7 @@ def main():
                     os.environ.pop(k, None)
                 else:
                     os.environ[k] = v
+            _lib.reload_switches()
 
 
 if __name__ == "__main__":

@@ -99,6 +99,7 @@ def main():
     g_ref = o.backward(sc.dL_dpix.numpy())
     for mode in ("dpp", "shfl"):
         os.environ["DAS3R_BWD_REDUCE"] = mode
+        _lib.reload_switches()
         out = _backward_impl(rs, I, scd.dL_dpix, scd.means3D, scd.shs, e, scd.opacities, scd.scales, scd.rotations, e, geom, binning, img)
         torch.cuda.synchronize()
         g_means2D, g_colors, g_opac, g_means3D, g_cov, g_sh, g_scales, g_rot = out

@@ -30,12 +30,14 @@ def main():
     P = sc.P
     tiles = ((sc.W + 15) // 16) * ((sc.H + 15) // 16)
     os.environ["DAS3R_SORT"] = "classic"
+    _lib.reload_switches()
     I0, _, _, geom0, binning0, img0 = _forward_impl(rs, sc.means3D, sc.shs, e, sc.opacities, sc.scales, sc.rotations, e)
     L0 = _lib.layout(P, I0, sc.W, sc.H)
     ref_sidx = _view(geom0, L0["sorted_idx"], torch.int32, P).clone()
     ref_pl = _view(binning0, L0["point_list"], torch.int32, I0).clone()
     ref_rg = _view(img0, L0["ranges"], torch.int32, 2 * tiles).clone()
     del os.environ["DAS3R_SORT"]
+    _lib.reload_switches()
     import time
     for it in range(args.iters):
         torch.cuda.synchronize(); t0 = time.perf_counter()
