@@ -48,7 +48,7 @@ class RasterLayout(C.Structure):
 
 
 # every symbol include/das3r_raster.h declares
-EXPORTS = ("das3r_raster_forward", "das3r_raster_backward", "das3r_raster_check", "das3r_mark_visible", "das3r_knn3_workspace_bytes",
+EXPORTS = ("das3r_raster_forward", "das3r_raster_backward", "das3r_raster_check", "das3r_raster_backward_scratch_bytes", "das3r_mark_visible", "das3r_knn3_workspace_bytes",
            "das3r_knn3_mean_dist2", "das3r_raster_get_layout", "das3r_abi_version", "das3r_last_error", "das3r_reload_switches", "das3r_get_stats",
            "das3r_profile_enable", "das3r_profile_report", "das3r_pretransform_forward", "das3r_pretransform_backward", "das3r_pose_matrices", "das3r_pose_chain",
            "das3r_adam_step", "das3r_adam_step_gated", "das3r_photometric_blocks", "das3r_photometric_forward", "das3r_photometric_backward")
@@ -79,6 +79,8 @@ def load():
     L.das3r_raster_backward.restype = C.c_int
     L.das3r_raster_backward.argtypes = [C.POINTER(RasterArgs), C.POINTER(RasterIn), C.POINTER(RasterSaved), C.c_void_p,
                                         C.POINTER(RasterGrads), C.c_void_p]
+    L.das3r_raster_backward_scratch_bytes.restype = C.c_size_t
+    L.das3r_raster_backward_scratch_bytes.argtypes = [C.c_int64]
     L.das3r_raster_check.restype = C.c_int
     L.das3r_raster_check.argtypes = [C.POINTER(RasterSaved), C.c_void_p]
     L.das3r_mark_visible.restype = C.c_int

@@ -53,7 +53,14 @@ static void load_switches() {
     w.fused_emit_off = (e = env("DAS3R_FUSED_EMIT")) && e[0] == '0';
     w.no_sh_stage = getenv("DAS3R_NO_SH_STAGE") != nullptr;
     if ((e = env("DAS3R_RENDER"))) w.render_fwd = e[0] == 'q' ? 1 : (e[0] == 'r' ? 2 : 0);
-    if ((e = env("DAS3R_RENDER_BWD"))) w.render_bwd = e[0] == 'd' ? 1 : (e[0] == 'm' ? 2 : (e[0] == 's' ? (strstr(e, "128") ? 4 : 3) : 0));
+    if ((e = env("DAS3R_RENDER_BWD"))) {   // dpp | mfma | scan[a][64|128|256|512]
+        w.render_bwd = e[0] == 'd' ? 1 : (e[0] == 'm' ? 2 : (strncmp(e, "stream", 6) == 0 ? 5 : (e[0] == 's' ? 3 : 0)));
+        if (w.render_bwd == 3) {
+            const char *d = e;
+            while (*d && (*d < '0' || *d > '9')) d++;
+            w.render_bwd_mb = (*d ? atoi(d) : 256) + (strncmp(e, "scana", 5) == 0 ? 1000 : 0);
+        }
+    }
     if ((e = env("DAS3R_BWD_REDUCE"))) { w.bwd_reduce_set = true; w.bwd_reduce_shfl = e[0] == 's'; }
     if ((e = env("DAS3R_ABLATE"))) { w.ablate_set = true; w.ablate = atoi(e); }
     w.tickets = -1;
@@ -264,11 +271,16 @@ static int examine_check_slot(volatile uint32_t *slot, uint32_t tag, bool wait, 
     }
     if (seen != tag) return 1;
     const uint32_t all_flags = slot[0], flags = all_flags & ~16u;
+    if (all_flags & 0x80000000u) return DAS3R_OK;   // this forward's failure has been reported already (by the backward pass / das3r_raster_check)
     stat_add(1);
     if (all_flags & 16u) stat_add(2);
     if (flags) stat_add(3);
     if ((all_flags & 16u) && switches().verbose) fprintf(stderr, "das3r: a look-back poll needed the read-modify-write path\n");
-    if (flags) { set_error("a forward's binning failed its self-check (flags 0x%x); its output is invalid", flags); return DAS3R_ERR_HIP; }
+    if (flags) {
+        slot[0] = all_flags | 0x80000000u;   // reported once: the thread that made the forward will not report it again at its next call
+        set_error("a forward's binning failed its self-check (flags 0x%x); its output is invalid", flags);
+        return DAS3R_ERR_HIP;
+    }
     return DAS3R_OK;
 }
 
@@ -504,11 +516,17 @@ extern "C" int das3r_raster_backward(const das3r_raster_args *a, const das3r_ras
     compute_layout(P, saved->capacity > 0 ? saved->capacity : saved->num_rendered, a->image_width, a->image_height, &L);
     // scratch = per-instance partial sums [num_rendered, 9]; no accumulator needs zeroing (no atomics anywhere)
     float *partial = g->scratch;
+    bool quad_rows = false;
     if (saved->num_rendered > 0) {
         if (!saved->binning) { set_error("das3r_raster_backward: binning buffer missing"); return DAS3R_ERR_INVALID_ARG; }
-        if ((rc = launch_render_backward(a, dL_dpix, saved->geom, saved->binning, saved->img, L, partial, s))) return rc;
+        if ((rc = launch_render_backward(a, dL_dpix, saved->geom, saved->binning, saved->img, L, partial, s, &quad_rows))) return rc;
     }
-    return launch_preprocess_backward(a, in, saved->geom, saved->binning, L, g, partial, s);
+    return launch_preprocess_backward(a, in, saved->geom, saved->binning, L, g, partial, s, quad_rows);
+}
+
+extern "C" size_t das3r_raster_backward_scratch_bytes(int64_t capacity) {
+    const size_t c = capacity > 0 ? (size_t)capacity : 1;
+    return std::max(c * 9 * sizeof(float), stream_scratch_bytes(capacity));
 }
 
 extern "C" int das3r_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,

@@ -28,7 +28,8 @@ struct Switches {
     bool fused_emit_off;   // DAS3R_FUSED_EMIT=0
     bool no_sh_stage;      // DAS3R_NO_SH_STAGE
     int render_fwd;        // DAS3R_RENDER=quad | rows: 1 | 2 (0: by list length)
-    int render_bwd;        // DAS3R_RENDER_BWD=dpp | mfma | scan | scan128: 1 | 2 | 3 | 4 (0: by list length)
+    int render_bwd;        // DAS3R_RENDER_BWD=dpp | mfma | scan... | stream: 1 | 2 | 3 | 5 (0: by list length)
+    int render_bwd_mb;     // scan64 / scan128 / scan256: entries per round; scana256 / scana512: 1000 + entries, atomic flush
     bool bwd_reduce_set, bwd_reduce_shfl;   // DAS3R_BWD_REDUCE=shfl | dpp (reference reduction of the pixel-per-lane kernel)
     bool ablate_set;       // DAS3R_ABLATE (perf experiments on the pixel-per-lane kernel)
     int ablate;
@@ -175,6 +176,10 @@ int launch_render_forward_rows(const das3r_raster_args *a, float *out_color, cha
                                const LocalBin &lb, hipStream_t s);
 int launch_render_backward_mfma(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
                                 float *partial, hipStream_t s);
+// independent waves (render_bwd_stream.hip): scratch = rows[capacity][4][12] + one byte per row that exists
+size_t stream_scratch_bytes(int64_t capacity);
+int launch_render_backward_stream(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
+                                  float *scratch, hipStream_t s);
 int launch_render_backward_scan(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
                                 float *partial, int mb, hipStream_t s);
 constexpr int LOCAL_MAX = 1024;   // longest tile list the forward kernels sort in LDS
@@ -191,10 +196,11 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
 int launch_render_forward(const das3r_raster_args *a, const float *colors_precomp, float *out_color, char *geom, char *binning,
                           char *img, const Layout &L, const LocalBin &lb, hipStream_t s);
 // partial: [num_rendered, 9] per-instance sums written by the render backward, gathered by the preprocess backward
+// *quad_rows (out): false = partial[I][9], one row per instance; true = the stream kernel's rows[I][4][12] + existence bytes
 int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
-                           float *partial, hipStream_t s);
+                           float *partial, hipStream_t s, bool *quad_rows);
 int launch_preprocess_backward(const das3r_raster_args *a, const das3r_raster_in *in, char *geom, char *binning, const Layout &L,
-                               const das3r_raster_grads *g, const float *partial, hipStream_t s);
+                               const das3r_raster_grads *g, const float *partial, hipStream_t s, bool quad_rows);
 
 // ---- device helpers ----
 #ifdef __HIPCC__

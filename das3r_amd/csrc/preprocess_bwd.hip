@@ -76,7 +76,8 @@ __global__ void __launch_bounds__(256, 3) preprocess_backward_kernel(
     const float *__restrict__ rotations, const float *__restrict__ shs, const float *__restrict__ cov3D_precomp,
     const float *__restrict__ viewmatrix, const float *__restrict__ projmatrix, const float *__restrict__ campos, int W, int H,
     float tanfovx, float tanfovy, const uint32_t *__restrict__ tiles_touched, const uint8_t *__restrict__ clamped,
-    const float *__restrict__ partial /*[I,9], row = emission slot*/, const uint32_t *__restrict__ off_by_gid,
+    const float *__restrict__ partial /*[I,9], row = emission slot — or, with row_exists, [I][4][12]: a row per (instance, quadrant)*/,
+    const uint8_t *__restrict__ row_exists /*[I][4] or null*/, const uint32_t *__restrict__ off_by_gid,
     float *__restrict__ dL_dmeans2D /*[P,3] out*/, float *__restrict__ dL_dopacity /*[P] out*/,
     float *__restrict__ dL_dcolors_precomp /*[P,3] out, precomp mode*/, float *__restrict__ dL_dmeans3D,
     float *__restrict__ dL_dscales, float *__restrict__ dL_drot, float *__restrict__ dL_dsh, float *__restrict__ dL_dcov3D) {
@@ -106,10 +107,27 @@ __global__ void __launch_bounds__(256, 3) preprocess_backward_kernel(
         for (int q = 0; q < 9; q++) acc[q] = 0.f;
         if (visible) {
             const uint32_t e0 = off_by_gid[idx];
-            for (uint32_t k = 0; k < ntiles_g; k++) {
-                const float *row = partial + (size_t)(e0 + k) * 9;   // rows are indexed by emission slot: contiguous per splat
+            if (row_exists) {   // render_bwd_stream.hip: up to four 48-byte rows per instance, one per quadrant of the tile that met the splat
+                for (uint32_t k = 0; k < ntiles_g; k++) {
+                    const uint32_t have = *reinterpret_cast<const uint32_t *>(row_exists + (size_t)(e0 + k) * 4);
 #pragma unroll
-                for (int q = 0; q < 9; q++) acc[q] += row[q];
+                    for (int w = 0; w < 4; w++) {
+                        if ((have >> (8 * w)) & 0xffu) {
+                            const float4 *row = reinterpret_cast<const float4 *>(partial + ((size_t)(e0 + k) * 4 + w) * 12);
+                            const float4 r0 = row[0], r1 = row[1];
+                            const float r2 = reinterpret_cast<const float *>(row)[8];
+                            acc[0] += r0.x; acc[1] += r0.y; acc[2] += r0.z; acc[3] += r0.w;
+                            acc[4] += r1.x; acc[5] += r1.y; acc[6] += r1.z; acc[7] += r1.w;
+                            acc[8] += r2;
+                        }
+                    }
+                }
+            } else {
+                for (uint32_t k = 0; k < ntiles_g; k++) {
+                    const float *row = partial + (size_t)(e0 + k) * 9;   // rows are indexed by emission slot: contiguous per splat
+#pragma unroll
+                    for (int q = 0; q < 9; q++) acc[q] += row[q];
+                }
             }
         }
         dL_dmeans2D[3 * (size_t)idx] = acc[3];
@@ -337,18 +355,20 @@ __global__ void __launch_bounds__(256, 3) preprocess_backward_kernel(
 }
 
 int launch_preprocess_backward(const das3r_raster_args *a, const das3r_raster_in *in, char *geom, char *binning, const Layout &L,
-                               const das3r_raster_grads *g, const float *partial, hipStream_t s) {
+                               const das3r_raster_grads *g, const float *partial, hipStream_t s, bool quad_rows) {
     const int P = a->P;
     if (P == 0) return DAS3R_OK;
     dim3 grid(div_up(P, 256)), block(256);
     const bool has_sh = in->shs != nullptr, has_cov = in->cov3D_precomp != nullptr;
     const bool nostage = switches().no_sh_stage;
+    const size_t cap_rows = L.capacity > 0 ? (size_t)L.capacity : 1;
+    const uint8_t *exists = quad_rows ? reinterpret_cast<const uint8_t *>(partial) + align_up(cap_rows * 4 * 12 * sizeof(float)) : nullptr;
     const bool stage_out = has_sh && a->M == 16 && ((uintptr_t)g->dL_dshs & 15) == 0 && !nostage;
     const bool stage_in = stage_out && a->sh_degree >= 2 && ((uintptr_t)in->shs & 15) == 0;
 #define ARGS                                                                                                                 \
     P, a->sh_degree, a->M, in->means3D, in->scales, a->scale_modifier, in->rotations, in->shs, in->cov3D_precomp,            \
         a->viewmatrix, a->projmatrix, a->campos, a->image_width, a->image_height, a->tanfovx, a->tanfovy,                    \
-        (const uint32_t *)(geom + L.pub.tiles_touched), (const uint8_t *)(geom + L.pub.clamped), partial,               \
+        (const uint32_t *)(geom + L.pub.tiles_touched), (const uint8_t *)(geom + L.pub.clamped), partial, exists,        \
         (const uint32_t *)(geom + L.g_off_by_gid), g->dL_dmeans2D, g->dL_dopacities, g->dL_dcolors_precomp, g->dL_dmeans3D,  \
         g->dL_dscales, g->dL_drotations, g->dL_dshs, g->dL_dcov3D
 #define LAUNCH(SH, COV, SI, SO) DAS3R_LAUNCH((preprocess_backward_kernel<SH, COV, SI, SO>), grid, block, 0, s, ARGS)

@@ -155,16 +155,28 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
 }
 
 int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
-                           float *partial, hipStream_t s) {
-    // Which decomposition (DAS3R_RENDER_BWD=dpp | mfma | scan | scan128 forces one):
-    //   scan  lanes = 4 pixels x 16 splats, sums on the matrix cores, recurrences as DPP row scans (render_bwd_scan.hip)
-    //   mfma  pixel per lane + LDS-transposed slab -> matrix cores (render_bwd_mfma.hip): very long lists of tiny splats
-    //   dpp   pixel per lane, cross-lane reduction on the vector ALU (this file)
+                           float *partial, hipStream_t s, bool *quad_rows) {
+    *quad_rows = false;
+    // Which decomposition (DAS3R_RENDER_BWD=dpp | mfma | scan<N> | scana<N> | stream forces one; measurements: DESIGN.md §4):
+    //   dpp     pixel per lane, cross-lane reduction on the vector ALU (this file): lists of a few hundred entries per tile
+    //   scan    lanes = 4 pixels x 16 splats, recurrences as DPP row scans, sums as split-bf16 products on the matrix cores
+    //           (render_bwd_scan.hip): long lists (the DAS3R shape)
+    //   stream  the same arithmetic, every wave streaming the tile's list on its own (render_bwd_stream.hip; experimental)
+    //   mfma    pixel per lane + LDS-transposed slab -> fp32 matrix cores (render_bwd_mfma.hip; superseded by scan)
     const Switches &sw = switches();
     int kind = sw.render_bwd;
-    if (kind == 0) kind = (sw.bwd_reduce_set || sw.ablate_set) ? 1 : 3;
+    int mb = sw.render_bwd_mb ? sw.render_bwd_mb : 256;
+    if (kind == 0) {
+        const bool long_lists = L.capacity >= (int64_t)2048 * L.ntiles;
+        kind = (sw.bwd_reduce_set || sw.ablate_set || !long_lists) ? 1 : 3;
+        mb = 256;
+    }
+    if (kind == 5) {
+        *quad_rows = true;
+        return launch_render_backward_stream(a, dL_dpix, geom, binning, img, L, partial, s);
+    }
     if (kind == 2) return launch_render_backward_mfma(a, dL_dpix, geom, binning, img, L, partial, s);
-    if (kind >= 3) return launch_render_backward_scan(a, dL_dpix, geom, binning, img, L, partial, kind == 4 ? 128 : 256, s);
+    if (kind >= 3) return launch_render_backward_scan(a, dL_dpix, geom, binning, img, L, partial, mb, s);
     const bool use_dpp = !sw.bwd_reduce_shfl;   // "shfl" selects the ds_bpermute reference reduction (diagnostics)
     const int ablate = sw.ablate;               // perf experiments only: bit0 = no partial stores, bit2 = no cross-lane reduction
 #define ARGS                                                                                                                 \

@@ -21,74 +21,15 @@
 // LDS stores into a WAVE-PRIVATE region (a wave meets a splat at most once per batch): no atomics anywhere; the four regions are
 // added per splat, under the waves' hit masks, when the batch is written out.  Geometry sums travel as raw moments of g about the
 // tile centre (exact fp32 FMA chains on the matrix core) and are converted once per (tile, splat), as in render_bwd_mfma.hip.
-#include "render_common.h"
+#include "render_scan.h"
 
 namespace das3r {
 
-namespace {
-
-constexpr int NACC = 9;   // C0, C1, C2, M0, Mu, Mv, Muu, Muv, Mvv
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-struct PixRow {   // one pixel of a wave's quadrant (32 B, two ds_read_b128)
-    float dLp0, dLp1, dLp2, tfbg;   // dL/dpixel, T_final * (bg . dL/dpixel)
-    float T, R;                     // replay state (render_common.h: ReplayState)
-    uint32_t last;                  // n_contrib: list positions >= last take no part
-    float zero;                     // (A operand of the lanes that carry no colour row)
-};
-
-// inclusive product / sum over the lanes of each 16-lane DPP row (Hillis-Steele, row_shr 1, 2, 4, 8)
-// product: a lane without a source lane must keep its value, which the update_dpp builtin only offers as mov + mov_dpp + mul;
-// v_mul_f32_dpp with bound_ctrl off leaves exactly those lanes unwritten.  Four independent chains per statement: a DPP read of
-// a register needs two wait states after the VALU write, here the three other chains' instructions.
-__device__ __forceinline__ void row_scan_mul_x4(float &x0, float &x1, float &x2, float &x3) {
-    asm("s_nop 1\n\t"
-        "v_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 0"
-        : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
-}
-// sum: the same network (a lane without a source lane keeps its value — what an inclusive scan wants).  Written out like the
-// product because the compiler serialises the four chains of a group and pads every step with s_nop.
-__device__ __forceinline__ void row_scan_add_x4(float &x0, float &x1, float &x2, float &x3) {
-    asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 0"
-        : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
-}
-
-}  // namespace
-
-template <int MB>
+// MB: staged list entries per round.  ATOM: the sums of a (wave, batch) are added to ONE shared accumulator array with LDS atomics
+// (small LDS footprint: more workgroups per CU, longer rounds) instead of being stored to wave-private regions and added afterwards.
+// ABL: timing experiments only (DAS3R_ABLATE with DAS3R_RENDER_BWD=scan128; results are wrong): 1 no MFMAs, 2 no DPP scans, 4 no batches at
+// all (what the rounds cost without them), 8 bounding-box cull only
+template <int MB, bool ATOM, int ABL = 0>
 __global__ void __launch_bounds__(256) render_backward_scan_kernel(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int tiles_x, int ntiles,
     const float4 *__restrict__ xyh, const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
@@ -96,20 +37,21 @@ __global__ void __launch_bounds__(256) render_backward_scan_kernel(
     const float *__restrict__ dL_dpix, const uint32_t *__restrict__ slot_list, float *__restrict__ partial /*[I,9]*/,
     uint32_t last_g, uint32_t cap /*bounds of the list contents: render_common.h safe_range*/) {
     // one LDS object (cdna_hip_programming.md: a second __shared__ array changes the waits the compiler emits)
-    constexpr int OFF_STAGE = 0;                                        // StagedSplat[MB]
-    constexpr int OFF_ACC8 = OFF_STAGE + MB * (int)sizeof(StagedSplat);  // float[4 waves][MB][8]: sums 0..7 of (wave, staged entry)
-    constexpr int OFF_ACC1 = OFF_ACC8 + 4 * MB * 8 * 4;                  // float[4][MB]: sum 8
-    constexpr int OFF_PIX = OFF_ACC1 + 4 * MB * 4;                       // PixRow[4][64]
-    constexpr int OFF_SLOT = OFF_PIX + 4 * 64 * (int)sizeof(PixRow);     // uint32_t[MB]
+    constexpr int NROW = 12;                                             // C0 C1 C2 M0 | Mu Mv Muu Muv | Mvv C0' C1' C2'  (' = from the low parts of dL/dpix)
+    constexpr int PIX_ROW = 8 * (int)sizeof(PixRow) + 16;                // one image row of a quadrant (+16: the four rows a step reads sit on different banks)
+    constexpr int PIX_WAVE = 8 * PIX_ROW;
+    constexpr int OFF_STAGE = 0;                                         // StagedSplat[MB]
+    constexpr int OFF_ACC = OFF_STAGE + MB * (int)sizeof(StagedSplat);   // float[ATOM ? 1 : 4 waves][MB][12]
+    constexpr int OFF_PIX = OFF_ACC + (ATOM ? 1 : 4) * MB * NROW * 4;    // 4 waves x 8 rows of PixRow[8]
+    constexpr int OFF_SLOT = OFF_PIX + 4 * PIX_WAVE;                     // uint32_t[MB]
     constexpr int OFF_HIT = OFF_SLOT + MB * 4;                           // uint64_t[4][MB / 64]
-    constexpr int OFF_LIST = OFF_HIT + 4 * (MB / 64) * 8;                // uint8_t[4][MB]
-    constexpr int OFF_MAX = OFF_LIST + 4 * MB;                           // uint32_t[4]
+    constexpr int OFF_LIST = OFF_HIT + 4 * (MB / 64) * 8;                // uint8_t / uint16_t [4][MB]
+    constexpr int OFF_MAX = OFF_LIST + 4 * MB * 2;                       // uint32_t[4]
     constexpr int LDS_BYTES = OFF_MAX + 16;
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     StagedSplat *const stage = reinterpret_cast<StagedSplat *>(lds + OFF_STAGE);
-    float *const acc8 = reinterpret_cast<float *>(lds + OFF_ACC8);
-    float *const acc1 = reinterpret_cast<float *>(lds + OFF_ACC1);
-    float *const outp = acc8;   // [MB][9] rows on their way to `partial`: reuses the accumulators once they have been read
+    float *const acc = reinterpret_cast<float *>(lds + OFF_ACC);
+    float *const outp = acc;   // [MB][9] rows on their way to `partial`: reuses the accumulators once they have been read
     uint32_t *const s_slot = reinterpret_cast<uint32_t *>(lds + OFF_SLOT);
     uint64_t *const s_hit = reinterpret_cast<uint64_t *>(lds + OFF_HIT);
     uint32_t *const s_max = reinterpret_cast<uint32_t *>(lds + OFF_MAX);
@@ -123,8 +65,9 @@ __global__ void __launch_bounds__(256) render_backward_scan_kernel(
     const float qcx = (float)qx0 + 3.5f, qcy = (float)qy0 + 3.5f;
     const float tcx = (float)(bx * TILE_X) + 7.5f, tcy = (float)(by * TILE_Y) + 7.5f;   // tile centre: origin of the moments
     const uint2 range = safe_range(ranges[tile], cap);
-    PixRow *const pixrow = reinterpret_cast<PixRow *>(lds + OFF_PIX) + wave * 64;
-    uint8_t *const list = reinterpret_cast<uint8_t *>(lds + OFF_LIST) + wave * MB;
+    char *const pix_wave = lds + OFF_PIX + wave * PIX_WAVE;
+    uint16_t *const list = reinterpret_cast<uint16_t *>(lds + OFF_LIST) + wave * MB;
+    auto pix_at = [&](const int x, const int y) { return reinterpret_cast<PixRow *>(pix_wave + y * PIX_ROW) + x; };
 
     // ---- the quadrant's pixels, one per lane (lane = 8 y + x): constants and initial state into the LDS rows ----
     uint32_t last_contributor;
@@ -149,7 +92,7 @@ __global__ void __launch_bounds__(256) render_backward_scan_kernel(
         row.R = 0.f;
         row.last = last_contributor;
         row.zero = 0.f;
-        pixrow[lane] = row;
+        *pix_at(lane & 7, lane >> 3) = row;
     }
     // no pixel of this tile blended anything past list position max_contrib: start the replay there
     uint32_t mx = last_contributor;
@@ -168,32 +111,49 @@ __global__ void __launch_bounds__(256) render_backward_scan_kernel(
         }
     }
 
-    // ---- lane (r, s) of the walk: pixel r of a step, splat s of a batch ----
+    // ---- lane (r, s) of the walk: splat s of a batch; image rows r and 4 + r of the quadrant, one column per step ----
+    // (the K index of v_mfma_f32_16x16x32_bf16 is 8 (lane >> 4) + element: a lane supplies eight consecutive k = the eight pixels
+    //  of ITS image row, so the sixteen steps of a batch are: columns 0..7 of rows r, then columns 0..7 of rows 4 + r)
     const int r = lane >> 4, s = lane & 15;
-    const float pxfA = (float)(qx0 + r), pxfB = (float)(qx0 + 4 + r);   // even steps: x = r, odd steps: x = 4 + r; y = step / 2
-    const float pyf0 = (float)qy0;
-    // A operands (constant for the tile): lane 16 r + q supplies weight q of pixel r of the step.  q < 3: dL/dpixel (read from the
-    // pixel's LDS row every step), q = 3..8: moment weights 1, u, v, uu, uv, vv of the pixel's offset from the tile centre
-    const char *const a1_addr = reinterpret_cast<const char *>(pixrow + r) + (s < 3 ? 4 * s : 28);   // + step * 4 rows
-    float A2[16];
+    const float pyfA = (float)(qy0 + r), pyfB = (float)(qy0 + 4 + r);
+    const float pxf0 = (float)qx0;
+    const unsigned long long lanes15 = 0x8000800080008000ull;
+    // (LDS byte addresses of the lane's two image rows: the low 32 bits of a generic pointer into LDS are its LDS address)
+    const uint32_t row_addr[2] = {(uint32_t)(uintptr_t)(pix_wave + r * PIX_ROW), (uint32_t)(uintptr_t)(pix_wave + (4 + r) * PIX_ROW)};
+    // A operand (constant for the tile), rows q = lane & 15 of the 16 x 32 weight matrix of each half:
+    //   q 0..2  bf16 high part of dL/dpixel (channel q)      q 3..8  moment weights 1, u, v, uu, uv, vv about the tile centre — half-
+    //   q 9..11 bf16 low part of dL/dpixel (channel q - 9)           integers below 8 and their products: EXACT in bf16's 8 bits
+    // every MFMA of a batch uses it: rows 0..2 + 9..11 of (A w) give the colour sums, rows 3..8 of (A g) the moments; the rest is ignored
+    U4 Aop[2];
 #pragma unroll
-    for (int kk = 0; kk < 16; kk++) {
-        const float u = ((kk & 1) ? pxfB : pxfA) - tcx, v = (pyf0 + (float)(kk >> 1)) - tcy;
-        A2[kk] = s == 3 ? 1.f : s == 4 ? u : s == 5 ? v : s == 6 ? u * u : s == 7 ? u * v : s == 8 ? v * v : 0.f;
+    for (int half = 0; half < 2; half++) {
+        float wv[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const PixRow *row = pix_at(i, 4 * half + r);
+            const float u = (float)(qx0 + i) - tcx, v = (float)(qy0 + 4 * half + r) - tcy;
+            const int ch = s < 3 ? s : s - 9;
+            const float d = (s < 3 || (s >= 9 && s < 12)) ? (ch == 0 ? row->dLp0 : ch == 1 ? row->dLp1 : row->dLp2) : 0.f;
+            const float mom = s == 3 ? 1.f : s == 4 ? u : s == 5 ? v : s == 6 ? u * u : s == 7 ? u * v : s == 8 ? v * v : 0.f;
+            wv[i] = s < 3 ? d : (s >= 9 && s < 12) ? lo_part(d) : mom;
+        }
+        Aop[half] = U4{pack_hi(wv[0], wv[1]), pack_hi(wv[2], wv[3]), pack_hi(wv[4], wv[5]), pack_hi(wv[6], wv[7])};
     }
-    const PixRow *const my_rows = pixrow + r;   // + 4 * step
 
     for (int i = 0; i < rounds; i++) {
         const int done_before = i * MB;
         const int n = min(MB, (int)max_contrib - done_before);
         // stage the batch in reverse list order; entry j holds list position (max_contrib - 1 - done_before - j)
-        if (tid < n) {
-            const uint32_t pos = range.x + max_contrib - 1 - done_before - tid;
+        for (int t = tid; t < n; t += TILE_PIX) {
+            const uint32_t pos = range.x + max_contrib - 1 - done_before - t;
             const uint32_t g = min(point_list[pos], last_g);
-            s_slot[tid] = min(slot_list[pos], cap - 1u);
-            stage[tid].xyh = xyh[(size_t)g * SPLAT_REC];           // one 64-byte record: a single cache line per splat
-            stage[tid].co = conic_opacity[(size_t)g * SPLAT_REC];
-            stage[tid].rgbd = rgbd[(size_t)g * SPLAT_REC];
+            s_slot[t] = min(slot_list[pos], cap - 1u);
+            stage[t].xyh = xyh[(size_t)g * SPLAT_REC];           // one 64-byte record: a single cache line per splat
+            stage[t].co = conic_opacity[(size_t)g * SPLAT_REC];
+            stage[t].rgbd = rgbd[(size_t)g * SPLAT_REC];
+        }
+        if constexpr (ATOM) {
+            for (int f = tid; f < MB * NROW; f += TILE_PIX) acc[f] = 0.f;
         }
         __syncthreads();
 
@@ -202,14 +162,15 @@ __global__ void __launch_bounds__(256) render_backward_scan_kernel(
 #pragma unroll
         for (int k = 0; k < MB / 64; k++) {
             const int j = k * 64 + lane;
-            const bool hit = j < n && quadrant_hit(stage[j].xyh, qcx, qcy);
+            const int jc = j < n ? j : 0;
+            const bool hit = j < n && quadrant_hit(stage[jc].xyh, qcx, qcy) && ((ABL & 8) || rect_hit_tight(stage[jc].xyh, stage[jc].co, (float)qx0, (float)qy0));
             const uint64_t m = __ballot(hit);
-            if (lane == 0) s_hit[wave * (MB / 64) + k] = m;
+            if (!ATOM && lane == 0) s_hit[wave * (MB / 64) + k] = m;
             const int at = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (hit) list[at] = (uint8_t)j;
+            if (hit) list[at] = (uint16_t)j;
             cnt += __popcll(m);
         }
-        cnt = __builtin_amdgcn_readfirstlane(cnt);
+        cnt = (ABL & 4) ? 0 : __builtin_amdgcn_readfirstlane(cnt);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the wave reads its own list back
 
         for (int b = 0; b < cnt; b += 16) {
@@ -223,92 +184,149 @@ __global__ void __launch_bounds__(256) render_backward_scan_kernel(
             const uint32_t position = max_contrib - 1 - done_before - j;   // 0-based list position of the lane's splat
             v4f Dw = {0.f, 0.f, 0.f, 0.f}, Dg = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k4 = 0; k4 < 16; k4 += 4) {
-                float am[4], Gm[4], rinv[4], Pinc[4];
-                float4 pc[4];
-                float stT[4], stR[4], a1[4];
+            for (int half = 0; half < 2; half++) {
+                const float pyf = half ? pyfB : pyfA;
+                const float dy = p.y - pyf;
+                const char *const rows = pix_wave + (4 * half + r) * PIX_ROW;
+                uint32_t whi[4], wlo[4], ghi[4], glo[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int kk = k4 + u;
-                    const PixRow *row = my_rows + 4 * kk;
-                    pc[u] = *reinterpret_cast<const float4 *>(&row->dLp0);
-                    const float4 st = *reinterpret_cast<const float4 *>(&row->T);
-                    stT[u] = st.x;
-                    stR[u] = st.y;
-                    a1[u] = *reinterpret_cast<const float *>(a1_addr + kk * 4 * (int)sizeof(PixRow));
-                    float dx, dy, G, alpha;
-                    const bool ok = pair_alpha(p.x, p.y, co, (kk & 1) ? pxfB : pxfA, pyf0 + (float)(kk >> 1), dx, dy, G, alpha);
-                    const bool active = ok & (position < __float_as_uint(st.z));
-                    am[u] = active ? alpha : 0.f;
-                    Gm[u] = active ? G : 0.f;
-                    rinv[u] = __builtin_amdgcn_rcpf(1.f - am[u]);   // v_rcp_f32: T is itself a reconstruction, 1 ulp is noise
-                    Pinc[u] = rinv[u];
-                }
-                row_scan_mul_x4(Pinc[0], Pinc[1], Pinc[2], Pinc[3]);   // lane s: product of 1/(1-alpha) over splats 0..s of the batch
-                float T[4], cd[4], wc[4], Sinc[4];
+                for (int k4 = 0; k4 < 8; k4 += 4) {
+                    float am[4], Gm[4], rinv[4], Pinc[4], w4[4], g4[4];
+                    float4 pc[4];
+                    float stT[4], stR[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    T[u] = stT[u] * Pinc[u];                           // transmittance in front of splat s at this pixel
-                    const float w = am[u] * T[u];
-                    cd[u] = c.x * pc[u].x + c.y * pc[u].y + c.z * pc[u].z;
-                    wc[u] = cd[u] * w;
-                    Sinc[u] = wc[u];
-                    Dw = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], w, Dw, 0, 0, 0);
-                }
-                row_scan_add_x4(Sinc[0], Sinc[1], Sinc[2], Sinc[3]);   // lane s: sum of w (c . dL/dpix) over splats 0..s of the batch
+                    for (int u = 0; u < 4; u++) {
+                        const PixRow *row = reinterpret_cast<const PixRow *>(rows) + (k4 + u);
+                        pc[u] = *reinterpret_cast<const float4 *>(&row->dLp0);
+                        const float4 st = *reinterpret_cast<const float4 *>(&row->T);
+                        stT[u] = st.x;
+                        stR[u] = st.y;
+                        // pair_alpha's arithmetic (render_common.h), dy shared by the eight steps of the half
+                        const float dx = p.x - (pxf0 + (float)(k4 + u));
+                        const float q = __fmaf_rn(__fmul_rn(co.x, dx), dx, __fmul_rn(__fmul_rn(co.z, dy), dy));
+                        const float power = __fmaf_rn(-0.5f, q, -__fmul_rn(__fmul_rn(co.y, dx), dy));
+                        const float G = __expf(power);
+                        const float alpha = fminf(0.99f, __fmul_rn(co.w, G));
+                        const bool active = (!(power > 0.0f)) & (alpha >= (1.0f / 255.0f)) & (position < __float_as_uint(st.z));
+                        am[u] = active ? alpha : 0.f;
+                        Gm[u] = active ? G : 0.f;
+                        rinv[u] = __builtin_amdgcn_rcpf(1.f - am[u]);   // v_rcp_f32: T is itself a reconstruction, 1 ulp is noise
+                        Pinc[u] = rinv[u];
+                    }
+                    if constexpr (!(ABL & 2)) row_scan_mul_x4(Pinc[0], Pinc[1], Pinc[2], Pinc[3]);   // lane s: product of 1/(1-alpha) over splats 0..s of the batch
+                    float T[4], cd[4], wc[4], Sinc[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int kk = k4 + u;
-                    const float Rex = (stR[u] - wc[u]) + Sinc[u];      // R behind splat s: the batch's earlier (= farther) splats + state
-                    const float dL_dalpha = T[u] * cd[u] - (Rex + pc[u].w) * rinv[u];
-                    const float g = Gm[u] * dL_dalpha;
-                    Dg = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[kk], g, Dg, 0, 0, 0);
-                    if (s == 15) {   // the row's totals are the pixel's state for the next batch
-                        PixRow *row = pixrow + r + 4 * kk;
-                        *reinterpret_cast<float2 *>(&row->T) = make_float2(T[u], stR[u] + Sinc[u]);
+                    for (int u = 0; u < 4; u++) {
+                        T[u] = stT[u] * Pinc[u];                           // transmittance in front of splat s at this pixel
+                        w4[u] = am[u] * T[u];
+                        cd[u] = c.x * pc[u].x + c.y * pc[u].y + c.z * pc[u].z;
+                        wc[u] = cd[u] * w4[u];
+                        Sinc[u] = wc[u];
+                    }
+                    if constexpr (!(ABL & 2)) row_scan_add_x4(Sinc[0], Sinc[1], Sinc[2], Sinc[3]);   // lane s: sum of w (c . dL/dpix) over splats 0..s of the batch
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const float Rex = (stR[u] - wc[u]) + Sinc[u];      // R behind splat s: the batch's earlier (= farther) splats + state
+                        const float dL_dalpha = T[u] * cd[u] - (Rex + pc[u].w) * rinv[u];
+                        g4[u] = Gm[u] * dL_dalpha;
+                        stR[u] += Sinc[u];
+                    }
+                    // the row's totals (lane 15) are the pixels' state for the next batch: PixRow.T / .R = dwords 4, 5 of the 8-dword row
+                    if (k4 == 0) {
+                        store2_lane15<4>(row_addr[half], T[0], stR[0], lanes15);
+                        store2_lane15<12>(row_addr[half], T[1], stR[1], lanes15);
+                        store2_lane15<20>(row_addr[half], T[2], stR[2], lanes15);
+                        store2_lane15<28>(row_addr[half], T[3], stR[3], lanes15);
+                    } else {
+                        store2_lane15<36>(row_addr[half], T[0], stR[0], lanes15);
+                        store2_lane15<44>(row_addr[half], T[1], stR[1], lanes15);
+                        store2_lane15<52>(row_addr[half], T[2], stR[2], lanes15);
+                        store2_lane15<60>(row_addr[half], T[3], stR[3], lanes15);
+                    }
+                    // the two scalars of the pair as bf16 high + low parts, two steps per register (element = column of the row)
+#pragma unroll
+                    for (int u = 0; u < 4; u += 2) {
+                        const int e2 = (k4 + u) >> 1;
+                        whi[e2] = pack_hi(w4[u], w4[u + 1]);
+                        wlo[e2] = pack_hi(lo_part(w4[u]), lo_part(w4[u + 1]));
+                        ghi[e2] = pack_hi(g4[u], g4[u + 1]);
+                        glo[e2] = pack_hi(lo_part(g4[u]), lo_part(g4[u + 1]));
                     }
                 }
+                if constexpr (ABL & 1) {
+                    asm volatile("" ::"v"(whi[0]), "v"(whi[1]), "v"(whi[2]), "v"(whi[3]), "v"(wlo[0]), "v"(wlo[1]), "v"(wlo[2]), "v"(wlo[3]));
+                    asm volatile("" ::"v"(ghi[0]), "v"(ghi[1]), "v"(ghi[2]), "v"(ghi[3]), "v"(glo[0]), "v"(glo[1]), "v"(glo[2]), "v"(glo[3]));
+                } else {
+                    const v8bf a = as_bf8(Aop[half]);
+                    Dw = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, as_bf8(U4{whi[0], whi[1], whi[2], whi[3]}), Dw, 0, 0, 0);
+                    Dg = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, as_bf8(U4{ghi[0], ghi[1], ghi[2], ghi[3]}), Dg, 0, 0, 0);
+                    Dw = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, as_bf8(U4{wlo[0], wlo[1], wlo[2], wlo[3]}), Dw, 0, 0, 0);
+                    Dg = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, as_bf8(U4{glo[0], glo[1], glo[2], glo[3]}), Dg, 0, 0, 0);
+                }
             }
-            // D[q = 4 r + reg][splat s]: rows 0..7 as two 16-byte stores per splat, row 8 on its own
-            const v4f D = Dw + Dg;
-            float *const a8 = acc8 + ((size_t)wave * MB + j) * 8;
-            if (valid && r < 2) *reinterpret_cast<v4f *>(a8 + 4 * r) = D;
-            if (valid && r == 2) acc1[wave * MB + j] = D[0];
+            // lane (r, s) holds rows 4 r .. 4 r + 3 of both products for splat s: the twelve useful ones leave as one 16-byte row piece per lane
+            //   r = 0: C0 C1 C2 (A w) | M0 (A g)      r = 1: Mu Mv Muu Muv (A g)      r = 2: Mvv (A g) | C0' C1' C2' (A w)
+            v4f D;
+            D[0] = r == 0 ? Dw[0] : Dg[0];
+            D[1] = r == 1 ? Dg[1] : Dw[1];
+            D[2] = r == 1 ? Dg[2] : Dw[2];
+            D[3] = r == 2 ? Dw[3] : Dg[3];
+            if constexpr (ATOM) {
+                float *const a12 = acc + (size_t)j * NROW + 4 * r;
+                if (valid && r < 3) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) __hip_atomic_fetch_add(a12 + q, D[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            } else {
+                float *const a12 = acc + ((size_t)wave * MB + j) * NROW + 4 * r;
+                if (valid && r < 3) *reinterpret_cast<v4f *>(a12) = D;
+            }
         }
         __syncthreads();
         // the four waves' sums of every staged entry, moments -> the nine per-instance sums
-        float a[NACC];
+        for (int t0 = 0; t0 < n; t0 += TILE_PIX) {
+            const int t = t0 + tid;
+            float a[NROW];
 #pragma unroll
-        for (int q = 0; q < NACC; q++) a[q] = 0.f;
-        if (tid < n) {
+            for (int q = 0; q < NROW; q++) a[q] = 0.f;
+            if (t < n) {
+                if constexpr (ATOM) {
 #pragma unroll
-            for (int w = 0; w < 4; w++) {
-                if ((s_hit[w * (MB / 64) + (tid >> 6)] >> (tid & 63)) & 1ull) {
-                    const v4f lo = *reinterpret_cast<const v4f *>(acc8 + ((size_t)w * MB + tid) * 8);
-                    const v4f hi = *reinterpret_cast<const v4f *>(acc8 + ((size_t)w * MB + tid) * 8 + 4);
-                    a[0] += lo[0]; a[1] += lo[1]; a[2] += lo[2]; a[3] += lo[3];
-                    a[4] += hi[0]; a[5] += hi[1]; a[6] += hi[2]; a[7] += hi[3];
-                    a[8] += acc1[w * MB + tid];
+                    for (int q = 0; q < NROW; q += 4) {
+                        const v4f v = *reinterpret_cast<const v4f *>(acc + (size_t)t * NROW + q);
+                        a[q] = v[0]; a[q + 1] = v[1]; a[q + 2] = v[2]; a[q + 3] = v[3];
+                    }
+                } else {
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        if ((s_hit[w * (MB / 64) + (t >> 6)] >> (t & 63)) & 1ull) {
+#pragma unroll
+                            for (int q = 0; q < NROW; q += 4) {
+                                const v4f v = *reinterpret_cast<const v4f *>(acc + ((size_t)w * MB + t) * NROW + q);
+                                a[q] += v[0]; a[q + 1] += v[1]; a[q + 2] += v[2]; a[q + 3] += v[3];
+                            }
+                        }
+                    }
                 }
             }
-        }
-        __syncthreads();   // every accumulator has been read: the region becomes the output rows
-        if (tid < n) {
-            const float4 p = stage[tid].xyh;
-            const float4 co = stage[tid].co;
-            const float M0 = a[3], Mu = a[4], Mv = a[5], Muu = a[6], Muv = a[7], Mvv = a[8];
-            const float X = p.x - tcx, Y = p.y - tcy, kh = -0.5f * co.w;
-            const float Sgx = kh * (X * M0 - Mu), Sgy = kh * (Y * M0 - Mv);   // -1/2 o sum g dx, dy  (dx = X - u)
-            float *row = outp + tid * NACC;
-            row[0] = a[0];
-            row[1] = a[1];
-            row[2] = a[2];
-            row[3] = (Sgx * co.x + Sgy * co.y) * (float)W;        // dL/dmean2D in NDC units: 2 * (W / 2)
-            row[4] = (Sgy * co.z + Sgx * co.y) * (float)H;
-            row[5] = kh * (X * X * M0 - 2.f * X * Mu + Muu);
-            row[6] = kh * (X * Y * M0 - X * Mv - Y * Mu + Muv);
-            row[7] = kh * (Y * Y * M0 - 2.f * Y * Mv + Mvv);
-            row[8] = M0;
+            __syncthreads();   // every accumulator of this slice has been read: the region becomes the output rows
+            if (t < n) {
+                const float4 p = stage[t].xyh;
+                const float4 co = stage[t].co;
+                const float M0 = a[3], Mu = a[4], Mv = a[5], Muu = a[6], Muv = a[7], Mvv = a[8];
+                const float X = p.x - tcx, Y = p.y - tcy, kh = -0.5f * co.w;
+                const float Sgx = kh * (X * M0 - Mu), Sgy = kh * (Y * M0 - Mv);   // -1/2 o sum g dx, dy  (dx = X - u)
+                float *row = outp + (size_t)t * NACC;
+                row[0] = a[0] + a[9];
+                row[1] = a[1] + a[10];
+                row[2] = a[2] + a[11];
+                row[3] = (Sgx * co.x + Sgy * co.y) * (float)W;        // dL/dmean2D in NDC units: 2 * (W / 2)
+                row[4] = (Sgy * co.z + Sgx * co.y) * (float)H;
+                row[5] = kh * (X * X * M0 - 2.f * X * Mu + Muu);
+                row[6] = kh * (X * Y * M0 - X * Mv - Y * Mu + Muv);
+                row[7] = kh * (Y * Y * M0 - 2.f * Y * Mv + Mvv);
+                row[8] = M0;
+            }
         }
         __syncthreads();
         // rows go to the emission slot of their entry (36-byte row stores, 9 lanes each)
@@ -328,8 +346,20 @@ int launch_render_backward_scan(const das3r_raster_args *a, const float *dL_dpix
         (const float4 *)(geom + L.pub.rgbd), a->bg, (const float *)(img + L.pub.final_T),                                 \
         (const uint32_t *)(img + L.pub.n_contrib), dL_dpix, (const uint32_t *)(binning + L.b_slot), partial,              \
         (uint32_t)(a->P - 1), (uint32_t)L.capacity
-    if (mb == 128) DAS3R_LAUNCH((render_backward_scan_kernel<128>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS);
-    else DAS3R_LAUNCH((render_backward_scan_kernel<256>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS);
+#define GO(MBV, AT, AB) DAS3R_LAUNCH((render_backward_scan_kernel<MBV, AT, AB>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS)
+    const int abl = switches().ablate_set ? switches().ablate : 0;
+    // mb: 64 / 128 / 256 private accumulator regions; 1256 / 1512: 256 / 512 entries per round with the atomic flush
+    if (mb == 128 && abl == 1) GO(128, false, 1);
+    else if (mb == 128 && abl == 2) GO(128, false, 2);
+    else if (mb == 128 && abl == 3) GO(128, false, 3);
+    else if (mb == 128 && abl == 4) GO(128, false, 4);
+    else if (mb == 128 && abl == 8) GO(128, false, 8);
+    else if (mb == 64) GO(64, false, 0);
+    else if (mb == 128) GO(128, false, 0);
+    else if (mb == 1256) GO(256, true, 0);
+    else if (mb == 1512) GO(512, true, 0);
+    else GO(256, false, 0);
+#undef GO
 #undef ARGS
     KERNEL_CHECK(s, a->debug, "render_backward_scan");
     return DAS3R_OK;

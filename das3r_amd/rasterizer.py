@@ -247,7 +247,8 @@ def _backward_impl(rs, num_rendered, grad_out_color, means3D, sh, colors_precomp
     g_cov = z(P, 6) if has_cov else None
     if P == 0:
         return g_means2D, g_colors, g_opac, g_means3D, g_cov, g_sh, g_scales, g_rot
-    scratch = z(max(capacity, 1), 9)   # per-instance partial sums (rows < num_rendered are fully written by the render backward)
+    # per-instance partial sums, written by the render backward and added per Gaussian (no atomics, no memset by the caller)
+    scratch = torch.empty(int(lib.das3r_raster_backward_scratch_bytes(max(capacity, 1))), dtype=torch.uint8, device=device)
     keep = []
     a = _fill_args(rs, P, M, device, keep)
     i = _fill_in(means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp)

@@ -113,7 +113,8 @@ typedef struct {
     float *dL_dscales;         /* [P,3]; NULL when cov3D_precomp was used */
     float *dL_drotations;      /* [P,4]; NULL when cov3D_precomp was used */
     float *dL_dcov3D;          /* [P,6]; NULL unless cov3D_precomp was used */
-    float *scratch;            /* [saved->capacity,9] caller-provided scratch: per-instance partial sums (no atomics) */
+    float *scratch;            /* das3r_raster_backward_scratch_bytes(saved->capacity) bytes of caller-provided scratch: partial
+                                * sums per instance (the compositing kernels use no atomics) */
 } das3r_raster_grads;
 
 /* Returns num_rendered (>= 0) or a negative das3r_status.  Fills *saved. */
@@ -123,6 +124,9 @@ int64_t das3r_raster_forward(const das3r_raster_args *args, const das3r_raster_i
 
 int das3r_raster_backward(const das3r_raster_args *args, const das3r_raster_in *in, const das3r_raster_saved *saved,
                           const float *dL_dpix /* [3,H,W] */, const das3r_raster_grads *grads, das3r_stream_t stream);
+
+/* Bytes of device scratch das3r_raster_backward needs in grads->scratch for a forward with the given saved->capacity. */
+size_t das3r_raster_backward_scratch_bytes(int64_t capacity);
 
 /* das3r_raster_forward returns as soon as its kernels are enqueued.  Its binning kernels check themselves (a bounded wait on
  * another workgroup that timed out, an index out of range, counts that do not add up) and leave one word for the host; this call
