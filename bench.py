@@ -326,35 +326,32 @@ def main():
     del ts_step
 
     extras, cpu_baseline = None, None
+    if rk.rank == 0 and rk.world == 1 and not args.no_extras:   # (still pinned; before the CPU baseline starts its OpenMP pool)
+        extras = {}
+        us_step, _ = train_step_timer(rk.dev, fused=False)
+        train["unfused"] = round(rk.timed(us_step, 30, 5) / 30 * 1e3, 4)
+        del us_step
+        for w, k in (("c2", 300), ("ds", 50), ("c1", 300), ("c4d", 700), ("c4", 200)):
+            if w == args.workload:
+                continue
+            torch.cuda.empty_cache()
+            j = RasterJob(w, rk.dev)
+            j.upload()
+            j.step()
+            t = rk.timed(j.step, k, 30) / k
+            kt, rf = kernel_table(j, min(k, 50)) if w != "c4d" else (None, None)
+            ent = {"workload": WORKLOAD_DESC[w], "ms_per_step": round(t * 1e3, 4), "Msplats_per_s": round(j.sc_cpu.P / t / 1e6, 2),
+                   "steps": k, "num_rendered": j.num_rendered}
+            if rf:
+                ent["roofline"] = {kk: rf[kk] for kk in ("kernel", "achieved", "frac", "avg_launch_ms", "pipeline")}
+                ent["kernel_ms"] = {kk: v["ms_per_step"] for kk, v in kt.items()}
+            if w == "c4d":
+                ent["growth"] = {"P_final": j.P, "events": len(j.events), "every": 100, "fraction": 0.05}
+            extras[w] = ent
+            del j
     unpin(pinned)   # the CPU baseline below uses every host core
-    if rk.rank == 0 and rk.world == 1:
-        if not args.no_cpu_baseline:
-            cpu_baseline = cpu_baseline_of(job.sc_cpu, args.workload if args.workload != "c4d" else "c4")
-        if not args.no_extras:
-            repin = pin_to_ccx(rk.local_rank)
-            extras = {}
-            us_step, _ = train_step_timer(rk.dev, fused=False)
-            train["unfused"] = round(rk.timed(us_step, 30, 5) / 30 * 1e3, 4)
-            del us_step
-            for w, k in (("c2", 200), ("ds", 50), ("c1", 200), ("c4d", 700), ("c4", 200)):
-                if w == args.workload:
-                    continue
-                torch.cuda.empty_cache()
-                j = RasterJob(w, rk.dev)
-                j.upload()
-                j.step()
-                t = rk.timed(j.step, k, 20) / k
-                kt, rf = kernel_table(j, min(k, 50)) if w != "c4d" else (None, None)
-                ent = {"workload": WORKLOAD_DESC[w], "ms_per_step": round(t * 1e3, 4), "Msplats_per_s": round(j.sc_cpu.P / t / 1e6, 2),
-                       "steps": k, "num_rendered": j.num_rendered}
-                if rf:
-                    ent["roofline"] = {kk: rf[kk] for kk in ("kernel", "achieved", "frac", "avg_launch_ms", "pipeline")}
-                    ent["kernel_ms"] = {kk: v["ms_per_step"] for kk, v in kt.items()}
-                if w == "c4d":
-                    ent["growth"] = {"P_final": j.P, "events": len(j.events), "every": 100, "fraction": 0.05}
-                extras[w] = ent
-                del j
-            unpin(repin)
+    if rk.rank == 0 and rk.world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = cpu_baseline_of(job.sc_cpu, args.workload if args.workload != "c4d" else "c4")
 
     if rk.rank == 0:
         sc = job.sc

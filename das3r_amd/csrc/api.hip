@@ -519,7 +519,7 @@ extern "C" int das3r_raster_backward(const das3r_raster_args *a, const das3r_ras
     bool quad_rows = false;
     if (saved->num_rendered > 0) {
         if (!saved->binning) { set_error("das3r_raster_backward: binning buffer missing"); return DAS3R_ERR_INVALID_ARG; }
-        if ((rc = launch_render_backward(a, dL_dpix, saved->geom, saved->binning, saved->img, L, partial, s, &quad_rows))) return rc;
+        if ((rc = launch_render_backward(a, dL_dpix, saved->geom, saved->binning, saved->img, L, partial, s, &quad_rows, saved->num_rendered))) return rc;
     }
     return launch_preprocess_backward(a, in, saved->geom, saved->binning, L, g, partial, s, quad_rows);
 }

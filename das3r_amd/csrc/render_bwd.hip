@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
 }
 
 int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
-                           float *partial, hipStream_t s, bool *quad_rows) {
+                           float *partial, hipStream_t s, bool *quad_rows, int64_t num_rendered) {
     *quad_rows = false;
     // Which decomposition (DAS3R_RENDER_BWD=dpp | mfma | scan<N> | scana<N> | stream forces one; measurements: DESIGN.md §4):
     //   dpp     pixel per lane, cross-lane reduction on the vector ALU (this file): lists of a few hundred entries per tile
@@ -167,7 +167,7 @@ int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, cha
     int kind = sw.render_bwd;
     int mb = sw.render_bwd_mb ? sw.render_bwd_mb : 256;
     if (kind == 0) {
-        const bool long_lists = L.capacity >= (int64_t)2048 * L.ntiles;
+        const bool long_lists = num_rendered >= (int64_t)2048 * L.ntiles;   // (the count, not the capacity: the same scene takes the same kernel however its buffer was sized)
         kind = (sw.bwd_reduce_set || sw.ablate_set || !long_lists) ? 1 : 3;
         mb = 256;
     }

@@ -68,3 +68,28 @@ def test_das3r_scale_init_recipe():
     dist2 = torch.clamp_min(distCUDA2(pts), 0.0000001)
     scales = torch.log(torch.sqrt(dist2))[..., None].repeat(1, 3)
     assert scales.shape == (4096, 3) and torch.isfinite(scales).all()
+
+
+def das3r_shaped_points(frames=20, H=208, W=512, seed=3):
+    """The point set DAS3R calls distCUDA2 on (scene/gaussian_model.py:641): every pixel of every frame un-projected with its
+    depth, frames seen from slightly different poses -> 2.1 M points on `frames` nearly coincident depth sheets."""
+    g = np.random.default_rng(seed)
+    ys, xs = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    out = []
+    for f in range(frames):
+        z = (4.0 + np.sin(xs / 37.0 + f) * 0.6 + np.cos(ys / 23.0) * 0.4 + 0.02 * g.random((H, W), dtype=np.float32)).astype(np.float32)
+        p = np.stack([(xs - W / 2) * z / 600.0 + 0.05 * f, (ys - H / 2) * z / 600.0, z], -1)
+        out.append(p.reshape(-1, 3))
+    return np.concatenate(out).astype(np.float32)
+
+
+def test_knn_at_das3r_scale_vs_kdtree():
+    """2.1 M points in the DAS3R shape (the largest tested P was 300 k) against scipy's exact k-d tree."""
+    from scipy.spatial import cKDTree
+    pts = das3r_shaped_points()
+    assert pts.shape[0] == 20 * 208 * 512
+    got = _run(pts)
+    p64 = pts.astype(np.float64)
+    d, _ = cKDTree(p64).query(p64, k=4, workers=-1)
+    ref = (d[:, 1:] ** 2).mean(1)
+    np.testing.assert_allclose(got, ref, rtol=5e-5, atol=1e-12)
