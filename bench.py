@@ -45,6 +45,7 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default=os.environ.get("DAS3R_BENCH_WORKLOAD", "c4"), choices=sorted(WORKLOAD_DESC))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--extras-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--stub", action="store_true",
                     help="CPU dry run of the launch / barrier / reduction logic with a stand-in step (gloo; tests/test_bench_launch.py)")
     return ap.parse_args(argv)
@@ -279,8 +280,61 @@ def train_step_timer(dev, fused, frames=20, W=512, H=208):
     return step, int(model.get_xyz.shape[0])
 
 
+def extras_main(main_workload):
+    """Child process of the default N = 1 run: the other BASELINE shapes and the unfused train step, one JSON object on stdout."""
+    import torch
+    from das3r_amd.hostpin import pin_to_ccx
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    rk = Ranks(parse_args(["--gpus", "1"]))
+    pin_to_ccx(0)
+    out = {}
+    us_step, _ = train_step_timer(dev, fused=False)
+    out["train_step_unfused_ms"] = round(rk.timed(us_step, 30, 5) / 30 * 1e3, 4)
+    del us_step
+    for w, k in (("c2", 300), ("ds", 50), ("c1", 300), ("c4d", 700), ("c4", 200)):
+        if w == main_workload:
+            continue
+        torch.cuda.empty_cache()
+        j = RasterJob(w, dev)
+        j.upload()
+        j.step()
+        t = rk.timed(j.step, k, 30) / k
+        kt, rf = kernel_table(j, min(k, 50)) if w != "c4d" else (None, None)
+        ent = {"workload": WORKLOAD_DESC[w], "ms_per_step": round(t * 1e3, 4), "Msplats_per_s": round(j.sc_cpu.P / t / 1e6, 2),
+               "steps": k, "num_rendered": j.num_rendered}
+        if rf:
+            ent["roofline"] = {kk: rf[kk] for kk in ("kernel", "achieved", "frac", "avg_launch_ms", "pipeline")}
+            ent["kernel_ms"] = {kk: v["ms_per_step"] for kk, v in kt.items()}
+        if w == "c4d":
+            ent["growth"] = {"P_final": j.P, "events": len(j.events), "every": 100, "fraction": 0.05}
+        out[w] = ent
+        del j
+    print("EXTRAS " + json.dumps(out), flush=True)
+
+
+def run_extras_child(main_workload):
+    """The extras run in a process of their own, with the profiler's hooks stripped from its environment: a rocprofv3
+    --kernel-trace --stats of `python bench.py` then holds the launches of the benchmarked workload only, and its per-kernel
+    averages can be compared with this line's `roofline` (the kernels of the other shapes carry the same names)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if not (k.startswith("ROCP") or k.startswith("ROCPROF") or k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE"))}
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--extras-child", "--workload", main_workload], capture_output=True,
+                           text=True, timeout=900, env=env, cwd=ROOT)
+        for line in p.stdout.splitlines():
+            if line.startswith("EXTRAS "):
+                return json.loads(line[7:])
+        return {"error": (p.stderr or p.stdout)[-500:]}
+    except Exception as ex:  # noqa: BLE001 - the extras never take the bench line down
+        return {"error": repr(ex)}
+
+
 def main():
     args = parse_args()
+    if args.extras_child:
+        return extras_main(args.workload)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn_under_torchrun(args)   # does not return
     import torch
@@ -326,29 +380,10 @@ def main():
     del ts_step
 
     extras, cpu_baseline = None, None
-    if rk.rank == 0 and rk.world == 1 and not args.no_extras:   # (still pinned; before the CPU baseline starts its OpenMP pool)
-        extras = {}
-        us_step, _ = train_step_timer(rk.dev, fused=False)
-        train["unfused"] = round(rk.timed(us_step, 30, 5) / 30 * 1e3, 4)
-        del us_step
-        for w, k in (("c2", 300), ("ds", 50), ("c1", 300), ("c4d", 700), ("c4", 200)):
-            if w == args.workload:
-                continue
-            torch.cuda.empty_cache()
-            j = RasterJob(w, rk.dev)
-            j.upload()
-            j.step()
-            t = rk.timed(j.step, k, 30) / k
-            kt, rf = kernel_table(j, min(k, 50)) if w != "c4d" else (None, None)
-            ent = {"workload": WORKLOAD_DESC[w], "ms_per_step": round(t * 1e3, 4), "Msplats_per_s": round(j.sc_cpu.P / t / 1e6, 2),
-                   "steps": k, "num_rendered": j.num_rendered}
-            if rf:
-                ent["roofline"] = {kk: rf[kk] for kk in ("kernel", "achieved", "frac", "avg_launch_ms", "pipeline")}
-                ent["kernel_ms"] = {kk: v["ms_per_step"] for kk, v in kt.items()}
-            if w == "c4d":
-                ent["growth"] = {"P_final": j.P, "events": len(j.events), "every": 100, "fraction": 0.05}
-            extras[w] = ent
-            del j
+    if rk.rank == 0 and rk.world == 1 and not args.no_extras:
+        extras = run_extras_child(args.workload)
+        if extras and "train_step_unfused_ms" in extras:
+            train["unfused"] = extras.pop("train_step_unfused_ms")
     unpin(pinned)   # the CPU baseline below uses every host core
     if rk.rank == 0 and rk.world == 1 and not args.no_cpu_baseline:
         cpu_baseline = cpu_baseline_of(job.sc_cpu, args.workload if args.workload != "c4d" else "c4")

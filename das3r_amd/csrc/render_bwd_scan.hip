@@ -30,7 +30,7 @@ namespace das3r {
 // ABL: timing experiments only (DAS3R_ABLATE with DAS3R_RENDER_BWD=scan128; results are wrong): 1 no MFMAs, 2 no DPP scans, 4 no batches at
 // all (what the rounds cost without them), 8 bounding-box cull only
 template <int MB, bool ATOM, int ABL = 0>
-__global__ void __launch_bounds__(256) render_backward_scan_kernel(
+__global__ void __launch_bounds__(256, (MB <= 128 ? 4 : 2)) render_backward_scan_kernel(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int tiles_x, int ntiles,
     const float4 *__restrict__ xyh, const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
     const float *__restrict__ bg, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,

@@ -29,8 +29,9 @@ constexpr int Q_XYH = PIX_WAVE, Q_CO = Q_XYH + QCAP * 16, Q_RGBP = Q_CO + QCAP *
 constexpr int WAVE_LDS = Q_OUT + 16 * 48;   // + the batch's 16 x 12 sums on their way out
 }  // namespace
 
-template <int ABL>
-__global__ void __launch_bounds__(256) render_backward_stream_kernel(
+// WPS: waves per SIMD the register allocation is held to (= workgroups per CU; 4: 128 VGPRs, no spills)
+template <int ABL, int WPS = 4>
+__global__ void __launch_bounds__(256, WPS) render_backward_stream_kernel(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int tiles_x, int ntiles,
     const float4 *__restrict__ xyh, const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
     const float *__restrict__ bg, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
@@ -338,6 +339,8 @@ int launch_render_backward_stream(const das3r_raster_args *a, const float *dL_dp
     else if (abl == 3) GO(3);
     else if (abl == 4) GO(4);
     else if (abl == 8) GO(8);
+    else if (abl == 103) DAS3R_LAUNCH((render_backward_stream_kernel<0, 3>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS);
+    else if (abl == 105) DAS3R_LAUNCH((render_backward_stream_kernel<0, 5>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS);
     else GO(0);
 #undef GO
 #undef ARGS
