@@ -25,6 +25,22 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     uint32_t zero_b_words, uint32_t *__restrict__ zero_c, uint32_t zero_c_words, unsigned long long *__restrict__ arrive,
     uint32_t *__restrict__ host_out, uint32_t tag, const EmitArgs em) {
     const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
+    // Every per-Gaussian input is requested FIRST, ahead of the SH staging loads and their barrier: one trip to memory per
+    // workgroup instead of two back to back (the kernel spent 77 % of its wave cycles parked on s_waitcnt at 1 M splats).
+    const bool live = gidx < P;   // lanes past the end stay alive (workgroup-wide reduction below): they redo the last splat and store nothing
+    const int idx = live ? gidx : P - 1;
+    const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+    const float op = opacities[idx];
+    float3 s_in = make_float3(0.f, 0.f, 0.f);
+    float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
+    float c3_in[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (HAS_COV) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) c3_in[i] = cov3D_precomp[6 * idx + i];
+    } else {
+        s_in = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
+        q_in = reinterpret_cast<const float4 *>(rotations)[idx];
+    }
     __shared__ uint32_t s_tiles;   // this workgroup's sum of tiles_touched (num_rendered is their grand total)
     if (threadIdx.x == 0) s_tiles = 0;
     if (!STAGE) __syncthreads();
@@ -37,7 +53,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     // float4 loads — every 128-B line exactly once — and re-read per lane from LDS.  Per-lane strided row loads re-fetch
     // lines evicted from L1/L2 between the 12 loads of a row: measured 2.5x the algorithmic HBM traffic at 1M splats.
     // Rows are padded to 13 float4 (208 B) so that the per-lane ds_read_b128 of a 16-lane group hit 16 distinct bank slots.
-    __shared__ float4 sh_lds[STAGE ? 256 * 13 : 256];   // (>= 4 KB: the fused emission's digit histograms reuse it)
+    __shared__ float4 sh_lds[STAGE ? 256 * 13 : 256 * 5];   // (the outgoing records and the fused emission's digit histograms reuse it)
     if (STAGE) {
         const float4 *src = reinterpret_cast<const float4 *>(shs) + (size_t)blockIdx.x * 256 * 12;
         const size_t limit = (size_t)P * 12 - (size_t)blockIdx.x * 256 * 12;  // float4s available from src
@@ -48,9 +64,6 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
         }
         __syncthreads();
     }
-    const bool live = gidx < P;   // lanes past the end stay alive (workgroup-wide reduction below): they redo the last splat and store nothing
-    const int idx = live ? gidx : P - 1;
-
     float V[16], PM[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
@@ -67,7 +80,6 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     float4 rgbd_out = make_float4(0.f, 0.f, 0.f, 0.f);
     int bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;   // binned tile rectangle (fused emission)
 
-    const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
     const float3 p_view = xform43(p, V);
     if (p_view.z > NEAR_PLANE) {
         const float4 p_hom = xform44(p, PM);
@@ -77,11 +89,9 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
         float c3[6];
         if (HAS_COV) {
 #pragma unroll
-            for (int i = 0; i < 6; i++) c3[i] = cov3D_precomp[6 * idx + i];
+            for (int i = 0; i < 6; i++) c3[i] = c3_in[i];
         } else {
-            const float3 s = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
-            const float4 q = reinterpret_cast<const float4 *>(rotations)[idx];
-            cov3d_from_scale_rot(s, scale_modifier, q, c3);
+            cov3d_from_scale_rot(s_in, scale_modifier, q_in, c3);
         }
         float T[2][3];
         float3 t;
@@ -125,7 +135,6 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
                 key_out = __float_as_uint(p_view.z);
                 // half extents of the axis-aligned box outside which alpha = opacity * exp(power) cannot reach 1/255
                 // (ellipse d^T Sigma'^-1 d <= 2 ln(255 o)); generous safety margin, used only for wave-level culling
-                const float op = opacities[idx];
                 float hx = -1e30f, hy = -1e30f;
                 if (255.0f * op > 1.0f) {
                     const float tau2 = 2.0f * __logf(255.0f * op) * 1.0005f + 1e-3f;
@@ -145,13 +154,29 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     radii[idx] = radius_out;
     depth_key[idx] = key_out;
     tiles_touched[idx] = tiles_out;
-    xyh[(size_t)idx * SPLAT_REC] = xy_out;            // three fields of the Gaussian's 64-byte record
-    conic_opacity[(size_t)idx * SPLAT_REC] = co_out;
-    rgbd[(size_t)idx * SPLAT_REC] = rgbd_out;
-    // fourth float4 of the record: (radius, tiles_touched) for the scan/emit kernel, which walks the splats in depth order and
-    // would otherwise pay three random cache lines per splat (record, radii[], tiles_touched[]); the whole line is written
-    rgbd[(size_t)idx * SPLAT_REC + 1] = make_float4(__int_as_float(radius_out), __uint_as_float(tiles_out), 0.f, 0.f);
     clamped[idx] = clamp_out;
+    }
+    // The 64-byte records (xyh | conic + opacity | rgb + depth | radius, tiles_touched) leave through LDS: written per lane they
+    // are four 16-byte stores at a 64-byte stride (256 separate write requests per wave); the workgroup's 256 records are one
+    // contiguous 16 KB run, stored here as four fully coalesced float4 sweeps.  The fourth float4 serves the scan/emit kernel,
+    // which walks the splats in depth order and would otherwise pay three random cache lines per splat.
+    {
+        __syncthreads();   // every lane is done with its SH row: the staging area is free
+        float4 *rec = sh_lds;   // [256][5]: records 80 bytes apart, so that the per-lane b128 writes spread over all banks
+        const int t = threadIdx.x, slot = t * 5;
+        rec[slot] = xy_out;
+        rec[slot + 1] = co_out;
+        rec[slot + 2] = rgbd_out;
+        rec[slot + 3] = make_float4(__int_as_float(radius_out), __uint_as_float(tiles_out), 0.f, 0.f);
+        __syncthreads();
+        float4 *dst = xyh + (size_t)blockIdx.x * 256 * SPLAT_REC;
+        const size_t lim = ((size_t)P - (size_t)blockIdx.x * 256) * SPLAT_REC;   // float4s of this workgroup's live records
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int f = i * 256 + t;
+            if ((size_t)f < lim) dst[f] = rec[f + (f >> 2)];
+        }
+        if (em.status != nullptr) __syncthreads();   // (the fused emission reuses the area once more)
     }
 
     // num_rendered = sum of tiles_touched does not depend on the depth order: deliver it to the host NOW, five kernels before the
