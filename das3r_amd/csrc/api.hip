@@ -68,6 +68,8 @@ static void load_switches() {
     if ((e = env("DAS3R_BWD_PAD_LDS"))) w.bwd_pad_lds = atoi(e);
     if ((e = env("DAS3R_FWD_PAD_LDS"))) w.fwd_pad_lds = atoi(e);
     if ((e = env("DAS3R_INJECT_FAULT"))) w.inject_fault = atoi(e);
+    w.bwd_buckets = -1;
+    if ((e = env("DAS3R_BWD_BUCKETS"))) w.bwd_buckets = atoi(e);
     g_sw = w;
     __atomic_store_n(&g_sw_loaded, true, __ATOMIC_RELEASE);
 }
@@ -150,6 +152,7 @@ void compute_layout(int P, int64_t I, int W, int H, Layout *L) {
     L->b_ticket = take(256);
     L->b_status = take(onesweep_status_bytes((int64_t)In, L->tile_passes));
     L->b_ctrl_bytes = o - L->b_ghist;
+    L->b_ckpt = take(((size_t)In / BUCKET + (size_t)(L->ntiles > 0 ? L->ntiles : 1) + 2) * 256 * 16);
     L->pub.binning_bytes = o;
     L->pub.point_list = (L->tile_passes & 1) ? L->b_valB : L->b_valA;
     // img
@@ -399,7 +402,7 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         uint32_t *dead_keys = nullptr;
         if ((r = launch_binning(P, cap, W, H, out->radii, saved->geom, saved->binning, saved->img, L, fused_scan, host_late, late_tag,
                                 a->debug != 0, s, &dead_keys, emit_slot))) return r;
-        LocalBin lb = {nullptr, nullptr, nullptr, nullptr, verdict.gen, (uint32_t)(P - 1), (uint32_t)cap};
+        LocalBin lb = {(float4 *)(saved->binning + L.b_ckpt), nullptr, nullptr, nullptr, nullptr, verdict.gen, (uint32_t)(P - 1), (uint32_t)cap};
         if (local_order && cap > 0) {
             lb.point_list = (uint32_t *)(saved->binning + L.pub.point_list);
             lb.slot_list = (uint32_t *)(saved->binning + L.b_slot);

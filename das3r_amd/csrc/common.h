@@ -35,6 +35,7 @@ struct Switches {
     int ablate;
     int tickets;           // DAS3R_TICKETS=always | never | <bound>: 0 | 1 << 30 | bound (-1: from the device's CU count)
     int bwd_pad_lds, fwd_pad_lds;   // DAS3R_BWD_PAD_LDS / DAS3R_FWD_PAD_LDS: extra dynamic LDS (occupancy experiments)
+    int bwd_buckets;       // DAS3R_BWD_BUCKETS=0 | <slices>: bucket-parallel backward off / forced with that many slices (-1: by list length)
     int inject_fault;      // DAS3R_INJECT_FAULT: bits OR-ed into the binning self-check word of every forward (fault-injection tests)
 };
 const Switches &switches();
@@ -103,6 +104,11 @@ static inline int tile_bits(int ntiles) {
     return b < 1 ? 1 : b;
 }
 
+// Long tile lists are cut into BUCKETs of list positions: the forward compositing kernels leave every pixel's (T, C) at the bucket
+// boundaries in the binning buffer (checkpoints: render_common.h), so that the backward pass can replay the buckets of a tile
+// in parallel workgroups (render_bwd_scan.hip) — the DAS3R shape has 416 tiles with ~14 k entries each: one workgroup per tile
+// leaves the chip at 1.6 waves per SIMD.
+constexpr int BUCKET = 1024;
 constexpr int SPLAT_REC = 4;   // float4s per Gaussian record (xyh, conic+opacity, rgb+depth, pad): 64 bytes, one cache-line gather
 
 struct Layout {
@@ -110,6 +116,7 @@ struct Layout {
     // private scratch offsets
     size_t g_keyA, g_keyB, g_valA, g_valB, g_hist, g_totals, g_blocksums, g_count, g_off_by_gid;
     size_t b_keyA, b_keyB, b_valA, b_valB, b_hist, b_totals, b_gid_of, b_slot;
+    size_t b_ckpt;   // float4[(capacity / BUCKET + ntiles + 2) * 256]: per-pixel (T, C) at the bucket boundaries of long tile lists
     // single-pass radix control words (sort_onesweep.hip): [global digit histograms][tickets][status granules], contiguous
     // so that one store loop / one memset zeroes them: geom side by preprocess_kernel, binning side by a memset before emit
     size_t g_ghist, g_ticket, g_status, g_scan_status, g_ctrl_bytes;
@@ -123,6 +130,7 @@ struct Layout {
 // the forward compositing kernel sorts each one by (depth bits, index) itself (render_common.h: local_sort_tile) — in LDS up
 // to LOCAL_MAX entries, in global memory (slow, rare) beyond.  point_list == null: the lists are already in depth order.
 struct LocalBin {
+    float4 *ckpt;                       // checkpoints of long tile lists (always set; see BUCKET)
     uint32_t *point_list, *slot_list;   // sorted in place
     uint32_t *keys;                     // u32[num_rendered] scratch for the lists that do not fit in LDS (the dead tile keys)
     uint32_t *host_flag;                // pinned mailbox word that receives flag_value when such a list was met
@@ -180,8 +188,9 @@ int launch_render_backward_mfma(const das3r_raster_args *a, const float *dL_dpix
 size_t stream_scratch_bytes(int64_t capacity);
 int launch_render_backward_stream(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
                                   float *scratch, hipStream_t s);
+// slices > 1: bucket-parallel replay (grid = tiles x slices; needs the forward's checkpoints)
 int launch_render_backward_scan(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
-                                float *partial, int mb, hipStream_t s);
+                                float *partial, int mb, int slices, hipStream_t s);
 constexpr int LOCAL_MAX = 1024;   // longest tile list the forward kernels sort in LDS
 // chained kernels (scan, radix passes) order their workgroups by ticket unless every workgroup of the grid is resident at once
 // (api.hip: grid_is_resident)

@@ -176,7 +176,15 @@ int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, cha
         return launch_render_backward_stream(a, dL_dpix, geom, binning, img, L, partial, s);
     }
     if (kind == 2) return launch_render_backward_mfma(a, dL_dpix, geom, binning, img, L, partial, s);
-    if (kind >= 3) return launch_render_backward_scan(a, dL_dpix, geom, binning, img, L, partial, mb, s);
+    if (kind >= 3) {
+        // long lists are replayed bucket by bucket in parallel workgroups (checkpoints from the forward: common.h BUCKET); slices =
+        // buckets of an average tile, so that a tile's workgroups take about one bucket each
+        int slices = sw.bwd_buckets;
+        if (slices < 0) slices = (int)std::min<int64_t>(32, std::max<int64_t>(1, num_rendered / ((int64_t)BUCKET * std::max(L.ntiles, 1))));
+        if (slices > 1 && mb > 256) slices = 1;
+        if (slices > 1 && !sw.render_bwd && !sw.render_bwd_mb) mb = 128;   // (with buckets a round is at most 1024 positions: 4 workgroups per CU beat longer rounds)
+        return launch_render_backward_scan(a, dL_dpix, geom, binning, img, L, partial, mb, slices, s);
+    }
     const bool use_dpp = !sw.bwd_reduce_shfl;   // "shfl" selects the ds_bpermute reference reduction (diagnostics)
     const int ablate = sw.ablate;               // perf experiments only: bit0 = no partial stores, bit2 = no cross-lane reduction
 #define ARGS                                                                                                                 \

@@ -35,14 +35,17 @@ __global__ void __launch_bounds__(256, (MB <= 128 ? 4 : 2)) render_backward_scan
     const float4 *__restrict__ xyh, const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
     const float *__restrict__ bg, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
     const float *__restrict__ dL_dpix, const uint32_t *__restrict__ slot_list, float *__restrict__ partial /*[I,9]*/,
-    uint32_t last_g, uint32_t cap /*bounds of the list contents: render_common.h safe_range*/) {
+    uint32_t last_g, uint32_t cap /*bounds of the list contents: render_common.h safe_range*/,
+    const float4 *__restrict__ ckpt /*forward's checkpoints of long lists (render_common.h); used when gridDim.y > 1*/) {
     // one LDS object (cdna_hip_programming.md: a second __shared__ array changes the waits the compiler emits)
-    constexpr int NROW = 12;                                             // C0 C1 C2 M0 | Mu Mv Muu Muv | Mvv C0' C1' C2'  (' = from the low parts of dL/dpix)
+    constexpr int NROW = ATOM ? 12 : 9;   // private regions: C0 C1 C2 M0 | Mu Mv Muu Muv (two 16-byte pieces) + Mvv in its own array; shared: + C0' C1' C2'
+    constexpr int NROW8 = ATOM ? 12 : 8;
     constexpr int PIX_ROW = 8 * (int)sizeof(PixRow) + 16;                // one image row of a quadrant (+16: the four rows a step reads sit on different banks)
     constexpr int PIX_WAVE = 8 * PIX_ROW;
     constexpr int OFF_STAGE = 0;                                         // StagedSplat[MB]
-    constexpr int OFF_ACC = OFF_STAGE + MB * (int)sizeof(StagedSplat);   // float[ATOM ? 1 : 4 waves][MB][12]
-    constexpr int OFF_PIX = OFF_ACC + (ATOM ? 1 : 4) * MB * NROW * 4;    // 4 waves x 8 rows of PixRow[8]
+    constexpr int OFF_ACC = OFF_STAGE + MB * (int)sizeof(StagedSplat);   // float[ATOM ? 1 : 4 waves][MB][12 | 8]
+    constexpr int OFF_ACC1 = OFF_ACC + (ATOM ? 1 : 4) * MB * NROW8 * 4;   // float[4 waves][MB]: Mvv (private regions only)
+    constexpr int OFF_PIX = OFF_ACC1 + (ATOM ? 0 : 4 * MB * 4);          // 4 waves x 8 rows of PixRow[8]
     constexpr int OFF_SLOT = OFF_PIX + 4 * PIX_WAVE;                     // uint32_t[MB]
     constexpr int OFF_HIT = OFF_SLOT + MB * 4;                           // uint64_t[4][MB / 64]
     constexpr int OFF_LIST = OFF_HIT + 4 * (MB / 64) * 8;                // uint8_t / uint16_t [4][MB]
@@ -51,6 +54,7 @@ __global__ void __launch_bounds__(256, (MB <= 128 ? 4 : 2)) render_backward_scan
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     StagedSplat *const stage = reinterpret_cast<StagedSplat *>(lds + OFF_STAGE);
     float *const acc = reinterpret_cast<float *>(lds + OFF_ACC);
+    float *const acc1 = reinterpret_cast<float *>(lds + OFF_ACC1);
     float *const outp = acc;   // [MB][9] rows on their way to `partial`: reuses the accumulators once they have been read
     uint32_t *const s_slot = reinterpret_cast<uint32_t *>(lds + OFF_SLOT);
     uint64_t *const s_hit = reinterpret_cast<uint64_t *>(lds + OFF_HIT);
@@ -71,6 +75,7 @@ __global__ void __launch_bounds__(256, (MB <= 128 ? 4 : 2)) render_backward_scan
 
     // ---- the quadrant's pixels, one per lane (lane = 8 y + x): constants and initial state into the LDS rows ----
     uint32_t last_contributor;
+    float my_T_final, my_dLp0, my_dLp1, my_dLp2;   // this lane's pixel (lane = 8 y + x), kept for the per-bucket state
     {
         const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
         const bool inside = px < W && py < H;
@@ -93,6 +98,10 @@ __global__ void __launch_bounds__(256, (MB <= 128 ? 4 : 2)) render_backward_scan
         row.last = last_contributor;
         row.zero = 0.f;
         *pix_at(lane & 7, lane >> 3) = row;
+        my_T_final = T_final;
+        my_dLp0 = dLp0;
+        my_dLp1 = dLp1;
+        my_dLp2 = dLp2;
     }
     // no pixel of this tile blended anything past list position max_contrib: start the replay there
     uint32_t mx = last_contributor;
@@ -100,17 +109,13 @@ __global__ void __launch_bounds__(256, (MB <= 128 ? 4 : 2)) render_backward_scan
     for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
     if (lane == 0) s_max[wave] = mx;
     __syncthreads();
-    const uint32_t max_contrib = min(max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])), range.y - range.x);
-    const int rounds = ((int)max_contrib + MB - 1) / MB;
-    {   // list entries beyond max_contrib receive no gradient from this tile: their partial rows are zero
-        const uint32_t len = range.y - range.x;
-        const uint32_t ntail = (len - max_contrib) * NACC;
-        for (uint32_t f = tid; f < ntail; f += TILE_PIX) {
-            const uint32_t t = f / NACC, q = f - t * NACC;
-            partial[(size_t)min(slot_list[range.x + max_contrib + t], cap - 1u) * NACC + q] = 0.f;
-        }
-    }
-
+    const uint32_t list_len = range.y - range.x;
+    const uint32_t tile_contrib = min(max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])), list_len);
+    // Bucket-parallel replay (gridDim.y = slices > 1): this workgroup takes buckets blockIdx.y, blockIdx.y + slices, ... of the
+    // tile's list; a bucket starts from the pixel states the forward left at its far end (checkpoints).  slices == 1: the whole list
+    // as one "bucket", starting from final_T.
+    const int slices = (int)gridDim.y;
+    const int nbuckets = slices > 1 ? max(ckpt_buckets(range), 1) : 1;
     // ---- lane (r, s) of the walk: splat s of a batch; image rows r and 4 + r of the quadrant, one column per step ----
     // (the K index of v_mfma_f32_16x16x32_bf16 is 8 (lane >> 4) + element: a lane supplies eight consecutive k = the eight pixels
     //  of ITS image row, so the sixteen steps of a batch are: columns 0..7 of rows r, then columns 0..7 of rows 4 + r)
@@ -140,12 +145,39 @@ __global__ void __launch_bounds__(256, (MB <= 128 ? 4 : 2)) render_backward_scan
         Aop[half] = U4{pack_hi(wv[0], wv[1]), pack_hi(wv[2], wv[3]), pack_hi(wv[4], wv[5]), pack_hi(wv[6], wv[7])};
     }
 
+    for (int bk = (int)blockIdx.y; bk < nbuckets; bk += slices) {
+    const uint32_t lo = slices > 1 ? (uint32_t)bk * BUCKET : 0u;                     // the bucket's list positions [lo, hi)
+    const uint32_t hi = slices > 1 ? min(list_len, lo + BUCKET) : list_len;
+    const uint32_t max_contrib = tile_contrib > lo ? min(tile_contrib, hi) - lo : 0u;   // entries of the bucket to replay (its first ones)
+    const int rounds = ((int)max_contrib + MB - 1) / MB;
+    {   // list entries beyond the last contributor receive no gradient from this tile: their partial rows are zero
+        const uint32_t ntail = (hi - lo - max_contrib) * NACC;
+        for (uint32_t f = tid; f < ntail; f += TILE_PIX) {
+            const uint32_t t = f / NACC, q = f - t * NACC;
+            partial[(size_t)min(slot_list[range.x + lo + max_contrib + t], cap - 1u) * NACC + q] = 0.f;
+        }
+    }
+    if (max_contrib == 0u) continue;   // (uniform)
+    if (slices > 1) {   // the pixels' state at the far end of the bucket
+        float T0 = my_T_final, R0 = 0.f;
+        if (bk < nbuckets - 1) {
+            const int cpix = (((wave >> 1) << 3) + (lane >> 3)) * 16 + ((wave & 1) << 3) + (lane & 7);
+            const float4 far = ckpt_slot(const_cast<float4 *>(ckpt), range, tile, bk)[cpix];            // (T, C) in front of position hi
+            const float4 fin = ckpt_slot(const_cast<float4 *>(ckpt), range, tile, nbuckets - 1)[cpix];  // final (T, C)
+            T0 = far.x;
+            R0 = my_dLp0 * (fin.y - far.y) + my_dLp1 * (fin.z - far.z) + my_dLp2 * (fin.w - far.w);   // (c . dL/dpix) alpha T of everything behind
+        }
+        PixRow *row = pix_at(lane & 7, lane >> 3);
+        row->T = T0;
+        row->R = R0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // (wave-private rows)
+    }
     for (int i = 0; i < rounds; i++) {
         const int done_before = i * MB;
         const int n = min(MB, (int)max_contrib - done_before);
         // stage the batch in reverse list order; entry j holds list position (max_contrib - 1 - done_before - j)
         for (int t = tid; t < n; t += TILE_PIX) {
-            const uint32_t pos = range.x + max_contrib - 1 - done_before - t;
+            const uint32_t pos = range.x + lo + max_contrib - 1 - done_before - t;
             const uint32_t g = min(point_list[pos], last_g);
             s_slot[t] = min(slot_list[pos], cap - 1u);
             stage[t].xyh = xyh[(size_t)g * SPLAT_REC];           // one 64-byte record: a single cache line per splat
@@ -181,7 +213,7 @@ __global__ void __launch_bounds__(256, (MB <= 128 ? 4 : 2)) render_backward_scan
             float4 co = stage[j].co;
             const float4 c = stage[j].rgbd;
             co.w = valid ? co.w : 0.f;   // an empty slot of the last batch: alpha = 0 on every pixel
-            const uint32_t position = max_contrib - 1 - done_before - j;   // 0-based list position of the lane's splat
+            const uint32_t position = lo + max_contrib - 1 - done_before - j;   // 0-based list position of the lane's splat
             v4f Dw = {0.f, 0.f, 0.f, 0.f}, Dg = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int half = 0; half < 2; half++) {
@@ -266,29 +298,39 @@ __global__ void __launch_bounds__(256, (MB <= 128 ? 4 : 2)) render_backward_scan
             }
             // lane (r, s) holds rows 4 r .. 4 r + 3 of both products for splat s: the twelve useful ones leave as one 16-byte row piece per lane
             //   r = 0: C0 C1 C2 (A w) | M0 (A g)      r = 1: Mu Mv Muu Muv (A g)      r = 2: Mvv (A g) | C0' C1' C2' (A w)
-            v4f D;
-            D[0] = r == 0 ? Dw[0] : Dg[0];
-            D[1] = r == 1 ? Dg[1] : Dw[1];
-            D[2] = r == 1 ? Dg[2] : Dw[2];
-            D[3] = r == 2 ? Dw[3] : Dg[3];
             if constexpr (ATOM) {
+                v4f D;
+                D[0] = r == 0 ? Dw[0] : Dg[0];
+                D[1] = r == 1 ? Dg[1] : Dw[1];
+                D[2] = r == 1 ? Dg[2] : Dw[2];
+                D[3] = r == 2 ? Dw[3] : Dg[3];
                 float *const a12 = acc + (size_t)j * NROW + 4 * r;
                 if (valid && r < 3) {
 #pragma unroll
                     for (int q = 0; q < 4; q++) __hip_atomic_fetch_add(a12 + q, D[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             } else {
-                float *const a12 = acc + ((size_t)wave * MB + j) * NROW + 4 * r;
-                if (valid && r < 3) *reinterpret_cast<v4f *>(a12) = D;
+                // colour rows: high-part products in lanes r = 0 (rows 0..2), low-part products in lanes r = 2 (rows 9..11): the upper
+                // half of the wave hands its three values down (v_permlane32_swap), so that a (wave, entry) record is 36 bytes
+                v4f D;
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(Dw[q + 1]), 0u, false, false);
+                    D[q] = Dw[q] + __uint_as_float(sw[1]);   // (lanes 0..15: own row q + row 9 + q of lanes 32..47)
+                }
+                D[3] = Dg[3];
+                if (r == 1) D = Dg;
+                if (valid && r < 2) *reinterpret_cast<v4f *>(acc + ((size_t)wave * MB + j) * 8 + 4 * r) = D;
+                if (valid && r == 2) acc1[wave * MB + j] = Dg[0];
             }
         }
         __syncthreads();
         // the four waves' sums of every staged entry, moments -> the nine per-instance sums
         for (int t0 = 0; t0 < n; t0 += TILE_PIX) {
             const int t = t0 + tid;
-            float a[NROW];
+            float a[12];
 #pragma unroll
-            for (int q = 0; q < NROW; q++) a[q] = 0.f;
+            for (int q = 0; q < 12; q++) a[q] = 0.f;
             if (t < n) {
                 if constexpr (ATOM) {
 #pragma unroll
@@ -300,11 +342,11 @@ __global__ void __launch_bounds__(256, (MB <= 128 ? 4 : 2)) render_backward_scan
 #pragma unroll
                     for (int w = 0; w < 4; w++) {
                         if ((s_hit[w * (MB / 64) + (t >> 6)] >> (t & 63)) & 1ull) {
-#pragma unroll
-                            for (int q = 0; q < NROW; q += 4) {
-                                const v4f v = *reinterpret_cast<const v4f *>(acc + ((size_t)w * MB + t) * NROW + q);
-                                a[q] += v[0]; a[q + 1] += v[1]; a[q + 2] += v[2]; a[q + 3] += v[3];
-                            }
+                            const v4f lo4 = *reinterpret_cast<const v4f *>(acc + ((size_t)w * MB + t) * 8);
+                            const v4f hi4 = *reinterpret_cast<const v4f *>(acc + ((size_t)w * MB + t) * 8 + 4);
+                            a[0] += lo4[0]; a[1] += lo4[1]; a[2] += lo4[2]; a[3] += lo4[3];
+                            a[4] += hi4[0]; a[5] += hi4[1]; a[6] += hi4[2]; a[7] += hi4[3];
+                            a[8] += acc1[w * MB + t];
                         }
                     }
                 }
@@ -317,9 +359,9 @@ __global__ void __launch_bounds__(256, (MB <= 128 ? 4 : 2)) render_backward_scan
                 const float X = p.x - tcx, Y = p.y - tcy, kh = -0.5f * co.w;
                 const float Sgx = kh * (X * M0 - Mu), Sgy = kh * (Y * M0 - Mv);   // -1/2 o sum g dx, dy  (dx = X - u)
                 float *row = outp + (size_t)t * NACC;
-                row[0] = a[0] + a[9];
-                row[1] = a[1] + a[10];
-                row[2] = a[2] + a[11];
+                row[0] = ATOM ? a[0] + a[NROW - 3] : a[0];
+                row[1] = ATOM ? a[1] + a[NROW - 2] : a[1];
+                row[2] = ATOM ? a[2] + a[NROW - 1] : a[2];
                 row[3] = (Sgx * co.x + Sgy * co.y) * (float)W;        // dL/dmean2D in NDC units: 2 * (W / 2)
                 row[4] = (Sgy * co.z + Sgx * co.y) * (float)H;
                 row[5] = kh * (X * X * M0 - 2.f * X * Mu + Muu);
@@ -336,17 +378,18 @@ __global__ void __launch_bounds__(256, (MB <= 128 ? 4 : 2)) render_backward_scan
         }
         __syncthreads();
     }
+    }
 }
 
 int launch_render_backward_scan(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
-                                float *partial, int mb, hipStream_t s) {
+                                float *partial, int mb, int slices, hipStream_t s) {
 #define ARGS                                                                                                              \
     (const uint2 *)(img + L.pub.ranges), (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height, \
         L.tiles_x, L.ntiles, (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),             \
         (const float4 *)(geom + L.pub.rgbd), a->bg, (const float *)(img + L.pub.final_T),                                 \
         (const uint32_t *)(img + L.pub.n_contrib), dL_dpix, (const uint32_t *)(binning + L.b_slot), partial,              \
-        (uint32_t)(a->P - 1), (uint32_t)L.capacity
-#define GO(MBV, AT, AB) DAS3R_LAUNCH((render_backward_scan_kernel<MBV, AT, AB>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS)
+        (uint32_t)(a->P - 1), (uint32_t)L.capacity, (const float4 *)(binning + L.b_ckpt)
+#define GO(MBV, AT, AB) DAS3R_LAUNCH((render_backward_scan_kernel<MBV, AT, AB>), dim3(xcd_grid(L.ntiles), slices > 1 ? slices : 1), dim3(TILE_PIX), 0, s, ARGS)
     const int abl = switches().ablate_set ? switches().ablate : 0;
     // mb: 64 / 128 / 256 private accumulator regions; 1256 / 1512: 256 / 512 entries per round with the atomic flush
     if (mb == 128 && abl == 1) GO(128, false, 1);

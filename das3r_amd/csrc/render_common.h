@@ -60,6 +60,16 @@ __device__ __forceinline__ bool quadrant_hit(const float4 xyh, const float cx, c
     return fabsf(xyh.x - cx) <= xyh.z + 3.5f && fabsf(xyh.y - cy) <= xyh.w + 3.5f;
 }
 
+// ---- checkpoints of long tile lists (common.h: BUCKET) -----------------------------------------------------------------------
+// A tile whose list has len > BUCKET entries owns nb = ceil(len / BUCKET) slots of 256 float4 (one per pixel, row-major inside the
+// tile), the first at block  range.x / BUCKET + tile  (distinct tiles never overlap: floor(a + b) >= floor(a) + floor(b)).
+// Slot s < nb - 1 holds the pixel's (T, C0, C1, C2) in front of list position (s + 1) * BUCKET; slot nb - 1 its final values
+// (C without the background).  Shorter lists write nothing.
+__device__ __forceinline__ float4 *ckpt_slot(float4 *ckpt, const uint2 range, const int tile, const int s) {
+    return ckpt + ((size_t)(range.x / BUCKET) + (size_t)tile + (size_t)s) * TILE_PIX;
+}
+__device__ __forceinline__ int ckpt_buckets(const uint2 range) { return (int)((range.y - range.x + BUCKET - 1) / BUCKET); }
+
 // ---- local binning front-end (local_bin.hip) -------------------------------------------------------------------------------
 // Local depth order (common.h: LocalBin): the tile's list arrives in index order; put it in the exact (depth bits, index)
 // order the global radix path produces, in place (point_list / slot_list are read by the backward pass and the tests).

@@ -38,8 +38,12 @@ __global__ void __launch_bounds__(256) render_forward_kernel(const uint2 *__rest
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     uint32_t last_contributor = 0;
 
+    const int nb = ckpt_buckets(range);                                 // (> 1: a long list, checkpointed for the bucket-parallel backward)
+    const int cpix = ((py - by * TILE_Y) << 4) + (px - bx * TILE_X);      // pixel's place in a checkpoint slot
+    int next_slot = 0;
     for (int i = 0; i < rounds; i++, toDo -= TILE_PIX) {
         if (__syncthreads_count(live == 0.f) == TILE_PIX) break;
+        if (nb > 1 && i > 0 && (i * TILE_PIX) % BUCKET == 0) ckpt_slot(lb.ckpt, range, tile, next_slot++)[cpix] = make_float4(T, C0, C1, C2);
         const uint32_t progress = range.x + i * TILE_PIX + tid;
         if (progress < range.y && !prestaged) {
             const uint32_t g = min(sorted_here ? s_gid[i * TILE_PIX + tid] : (lb.point_list ? lb.point_list[progress] : point_list[progress]), lb.last_g);
@@ -85,6 +89,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(const uint2 *__rest
             }
         }
     }
+    for (; nb > 1 && next_slot < nb; next_slot++) ckpt_slot(lb.ckpt, range, tile, next_slot)[cpix] = make_float4(T, C0, C1, C2);   // (early exit: nothing changes any more)
     if (inside) {
         const size_t pix = (size_t)py * W + px, plane = (size_t)H * W;
         final_T[pix] = T;

@@ -325,6 +325,30 @@ def test_every_backward_kernel_vs_oracle(name, kind, monkeypatch):
         util.assert_grad_close(t.cpu().numpy(), ref_g[gmap[k]], f"{name} [{kind}] dL/d{k}")
 
 
+@pytest.mark.parametrize("kind", ["scan128", "scan256"])
+@pytest.mark.parametrize("slices", [2, 5])
+@pytest.mark.parametrize("name", ["deep", "long_lists", "basic_deg3"])
+def test_bucket_parallel_backward(name, kind, slices, monkeypatch):
+    """Long tile lists replayed bucket by bucket in parallel workgroups, each from the pixel states the forward checkpointed at
+    the bucket boundaries (common.h BUCKET = 1024 list positions; "deep" has ~4000 entries per tile, "long_lists" ~1500 and
+    saturating pixels, "basic_deg3" none that long: every tile is its own last bucket) — against the oracle and against the
+    sequential replay."""
+    sc, mode = util.scene_variant(name)
+    _, _, ref_g, S = util.run_oracle(sc, mode)
+    monkeypatch.setenv("DAS3R_RENDER_BWD", kind)
+    monkeypatch.setenv("DAS3R_BWD_BUCKETS", "0")
+    _, _, g_seq, fn = _run_hip(sc, mode)
+    monkeypatch.setenv("DAS3R_BWD_BUCKETS", str(slices))
+    _, _, g, _ = _run_hip(sc, mode)
+    if name != "basic_deg3":
+        tiles = ((sc.W + 15) // 16) * ((sc.H + 15) // 16)
+        assert fn.num_rendered > 1024 * tiles, "the scene is meant to have lists of several buckets"
+    gmap = {"means3D": "means3D", "opacities": "opacities", "shs": "shs", "scales": "scales", "rotations": "rotations", "means2D": "means2D"}
+    for k, t in g.items():
+        util.assert_grad_close(t.cpu().numpy(), ref_g[gmap[k]], f"{name} [{kind}, {slices} slices] dL/d{k}")
+        util.assert_grad_close(t.cpu().numpy(), g_seq[k].cpu().numpy(), f"{name} bucket-parallel vs sequential dL/d{k}", tol=5e-5)
+
+
 def test_failed_binning_is_reported_before_the_backward_pass(monkeypatch):
     """A forward whose binning kernels fail their self-check (here: a look-back timeout forced into the word the last binning
     kernel hands to the host, DAS3R_INJECT_FAULT) must not get as far as a parameter update: the backward pass examines the
