@@ -70,9 +70,11 @@ __device__ __forceinline__ void sh_basis(const int D, const float x, const float
         }                                                                                                                       \
     } while (0)
 
-template <bool HAS_SH, bool HAS_COV, bool STAGE_IN, bool STAGE_OUT>
-__global__ void __launch_bounds__(256, 3) preprocess_backward_kernel(
-    int P, int D, int M, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
+// DEG0: the active degree is 0 (DAS3R's own setting, arguments.py sh_degree): no SH row is read and the view-direction terms
+// vanish at compile time, which halves the register count of the unstaged variant (6 waves per SIMD instead of 3)
+template <bool HAS_SH, bool HAS_COV, bool STAGE_IN, bool STAGE_OUT, bool DEG0 = false>
+__global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
+    int P, int D_in, int M, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
     const float *__restrict__ rotations, const float *__restrict__ shs, const float *__restrict__ cov3D_precomp,
     const float *__restrict__ viewmatrix, const float *__restrict__ projmatrix, const float *__restrict__ campos, int W, int H,
     float tanfovx, float tanfovy, const uint32_t *__restrict__ tiles_touched, const uint8_t *__restrict__ clamped,
@@ -84,6 +86,7 @@ __global__ void __launch_bounds__(256, 3) preprocess_backward_kernel(
     // one 208-byte (13 x float4) LDS row per lane: SH coefficients in (STAGE_IN), dL_dsh out (STAGE_OUT)
     __shared__ float4 sh_lds[(STAGE_IN || STAGE_OUT) ? 256 * 13 : 1];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int D = DEG0 ? 0 : D_in;
     // Everything a lane needs that does not depend on another load is requested FIRST, ahead of the SH staging loads and their
     // barrier (one trip to memory instead of three in a row: tiles_touched -> off_by_gid -> partial rows used to start behind it)
     const int ic = idx < P ? idx : P - 1;
@@ -102,12 +105,73 @@ __global__ void __launch_bounds__(256, 3) preprocess_backward_kernel(
     }
     const size_t blk4 = (size_t)blockIdx.x * 256 * 12;                    // first float4 of this workgroup's rows
     const size_t limit4 = (size_t)P * 12 > blk4 ? (size_t)P * 12 - blk4 : 0;  // float4s this workgroup owns
-    if (STAGE_IN) {
+    // The staged variants gather the per-instance rows THROUGH LDS: the rows of 256 consecutive splats are one contiguous run of
+    // partial[] (rows are indexed by emission slot and slots are handed out in splat order), so the workgroup streams that run in
+    // with coalesced loads, 1024 rows at a time, and each lane then adds its own rows out of LDS in the same order as before
+    // (bit-identical sums).  A lane used to walk its rows with one trip to L2 per row: the longest walk of 64 lanes set the pace.
+    constexpr bool LDS_GATHER = STAGE_OUT;
+    constexpr int CHUNK_ROWS = 1024;                                      // 36 KB of the 52 KB region
+    float acc[9];
+#pragma unroll
+    for (int q = 0; q < 9; q++) acc[q] = 0.f;
+    float4 sh_in[STAGE_IN ? 12 : 1];
+    if (STAGE_IN) {   // requested now, parked in registers while the region serves the gather
         const float4 *src = reinterpret_cast<const float4 *>(shs) + blk4;
 #pragma unroll
         for (int i = 0; i < 12; i++) {
             const int f = i * 256 + threadIdx.x;
-            if ((size_t)f < limit4) sh_lds[(f / 12) * 13 + (f % 12)] = src[f];
+            sh_in[i] = (size_t)f < limit4 ? src[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    bool gathered = false;
+    uint32_t run0 = 0u, run1 = 0u;
+    if (LDS_GATHER && !row_exists) {
+        // Is it one run?  Splat-order emission (local depth order) makes it so; the globally sorted path hands slots out in depth
+        // order and culled splats have no slot at all.  The workgroup decides for itself: the rows of its visible splats are
+        // disjoint intervals, so they tile [min first, max end) exactly when their lengths add up to max end - min first.
+        __shared__ uint32_t s_run[4][3];
+        uint32_t lo = ntiles_g ? e0_in : 0xFFFFFFFFu, hi = ntiles_g ? e0_in + ntiles_g : 0u, cnt = ntiles_g;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            lo = min(lo, (uint32_t)__shfl_xor((int)lo, o, 64));
+            hi = max(hi, (uint32_t)__shfl_xor((int)hi, o, 64));
+            cnt += (uint32_t)__shfl_xor((int)cnt, o, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            s_run[threadIdx.x >> 6][0] = lo;
+            s_run[threadIdx.x >> 6][1] = hi;
+            s_run[threadIdx.x >> 6][2] = cnt;
+        }
+        __syncthreads();
+        run0 = min(min(s_run[0][0], s_run[1][0]), min(s_run[2][0], s_run[3][0]));
+        run1 = max(max(s_run[0][1], s_run[1][1]), max(s_run[2][1], s_run[3][1]));
+        const uint32_t rows = s_run[0][2] + s_run[1][2] + s_run[2][2] + s_run[3][2];
+        gathered = rows == 0u || rows == run1 - run0;   // (workgroup-uniform)
+    }
+    if (gathered) {
+        float *const buf = reinterpret_cast<float *>(sh_lds);
+        const uint32_t mine0 = e0_in, mine1 = e0_in + ntiles_g;
+        for (uint32_t c0 = run0; c0 < run1; c0 += CHUNK_ROWS) {
+            const uint32_t nrows = min((uint32_t)CHUNK_ROWS, run1 - c0);
+            const float *src = partial + (size_t)c0 * 9;
+            const int n9 = (int)nrows * 9;
+#pragma unroll 4
+            for (int f = threadIdx.x; f < n9; f += 256) buf[f] = src[f];
+            __syncthreads();
+            const uint32_t k0 = max(mine0, c0), k1 = min(mine1, c0 + nrows);
+            for (uint32_t k = k0; k < k1; k++) {
+                const float *row = buf + (k - c0) * 9;   // (stride 9 words: consecutive rows fall in different banks)
+#pragma unroll
+                for (int q = 0; q < 9; q++) acc[q] += row[q];
+            }
+            __syncthreads();
+        }
+    }
+    if (STAGE_IN) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const int f = i * 256 + threadIdx.x;
+            if ((size_t)f < limit4) sh_lds[(f / 12) * 13 + (f % 12)] = sh_in[i];
         }
         __syncthreads();
     }
@@ -117,10 +181,7 @@ __global__ void __launch_bounds__(256, 3) preprocess_backward_kernel(
         const bool visible = ntiles_g > 0;
 
         // add this splat's per-instance sums (one row per touched tile; the render backward wrote them at the emission slots)
-        float acc[9];
-#pragma unroll
-        for (int q = 0; q < 9; q++) acc[q] = 0.f;
-        if (visible) {
+        if (visible && !gathered) {
             const uint32_t e0 = e0_in;
             if (row_exists) {   // render_bwd_stream.hip: up to four 48-byte rows per instance, one per quadrant of the tile that met the splat
                 for (uint32_t k = 0; k < ntiles_g; k++) {
@@ -385,13 +446,17 @@ int launch_preprocess_backward(const das3r_raster_args *a, const das3r_raster_in
         (const uint32_t *)(geom + L.g_off_by_gid), g->dL_dmeans2D, g->dL_dopacities, g->dL_dcolors_precomp, g->dL_dmeans3D,  \
         g->dL_dscales, g->dL_drotations, g->dL_dshs, g->dL_dcov3D
 #define LAUNCH(SH, COV, SI, SO) DAS3R_LAUNCH((preprocess_backward_kernel<SH, COV, SI, SO>), grid, block, 0, s, ARGS)
+#define LAUNCH0(SH, COV) DAS3R_LAUNCH((preprocess_backward_kernel<SH, COV, false, false, true>), grid, block, 0, s, ARGS)
+    const bool deg0 = a->sh_degree == 0 && !stage_out;
     if (has_sh && !has_cov) {
         if (stage_in) LAUNCH(true, false, true, true);
         else if (stage_out) LAUNCH(true, false, false, true);
+        else if (deg0) LAUNCH0(true, false);
         else LAUNCH(true, false, false, false);
     } else if (has_sh && has_cov) {
         if (stage_in) LAUNCH(true, true, true, true);
         else if (stage_out) LAUNCH(true, true, false, true);
+        else if (deg0) LAUNCH0(true, true);
         else LAUNCH(true, true, false, false);
     } else if (!has_sh && !has_cov) {
         LAUNCH(false, false, false, false);
@@ -399,6 +464,7 @@ int launch_preprocess_backward(const das3r_raster_args *a, const das3r_raster_in
         LAUNCH(false, true, false, false);
     }
 #undef LAUNCH
+#undef LAUNCH0
 #undef ARGS
     KERNEL_CHECK(s, a->debug, "preprocess_backward");
     return DAS3R_OK;
