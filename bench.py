@@ -46,6 +46,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--extras-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic then quotes profiles/)")
+    ap.add_argument("--full-line", action="store_true", help="put the per-workload extras into the JSON line itself instead of stderr")
     ap.add_argument("--stub", action="store_true",
                     help="CPU dry run of the launch / barrier / reduction logic with a stand-in step (gloo; tests/test_bench_launch.py)")
     return ap.parse_args(argv)
@@ -186,7 +189,7 @@ class RasterJob:
         return color
 
 
-def kernel_table(job, steps):
+def kernel_table(job, steps, measured=None):
     """The same K steps again with every kernel launch bracketed by HIP events on its launch stream (das3r_profile_*), kept apart
     from the timed region so that `value` is not perturbed.  -> (kernels dict, roofline dict)"""
     import glob
@@ -216,19 +219,27 @@ def kernel_table(job, steps):
     dom_ms = kernels[dom]["ms_per_step"]
     achieved = per_kernel[dom] / (dom_ms * 1e-3) / 1e9
     total_ms = sum(v["ms_per_step"] for v in kernels.values())
-    # HBM bytes per launch: NOT measured in this run — PMC counters need their own rocprofv3 --pmc passes (tools/pmc_collect.sh);
-    # the committed summary of the latest round is quoted, with its source
+    # HBM bytes per launch: PMC counters need rocprofv3 passes of their own — measure_traffic() runs them as children of this
+    # run when it can; otherwise the committed summary of the latest round is quoted, with its source
     traffic, traffic_source = None, None
     wname = "c4" if job.name == "c4d" else job.name
+    if measured is not None and measured[0]:
+        for k, ent in kernels.items():
+            if k in measured[0]:
+                ent["hbm_bytes"] = int(measured[0][k])
+                if "alg_bytes" in ent:
+                    ent["traffic_over_alg"] = round(measured[0][k] / ent["alg_bytes"], 3)
+        traffic, traffic_source = kernels[dom].get("hbm_bytes"), measured[1]
     pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc_{wname}.json")))
-    if pmc:
+    if traffic is None and pmc:
         try:
             ent = json.load(open(pmc[-1]))
             rec = ent.get(dom) or ent.get({"render_backward_kernel": "render_backward_scan_kernel"}.get(dom, dom)) or {}
             traffic = rec.get("hbm_bytes_per_launch")
             if traffic is not None:
                 traffic_source = (f"{os.path.relpath(pmc[-1], ROOT)} (separate rocprofv3 --pmc passes of the same workload, committed; "
-                                  f"FETCH_SIZE doubled per MI355X_MICROARCH.md) — not collected by this run")
+                                  f"FETCH_SIZE doubled per MI355X_MICROARCH.md) — not collected by this run"
+                                  + (f" ({measured[1]})" if measured is not None else ""))
         except Exception:  # noqa: BLE001
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -239,6 +250,74 @@ def kernel_table(job, steps):
                              "frac": round((b_fwd + b_bwd) / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
                 "how": "HIP events around every launch on the launch stream, separate instrumented pass of the same K steps"}
     return kernels, roofline
+
+
+def measure_traffic(workload, timeout_s=150):
+    """HBM bytes per launch of every kernel of `workload`, MEASURED BY THIS RUN: two child passes of rocprofv3 --pmc (FETCH_SIZE,
+    then WRITE_SIZE — separate passes, kernel trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) over three steps
+    of the same workload.  FETCH_SIZE / WRITE_SIZE come in KiB; on gfx950 FETCH_SIZE under-counts wide reads by 2x (same guide),
+    so bytes = 2 * fetch + write.  -> ({kernel group: bytes per step}, note) or (None, why not)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    from das3r_amd.roofline import ALIASES, BINNING_KERNELS
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    if any(k.startswith("ROCP") for k in os.environ):
+        return None, "this process is itself under a profiler"
+    env = dict(os.environ, TMPDIR="/tmp", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    steps = 3
+    tot, raw = {}, {}
+    work = tempfile.mkdtemp(prefix="das3r_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(work, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--", sys.executable,
+                   os.path.abspath(__file__), "--pmc-child", "--workload", workload, "--steps", str(steps)]
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                p.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, 9)   # (the group this call started: the profiler and its child)
+                p.wait()
+                return None, f"rocprofv3 --pmc {counter} pass exceeded {timeout_s} s"
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, f"rocprofv3 --pmc {counter} pass wrote no counter file (rc {p.returncode})"
+            for f in files:
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] != counter:
+                        continue
+                    k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("das3r::", "").split("<")[0]
+                    if not (k in BINNING_KERNELS or k in ALIASES or k.startswith("render_") or k.startswith("preprocess_")):
+                        continue
+                    b = float(r["Counter_Value"]) * 1024.0 * (2.0 if counter == "FETCH_SIZE" else 1.0)
+                    key = "binning" if k in BINNING_KERNELS else ALIASES.get(k, k)
+                    tot[key] = tot.get(key, 0.0) + b
+                    if key == "binning":
+                        raw[k] = raw.get(k, 0.0) + b
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    # the child ran one initialisation step + `steps` steps, every one of them counted
+    print(json.dumps({"bench_binning_hbm_bytes_per_step": {k: int(v / (steps + 1)) for k, v in raw.items()}}), file=sys.stderr, flush=True)
+    return ({k: v / (steps + 1) for k, v in tot.items()},
+            f"measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two separate passes over {steps + 1} steps of the same "
+            f"workload, bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction, MI355X_MICROARCH.md)")
+
+
+def pmc_child_main(args):
+    """What the rocprofv3 --pmc passes of measure_traffic() run: a few steps of the workload, nothing else."""
+    import torch
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    job = RasterJob(args.workload, dev)
+    job.upload()
+    for _ in range(args.steps + 1):
+        job.step()
+    torch.cuda.synchronize()
 
 
 def cpu_baseline_of(sc_cpu, name, budget_s=20.0):
@@ -335,6 +414,8 @@ def main():
     args = parse_args()
     if args.extras_child:
         return extras_main(args.workload)
+    if args.pmc_child:
+        return pmc_child_main(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn_under_torchrun(args)   # does not return
     import torch
@@ -368,7 +449,8 @@ def main():
 
     kernels, roofline = (None, None)
     if rk.rank == 0:
-        kernels, roofline = kernel_table(job, args.steps)
+        measured = measure_traffic(args.workload) if (rk.world == 1 and not args.no_pmc) else None
+        kernels, roofline = kernel_table(job, args.steps, measured)
 
     # ---- train-step ms (fused §8f path) on every rank under the same protocol -> scenes/hour of the farm
     ts_step, ts_splats = train_step_timer(rk.dev, fused=True)
@@ -403,6 +485,15 @@ def main():
                "train_step_ms": train, "scenes_per_hour": round(scenes_per_hour, 2),
                "scenes_per_hour_def": f"N GPUs x 3600 s / ({ITERS_PER_SCENE} iterations x train_step_ms.fused, max over ranks)",
                "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels, "extras": extras}
+        if extras and not args.full_line:
+            # the line stays short enough for any log tail: per-workload detail goes to stderr (and to gpurun_out/ when it exists)
+            detail = json.dumps({"bench_extras": extras})
+            print(detail, file=sys.stderr, flush=True)
+            if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+                with open(os.path.join(ROOT, "gpurun_out", "bench_extras.json"), "w") as f:
+                    f.write(detail + "\n")
+            out["extras"] = {w: (e.get("ms_per_step") if isinstance(e, dict) else e) for w, e in extras.items()}
+            out["extras_unit"] = "ms_per_step of the other BASELINE shapes (detail: stderr line 'bench_extras')"
         print(json.dumps(out), flush=True)
     rk.close()
 

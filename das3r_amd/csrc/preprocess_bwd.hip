@@ -175,7 +175,6 @@ __global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
         }
         __syncthreads();
     }
-    float *const lrow = reinterpret_cast<float *>(&sh_lds[(STAGE_IN || STAGE_OUT) ? threadIdx.x * 13 : 0]);
 
     if (idx < P) {
         const bool visible = ntiles_g > 0;
@@ -316,10 +315,19 @@ __global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
                 float ddir[3] = {0.f, 0.f, 0.f};
                 if (D > 0) {
                     if (STAGE_IN) {
+                        // the lane's 48 coefficients come out of LDS as twelve 16-byte reads (rows are 13 quad-words apart: no
+                        // bank conflict); single-word reads of the same rows collide four ways (52-word stride; r02 PMC:
+                        // 6.8e6 conflict cycles per launch at 1 M splats)
+                        float shl[48];
+#pragma unroll
+                        for (int i = 0; i < 12; i++) {
+                            const float4 v = sh_lds[threadIdx.x * 13 + i];
+                            shl[4 * i] = v.x; shl[4 * i + 1] = v.y; shl[4 * i + 2] = v.z; shl[4 * i + 3] = v.w;
+                        }
 #pragma unroll
                         for (int c = 0; c < 3; c++) {
                             float dRdx, dRdy, dRdz;
-#define SHC_LDS(k) lrow[(k) * 3 + c]
+#define SHC_LDS(k) shl[(k) * 3 + c]
                             SH_DDIR(SHC_LDS, dRdx, dRdy, dRdz);
 #undef SHC_LDS
                             ddir[0] += dRdx * g[c];
