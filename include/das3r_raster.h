@@ -23,6 +23,21 @@
  * memory across calls: scratch comes from caller-supplied allocators (mirroring upstream's
  * std::function<char*(size_t)> resize callbacks) and stays alive in the caller's autograd context until
  * backward.  All work is enqueued on the caller's HIP stream.
+ *
+ * Deviations from the design-target ABI of SURVEY.md §8b, on purpose:
+ *   - NO `_cpu` twins of the entry points.  The survey's table lists CPU variants next to the device ones; here the CPU
+ *     side of every comparison is the oracle (oracle/raster_oracle.c, oracle/knn_oracle.c: test infrastructure, also the
+ *     reported `cpu_baseline`), and the product has no CPU path at all — a missing GPU / library / device tensor is an
+ *     error, never a fallback.  A `_cpu` twin inside this library would be exactly the fallback the parity rules forbid.
+ *   - das3r_raster_forward returns the instance count as int64 and fills a `saved` record (num_rendered, capacity, the
+ *     self-check ticket) instead of upstream's tuple; `capacity_hint` lets a caller forbid the speculative buffer layout;
+ *     the k-NN entry point takes a caller-owned workspace.
+ *
+ * State between calls: the library owns no tensor, scratch or stream.  Per host thread and per device it keeps a pinned
+ * host mailbox (instance count, error word, a ring of 16 self-check tickets), the arrival counters of the count reduction,
+ * the control ring of the fused scan and the last shape's instance counts (speculative capacity).  Calls of one thread on
+ * one device must be issued in stream order; different threads / devices are independent.  Experiment switches (DAS3R_*
+ * environment variables) are read once and cached; das3r_reload_switches() re-reads them.
  */
 #ifndef DAS3R_RASTER_H
 #define DAS3R_RASTER_H
