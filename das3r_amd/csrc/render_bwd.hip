@@ -167,9 +167,13 @@ int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, cha
     int kind = sw.render_bwd;
     int mb = sw.render_bwd_mb ? sw.render_bwd_mb : 256;
     if (kind == 0) {
-        const bool long_lists = num_rendered >= (int64_t)2048 * L.ntiles;   // (the count, not the capacity: the same scene takes the same kernel however its buffer was sized)
+        // measured crossover at 1080p (render backward, ms; tools/gpu_perf.py --workloads c4:<P>): mean list 80: dpp 0.149 / scan 0.177,
+        // 128: 0.227 / 0.247, 192: 0.331 / 0.320, 320: 0.533 / 0.489, 640: 0.753 / 0.754, 1280: 0.810 / 0.827 (saturating pixels cut
+        // dpp's walk short); DAS3R shape (13 800, bucket-parallel from 2048): 1.91 / 0.81
+        const int64_t mean_list = num_rendered / std::max(L.ntiles, 1);   // (the count, not the capacity: the same scene takes the same kernel however its buffer was sized)
+        const bool long_lists = (mean_list >= 192 && mean_list < 512) || mean_list >= 2048;
         kind = (sw.bwd_reduce_set || sw.ablate_set || !long_lists) ? 1 : 3;
-        mb = 256;
+        mb = 128;   // 4 workgroups per CU
     }
     if (kind == 5) {
         *quad_rows = true;
@@ -182,7 +186,6 @@ int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, cha
         int slices = sw.bwd_buckets;
         if (slices < 0) slices = (int)std::min<int64_t>(32, std::max<int64_t>(1, num_rendered / ((int64_t)BUCKET * std::max(L.ntiles, 1))));
         if (slices > 1 && mb > 256) slices = 1;
-        if (slices > 1 && !sw.render_bwd && !sw.render_bwd_mb) mb = 128;   // (with buckets a round is at most 1024 positions: 4 workgroups per CU beat longer rounds)
         return launch_render_backward_scan(a, dL_dpix, geom, binning, img, L, partial, mb, slices, s);
     }
     const bool use_dpp = !sw.bwd_reduce_shfl;   // "shfl" selects the ds_bpermute reference reduction (diagnostics)

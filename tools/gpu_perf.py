@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel timing of the hot path for perf experiments (HIP events through das3r_profile_*).
 
-    python tools/gpu_perf.py --workloads c2,c4 --steps 10 [--env DAS3R_ABLATE=1 ...]
+    python tools/gpu_perf.py --workloads c2,c4[,c4:400000] --steps 10 [--env DAS3R_ABLATE=1 ...]
 Each --env K=V variant is timed in turn (the library reads its experiment switches on every launch)."""
 import argparse
 import os
@@ -25,7 +25,8 @@ def main():
     dev = torch.device("cuda:0")
     variants = [""] + args.env
     for w in args.workloads.split(","):
-        sc = make_workload(w).to(dev)
+        wname, _, wp = w.partition(":")          # "c4:400000" = the c4 shape with 400 k splats
+        sc = make_workload(wname, int(wp) if wp else None).to(dev)
         rs = GaussianRasterizationSettings(**sc.settings_kwargs())
         e = torch.empty(0, device=dev)
         for var in variants:
