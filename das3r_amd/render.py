@@ -64,19 +64,31 @@ def covariance_from_scaling_rotation(scaling, scaling_modifier, rotation):
     return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1)
 
 
-def _settings(cam, pc, pipe, bg_color, scaling_modifier, device):
+def _settings(cam, pc, pipe, bg_color, scaling_modifier, device, model_fov=False):
     ident = torch.eye(4, device=device)
-    proj = ident.unsqueeze(0).bmm(cam.projection_matrix.to(device).unsqueeze(0)).squeeze(0)
+    # render_no_soft (gaussian_renderer/__init__.py:308-319) takes the field of view from the MODEL (pc.FoVx / FoVy, the two inert
+    # optimizer groups of scene/gaussian_model.py:165-166,253-254) and rebuilds the projection from it
+    fovx, fovy = (pc.FoVx, pc.FoVy) if model_fov else (cam.FoVx, cam.FoVy)
+    pm = cam.get_projection_matrix(fovx, fovy) if model_fov else cam.projection_matrix
+    proj = ident.unsqueeze(0).bmm(pm.to(device).unsqueeze(0)).squeeze(0)
     return GaussianRasterizationSettings(
-        image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=math.tan(float(cam.FoVx) * 0.5),
-        tanfovy=math.tan(float(cam.FoVy) * 0.5), bg=bg_color, scale_modifier=scaling_modifier, viewmatrix=ident, projmatrix=proj,
+        image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=math.tan(float(fovx) * 0.5),
+        tanfovy=math.tan(float(fovy) * 0.5), bg=bg_color, scale_modifier=scaling_modifier, viewmatrix=ident, projmatrix=proj,
         sh_degree=pc.active_sh_degree, campos=ident.inverse()[3, :3], prefiltered=False, debug=bool(getattr(pipe, "debug", False)))
 
 
+VARIANTS = ("render", "test", "no_soft", "confidence")
+
+
 def rasterizer_inputs(cam, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, camera_pose=None, filtering=None,
-                      use_conf=True, fused=False):
+                      use_conf=True, fused=False, variant="render"):
     """-> (GaussianRasterizationSettings, kwargs of GaussianRasterizer.forward): everything render() computes in front of the
-    rasterizer."""
+    rasterizer.  `variant` selects one of the reference's four renderers, which differ in three places only
+    (gaussian_renderer/__init__.py): "render" (:23-149) opacity * conf_static[aggregated_mask]; "test" (render_test, :152-277)
+    opacity * conf_static as stored; "no_soft" (render_no_soft, :279-408) no confidence factor, field of view and projection
+    from the model's FoVx / FoVy; "confidence" (render_confidence, :410-510) opacity = 1 and the per-Gaussian confidence as a
+    grey precomputed colour."""
+    assert variant in VARIANTS, variant
     xyz = pc.get_xyz
     device = xyz.device
     everything = filtering is None
@@ -87,11 +99,11 @@ def rasterizer_inputs(cam, pc, pipe, bg_color, scaling_modifier=1.0, override_co
         means2D.retain_grad()
     except Exception:  # noqa: BLE001
         pass
-    settings = _settings(cam, pc, pipe, bg_color, scaling_modifier, device)
+    settings = _settings(cam, pc, pipe, bg_color, scaling_modifier, device, model_fov=variant == "no_soft")
     cov_python = bool(getattr(pipe, "compute_cov3D_python", False))
     sh_python = bool(getattr(pipe, "convert_SHs_python", False))
 
-    if fused and override_color is None and not cov_python and not sh_python and use_conf and everything:
+    if fused and override_color is None and not cov_python and not sh_python and use_conf and everything and variant == "render":
         # opt-in: pose -> camera frame, quaternion product, exp / sigmoid * conf as ONE HIP kernel each way
         from .fused import pretransform
         idx = getattr(pc, "_mask_index", None)
@@ -111,7 +123,11 @@ def rasterizer_inputs(cam, pc, pipe, bg_color, scaling_modifier=1.0, override_co
     means3D = (w2c @ homo.T).T[:, :3]
     rot_cam = quat_multiply(camera_pose[:4], pc._rotation.clone()[filtering])
     opacity = pc.get_opacity[filtering]
-    if use_conf:
+    if variant == "confidence":
+        opacity = torch.ones_like(opacity)
+    elif variant == "test":
+        opacity = opacity * pc._conf_static
+    elif variant == "render" and use_conf:
         opacity = opacity * pc._conf_static.reshape(-1, 1)[pc.aggregated_mask]
     kw = dict(means3D=means3D, means2D=means2D, shs=None, colors_precomp=None, opacities=opacity, scales=None, rotations=None,
               cov3D_precomp=None)
@@ -120,7 +136,9 @@ def rasterizer_inputs(cam, pc, pipe, bg_color, scaling_modifier=1.0, override_co
                                else covariance_from_scaling_rotation(pc.get_scaling, scaling_modifier, pc._rotation))
     else:
         kw["scales"], kw["rotations"] = pc.get_scaling[filtering], rot_cam
-    if override_color is not None:
+    if variant == "confidence":
+        kw["colors_precomp"] = pc._conf[filtering].unsqueeze(1).repeat(1, 3)
+    elif override_color is not None:
         kw["colors_precomp"] = override_color
     elif sh_python:
         feats = pc.get_features
@@ -133,11 +151,28 @@ def rasterizer_inputs(cam, pc, pipe, bg_color, scaling_modifier=1.0, override_co
 
 
 def das3r_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, camera_pose=None,
-                 filtering=None, use_conf=True, fused=False):
+                 filtering=None, use_conf=True, fused=False, variant="render"):
     """viewpoint_camera: .FoVx .FoVy .image_height .image_width .projection_matrix (4x4, already transposed) [.camera_center for
     pipe.convert_SHs_python]; pc: splat model (das3r_amd.model.SplatModel or anything with the same attributes); pipe: .debug
     .compute_cov3D_python .convert_SHs_python; camera_pose: (7,) tensor (qw,qx,qy,qz,tx,ty,tz), may require grad."""
     settings, kw = rasterizer_inputs(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, camera_pose, filtering,
-                                     use_conf, fused)
+                                     use_conf, fused, variant)
     image, radii = GaussianRasterizer(raster_settings=settings)(**kw)
+    if variant == "confidence":
+        return image   # (render_confidence returns the image alone: gaussian_renderer/__init__.py:510)
     return {"render": image, "viewspace_points": kw["means2D"], "visibility_filter": radii > 0, "radii": radii}
+
+
+def das3r_render_test(*a, **k):
+    """gaussian_renderer/__init__.py:152 render_test"""
+    return das3r_render(*a, variant="test", **k)
+
+
+def das3r_render_no_soft(*a, **k):
+    """gaussian_renderer/__init__.py:279 render_no_soft"""
+    return das3r_render(*a, variant="no_soft", **k)
+
+
+def das3r_render_confidence(*a, **k):
+    """gaussian_renderer/__init__.py:410 render_confidence"""
+    return das3r_render(*a, variant="confidence", **k)

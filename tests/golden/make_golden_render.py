@@ -15,7 +15,8 @@ What each vector pins (SURVEY.md §8c "what can be imported here", VERDICT r1 "p
             (Appendix A.3: the kernel's formula for unit quaternions; the reference normalises, the kernel does not)
   render_*  gaussian_renderer/__init__.py:23-149 render(): the GaussianRasterizationSettings and the eight tensor arguments it
             hands to GaussianRasterizer (recorded by a stand-in rasterizer), for seeded models in three pipe modes
-            (default / compute_cov3D_python / convert_SHs_python) -> the whole pre-transform of §8 a1
+            (default / compute_cov3D_python / convert_SHs_python) -> the whole pre-transform of §8 a1; cases 4..6 the same for the
+            three sibling renderers render_test (:152), render_no_soft (:279), render_confidence (:410)
 """
 import math
 import os
@@ -101,7 +102,7 @@ def main():
         from utils.general_utils import build_rotation, build_scaling_rotation, strip_symmetric
         from utils.graphics_utils import getProjectionMatrix
         from scene.gaussian_model import GaussianModel
-        from gaussian_renderer import render
+        from gaussian_renderer import render, render_confidence, render_no_soft, render_test
 
         # ---- (1) covariance helpers
         N = 96
@@ -119,8 +120,13 @@ def main():
         # ---- (2) render(): what reaches the rasterizer
         frames, H, W = 3, 6, 8
         P = frames * H * W - 17          # aggregated_mask drops 17 pixels
-        for case, (deg, cov_py, sh_py, mod) in enumerate([(0, False, False, 1.0), (2, True, False, 1.3), (3, False, True, 1.0),
-                                                          (1, False, False, 0.8)]):
+        # cases 4..6: the sibling renderers (render_test :152, render_no_soft :279, render_confidence :410), appended so that the
+        # seeded stream of cases 0..3 is unchanged
+        fns = {"render": render, "test": render_test, "no_soft": render_no_soft, "confidence": render_confidence}
+        for case, (deg, cov_py, sh_py, mod, variant) in enumerate([(0, False, False, 1.0, "render"), (2, True, False, 1.3, "render"),
+                                                                   (3, False, True, 1.0, "render"), (1, False, False, 0.8, "render"),
+                                                                   (1, False, False, 1.0, "test"), (2, False, False, 1.2, "no_soft"),
+                                                                   (0, True, False, 1.0, "confidence")]):
             pc = GaussianModel(3)
             pc.active_sh_degree = deg
             pc._xyz = torch.randn(P, 3, generator=g) * 2.0 + torch.tensor([0.0, 0.0, 5.0])
@@ -141,9 +147,22 @@ def main():
                                   camera_center=torch.randn(3, generator=g))
             pipe = SimpleNamespace(debug=False, compute_cov3D_python=cov_py, convert_SHs_python=sh_py)
             bg = torch.rand(3, generator=g)
+            if variant == "test":          # render_test multiplies by conf_static as stored: one value per Gaussian
+                pc._conf_static = torch.rand(P, 1, generator=g)
+            if variant == "no_soft":       # field of view and projection from the model
+                pc.FoVx, pc.FoVy = torch.tensor(fovx * 1.07), torch.tensor(fovy * 0.93)
+                cam.get_projection_matrix = lambda fx, fy: getProjectionMatrix(0.01, 100.0, fx, fy).transpose(0, 1)
+            if variant == "confidence":
+                pc._conf = torch.rand(P, generator=g)
             _Recorder.calls.clear()
-            pkg = render(cam, pc, pipe, bg, scaling_modifier=mod, camera_pose=pose)
-            assert sorted(pkg) == ["radii", "render", "viewspace_points", "visibility_filter"] and len(_Recorder.calls) == 1
+            pkg = fns[variant](cam, pc, pipe, bg, scaling_modifier=mod, camera_pose=pose)
+            assert len(_Recorder.calls) == 1
+            assert torch.is_tensor(pkg) if variant == "confidence" else sorted(pkg) == ["radii", "render", "viewspace_points", "visibility_filter"]
+            out[f"render{case}_variant"] = np.array(variant)
+            if variant == "no_soft":
+                out[f"render{case}_pc_fov"] = np.array([float(pc.FoVx), float(pc.FoVy)])
+            if variant == "confidence":
+                out[f"render{case}_pc_conf"] = pc._conf.numpy()
             rs, kw = _Recorder.calls[0]
             pre = f"render{case}_"
             for name in ("_xyz", "_rotation", "_scaling", "_opacity", "_features_dc", "_features_rest", "_conf_static"):
