@@ -70,6 +70,8 @@ static void load_switches() {
     if ((e = env("DAS3R_INJECT_FAULT"))) w.inject_fault = atoi(e);
     w.bwd_buckets = -1;
     if ((e = env("DAS3R_BWD_BUCKETS"))) w.bwd_buckets = atoi(e);
+    w.tile_strip = 8;
+    if ((e = env("DAS3R_TILE_STRIP"))) w.tile_strip = std::max(0, std::min(64, atoi(e)));
     g_sw = w;
     __atomic_store_n(&g_sw_loaded, true, __ATOMIC_RELEASE);
 }
@@ -132,6 +134,7 @@ void compute_layout(int P, int64_t I, int W, int H, Layout *L) {
     L->g_blocksums = take(4 * (size_t)div_up((int64_t)Pn, 4096));
     L->g_count = take(256);
     L->g_off_by_gid = take(4 * Pn);
+    L->g_rect = take(4 * Pn);
     L->g_ghist = take(4 * 4 * RADIX_SIZE);
     L->g_ticket = take(256);
     L->g_status = take(onesweep_status_bytes((int64_t)Pn, 4));

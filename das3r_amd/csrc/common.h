@@ -36,7 +36,8 @@ struct Switches {
     int tickets;           // DAS3R_TICKETS=always | never | <bound>: 0 | 1 << 30 | bound (-1: from the device's CU count)
     int bwd_pad_lds, fwd_pad_lds;   // DAS3R_BWD_PAD_LDS / DAS3R_FWD_PAD_LDS: extra dynamic LDS (occupancy experiments)
     int bwd_buckets;       // DAS3R_BWD_BUCKETS=0 | <slices>: bucket-parallel backward off / forced with that many slices (-1: by list length)
-    int inject_fault;      // DAS3R_INJECT_FAULT: bits OR-ed into the binning self-check word of every forward (fault-injection tests)
+    int inject_fault;
+    int tile_strip;   // DAS3R_TILE_STRIP: rows per strip of the compositing kernels' tile order (0 = row-major)      // DAS3R_INJECT_FAULT: bits OR-ed into the binning self-check word of every forward (fault-injection tests)
 };
 const Switches &switches();
 
@@ -114,7 +115,7 @@ constexpr int SPLAT_REC = 4;   // float4s per Gaussian record (xyh, conic+opacit
 struct Layout {
     das3r_raster_layout pub;
     // private scratch offsets
-    size_t g_keyA, g_keyB, g_valA, g_valB, g_hist, g_totals, g_blocksums, g_count, g_off_by_gid;
+    size_t g_keyA, g_keyB, g_valA, g_valB, g_hist, g_totals, g_blocksums, g_count, g_off_by_gid, g_rect;   // g_rect: u32 per splat, binned tile rectangle x0 | x1 << 8 | y0 << 16 | y1 << 24 (0 = none)
     size_t b_keyA, b_keyB, b_valA, b_valB, b_hist, b_totals, b_gid_of, b_slot;
     size_t b_ckpt;   // float4[(capacity / BUCKET + ntiles + 2) * 256]: per-pixel (T, C) at the bucket boundaries of long tile lists
     // single-pass radix control words (sort_onesweep.hip): [global digit histograms][tickets][status granules], contiguous

@@ -21,7 +21,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     const float *__restrict__ projmatrix, const float *__restrict__ campos, int W, int H, float tanfovx, float tanfovy,
     int tiles_x, int tiles_y, int32_t *__restrict__ radii, uint32_t *__restrict__ depth_key, float4 *__restrict__ xyh,
     float4 *__restrict__ conic_opacity, float4 *__restrict__ rgbd, uint8_t *__restrict__ clamped,
-    uint32_t *__restrict__ tiles_touched, int tight_rect, uint32_t *__restrict__ zero_a, uint32_t zero_a_words, uint32_t *__restrict__ zero_b,
+    uint32_t *__restrict__ tiles_touched, uint32_t *__restrict__ rect32, int tight_rect, uint32_t *__restrict__ zero_a, uint32_t zero_a_words, uint32_t *__restrict__ zero_b,
     uint32_t zero_b_words, uint32_t *__restrict__ zero_c, uint32_t zero_c_words, unsigned long long *__restrict__ arrive,
     uint32_t *__restrict__ host_out, uint32_t tag, const EmitArgs em) {
     const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -154,6 +154,8 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     radii[idx] = radius_out;
     depth_key[idx] = key_out;
     tiles_touched[idx] = tiles_out;
+    // the binned rectangle, packed (tile counts <= 255 per axis: 4080 pixels; above that the scan reads the records instead)
+    rect32[idx] = tiles_out ? ((uint32_t)bx0 | ((uint32_t)bx1 << 8) | ((uint32_t)by0 << 16) | ((uint32_t)by1 << 24)) : 0u;
     clamped[idx] = clamp_out;
     }
     // The 64-byte records (xyh | conic + opacity | rgb + depth | radius, tiles_touched) leave through LDS: written per lane they
@@ -324,7 +326,7 @@ int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int
         in->cov3D_precomp, in->colors_precomp, a->viewmatrix, a->projmatrix, a->campos, a->image_width, a->image_height,  \
         a->tanfovx, a->tanfovy, L.tiles_x, L.tiles_y, radii, (uint32_t *)(geom + L.g_keyA), (float4 *)(geom + L.pub.xy),  \
         (float4 *)(geom + L.pub.conic_opacity), (float4 *)(geom + L.pub.rgbd), (uint8_t *)(geom + L.pub.clamped),         \
-        (uint32_t *)(geom + L.pub.tiles_touched), use_tight_rect() ? 1 : 0, (uint32_t *)(geom + L.g_ghist), (uint32_t)(L.g_ctrl_bytes / 4),                 \
+        (uint32_t *)(geom + L.pub.tiles_touched), (uint32_t *)(geom + L.g_rect), use_tight_rect() ? 1 : 0, (uint32_t *)(geom + L.g_ghist), (uint32_t)(L.g_ctrl_bytes / 4),                 \
         (uint32_t *)(img + L.pub.ranges), (uint32_t)(2 * L.ntiles), (uint32_t *)binning_ctrl, (uint32_t)(binning_ctrl_bytes / 4), arrive, host_out, tag, em
     const bool stage = has_sh && a->M == 16 && a->sh_degree >= 2 && ((uintptr_t)in->shs & 15) == 0 && !switches().no_sh_stage;
     if (has_sh && !has_cov && stage) DAS3R_LAUNCH((preprocess_kernel<true, false, true>), grid, block, 0, s, ARGS);

@@ -19,7 +19,7 @@ constexpr int NACC = 9;  // dcolor[3], dmean2D[2], dconic[3], dopacity
 
 template <bool USE_DPP>
 __global__ void __launch_bounds__(256) render_backward_kernel(
-    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int tiles_x, int ntiles,
+    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int tiles_x, int ntiles_strip /*tiles | strip height << 24: render_common.h xcd_tile*/,
     const float4 *__restrict__ xyh, const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
     const float *__restrict__ bg, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
     const float *__restrict__ dL_dpix, const uint32_t *__restrict__ slot_list, float *__restrict__ partial /*[I,9]*/, int ablate,
@@ -29,7 +29,8 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
     __shared__ float acc[TILE_PIX * NACC];
     __shared__ uint32_t s_max[4];
 
-    const int tile = xcd_tile(blockIdx.x, ntiles);
+    const int ntiles = ntiles_strip & 0xFFFFFF;
+    const int tile = xcd_tile(blockIdx.x, ntiles, tiles_x, ntiles_strip >> 24);
     if (tile < 0) return;
     const int tid = threadIdx.x, lane = __lane_id(), wave = tid >> 6;
     const int bx = tile % tiles_x, by = tile / tiles_x;
@@ -192,7 +193,7 @@ int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, cha
     const int ablate = sw.ablate;               // perf experiments only: bit0 = no partial stores, bit2 = no cross-lane reduction
 #define ARGS                                                                                                                 \
     (const uint2 *)(img + L.pub.ranges), (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height,    \
-        L.tiles_x, L.ntiles, (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),                \
+        L.tiles_x, pack_tiles(L), (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),                \
         (const float4 *)(geom + L.pub.rgbd), a->bg, (const float *)(img + L.pub.final_T),                                    \
         (const uint32_t *)(img + L.pub.n_contrib), dL_dpix, (const uint32_t *)(binning + L.b_slot), partial, ablate, \
         (uint32_t)(a->P - 1), (uint32_t)L.capacity

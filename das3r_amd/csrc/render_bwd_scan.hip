@@ -31,7 +31,7 @@ namespace das3r {
 // all (what the rounds cost without them), 8 bounding-box cull only
 template <int MB, bool ATOM, int ABL = 0>
 __global__ void __launch_bounds__(256, (MB <= 128 ? 4 : 2)) render_backward_scan_kernel(
-    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int tiles_x, int ntiles,
+    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int tiles_x, int ntiles_strip /*tiles | strip height << 24: render_common.h xcd_tile*/,
     const float4 *__restrict__ xyh, const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
     const float *__restrict__ bg, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
     const float *__restrict__ dL_dpix, const uint32_t *__restrict__ slot_list, float *__restrict__ partial /*[I,9]*/,
@@ -60,7 +60,8 @@ __global__ void __launch_bounds__(256, (MB <= 128 ? 4 : 2)) render_backward_scan
     uint64_t *const s_hit = reinterpret_cast<uint64_t *>(lds + OFF_HIT);
     uint32_t *const s_max = reinterpret_cast<uint32_t *>(lds + OFF_MAX);
 
-    const int tile = xcd_tile(blockIdx.x, ntiles);
+    const int ntiles = ntiles_strip & 0xFFFFFF;
+    const int tile = xcd_tile(blockIdx.x, ntiles, tiles_x, ntiles_strip >> 24);
     if (tile < 0) return;
     const int tid = threadIdx.x, lane = __lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -385,7 +386,7 @@ int launch_render_backward_scan(const das3r_raster_args *a, const float *dL_dpix
                                 float *partial, int mb, int slices, hipStream_t s) {
 #define ARGS                                                                                                              \
     (const uint2 *)(img + L.pub.ranges), (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height, \
-        L.tiles_x, L.ntiles, (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),             \
+        L.tiles_x, pack_tiles(L), (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),             \
         (const float4 *)(geom + L.pub.rgbd), a->bg, (const float *)(img + L.pub.final_T),                                 \
         (const uint32_t *)(img + L.pub.n_contrib), dL_dpix, (const uint32_t *)(binning + L.b_slot), partial,              \
         (uint32_t)(a->P - 1), (uint32_t)L.capacity, (const float4 *)(binning + L.b_ckpt)

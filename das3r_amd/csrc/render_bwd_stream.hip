@@ -32,13 +32,14 @@ constexpr int WAVE_LDS = Q_OUT + 16 * 48;   // + the batch's 16 x 12 sums on the
 // WPS: waves per SIMD the register allocation is held to (= workgroups per CU; 4: 128 VGPRs, no spills)
 template <int ABL, int WPS = 4>
 __global__ void __launch_bounds__(256, WPS) render_backward_stream_kernel(
-    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int tiles_x, int ntiles,
+    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int tiles_x, int ntiles_strip /*tiles | strip height << 24: render_common.h xcd_tile*/,
     const float4 *__restrict__ xyh, const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
     const float *__restrict__ bg, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
     const float *__restrict__ dL_dpix, const uint32_t *__restrict__ slot_list, float *__restrict__ rows /*[cap][4][12]*/,
     uint8_t *__restrict__ row_exists /*[cap][4], zero on entry*/, uint32_t last_g, uint32_t cap) {
     __shared__ __attribute__((aligned(16))) char lds[4 * WAVE_LDS];
-    const int tile = xcd_tile(blockIdx.x, ntiles);
+    const int ntiles = ntiles_strip & 0xFFFFFF;
+    const int tile = xcd_tile(blockIdx.x, ntiles, tiles_x, ntiles_strip >> 24);
     if (tile < 0) return;
     const int lane = __lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -328,7 +329,7 @@ int launch_render_backward_stream(const das3r_raster_args *a, const float *dL_dp
     HIP_TRY(hipMemsetAsync(exists, 0, c * 4, s));
 #define ARGS                                                                                                              \
     (const uint2 *)(img + L.pub.ranges), (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height, \
-        L.tiles_x, L.ntiles, (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),             \
+        L.tiles_x, pack_tiles(L), (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),             \
         (const float4 *)(geom + L.pub.rgbd), a->bg, (const float *)(img + L.pub.final_T),                                 \
         (const uint32_t *)(img + L.pub.n_contrib), dL_dpix, (const uint32_t *)(binning + L.b_slot), scratch, exists,     \
         (uint32_t)(a->P - 1), (uint32_t)L.capacity

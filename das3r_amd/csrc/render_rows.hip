@@ -64,7 +64,7 @@ __device__ __forceinline__ void build_row_lists(const StagedSplat *stage, const 
 }
 
 __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
-                                                                  int W, int H, int tiles_x, int ntiles, const float4 *__restrict__ xyh,
+                                                                  int W, int H, int tiles_x, int ntiles_strip /*tiles | strip height << 24: render_common.h xcd_tile*/, const float4 *__restrict__ xyh,
                                                                   const float4 *__restrict__ conic_opacity,
                                                                   const float4 *__restrict__ rgbd, const float *__restrict__ bg,
                                                                   float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
@@ -72,7 +72,8 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
     __shared__ StagedSplat stage[TILE_PIX];
     __shared__ uint32_t s_gid[LOCAL_MAX];   // local depth order: the tile's sorted list
     __shared__ uint8_t lists[4][4][ROW_LIST_STRIDE];   // [wave][row][position]
-    const int tile = xcd_tile(blockIdx.x, ntiles);
+    const int ntiles = ntiles_strip & 0xFFFFFF;
+    const int tile = xcd_tile(blockIdx.x, ntiles, tiles_x, ntiles_strip >> 24);
     if (tile < 0) return;
     const int tid = threadIdx.x, lane = __lane_id(), wave = tid >> 6, row = lane >> 4;
     const int bx = tile % tiles_x, by = tile / tiles_x;
@@ -163,7 +164,7 @@ bool use_row_private(int64_t instances, int ntiles) {
 int launch_render_forward_rows(const das3r_raster_args *a, float *out_color, char *geom, char *binning, char *img, const Layout &L,
                                const LocalBin &lb, hipStream_t s) {
     DAS3R_LAUNCH(render_forward_rows_kernel, dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, (const uint2 *)(img + L.pub.ranges),
-                 (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height, L.tiles_x, L.ntiles,
+                 (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height, L.tiles_x, pack_tiles(L),
                  (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),
                  (const float4 *)(geom + L.pub.rgbd), a->bg, (float *)(img + L.pub.final_T), (uint32_t *)(img + L.pub.n_contrib),
                  out_color, lb);

@@ -47,7 +47,8 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
     uint32_t *__restrict__ ticket, uint32_t *__restrict__ err, uint32_t *__restrict__ host_out /*pinned host mailbox*/, uint32_t tag,
     // emission (EMIT only)
     int tiles_x, int tiles_y, const float4 *__restrict__ xyh, const int32_t *__restrict__ radii, uint32_t *__restrict__ tile_keys,
-    uint32_t *__restrict__ gids, uint32_t cap, uint32_t *__restrict__ ghist /*[passes][256]*/, int tbits, int tight_rect) {
+    uint32_t *__restrict__ gids, uint32_t cap, uint32_t *__restrict__ ghist /*[passes][256]*/, int tbits, int tight_rect,
+    const uint32_t *__restrict__ rect32 /*packed binned rectangles by splat (common.h g_rect) or null*/) {
     __shared__ uint32_t ws[4];
     __shared__ uint32_t s_block, s_carry;
     __shared__ uint32_t h[EMIT ? 4 : 1][RADIX_SIZE];
@@ -64,7 +65,7 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
     const uint32_t b = s_block;
     const int base = (int)b * 256 * SCAN_ITEMS;
 
-    uint32_t g[SCAN_ITEMS], v[SCAN_ITEMS], sum = 0;
+    uint32_t g[SCAN_ITEMS], v[SCAN_ITEMS], rc[SCAN_ITEMS], sum = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
         const int r = base + k * 256 + tid;
@@ -73,9 +74,17 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
         const int r = base + k * 256 + tid;
-        // tiles_touched: from the splat's 64-byte record in depth order (one random line instead of two), from the plain array
-        // in index order
-        v[k] = r < P ? (sorted_idx ? __float_as_uint(xyh[(size_t)g[k] * SPLAT_REC + 3].y) : tiles_touched[r]) : 0u;
+        // In depth order everything the scan and the emission need of a splat is its binned rectangle: ONE random 4-byte read
+        // of the packed array (a 32-byte sector) instead of the first and the last 16 bytes of its 64-byte record (r02: the
+        // 5 M-splat DAS3R-shaped scene spent 0.31 ms here).  Without the array (more than 255 tiles per axis): tiles_touched
+        // from the record.  In index order: the plain array, coalesced.
+        rc[k] = 0u;
+        if (r < P && sorted_idx && rect32) {
+            rc[k] = rect32[g[k]];
+            v[k] = (((rc[k] >> 8) & 255u) - (rc[k] & 255u)) * ((rc[k] >> 24) - ((rc[k] >> 16) & 255u));
+        } else {
+            v[k] = r < P ? (sorted_idx ? __float_as_uint(xyh[(size_t)g[k] * SPLAT_REC + 3].y) : tiles_touched[r]) : 0u;
+        }
         sum += v[k];
     }
     uint32_t total;
@@ -102,10 +111,14 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
             offsets[r] = o;
             off_by_gid[g[k]] = o;   // first emission slot of splat g (its instances are emitted contiguously)
             if (EMIT && v[k] != 0u) {
-                const float4 p = xyh[(size_t)g[k] * SPLAT_REC];
-                const int radius = __float_as_int(xyh[(size_t)g[k] * SPLAT_REC + 3].x);
                 int rminx, rminy, rmaxx, rmaxy;
-                binned_rect(p, radius, tiles_x, tiles_y, tight_rect != 0, rminx, rminy, rmaxx, rmaxy);
+                if (sorted_idx && rect32) {
+                    rminx = (int)(rc[k] & 255u), rmaxx = (int)((rc[k] >> 8) & 255u), rminy = (int)((rc[k] >> 16) & 255u), rmaxy = (int)(rc[k] >> 24);
+                } else {
+                    const float4 p = xyh[(size_t)g[k] * SPLAT_REC];
+                    const int radius = __float_as_int(xyh[(size_t)g[k] * SPLAT_REC + 3].x);
+                    binned_rect(p, radius, tiles_x, tiles_y, tight_rect != 0, rminx, rminy, rmaxx, rmaxy);
+                }
                 for (int y = rminy; y < rmaxy; y++)
                     for (int x = rminx; x < rmaxx; x++) {
                         if (o < cap) {   // cap < num_rendered only when the capacity hint was too small (the binning is then redone)
@@ -158,6 +171,7 @@ size_t scan_status_bytes(int P) {
     return (size_t)(nblocks + div_up(nblocks, 1 << SCAN_GROUP_LOG2)) * sizeof(u64);
 }
 
+#define RECT32 ((L.tiles_x <= 255 && L.tiles_y <= 255) ? (const uint32_t *)(geom + L.g_rect) : (const uint32_t *)nullptr)
 #define SCAN_COMMON                                                                                                           \
     P, order, (const uint32_t *)(geom + L.pub.tiles_touched),                          \
         (uint32_t *)(geom + L.pub.offsets), (uint32_t *)(geom + L.g_off_by_gid), (uint32_t *)(geom + L.g_count),             \
@@ -171,7 +185,7 @@ int launch_scan(int P, char *geom, const Layout &L, uint32_t *host_out, uint32_t
 #define GO(IT)                                                                                                               \
     DAS3R_LAUNCH((scan_emit_kernel<false, IT>), dim3(nblocks), dim3(256), 0, s, SCAN_COMMON, 0, 0,                            \
                  (const float4 *)(geom + L.pub.xy),                                                                           \
-                 (const int32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (uint32_t *)nullptr, 0, 0)
+                 (const int32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (uint32_t *)nullptr, 0, 0, RECT32)
     switch (scan_items(P)) { case 1: GO(1); break; case 2: GO(2); break; case 4: GO(4); break; case 8: GO(8); break; default: GO(16); }
 #undef GO
     KERNEL_CHECK(s, debug, "scan");
@@ -185,7 +199,7 @@ int launch_scan_emit(int P, int64_t cap, const int32_t *radii, char *geom, char 
 #define GO(IT)                                                                                                               \
     DAS3R_LAUNCH((scan_emit_kernel<true, IT>), dim3(nblocks), dim3(256), 0, s, SCAN_COMMON, L.tiles_x, L.tiles_y,              \
                  (const float4 *)(geom + L.pub.xy), radii, (uint32_t *)(binning + L.b_keyA), (uint32_t *)(binning + L.b_gid_of), \
-                 (uint32_t)cap, (uint32_t *)(binning + L.b_ghist), L.tbits, use_tight_rect() ? 1 : 0)
+                 (uint32_t)cap, (uint32_t *)(binning + L.b_ghist), L.tbits, use_tight_rect() ? 1 : 0, RECT32)
     switch (scan_items(P)) { case 1: GO(1); break; case 2: GO(2); break; case 4: GO(4); break; case 8: GO(8); break; default: GO(16); }
 #undef GO
     KERNEL_CHECK(s, debug, "scan_emit");
