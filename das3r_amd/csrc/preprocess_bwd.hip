@@ -70,6 +70,26 @@ __device__ __forceinline__ void sh_basis(const int D, const float x, const float
         }                                                                                                                       \
     } while (0)
 
+// A wave's 64 rows of K floats (12- or 24-byte AoS gradient rows), stored with unit-stride dword stores: every lane parks its
+// row in the wave's private LDS scratch and the wave writes the 64 K floats back out in order.  Written lane by lane these rows
+// are K stores of 4 bytes at a K-word stride; on the 5 M-splat DAS3R-shaped scene the per-Gaussian backward wrote 1.24 GB for
+// 0.34 GB of gradients that way (r02 PMC WRITE_SIZE): the partial sectors leave the L2 before their neighbours arrive.
+// All 64 lanes must call it; rows_valid = rows of this wave that exist (0..64).
+template <int K>
+__device__ __forceinline__ void wave_store_rows(float *__restrict__ dst /*row 0 of the wave*/, const int rows_valid, const float (&v)[K],
+                                                float *scratch /*[64 * K], wave-private*/, const int lane) {
+#pragma unroll
+    for (int q = 0; q < K; q++) scratch[lane * K + q] = v[q];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // (the wave reads its own words back: LDS is in order per wave)
+    const int n = rows_valid * K;
+#pragma unroll
+    for (int q = 0; q < K; q++) {
+        const int e = q * 64 + lane;
+        if (e < n) dst[e] = scratch[e];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // before the scratch is reused
+}
+
 // DEG0: the active degree is 0 (DAS3R's own setting, arguments.py sh_degree): no SH row is read and the view-direction terms
 // vanish at compile time, which halves the register count of the unstaged variant (6 waves per SIMD instead of 3)
 template <bool HAS_SH, bool HAS_COV, bool STAGE_IN, bool STAGE_OUT, bool DEG0 = false>
@@ -176,6 +196,17 @@ __global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
         __syncthreads();
     }
 
+    // unstaged variants: AoS gradient rows leave through a wave-private LDS scratch (wave_store_rows); the staged ones (M == 16)
+    // keep their direct stores — their LDS is spoken for and their 12-byte rows are a small share next to the 192-byte SH rows
+    constexpr bool XPOSE = !STAGE_OUT;
+    __shared__ float xp_lds[XPOSE ? 4 * 64 * 6 : 1];
+    float *const xp = xp_lds + (XPOSE ? (threadIdx.x >> 6) * 64 * 6 : 0);
+    const int lane = threadIdx.x & 63;
+    const int wave_first = blockIdx.x * 256 + (int)(threadIdx.x & ~63u);
+    const int rows_valid = min(max(P - wave_first, 0), 64);
+    float o_m2d[3] = {0.f, 0.f, 0.f}, o_m3d[3] = {0.f, 0.f, 0.f}, o_sc[3] = {0.f, 0.f, 0.f}, o_cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float o_col[3] = {0.f, 0.f, 0.f}, o_sh0[3] = {0.f, 0.f, 0.f};
+
     if (idx < P) {
         const bool visible = ntiles_g > 0;
 
@@ -205,14 +236,19 @@ __global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
                 }
             }
         }
-        dL_dmeans2D[3 * (size_t)idx] = acc[3];
-        dL_dmeans2D[3 * (size_t)idx + 1] = acc[4];
-        dL_dmeans2D[3 * (size_t)idx + 2] = 0.f;
         dL_dopacity[idx] = acc[8];
-        if (!HAS_SH) {
-            dL_dcolors_precomp[3 * (size_t)idx] = acc[0];
-            dL_dcolors_precomp[3 * (size_t)idx + 1] = acc[1];
-            dL_dcolors_precomp[3 * (size_t)idx + 2] = acc[2];
+        if (XPOSE) {
+            o_m2d[0] = acc[3]; o_m2d[1] = acc[4];
+            o_col[0] = acc[0]; o_col[1] = acc[1]; o_col[2] = acc[2];
+        } else {
+            dL_dmeans2D[3 * (size_t)idx] = acc[3];
+            dL_dmeans2D[3 * (size_t)idx + 1] = acc[4];
+            dL_dmeans2D[3 * (size_t)idx + 2] = 0.f;
+            if (!HAS_SH) {
+                dL_dcolors_precomp[3 * (size_t)idx] = acc[0];
+                dL_dcolors_precomp[3 * (size_t)idx + 1] = acc[1];
+                dL_dcolors_precomp[3 * (size_t)idx + 2] = acc[2];
+            }
         }
 
         float dmean[3] = {0.f, 0.f, 0.f};
@@ -387,17 +423,24 @@ __global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
             }
         }
 
-        dL_dmeans3D[3 * (size_t)idx] = dmean[0];
-        dL_dmeans3D[3 * (size_t)idx + 1] = dmean[1];
-        dL_dmeans3D[3 * (size_t)idx + 2] = dmean[2];
-        if (HAS_COV) {
+        if (XPOSE) {
 #pragma unroll
-            for (int i = 0; i < 6; i++) dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+            for (int k = 0; k < 3; k++) o_m3d[k] = dmean[k], o_sc[k] = dscale[k];
+#pragma unroll
+            for (int i = 0; i < 6; i++) o_cov[i] = dcov[i];
         } else {
+            dL_dmeans3D[3 * (size_t)idx] = dmean[0];
+            dL_dmeans3D[3 * (size_t)idx + 1] = dmean[1];
+            dL_dmeans3D[3 * (size_t)idx + 2] = dmean[2];
+            if (HAS_COV) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) dL_dscales[3 * (size_t)idx + k] = dscale[k];
-            reinterpret_cast<float4 *>(dL_drot)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+                for (int i = 0; i < 6; i++) dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; k++) dL_dscales[3 * (size_t)idx + k] = dscale[k];
+            }
         }
+        if (!HAS_COV) reinterpret_cast<float4 *>(dL_drot)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);   // (16-byte rows: unit stride as they are)
         // ---- dL_dsh row: basis[k] * g[c] for the active coefficients, zero above; zero row for culled splats
         if (HAS_SH) {
             const int nk = visible ? (D + 1) * (D + 1) : 0;
@@ -412,6 +455,9 @@ __global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
                     }
                     sh_lds[threadIdx.x * 13 + i] = make_float4(o[0], o[1], o[2], o[3]);
                 }
+            } else if (XPOSE && M == 1) {   // (uniform) one coefficient per splat: a 12-byte row like the others
+#pragma unroll
+                for (int c = 0; c < 3; c++) o_sh0[c] = nk > 0 ? basis[0] * g[c] : 0.f;
             } else {
                 float *row = dL_dsh + (size_t)idx * M * 3;
 #pragma unroll
@@ -424,6 +470,14 @@ __global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
                 }
             }
         }
+    }
+    if (XPOSE) {   // every lane of the wave takes part (rows_valid guards the stores)
+        wave_store_rows<3>(dL_dmeans2D + 3 * (size_t)wave_first, rows_valid, o_m2d, xp, lane);
+        wave_store_rows<3>(dL_dmeans3D + 3 * (size_t)wave_first, rows_valid, o_m3d, xp, lane);
+        if (HAS_COV) wave_store_rows<6>(dL_dcov3D + 6 * (size_t)wave_first, rows_valid, o_cov, xp, lane);
+        else wave_store_rows<3>(dL_dscales + 3 * (size_t)wave_first, rows_valid, o_sc, xp, lane);
+        if (!HAS_SH) wave_store_rows<3>(dL_dcolors_precomp + 3 * (size_t)wave_first, rows_valid, o_col, xp, lane);
+        else if (M == 1) wave_store_rows<3>(dL_dsh + 3 * (size_t)wave_first, rows_valid, o_sh0, xp, lane);
     }
     if (STAGE_OUT) {
         __syncthreads();
