@@ -55,7 +55,6 @@ __global__ void __launch_bounds__(256, (MB <= 128 ? 4 : 2)) render_backward_scan
     StagedSplat *const stage = reinterpret_cast<StagedSplat *>(lds + OFF_STAGE);
     float *const acc = reinterpret_cast<float *>(lds + OFF_ACC);
     float *const acc1 = reinterpret_cast<float *>(lds + OFF_ACC1);
-    float *const outp = acc;   // [MB][9] rows on their way to `partial`: reuses the accumulators once they have been read
     uint32_t *const s_slot = reinterpret_cast<uint32_t *>(lds + OFF_SLOT);
     uint64_t *const s_hit = reinterpret_cast<uint64_t *>(lds + OFF_HIT);
     uint32_t *const s_max = reinterpret_cast<uint32_t *>(lds + OFF_MAX);
@@ -352,14 +351,15 @@ __global__ void __launch_bounds__(256, (MB <= 128 ? 4 : 2)) render_backward_scan
                     }
                 }
             }
-            __syncthreads();   // every accumulator of this slice has been read: the region becomes the output rows
+            // the row goes straight to the emission slot of its entry: rows of one tile are scattered over `partial` anyway (slots
+            // follow the splat order), so bouncing them through LDS for "coalesced" 9-lane stores bought nothing but two barriers
             if (t < n) {
                 const float4 p = stage[t].xyh;
                 const float4 co = stage[t].co;
                 const float M0 = a[3], Mu = a[4], Mv = a[5], Muu = a[6], Muv = a[7], Mvv = a[8];
                 const float X = p.x - tcx, Y = p.y - tcy, kh = -0.5f * co.w;
                 const float Sgx = kh * (X * M0 - Mu), Sgy = kh * (Y * M0 - Mv);   // -1/2 o sum g dx, dy  (dx = X - u)
-                float *row = outp + (size_t)t * NACC;
+                float *row = partial + (size_t)s_slot[t] * NACC;
                 row[0] = ATOM ? a[0] + a[NROW - 3] : a[0];
                 row[1] = ATOM ? a[1] + a[NROW - 2] : a[1];
                 row[2] = ATOM ? a[2] + a[NROW - 1] : a[2];
@@ -371,13 +371,7 @@ __global__ void __launch_bounds__(256, (MB <= 128 ? 4 : 2)) render_backward_scan
                 row[8] = M0;
             }
         }
-        __syncthreads();
-        // rows go to the emission slot of their entry (36-byte row stores, 9 lanes each)
-        for (int f = tid; f < n * NACC; f += TILE_PIX) {
-            const int j = f / NACC, q = f - j * NACC;
-            partial[(size_t)s_slot[j] * NACC + q] = outp[f];
-        }
-        __syncthreads();
+        __syncthreads();   // stage / s_slot / the accumulators are free for the next round
     }
     }
 }

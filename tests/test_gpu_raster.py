@@ -55,6 +55,26 @@ def test_forward_backward_vs_oracle(name):
     # viewspace gradient convention: z component stays zero
     assert float(g["means2D"][:, 2].abs().max()) == 0.0
 
+@pytest.mark.parametrize("degree", [0, 1, 2])
+def test_compact_sh_layouts_and_ragged_waves_vs_oracle(degree):
+    """SH tensors that hold exactly (D + 1)^2 coefficients (M = 1, 4, 9: what the fused render path hands over while the active
+    degree is 0, and what vanilla 3DGS checkpoints of lower degree hold) take the unstaged per-Gaussian kernels, whose 12-byte
+    gradient rows leave through the wave-private LDS transpose (preprocess_bwd.hip wave_store_rows); P = 64 k + 37 leaves the
+    last wave of the last workgroup partly empty."""
+    from das3r_amd.synth import make_scene
+    sc = make_scene(P=64 * 21 + 37, W=112, H=80, focal=90.0, sh_degree=degree, seed=50 + degree, max_sh_degree=degree)
+    assert sc.shs.shape[1] == (degree + 1) ** 2
+    mode = dict(colors_precomp=False, cov3D_precomp=False, scale_modifier=1.0)
+    ref_color, ref_radii, ref_g, S = util.run_oracle(sc, mode)
+    color, radii, g, fn = _run_hip(sc, mode)
+    assert np.array_equal(radii.cpu().numpy(), ref_radii)
+    util.assert_color_close(color.cpu().numpy(), ref_color, f"M={sc.shs.shape[1]} colour")
+    gmap = {"means3D": "means3D", "opacities": "opacities", "shs": "shs", "scales": "scales", "rotations": "rotations", "means2D": "means2D"}
+    for k, t in g.items():
+        util.assert_grad_close(t.cpu().numpy(), ref_g[gmap[k]], f"M={sc.shs.shape[1]} dL/d{k}")
+        util.assert_grad_elementwise(t.cpu().numpy(), ref_g[gmap[k]], f"M={sc.shs.shape[1]} dL/d{k}")
+
+
 
 @pytest.mark.parametrize("binning_path", ["radix", "local"])
 @pytest.mark.parametrize("name", ["basic_deg3", "ragged_image", "long_lists", "deep", "culled", "depth_ties", "world_camera"])
