@@ -386,7 +386,7 @@ int launch_render_backward_scan(const das3r_raster_args *a, const float *dL_dpix
         (uint32_t)(a->P - 1), (uint32_t)L.capacity, (const float4 *)(binning + L.b_ckpt)
 #define GO(MBV, AT, AB) DAS3R_LAUNCH((render_backward_scan_kernel<MBV, AT, AB>), dim3(xcd_grid(L.ntiles), slices > 1 ? slices : 1), dim3(TILE_PIX), 0, s, ARGS)
     const int abl = switches().ablate_set ? switches().ablate : 0;
-    // mb: 64 / 128 / 256 private accumulator regions; 1256 / 1512: 256 / 512 entries per round with the atomic flush
+    // mb: 64 / 128 / 256 private accumulator regions; 1256: 256 entries per round with the atomic flush
     if (mb == 128 && abl == 1) GO(128, false, 1);
     else if (mb == 128 && abl == 2) GO(128, false, 2);
     else if (mb == 128 && abl == 3) GO(128, false, 3);
@@ -394,8 +394,7 @@ int launch_render_backward_scan(const das3r_raster_args *a, const float *dL_dpix
     else if (mb == 128 && abl == 8) GO(128, false, 8);
     else if (mb == 64) GO(64, false, 0);
     else if (mb == 128) GO(128, false, 0);
-    else if (mb == 1256) GO(256, true, 0);
-    else if (mb == 1512) GO(512, true, 0);
+    else if (mb >= 1000) GO(256, true, 0);
     else GO(256, false, 0);
 #undef GO
 #undef ARGS
