@@ -70,6 +70,7 @@ static void load_switches() {
     if ((e = env("DAS3R_INJECT_FAULT"))) w.inject_fault = atoi(e);
     w.bwd_buckets = -1;
     if ((e = env("DAS3R_BWD_BUCKETS"))) w.bwd_buckets = atoi(e);
+    w.fwd_no_prefetch = (e = env("DAS3R_FWD_PREFETCH")) && e[0] == '0';
     w.tile_strip = 8;
     if ((e = env("DAS3R_TILE_STRIP"))) w.tile_strip = std::max(0, std::min(64, atoi(e)));
     g_sw = w;

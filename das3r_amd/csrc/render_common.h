@@ -18,6 +18,16 @@ struct StagedSplat {   // one LDS-staged entry of a tile's splat list (48 B)
     float4 rgbd;       // r, g, b, (depth)
 };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() fences every address space: on gfx950 (one vmcnt for loads and
+// stores) that is s_waitcnt vmcnt(0) in front of s_barrier, i.e. global loads issued ahead of their use — a software prefetch —
+// are waited for at the very next barrier.  Fences restricted to the LDS address space leave them in flight (s_waitcnt lgkmcnt(0)
+// only).  Use it only where no global-memory hand-off between the waves of the workgroup depends on the barrier.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // XCD-aware block -> tile map.  The dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md): every XCD gets one contiguous
 // piece of a LOCALITY ORDER of the tiles, so that the tiles a splat touches (2.6 on average at 1080p, mostly a 2 x 2 or 1 x 2
 // patch) are composited on the same XCD at about the same time and find the splat's record in that XCD's 4 MiB L2.  The order:

@@ -63,6 +63,10 @@ __device__ __forceinline__ void build_row_lists(const StagedSplat *stage, const 
     }
 }
 
+// PREFETCH (few tiles, long lists, globally sorted: the DAS3R shape — 416 workgroups for 1024 workgroup slots, so nobody else
+// covers a workgroup's trips to memory): the records of batch i + 1 and the list words of batch i + 2 are in flight while batch i
+// composites; a batch used to start with two trips in a row (list word -> record) behind the barrier.
+template <bool PREFETCH>
 __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
                                                                   int W, int H, int tiles_x, int ntiles_strip /*tiles | strip height << 24: render_common.h xcd_tile*/, const float4 *__restrict__ xyh,
                                                                   const float4 *__restrict__ conic_opacity,
@@ -98,17 +102,44 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
     const int nb = ckpt_buckets(range);                                 // (> 1: a long list, checkpointed for the bucket-parallel backward)
     const int cpix = ((py - by * TILE_Y) << 4) + (px - bx * TILE_X);      // pixel's place in a checkpoint slot
     int next_slot = 0;
+    // PREFETCH state: pf = record of this thread's entry of the batch about to be staged, g_ahead = its list word one batch further
+    float4 pf0 = make_float4(0.f, 0.f, 0.f, 0.f), pf1 = pf0, pf2 = pf0;
+    uint32_t g_ahead = 0u;
+    if (PREFETCH) {
+        const uint32_t len = range.y - range.x;
+        if ((uint32_t)tid < len) {
+            const uint32_t g = min(point_list[range.x + tid], lb.last_g);
+            pf0 = xyh[(size_t)g * SPLAT_REC];
+            pf1 = conic_opacity[(size_t)g * SPLAT_REC];
+            pf2 = rgbd[(size_t)g * SPLAT_REC];
+        }
+        if ((uint32_t)(TILE_PIX + tid) < len) g_ahead = point_list[range.x + TILE_PIX + tid];
+    }
     for (int i = 0; i < rounds; i++, toDo -= TILE_PIX) {
         if (__syncthreads_count(live == 0.f) == TILE_PIX) break;
         if (nb > 1 && i > 0 && (i * TILE_PIX) % BUCKET == 0) ckpt_slot(lb.ckpt, range, tile, next_slot++)[cpix] = make_float4(T, C0, C1, C2);
         const uint32_t progress = range.x + i * TILE_PIX + tid;
-        if (progress < range.y && !prestaged) {
+        if (PREFETCH) {
+            if (progress < range.y) {
+                stage[tid].xyh = pf0;
+                stage[tid].co = pf1;
+                stage[tid].rgbd = pf2;
+            }
+            if (progress + TILE_PIX < range.y) {       // batch i + 1: its list word arrived a batch ago
+                const uint32_t g = min(g_ahead, lb.last_g);
+                pf0 = xyh[(size_t)g * SPLAT_REC];
+                pf1 = conic_opacity[(size_t)g * SPLAT_REC];
+                pf2 = rgbd[(size_t)g * SPLAT_REC];
+            }
+            if (progress + 2 * TILE_PIX < range.y) g_ahead = point_list[progress + 2 * TILE_PIX];
+        } else if (progress < range.y && !prestaged) {
             const uint32_t g = min(sorted_here ? s_gid[i * TILE_PIX + tid] : (lb.point_list ? lb.point_list[progress] : point_list[progress]), lb.last_g);
             stage[tid].xyh = xyh[(size_t)g * SPLAT_REC];           // one 64-byte record: a single cache line per splat
             stage[tid].co = conic_opacity[(size_t)g * SPLAT_REC];
             stage[tid].rgbd = rgbd[(size_t)g * SPLAT_REC];
         }
-        __syncthreads();
+        if (PREFETCH) lds_barrier();   // (the loads just issued stay in flight: render_common.h)
+        else __syncthreads();
         const int n = toDo < TILE_PIX ? toDo : TILE_PIX;
         int len[4];
         build_row_lists(stage, n, q0x, q0y, lane, lists[wave], len);
@@ -163,11 +194,16 @@ bool use_row_private(int64_t instances, int ntiles) {
 
 int launch_render_forward_rows(const das3r_raster_args *a, float *out_color, char *geom, char *binning, char *img, const Layout &L,
                                const LocalBin &lb, hipStream_t s) {
-    DAS3R_LAUNCH(render_forward_rows_kernel, dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, (const uint2 *)(img + L.pub.ranges),
-                 (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height, L.tiles_x, pack_tiles(L),
-                 (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),
-                 (const float4 *)(geom + L.pub.rgbd), a->bg, (float *)(img + L.pub.final_T), (uint32_t *)(img + L.pub.n_contrib),
-                 out_color, lb);
+#define ARGS                                                                                                              \
+    (const uint2 *)(img + L.pub.ranges), (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height,  \
+        L.tiles_x, pack_tiles(L), (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),         \
+        (const float4 *)(geom + L.pub.rgbd), a->bg, (float *)(img + L.pub.final_T), (uint32_t *)(img + L.pub.n_contrib),   \
+        out_color, lb
+    // globally sorted lists and fewer tiles than the chip has workgroup slots (4 per CU and more): see PREFETCH
+    const bool prefetch = lb.point_list == nullptr && L.ntiles <= 1024 && !switches().fwd_no_prefetch;
+    if (prefetch) DAS3R_LAUNCH((render_forward_rows_kernel<true>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS);
+    else DAS3R_LAUNCH((render_forward_rows_kernel<false>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS);
+#undef ARGS
     KERNEL_CHECK(s, a->debug, "render_forward_rows");
     return DAS3R_OK;
 }
