@@ -73,7 +73,13 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
                                                                   const float4 *__restrict__ rgbd, const float *__restrict__ bg,
                                                                   float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                                                                   float *__restrict__ out_color, const LocalBin lb) {
-    __shared__ StagedSplat stage[TILE_PIX];
+    // PREFETCH: two staging areas in turn — ONE barrier per batch (publish the batch); a wave that is done with batch i goes on
+    // to stage batch i + 1 into the other area while slower waves still composite batch i (the barrier of batch i + 1 needs
+    // everybody past batch i: the area being overwritten held batch i - 1).  The four quadrants of a tile rarely have equally long sub-lists, and with
+    // 1.6 workgroups per CU nobody else fills the wait: PMC on the DAS3R shape showed 58 % of the wave cycles waiting.
+    constexpr int NBUF = PREFETCH ? 2 : 1;
+    __shared__ StagedSplat stage_all[NBUF * TILE_PIX];
+    StagedSplat *stage = stage_all;
     __shared__ uint32_t s_gid[LOCAL_MAX];   // local depth order: the tile's sorted list
     __shared__ uint8_t lists[4][4][ROW_LIST_STRIDE];   // [wave][row][position]
     const int ntiles = ntiles_strip & 0xFFFFFF;
@@ -116,7 +122,10 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
         if ((uint32_t)(TILE_PIX + tid) < len) g_ahead = point_list[range.x + TILE_PIX + tid];
     }
     for (int i = 0; i < rounds; i++, toDo -= TILE_PIX) {
-        if (__syncthreads_count(live == 0.f) == TILE_PIX) break;
+        if (PREFETCH) {
+            stage = stage_all + (i % NBUF) * TILE_PIX;
+            if ((i & 15) == 0 && __syncthreads_count(live == 0.f) == TILE_PIX) break;   // (rare on this path: checked every 16 batches)
+        } else if (__syncthreads_count(live == 0.f) == TILE_PIX) break;
         if (nb > 1 && i > 0 && (i * TILE_PIX) % BUCKET == 0) ckpt_slot(lb.ckpt, range, tile, next_slot++)[cpix] = make_float4(T, C0, C1, C2);
         const uint32_t progress = range.x + i * TILE_PIX + tid;
         if (PREFETCH) {
