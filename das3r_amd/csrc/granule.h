@@ -37,20 +37,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
     return v;
 }
 
-__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
-    const int lane = __lane_id();
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t n = __shfl_up(v, o, 64);
-        if (lane >= o) v += n;
-    }
-    return v;
-}
-
 // exclusive scan across a 256-thread block; returns the exclusive prefix of `v`, *total = block sum
 __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t *lds_wave_sums /*[4]*/, uint32_t *total) {
     const int lane = __lane_id(), wave = threadIdx.x >> 6;
-    const uint32_t incl = wave_inclusive_scan_u32(v);
+    const uint32_t incl = wave_incl_scan_u32(v);
     __syncthreads();  // protect lds_wave_sums reuse across calls
     if (lane == 63) lds_wave_sums[wave] = incl;
     __syncthreads();

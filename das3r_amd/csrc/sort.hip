@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(256) radix_scatter_kernel(const uint32_t *__re
             h[q] = hist[(size_t)(4 * lane + q) * nchunks + chunk];
             sum += t[q];
         }
-        uint32_t ex = wave_inclusive_scan_u32(sum) - sum;
+        uint32_t ex = wave_incl_scan_u32(sum) - sum;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             off[4 * lane + q] = ex + h[q];
