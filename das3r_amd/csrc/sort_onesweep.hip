@@ -107,11 +107,39 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
         k[s] = i < n ? keys_in[i] : 0u;
         v[s] = (vals_in && i < n) ? vals_in[i] : i;
     }
+    // Count AND rank in one sweep, without LDS atomics (ds_add costs ~12 cycles per active lane on this chip: 16 of them per lane
+    // were the longest phase of the pass).  Per row of 64 keys: match-any over the digit bits -> every key knows its peers; the
+    // first peer reads the wave's running count of the digit and adds the group's size (plain read + write: one writer per digit
+    // and row, rows in program order, LDS in order per wave).  local[s] = (same-digit keys of this wave before this one).
+    uint32_t local[IPL];
+    {
+        volatile uint32_t *cw = cnt[wave];
 #pragma unroll
-    for (int s = 0; s < IPL; s++) {
-        const uint32_t i = base + s * 64 + lane;
-        out[s] = v[s];   // FINAL: the staged payload stays the emission slot; the splat id is gathered at write-out
-        if (i < n) atomicAdd(&cnt[wave][(k[s] >> shift) & mask], 1u);
+        for (int s = 0; s < IPL; s++) {
+            const uint32_t i = base + s * 64 + lane;
+            out[s] = v[s];   // FINAL: the staged payload stays the emission slot; the splat id is gathered at write-out
+            const bool valid = i < n;
+            const uint32_t digit = (k[s] >> shift) & mask;
+            // match-any over the 8 digit bits (bits above `bits` are zero in every lane: harmless).  Kept in 32-bit halves so
+            // that every step is v_xnor + v_and on VGPRs; rank = v_mbcnt of the peer mask
+            const uint64_t vm = __ballot(valid);
+            uint32_t plo = (uint32_t)vm, phi = (uint32_t)(vm >> 32);
+#pragma unroll
+            for (int bb = 0; bb < RADIX_BITS; bb++) {
+                const uint32_t sel = 0u - ((digit >> bb) & 1u);          // all ones if my bit is set
+                const uint64_t m = __ballot((digit >> bb) & 1u);
+                plo &= ~((uint32_t)m ^ sel);
+                phi &= ~((uint32_t)(m >> 32) ^ sel);
+            }
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+            const uint32_t count = (uint32_t)__popc(plo) + (uint32_t)__popc(phi);
+            uint32_t before = 0;
+            if (valid) before = cw[digit];
+            __builtin_amdgcn_wave_barrier();
+            if (valid && rank == 0) cw[digit] = before + count;
+            __builtin_amdgcn_wave_barrier();
+            local[s] = before + rank;
+        }
     }
     __syncthreads();
 
@@ -148,34 +176,13 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
     }
     __syncthreads();
 
-    // rank every key inside the workgroup and stage it at its local slot: the staging area ends up grouped by digit, in
-    // stable order
-    volatile uint32_t *off = cnt[wave];
+    // stage every key at its local slot: the staging area ends up grouped by digit, in stable order
+    //   slot = (digit's first slot in the workgroup + same-digit keys of earlier waves) [cnt[wave][digit] now] + local[s]
 #pragma unroll
     for (int s = 0; s < IPL; s++) {
         const uint32_t i = base + s * 64 + lane;
-        const bool valid = i < n;
-        const uint32_t digit = (k[s] >> shift) & mask;
-        // match-any over the 8 digit bits (bits above `bits` are zero in every lane: harmless).  Kept in 32-bit halves so
-        // that every step is v_xnor + v_and on VGPRs; rank = v_mbcnt of the peer mask
-        const uint64_t vm = __ballot(valid);
-        uint32_t plo = (uint32_t)vm, phi = (uint32_t)(vm >> 32);
-#pragma unroll
-        for (int bb = 0; bb < RADIX_BITS; bb++) {
-            const uint32_t sel = 0u - ((digit >> bb) & 1u);          // all ones if my bit is set
-            const uint64_t m = __ballot((digit >> bb) & 1u);
-            plo &= ~((uint32_t)m ^ sel);
-            phi &= ~((uint32_t)(m >> 32) ^ sel);
-        }
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
-        const uint32_t count = (uint32_t)__popc(plo) + (uint32_t)__popc(phi);
-        uint32_t o = 0;
-        if (valid) o = off[digit];
-        __builtin_amdgcn_wave_barrier();
-        if (valid && rank == 0) off[digit] = o + count;
-        __builtin_amdgcn_wave_barrier();
-        if (valid) {
-            const uint32_t slot = o + rank;
+        if (i < n) {
+            const uint32_t slot = cnt[wave][(k[s] >> shift) & mask] + local[s];
             sk[slot] = k[s];
             sv[slot] = out[s];
         }
