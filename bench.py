@@ -208,11 +208,10 @@ def kernel_table(job, steps, measured=None):
     kernels = {}
     for name, (n, ms) in sorted(group_kernel_times(rep).items(), key=lambda kv: -kv[1][1]):
         avg_ms = ms / steps   # per step (the 'binning' entry = all its launches)
-        ent = {"ms_per_step": round(avg_ms, 5), "launches_per_step": n / steps}
+        ent = {"ms_per_step": round(avg_ms, 5)}
         if name in per_kernel:
             ent["alg_bytes"] = per_kernel[name]
-            ent["GBps"] = round(per_kernel[name] / (avg_ms * 1e-3) / 1e9, 2)
-            ent["frac_of_peak"] = round(ent["GBps"] / HBM_PEAK_GBS, 5)
+            ent["GBps"] = round(per_kernel[name] / (avg_ms * 1e-3) / 1e9, 1)
         kernels[name] = ent
     # dominant KERNEL = the single kernel with the largest time per step (the 'binning' entry is a group of small launches)
     dom = next(k for k in kernels if k in per_kernel and k != "binning")
@@ -248,7 +247,7 @@ def kernel_table(job, steps, measured=None):
                 "pipeline": {"alg_bytes_fwd_bwd": b_fwd + b_bwd, "kernel_ms_per_step": round(total_ms, 5),
                              "GBps": round((b_fwd + b_bwd) / (total_ms * 1e-3) / 1e9, 2),
                              "frac": round((b_fwd + b_bwd) / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
-                "how": "HIP events around every launch on the launch stream, separate instrumented pass of the same K steps"}
+                "how": "HIP events around every launch, separate pass of the same K steps"}
     return kernels, roofline
 
 
@@ -304,8 +303,7 @@ def measure_traffic(workload, timeout_s=150):
     # the child ran one initialisation step + `steps` steps, every one of them counted
     print(json.dumps({"bench_binning_hbm_bytes_per_step": {k: int(v / (steps + 1)) for k, v in raw.items()}}), file=sys.stderr, flush=True)
     return ({k: v / (steps + 1) for k, v in tot.items()},
-            f"measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two separate passes over {steps + 1} steps of the same "
-            f"workload, bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction, MI355X_MICROARCH.md)")
+            f"this run: rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE (separate passes, {steps + 1} steps), bytes = 2*FETCH + WRITE (gfx950)")
 
 
 def pmc_child_main(args):
@@ -457,7 +455,7 @@ def main():
     ts_iters = max(20, min(100, args.steps))
     ts_ms = rk.timed(ts_step, ts_iters, 10) / ts_iters * 1e3
     train = {"fused": round(ts_ms, 4), "splats": ts_splats, "frames": 20, "image": [512, 208], "iters": ts_iters,
-             "what": "render + masked L1/SSIM loss + backward + both Adam steps (train_gui.py:542-589 counterpart), opt-in fused kernels"}
+             "what": "render + masked L1/SSIM loss + backward + both Adam steps (train_gui.py:542-589), fused kernels"}
     scenes_per_hour = rk.world * 3600e3 / (ITERS_PER_SCENE * ts_ms)
     del ts_step
 
@@ -483,7 +481,7 @@ def main():
                           "host_cpus": (f"pinned to CPUs {pinned[1][0]}-{pinned[1][-1]} (one core complex per rank)" if pinned
                                         else "not pinned")},
                "train_step_ms": train, "scenes_per_hour": round(scenes_per_hour, 2),
-               "scenes_per_hour_def": f"N GPUs x 3600 s / ({ITERS_PER_SCENE} iterations x train_step_ms.fused, max over ranks)",
+               "scenes_per_hour_def": f"N x 3600 s / ({ITERS_PER_SCENE} it x train_step_ms.fused)",
                "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels, "extras": extras}
         if extras and not args.full_line:
             # the line stays short enough for any log tail: per-workload detail goes to stderr (and to gpurun_out/ when it exists)
@@ -493,7 +491,7 @@ def main():
                 with open(os.path.join(ROOT, "gpurun_out", "bench_extras.json"), "w") as f:
                     f.write(detail + "\n")
             out["extras"] = {w: (e.get("ms_per_step") if isinstance(e, dict) else e) for w, e in extras.items()}
-            out["extras_unit"] = "ms_per_step of the other BASELINE shapes (detail: stderr line 'bench_extras')"
+            out["extras_unit"] = "ms_per_step (detail: stderr bench_extras)"
         print(json.dumps(out), flush=True)
     rk.close()
 
