@@ -100,6 +100,13 @@ static inline int sort_items_per_lane(int64_t n) {
     return o ? o : (n >= (int64_t)(1 << 21) ? 16 : (n >= (1 << 17) ? 8 : 4));
 }
 static inline int sort_num_chunks(int64_t n) { return n == 0 ? 0 : div_up(n, (int64_t)WAVE * sort_items_per_lane(n)); }
+// Width of a tile-id digit: the tile bits are split EVENLY over the ceil(tbits / 8) partition passes (13 bits = 7 + 6, 9 = 5 + 4)
+// instead of 8 + rest: a pass costs per digit VALUE (counters to publish and to look back over, write heads kept open), so two
+// narrow passes beat a wide one next to a nearly empty one.
+__host__ __device__ static inline int tile_digit_width(int tbits) {
+    const int passes = (tbits + 7) / 8;
+    return passes > 0 ? (tbits + passes - 1) / passes : 8;
+}
 static inline int tile_bits(int ntiles) {
     int b = 0;
     while ((1 << b) < ntiles) b++;

@@ -248,8 +248,8 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
                         const uint32_t t = (uint32_t)(y * tiles_x + x);
                         em.tile_keys[o] = t;
                         em.gids[o] = (uint32_t)idx;
-                        for (int q = 0, sh = 0; sh < em.tbits; q++, sh += 8) {
-                            const int bits = (em.tbits - sh) < 8 ? (em.tbits - sh) : 8;
+                        for (int q = 0, sh = 0, dw = tile_digit_width(em.tbits); sh < em.tbits; q++, sh += dw) {
+                            const int bits = (em.tbits - sh) < dw ? (em.tbits - sh) : dw;
                             atomicAdd(&h[q][(t >> sh) & ((1u << bits) - 1u)], 1u);
                         }
                     }
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
             __hip_atomic_store(em.count_out + 2, em.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         __syncthreads();
-        for (int q = 0, sh = 0; sh < em.tbits; q++, sh += 8) {
+        for (int q = 0, sh = 0, dw = tile_digit_width(em.tbits); sh < em.tbits; q++, sh += dw) {
             const uint32_t c = h[q][tid];
             if (c) atomicAdd(&em.ghist[q * RADIX_SIZE + tid], c);
         }

@@ -125,8 +125,8 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
                             const uint32_t t = (uint32_t)(y * tiles_x + x);
                             tile_keys[o] = t;
                             gids[o] = g[k];   // gid_of[emission slot]
-                            for (int q = 0, sh = 0; sh < tbits; q++, sh += 8) {
-                                const int bits = (tbits - sh) < 8 ? (tbits - sh) : 8;
+                            for (int q = 0, sh = 0, dw = tile_digit_width(tbits); sh < tbits; q++, sh += dw) {
+                                const int bits = (tbits - sh) < dw ? (tbits - sh) : dw;
                                 atomicAdd(&h[EMIT ? q : 0][(t >> sh) & ((1u << bits) - 1u)], 1u);
                             }
                         }
@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
     }
     if (EMIT) {
         __syncthreads();
-        for (int q = 0, sh = 0; sh < tbits; q++, sh += 8) {
+        for (int q = 0, sh = 0, dw = tile_digit_width(tbits); sh < tbits; q++, sh += dw) {
             const uint32_t c = h[EMIT ? q : 0][tid];
             if (c) atomicAdd(&ghist[q * RADIX_SIZE + tid], c);
         }

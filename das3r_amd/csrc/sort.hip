@@ -218,8 +218,8 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, int tiles
                     tile_keys[o] = t;
                     gids[o] = g;  // gid_of[emission slot]
                     if (ghist) {
-                        for (int q = 0, sh = 0; sh < tbits; q++, sh += 8) {
-                            const int bits = (tbits - sh) < 8 ? (tbits - sh) : 8;
+                        for (int q = 0, sh = 0, dw = tile_digit_width(tbits); sh < tbits; q++, sh += dw) {
+                            const int bits = (tbits - sh) < dw ? (tbits - sh) : dw;
                             atomicAdd(&h[q][(t >> sh) & ((1u << bits) - 1u)], 1u);
                         }
                     }
@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, int tiles
     }
     if (ghist) {
         __syncthreads();
-        for (int q = 0, sh = 0; sh < tbits; q++, sh += 8) {
+        for (int q = 0, sh = 0, dw = tile_digit_width(tbits); sh < tbits; q++, sh += dw) {
             const uint32_t c = h[q][threadIdx.x];
             if (c) atomicAdd(&ghist[q * RADIX_SIZE + threadIdx.x], c);
         }
@@ -324,7 +324,7 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
     uint32_t *kin = keyA, *vin = nullptr, *kout = keyB, *vout = valB;
     int shift = 0, rc;
     for (int p = 0; p < L.tile_passes; p++) {
-        const int bits = (L.tbits - shift) < 8 ? (L.tbits - shift) : 8;
+        const int dw = tile_digit_width(L.tbits), bits = (L.tbits - shift) < dw ? (L.tbits - shift) : dw;
         const bool last = p == L.tile_passes - 1;
         if ((rc = radix_pass(kin, vin, kout, vout, I, shift, bits, hist, totals, debug, s, last ? gid_of : nullptr, last ? inv : nullptr, n_ptr)))
             return rc;

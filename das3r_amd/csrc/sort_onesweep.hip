@@ -314,7 +314,7 @@ int launch_onesweep_partition(int64_t cap, char *geom, char *binning, const Layo
     uint32_t *kin = keyA, *vin = nullptr, *kout = keyB, *vout = valB;
     int shift = 0, rc;
     for (int p = 0; p < L.tile_passes; p++) {
-        const int bits = (L.tbits - shift) < 8 ? (L.tbits - shift) : 8;
+        const int dw = tile_digit_width(L.tbits), bits = (L.tbits - shift) < dw ? (L.tbits - shift) : dw;
         const bool last = p == L.tile_passes - 1;
         if ((rc = onesweep_pass(kin, vin, kout, vout, cap, n_ptr, shift, bits, ghist + p * 256, status + p * per_pass, ticket + p,
                                 last ? gid_of : nullptr, last ? inv : nullptr, err, debug, s)))
