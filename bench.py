@@ -251,7 +251,7 @@ def kernel_table(job, steps, measured=None):
     return kernels, roofline
 
 
-def measure_traffic(workload, timeout_s=150):
+def measure_traffic(workload, timeout_s=90):
     """HBM bytes per launch of every kernel of `workload`, MEASURED BY THIS RUN: two child passes of rocprofv3 --pmc (FETCH_SIZE,
     then WRITE_SIZE — separate passes, kernel trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) over three steps
     of the same workload.  FETCH_SIZE / WRITE_SIZE come in KiB; on gfx950 FETCH_SIZE under-counts wide reads by 2x (same guide),
