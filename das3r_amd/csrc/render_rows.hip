@@ -184,7 +184,8 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
 #pragma unroll
             for (int u = 0; u < UNROLL; u++) {
                 const float a = aa[u] * live;   // (live may have changed with the position before)
-                if (__ballot(a > 0.f) == 0ull) continue;
+                // (no wave-uniform skip here: a listed position nearly always has a taker among the four rows, and every such test is a
+                //  VALU -> SALU -> branch round trip)
                 const int j = jj[u];
                 const float4 c = stage[j].rgbd;
                 const float test_T = T * (1.0f - a);
