@@ -2,25 +2,29 @@
 // Replaces upstream:cuda_rasterizer/backward.cu renderCUDA like render_bwd.hip; same inputs, same partial rows.
 //
 // Why a third decomposition.  With a pixel per lane (render_bwd.hip) every (splat, quadrant) iteration ends in a 64-lane
-// reduction of nine sums: 30 % of that kernel, on top of ~15 products per pair that exist only to be reduced.  The MFMA variant
-// (render_bwd_mfma.hip) moves the reduction to the matrix cores but has to transpose its operands through a 44 KB LDS slab,
-// because v_mfma_f32_16x16x4_f32 contracts over (lane >> 4) and the step index, never over the lanes of a DPP row.
+// reduction of nine sums: 30 % of that kernel, on top of ~15 products per pair that exist only to be reduced.  The first MFMA
+// variant (render_bwd_mfma.hip) moves the reduction to the matrix cores but has to transpose its operands through a 44 KB LDS
+// slab, and its exact-fp32 v_mfma_f32_16x16x4_f32 holds the SIMD's vector ALU for 32 cycles per instruction.
 // Here the lanes are laid out the way the matrix core wants its B operand in the first place:
-//     lane = 16 r + s     r = pixel of the current 4-pixel step,  s = splat of the current 16-splat batch,
-// so the two per-pair scalars (w = alpha T and g = G dL/dalpha) are MFMA operands the moment they are computed, and sixteen
-// steps (the 64 pixels of the wave's 8x8 quadrant) accumulate D[9 sums x 16 splats] on the matrix pipe while the vector ALU
-// evaluates the next step.  What the layout costs: the per-pixel recurrences (T, R) now run ACROSS the sixteen lanes of a row —
-// two 4-step DPP scans per step (product of 1/(1-alpha) for T, sum of w (c . dL/dpix) for R), 8 full-rate instructions, against the
-// 18 + 6 cross-lane and ~15 product instructions they replace.  Per 64 pairs: ~45 VALU + 2 MFMA instead of ~110 VALU.
+//     lane = 16 r + s     r = pixel row of the current step,  s = splat of the current 16-splat batch,
+// so the two per-pair scalars (w = alpha T and g = G dL/dalpha) are MFMA operands the moment they are computed: split into bf16
+// high + low parts (16 mantissa bits together, products accumulated in fp32) they meet ONE constant A operand per pixel group
+// (dL/dpixel hi, the six moment weights about the tile centre — exact in bf16 —, dL/dpixel lo) on v_mfma_f32_16x16x32_bf16,
+// which takes 16 cycles and leaves the vector ALU to the other waves.  Four MFMAs per half batch (32 pixels x 16 splats) give
+// D[12 rows x 16 splats]: the colour sums (hi + lo rows) and the six moments.  What the layout costs: the per-pixel recurrences
+// (T, R) now run ACROSS the sixteen lanes of a row — two 4-step DPP scans per step (product of 1/(1-alpha) for T, sum of
+// w (c . dL/dpix) for R), four independent chains interleaved (render_scan.h).  Per 64 pairs: ~45 VALU + 2 transcendentals.
 //
-// Per staged batch (MB list entries in reverse list order, as in render_bwd.hip) every wave culls the batch against its quadrant
-// (ballot), compacts the survivors to a u8 index list in LDS and walks it 16 entries at a time; lane (r, s) keeps splat s of the
-// batch in registers for the sixteen steps.  Per-pixel constants (dL/dpix, T_final (bg . dL/dpix), n_contrib) and the running
-// state (T, R) live in a 32-byte LDS row per pixel: a step reads them with two broadcast ds_read_b128 (four addresses per
-// instruction) and lane 15 of every row writes the state back.  The nine sums of a (wave, splat) leave the accumulator with plain
-// LDS stores into a WAVE-PRIVATE region (a wave meets a splat at most once per batch): no atomics anywhere; the four regions are
-// added per splat, under the waves' hit masks, when the batch is written out.  Geometry sums travel as raw moments of g about the
-// tile centre (exact fp32 FMA chains on the matrix core) and are converted once per (tile, splat), as in render_bwd_mfma.hip.
+// Per round (MB list entries in reverse list order, as in render_bwd.hip) every wave culls the entries against its quadrant
+// (bounding box, then the exact ellipse-vs-rectangle test), compacts the survivors to an index list in LDS and walks it 16 at a
+// time; lane (r, s) keeps splat s of the batch in registers for the sixteen steps.  Per-pixel constants (dL/dpix, T_final
+// (bg . dL/dpix), n_contrib) and the running state (T, R) live in a 32-byte LDS row per pixel: a step reads them with two
+// broadcast ds_read_b128 (four addresses per instruction) and lane 15 of every row writes the state back (exec-masked
+// ds_write2_b32).  The sums of a (wave, splat) leave the accumulator as one 36-byte record in a WAVE-PRIVATE region (a wave
+// meets a splat at most once per round): no atomics anywhere; the four regions are added per splat, under the waves' hit masks,
+// when the round is written out, the moments become the nine per-instance sums (once per (tile, splat)) and the row goes straight
+// to the entry's emission slot.  Long lists are replayed bucket by bucket in parallel workgroups from the forward's checkpoints
+// (gridDim.y > 1; common.h BUCKET).  CPU models of the arithmetic: tests/test_scan_model.py, tests/test_bucket_model.py.
 #include "render_scan.h"
 
 namespace das3r {
