@@ -252,6 +252,22 @@ def kernel_table(job, steps, measured=None):
     return kernels, roofline
 
 
+def pmc_rows(files, counter):
+    """rocprofv3 counter_collection CSVs -> (kernel group, kernel name, bytes) per launch of this library's kernels.  FETCH_SIZE /
+    WRITE_SIZE are in KiB; FETCH_SIZE is doubled (gfx950: wide reads are under-counted by 2x, MI355X_MICROARCH.md)."""
+    import csv
+    from das3r_amd.roofline import ALIASES, BINNING_KERNELS
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("das3r::", "").split("<")[0]
+            if not (k in BINNING_KERNELS or k in ALIASES or k.startswith("render_") or k.startswith("preprocess_")):
+                continue
+            b = float(r["Counter_Value"]) * 1024.0 * (2.0 if counter == "FETCH_SIZE" else 1.0)
+            yield ("binning" if k in BINNING_KERNELS else ALIASES.get(k, k)), k, b
+
+
 def measure_traffic(workload, timeout_s=90):
     """HBM bytes per launch of every kernel of `workload`, MEASURED BY THIS RUN: two child passes of rocprofv3 --pmc (FETCH_SIZE,
     then WRITE_SIZE — separate passes, kernel trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) over three steps
@@ -287,18 +303,10 @@ def measure_traffic(workload, timeout_s=90):
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if not files:
                 return None, f"rocprofv3 --pmc {counter} pass wrote no counter file (rc {p.returncode})"
-            for f in files:
-                for r in csv.DictReader(open(f)):
-                    if r["Counter_Name"] != counter:
-                        continue
-                    k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("das3r::", "").split("<")[0]
-                    if not (k in BINNING_KERNELS or k in ALIASES or k.startswith("render_") or k.startswith("preprocess_")):
-                        continue
-                    b = float(r["Counter_Value"]) * 1024.0 * (2.0 if counter == "FETCH_SIZE" else 1.0)
-                    key = "binning" if k in BINNING_KERNELS else ALIASES.get(k, k)
-                    tot[key] = tot.get(key, 0.0) + b
-                    if key == "binning":
-                        raw[k] = raw.get(k, 0.0) + b
+            for key, raw_name, b in pmc_rows(files, counter):
+                tot[key] = tot.get(key, 0.0) + b
+                if key == "binning":
+                    raw[raw_name] = raw.get(raw_name, 0.0) + b
     finally:
         shutil.rmtree(work, ignore_errors=True)
     # the child ran one initialisation step + `steps` steps, every one of them counted

@@ -41,3 +41,31 @@ def test_single_rank_stub_and_world_size_mismatch():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--stub"],
                        capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
+
+
+def test_counter_csv_rows_are_grouped_and_converted(tmp_path):
+    """bench.py pmc_rows: rocprofv3 counter_collection CSV -> bytes per launch and kernel group (KiB -> bytes, FETCH_SIZE doubled,
+    foreign kernels dropped, template arguments and namespaces stripped, binning kernels folded into one group)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    head = ('"Correlation_Id","Dispatch_Id","Agent_Id","Queue_Id","Process_Id","Thread_Id","Grid_Size","Kernel_Id","Kernel_Name",'
+            '"Workgroup_Size","LDS_Block_Size","Scratch_Size","VGPR_Count","Accum_VGPR_Count","SGPR_Count","Counter_Name","Counter_Value",'
+            '"Start_Timestamp","End_Timestamp"\n')
+    def row(i, name, counter, value):
+        return f'{i},{i},"Agent 2",1,5,5,512,8,"{name}",256,0,0,8,0,32,"{counter}",{value:.8e},1,2\n'
+    f = tmp_path / "pmc_counter_collection.csv"
+    f.write_text(head
+                 + row(1, "__amd_rocclr_copyBuffer", "FETCH_SIZE", 64.0)
+                 + row(2, "void das3r::render_backward_scan_kernel<128, false, 0>(HIP_vector_type<unsigned int, 2u> const*, int)", "FETCH_SIZE", 100.0)
+                 + row(3, "das3r::render_forward_rows_kernel<true>(int)", "FETCH_SIZE", 10.0)
+                 + row(4, "void das3r::onesweep_pass_kernel<16, true>(unsigned int const*)", "FETCH_SIZE", 3.0)
+                 + row(5, "das3r::scan_emit_kernel<true, 8>(int)", "FETCH_SIZE", 1.0)
+                 + row(6, "void das3r::preprocess_kernel<true, false, true>(int)", "WRITE_SIZE", 7.0)
+                 + row(7, "void at::native::vectorized_elementwise_kernel<4>(int)", "FETCH_SIZE", 9.0))
+    got = list(bench.pmc_rows([str(f)], "FETCH_SIZE"))
+    assert got == [("render_backward_kernel", "render_backward_scan_kernel", 100.0 * 1024 * 2),
+                   ("render_forward_kernel", "render_forward_rows_kernel", 10.0 * 1024 * 2),
+                   ("binning", "onesweep_pass_kernel", 3.0 * 1024 * 2), ("binning", "scan_emit_kernel", 1.0 * 1024 * 2)]
+    assert list(bench.pmc_rows([str(f)], "WRITE_SIZE")) == [("preprocess_kernel", "preprocess_kernel", 7.0 * 1024)]
