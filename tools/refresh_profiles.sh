@@ -14,7 +14,7 @@ done
 cd /tmp; export TMPDIR=/tmp
 for w in c4 c2 ds; do
   rm -rf /tmp/kt_$w
-  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt_$w -o kt --output-format csv -- python $R/bench.py --workload $w --no-cpu-baseline --no-extras --no-pmc > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt_$w -o kt --output-format csv -- python $R/bench.py --workload $w --no-cpu-baseline --no-pmc > /dev/null 2>&1
   f=$(find /tmp/kt_$w -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp $f $OUT/${RN}_${w}_kernel_stats.csv
 done
