@@ -163,6 +163,40 @@ def das3r_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, ove
     return {"render": image, "viewspace_points": kw["means2D"], "visibility_filter": radii > 0, "radii": radii}
 
 
+def das3r_render_3dgs(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):
+    """The vanilla 3DGS renderer the reference keeps beside its own (gaussian_renderer/__init__3dgs.py:18-99): Gaussians in WORLD
+    space, the camera in the settings (world_view_transform / full_proj_transform / camera_center), no pose tensor, no
+    confidence factor, rotations normalised by the model's activation."""
+    device = pc.get_xyz.device
+    means2D = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True, device=device) + 0
+    try:
+        means2D.retain_grad()
+    except Exception:  # noqa: BLE001
+        pass
+    settings = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(float(viewpoint_camera.FoVx) * 0.5), tanfovy=math.tan(float(viewpoint_camera.FoVy) * 0.5), bg=bg_color,
+        scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
+        sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False, debug=bool(getattr(pipe, "debug", False)))
+    kw = dict(means3D=pc.get_xyz, means2D=means2D, shs=None, colors_precomp=None, opacities=pc.get_opacity, scales=None, rotations=None,
+              cov3D_precomp=None)
+    if bool(getattr(pipe, "compute_cov3D_python", False)):
+        kw["cov3D_precomp"] = pc.get_covariance(scaling_modifier)
+    else:
+        kw["scales"], kw["rotations"] = pc.get_scaling, pc.get_rotation
+    if override_color is not None:
+        kw["colors_precomp"] = override_color
+    elif bool(getattr(pipe, "convert_SHs_python", False)):
+        feats = pc.get_features
+        per_channel = feats.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+        away = pc.get_xyz - viewpoint_camera.camera_center.repeat(feats.shape[0], 1)
+        kw["colors_precomp"] = torch.clamp_min(sh_to_rgb(pc.active_sh_degree, per_channel, away / away.norm(dim=1, keepdim=True)) + 0.5, 0.0)
+    else:
+        kw["shs"] = pc.get_features
+    image, radii = GaussianRasterizer(raster_settings=settings)(**kw)
+    return {"render": image, "viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii}
+
+
 def das3r_render_test(*a, **k):
     """gaussian_renderer/__init__.py:152 render_test"""
     return das3r_render(*a, variant="test", **k)

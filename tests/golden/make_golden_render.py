@@ -17,6 +17,7 @@ What each vector pins (SURVEY.md §8c "what can be imported here", VERDICT r1 "p
             hands to GaussianRasterizer (recorded by a stand-in rasterizer), for seeded models in three pipe modes
             (default / compute_cov3D_python / convert_SHs_python) -> the whole pre-transform of §8 a1; cases 4..6 the same for the
             three sibling renderers render_test (:152), render_no_soft (:279), render_confidence (:410)
+  r3dgs*    gaussian_renderer/__init__3dgs.py:18-99 render(): the vanilla 3DGS renderer (world-space Gaussians, camera in the settings)
 """
 import math
 import os
@@ -172,6 +173,51 @@ def main():
             out[pre + "cam"] = np.array([fovx, fovy, cam.image_height, cam.image_width], dtype=np.float64)
             out[pre + "cam_center"] = cam.camera_center.numpy()
             out[pre + "cam_proj"] = cam.projection_matrix.numpy()
+            out[pre + "mode"] = np.array([deg, int(cov_py), int(sh_py)], dtype=np.int64)
+            out[pre + "mod"] = np.array(mod)
+            for f in FIELDS:
+                v = getattr(rs, f)
+                out[pre + "rs_" + f] = v.detach().numpy() if torch.is_tensor(v) else np.array(v)
+            for k, v in kw.items():
+                out[pre + "kw_" + k] = v.detach().numpy() if v is not None else np.zeros(0, dtype=np.float32)
+            out[pre + "kw_none"] = np.array([k for k, v in kw.items() if v is None])
+    # ---- (3) the vanilla 3DGS renderer kept beside render(): gaussian_renderer/__init__3dgs.py:18-99 (world-space Gaussians, camera
+    #          in the settings); appended after everything else so that the seeded stream above is unchanged
+    with _NoCuda():
+        import importlib
+        render_3dgs = importlib.import_module("gaussian_renderer.__init__3dgs").render
+        from scene.gaussian_model import GaussianModel
+        from utils.graphics_utils import getProjectionMatrix, getWorld2View2
+        for case, (deg, cov_py, sh_py, mod) in enumerate([(3, False, False, 1.0), (1, True, True, 1.4)]):
+            P = 90
+            pc = GaussianModel(3)
+            pc.active_sh_degree = deg
+            pc._xyz = torch.randn(P, 3, generator=g) * 1.5
+            pc._rotation = torch.randn(P, 4, generator=g) * (0.6 + 0.8 * torch.rand(P, 1, generator=g))
+            pc._scaling = torch.randn(P, 3, generator=g) * 0.5 - 2.5
+            pc._opacity = torch.randn(P, 1, generator=g)
+            pc._features_dc = torch.randn(P, 1, 3, generator=g)
+            pc._features_rest = torch.randn(P, 15, 3, generator=g) * 0.2
+            Rm = torch.linalg.qr(torch.randn(3, 3, generator=g))[0].numpy()
+            tv = (torch.randn(3, generator=g) + torch.tensor([0.0, 0.0, 6.0])).numpy()
+            fovx, fovy = 0.9 + 0.2 * case, 0.7
+            wvt = torch.tensor(getWorld2View2(Rm, tv)).transpose(0, 1)
+            proj = getProjectionMatrix(0.01, 100.0, fovx, fovy).transpose(0, 1)
+            full = (wvt.unsqueeze(0).bmm(proj.unsqueeze(0))).squeeze(0)
+            cam = SimpleNamespace(FoVx=fovx, FoVy=fovy, image_height=36, image_width=48 + case, world_view_transform=wvt,
+                                  full_proj_transform=full, camera_center=wvt.inverse()[3, :3])
+            pipe = SimpleNamespace(debug=False, compute_cov3D_python=cov_py, convert_SHs_python=sh_py)
+            bg = torch.rand(3, generator=g)
+            _Recorder.calls.clear()
+            pkg = render_3dgs(cam, pc, pipe, bg, scaling_modifier=mod)
+            assert sorted(pkg) == ["radii", "render", "viewspace_points", "visibility_filter"] and len(_Recorder.calls) == 1
+            rs, kw = _Recorder.calls[0]
+            pre = f"r3dgs{case}_"
+            for name in ("_xyz", "_rotation", "_scaling", "_opacity", "_features_dc", "_features_rest"):
+                out[pre + "pc" + name] = getattr(pc, name).detach().numpy()
+            out[pre + "bg"] = bg.numpy()
+            out[pre + "cam"] = np.array([fovx, fovy, cam.image_height, cam.image_width], dtype=np.float64)
+            out[pre + "cam_wvt"], out[pre + "cam_full"], out[pre + "cam_center"] = wvt.numpy(), full.numpy(), cam.camera_center.numpy()
             out[pre + "mode"] = np.array([deg, int(cov_py), int(sh_py)], dtype=np.int64)
             out[pre + "mod"] = np.array(mod)
             for f in FIELDS:
