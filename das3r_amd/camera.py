@@ -79,3 +79,17 @@ def quat_multiply(q1, q2):
                         w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
                         w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
                         w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], dim=-1)
+
+
+def world_camera(R, t, fovx, fovy, image_height, image_width, device="cpu", znear=0.01, zfar=100.0, translate=(0.0, 0.0, 0.0), scale=1.0):
+    """The geometric half of the reference's Camera (scene/cameras.py:84-100): world_view_transform = getWorld2View2(R, T)^T,
+    projection_matrix = getProjectionMatrix(...)^T, full_proj_transform = their product, camera_center = row 3 of the inverse
+    view transform — what the vanilla 3DGS renderer (das3r_render_3dgs) reads from its viewpoint camera."""
+    from types import SimpleNamespace
+    wvt = world2view(R, t, translate, scale).transpose(0, 1).to(device)
+    proj = projection_matrix(znear, zfar, fovx, fovy).transpose(0, 1).to(device)
+    cam = SimpleNamespace(FoVx=fovx, FoVy=fovy, image_height=int(image_height), image_width=int(image_width), znear=znear, zfar=zfar,
+                          world_view_transform=wvt, projection_matrix=proj,
+                          full_proj_transform=(wvt.unsqueeze(0).bmm(proj.unsqueeze(0))).squeeze(0), camera_center=wvt.inverse()[3, :3])
+    cam.get_projection_matrix = lambda fx, fy: projection_matrix(znear, zfar, float(fx), float(fy)).transpose(0, 1).to(device)
+    return cam

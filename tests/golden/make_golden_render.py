@@ -218,6 +218,7 @@ def main():
             out[pre + "bg"] = bg.numpy()
             out[pre + "cam"] = np.array([fovx, fovy, cam.image_height, cam.image_width], dtype=np.float64)
             out[pre + "cam_wvt"], out[pre + "cam_full"], out[pre + "cam_center"] = wvt.numpy(), full.numpy(), cam.camera_center.numpy()
+            out[pre + "cam_R"], out[pre + "cam_t"] = Rm, tv
             out[pre + "mode"] = np.array([deg, int(cov_py), int(sh_py)], dtype=np.int64)
             out[pre + "mod"] = np.array(mod)
             for f in FIELDS:
