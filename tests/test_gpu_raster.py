@@ -591,3 +591,50 @@ def test_speculative_forward_builds_the_same_lists(fused, monkeypatch):
     for a, b in zip(grads0, grads1):
         if a is not None:
             util.assert_grad_close(b.cpu().numpy(), a.cpu().numpy(), "speculative forward", tol=1e-5)
+
+
+def test_vanilla_3dgs_renderer_end_to_end_vs_oracle():
+    """das3r_render_3dgs (gaussian_renderer/__init__3dgs.py counterpart) with a camera built by world_camera (scene/cameras.py
+    counterpart): image and gradients through the drop-in rasterizer against the C oracle fed with the same settings."""
+    from types import SimpleNamespace
+    from das3r_amd.camera import world_camera
+    from das3r_amd.render import das3r_render_3dgs
+    from oracle import c_oracle
+    dev = _dev()
+    g = torch.Generator().manual_seed(77)
+    P, H, W = 900, 72, 104
+    xyz = torch.randn(P, 3, generator=g) * 1.2
+    rot_raw = torch.randn(P, 4, generator=g)
+    log_s = torch.randn(P, 3, generator=g) * 0.4 - 2.2
+    op_raw = torch.randn(P, 1, generator=g)
+    feats = torch.randn(P, 16, 3, generator=g) * 0.2
+    Rm = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+    if torch.linalg.det(Rm) < 0:
+        Rm[:, 0] = -Rm[:, 0]
+    cam = world_camera(Rm.numpy(), np.array([0.1, -0.2, 6.0]), 0.9, 0.7, H, W, device=dev)
+    leaves = {k: v.to(dev).requires_grad_(True) for k, v in dict(xyz=xyz, rot=rot_raw, log_s=log_s, op=op_raw, feats=feats).items()}
+    pc = SimpleNamespace(active_sh_degree=2, max_sh_degree=3, get_xyz=leaves["xyz"], get_opacity=torch.sigmoid(leaves["op"]),
+                         get_scaling=torch.exp(leaves["log_s"]), get_rotation=torch.nn.functional.normalize(leaves["rot"]),
+                         get_features=leaves["feats"])
+    pipe = SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    pkg = das3r_render_3dgs(cam, pc, pipe, bg)
+    dL = torch.randn(3, H, W, generator=g) / float(H * W)
+    pkg["render"].backward(dL.to(dev))
+    o = c_oracle.RasterOracle(image_height=H, image_width=W, tanfovx=float(np.tan(0.45)), tanfovy=float(np.tan(0.35)), bg=bg.cpu().numpy(),
+                              scale_modifier=1.0, viewmatrix=cam.world_view_transform.cpu().numpy(), projmatrix=cam.full_proj_transform.cpu().numpy(),
+                              sh_degree=2, campos=cam.camera_center.cpu().numpy(), prefiltered=False, debug=False)
+    ref_color, ref_radii = o.forward(xyz.numpy(), torch.sigmoid(op_raw).numpy(), shs=feats.numpy(), scales=torch.exp(log_s).numpy(),
+                                     rotations=torch.nn.functional.normalize(rot_raw).numpy())
+    ref_g = o.backward(dL.numpy())
+    o.free()
+    assert np.array_equal(pkg["radii"].cpu().numpy(), ref_radii) and (ref_radii > 0).sum() > P // 4
+    util.assert_color_close(pkg["render"].detach().cpu().numpy(), ref_color, "3dgs colour")
+    util.assert_grad_close(leaves["xyz"].grad.cpu().numpy(), ref_g["means3D"], "3dgs dL/dxyz")
+    util.assert_grad_close(leaves["feats"].grad.cpu().numpy(), ref_g["shs"], "3dgs dL/dshs")
+    util.assert_grad_close(pkg["viewspace_points"].grad.cpu().numpy(), ref_g["means2D"], "3dgs dL/dmeans2D")
+    # through the activations: chain rule of the oracle's gradients in float64
+    go = torch.from_numpy(ref_g["opacities"]).double() * (torch.sigmoid(op_raw) * (1 - torch.sigmoid(op_raw))).double()
+    util.assert_grad_close(leaves["op"].grad.cpu().numpy(), go.numpy(), "3dgs dL/dopacity_raw")
+    gs = torch.from_numpy(ref_g["scales"]).double() * torch.exp(log_s).double()
+    util.assert_grad_close(leaves["log_s"].grad.cpu().numpy(), gs.numpy(), "3dgs dL/dlog_scale")
