@@ -51,7 +51,8 @@ class RasterLayout(C.Structure):
 EXPORTS = ("das3r_raster_forward", "das3r_raster_backward", "das3r_raster_check", "das3r_raster_backward_scratch_bytes", "das3r_mark_visible", "das3r_knn3_workspace_bytes",
            "das3r_knn3_mean_dist2", "das3r_raster_get_layout", "das3r_abi_version", "das3r_last_error", "das3r_reload_switches", "das3r_get_stats",
            "das3r_profile_enable", "das3r_profile_report", "das3r_pretransform_forward", "das3r_pretransform_backward", "das3r_pose_matrices", "das3r_pose_chain",
-           "das3r_adam_step", "das3r_adam_step_gated", "das3r_photometric_blocks", "das3r_photometric_forward", "das3r_photometric_backward")
+           "das3r_adam_step", "das3r_adam_step_gated", "das3r_photometric_blocks", "das3r_photometric_forward", "das3r_photometric_backward",
+           "das3r_has_experiments")
 
 _lib = None
 
@@ -120,6 +121,15 @@ def reload_switches():
     L.das3r_reload_switches.restype = None
     L.das3r_reload_switches.argtypes = []
     L.das3r_reload_switches()
+
+
+def has_experiments():
+    """True when the library was built with `make EXPERIMENTS=1` (superseded kernels behind DAS3R_RENDER_BWD=mfma | stream,
+    DAS3R_SORT=classic)."""
+    L = load()
+    L.das3r_has_experiments.restype = C.c_int
+    L.das3r_has_experiments.argtypes = []
+    return bool(L.das3r_has_experiments())
 
 
 def stats():

@@ -100,7 +100,11 @@ bool grid_is_resident(int nblocks) {
 }
 
 int sort_ipl_override() { return switches().sort_ipl; }
+#ifdef DAS3R_EXPERIMENTS
 bool use_onesweep() { return !switches().sort_classic; }
+#else
+bool use_onesweep() { return true; }   // the three-kernel radix passes are built with EXPERIMENTS=1 only
+#endif
 bool use_tight_rect() { return !switches().rect_upstream; }
 
 void compute_layout(int P, int64_t I, int W, int H, Layout *L) {
@@ -531,9 +535,22 @@ extern "C" int das3r_raster_backward(const das3r_raster_args *a, const das3r_ras
     return launch_preprocess_backward(a, in, saved->geom, saved->binning, L, g, partial, s, quad_rows);
 }
 
+// One 36-byte row of partial sums per instance.  (The experimental stream kernel — EXPERIMENTS=1 builds, DAS3R_RENDER_BWD=stream —
+// needs up to four 48-byte rows per instance: only then is the larger figure returned.)
 extern "C" size_t das3r_raster_backward_scratch_bytes(int64_t capacity) {
     const size_t c = capacity > 0 ? (size_t)capacity : 1;
-    return std::max(c * 9 * sizeof(float), stream_scratch_bytes(capacity));
+#ifdef DAS3R_EXPERIMENTS
+    if (switches().render_bwd == 5) return std::max(c * 9 * sizeof(float), stream_scratch_bytes(capacity));
+#endif
+    return c * 9 * sizeof(float);
+}
+
+extern "C" int das3r_has_experiments(void) {
+#ifdef DAS3R_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 extern "C" int das3r_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,

@@ -213,6 +213,7 @@ __global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
         // add this splat's per-instance sums (one row per touched tile; the render backward wrote them at the emission slots)
         if (visible && !gathered) {
             const uint32_t e0 = e0_in;
+#ifdef DAS3R_EXPERIMENTS
             if (row_exists) {   // render_bwd_stream.hip: up to four 48-byte rows per instance, one per quadrant of the tile that met the splat
                 for (uint32_t k = 0; k < ntiles_g; k++) {
                     const uint32_t have = *reinterpret_cast<const uint32_t *>(row_exists + (size_t)(e0 + k) * 4);
@@ -228,7 +229,9 @@ __global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
                         }
                     }
                 }
-            } else {
+            } else
+#endif
+            {
                 for (uint32_t k = 0; k < ntiles_g; k++) {
                     const float *row = partial + (size_t)(e0 + k) * 9;   // rows are indexed by emission slot: contiguous per splat
 #pragma unroll

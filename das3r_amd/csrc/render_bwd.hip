@@ -176,11 +176,18 @@ int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, cha
         kind = (sw.bwd_reduce_set || sw.ablate_set || !long_lists) ? 1 : 3;
         mb = 128;   // 4 workgroups per CU
     }
+#ifdef DAS3R_EXPERIMENTS
     if (kind == 5) {
         *quad_rows = true;
         return launch_render_backward_stream(a, dL_dpix, geom, binning, img, L, partial, s);
     }
     if (kind == 2) return launch_render_backward_mfma(a, dL_dpix, geom, binning, img, L, partial, s);
+#else
+    if (kind == 5 || kind == 2) {
+        set_error("DAS3R_RENDER_BWD=%s: this library was built without the superseded kernels (make EXPERIMENTS=1)", kind == 5 ? "stream" : "mfma");
+        return DAS3R_ERR_INVALID_ARG;
+    }
+#endif
     if (kind >= 3) {
         // long lists are replayed bucket by bucket in parallel workgroups (checkpoints from the forward: common.h BUCKET); slices =
         // buckets of an average tile, so that a tile's workgroups take about one bucket each

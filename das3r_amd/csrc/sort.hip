@@ -21,6 +21,8 @@
 namespace das3r {
 
 // ---------------------------------------------------------------- radix pass
+// (hist -> rowscan -> scatter: what distCUDA2's Morton sort uses (knn.hip); the binning's own passes are sort_onesweep.hip's —
+//  its "classic" variant on these kernels is an EXPERIMENTS=1 build option)
 // IPL = keys per lane (compile time): the whole chunk is fetched into registers before any of it is ranked, so the
 // HBM/L2 latency is paid once per wave instead of once per 64 keys.
 template <int IPL>
@@ -190,6 +192,7 @@ int radix_sort_u32_pairs(const uint32_t *keys_in, uint32_t *keyA, uint32_t *keyB
     return DAS3R_OK;
 }
 
+#ifdef DAS3R_EXPERIMENTS   // the "classic" binning (DAS3R_SORT=classic): separate emission kernel + three-kernel partition passes
 // ---------------------------------------------------------------- instance emission (depth-rank order)
 __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, int tiles_y, const uint32_t *__restrict__ sorted_idx,
                                                    const uint32_t *__restrict__ tiles_touched, const uint32_t *__restrict__ offsets,
@@ -236,6 +239,8 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, int tiles
     }
 }
 
+#endif   // DAS3R_EXPERIMENTS
+
 __global__ void __launch_bounds__(256) tile_ranges_kernel(uint32_t cap, const uint32_t *__restrict__ n_ptr,
                                                           const uint32_t *__restrict__ tile_keys, uint2 *__restrict__ ranges,
                                                           uint32_t *__restrict__ err, uint32_t *__restrict__ host_late, uint32_t tag,
@@ -270,11 +275,15 @@ int launch_depth_sort(int P, char *geom, const Layout &L, int part, char *binnin
     // 4 passes: A -> B -> A -> B -> A ; final ranks land in valA (== pub.sorted_idx)
     int rc;
     if (use_onesweep()) return launch_onesweep_depth_sort(P, geom, L, part, (uint32_t *)binning_ctrl, (uint32_t)(binning_ctrl_bytes / 4), debug, s);
+#ifdef DAS3R_EXPERIMENTS
     if (part == 1) return DAS3R_OK;   // classic path: everything ran in part 0 (its binning does not use control words)
     if ((rc = radix_pass(keyA, nullptr, keyB, valB, P, 0, 8, hist, totals, debug, s))) return rc;
     if ((rc = radix_pass(keyB, valB, keyA, valA, P, 8, 8, hist, totals, debug, s))) return rc;
     if ((rc = radix_pass(keyA, valA, keyB, valB, P, 16, 8, hist, totals, debug, s))) return rc;
     if ((rc = radix_pass(keyB, valB, nullptr, valA, P, 24, 8, hist, totals, debug, s))) return rc;
+#else
+    (void)keyA; (void)keyB; (void)valA; (void)valB; (void)hist; (void)totals; (void)rc;
+#endif
     return DAS3R_OK;
 }
 
@@ -300,6 +309,7 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
     uint32_t *gid_of = (uint32_t *)(binning + L.b_gid_of), *inv = (uint32_t *)(binning + L.b_slot);
     const bool onesweep = use_onesweep();
     (void)onesweep;   // the binning control words were zeroed by the last depth pass (launch_depth_sort part 1)
+#ifdef DAS3R_EXPERIMENTS
     if (!fused_scan) {   // (hinted path: launch_binning_scan_emit has already emitted the instances)
     const int emit_blocks = div_up(P, 256) < 1024 ? div_up(P, 256) : 1024;
     DAS3R_LAUNCH(emit_kernel, dim3(emit_blocks), dim3(256), 0, s, P, L.tiles_x, L.tiles_y,
@@ -308,6 +318,9 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
                  onesweep ? (uint32_t *)(binning + L.b_ghist) : (uint32_t *)nullptr, L.tbits, use_tight_rect() ? 1 : 0);
     KERNEL_CHECK(s, debug, "emit");
     }
+#else
+    (void)radii; (void)fused_scan; (void)gid_of;
+#endif
     if (onesweep) {
         uint32_t *kfinal = nullptr;
         int rc1 = launch_onesweep_partition(I, geom, binning, L, &kfinal, debug, s, emit_slot ? emit_slot + 64 : nullptr, emit_slot);
@@ -319,6 +332,7 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
         KERNEL_CHECK(s, debug, "tile_ranges");
         return DAS3R_OK;
     }
+#ifdef DAS3R_EXPERIMENTS
     // stable partition by tile id: tile_passes passes of <= 8 bits; ping-pong A -> B (-> A)
     // payload = emission slot e (identity on the first pass); the last pass turns it into the splat id and records inv[e]
     uint32_t *kin = keyA, *vin = nullptr, *kout = keyB, *vout = valB;
@@ -338,6 +352,9 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
     DAS3R_LAUNCH(tile_ranges_kernel, dim3(div_up(I, 256)), dim3(256), 0, s, (uint32_t)I, n_ptr, kin, ranges,
                  (uint32_t *)(geom + L.g_ticket) + 8, host_late, tag, 0u, (uint32_t)switches().inject_fault);
     KERNEL_CHECK(s, debug, "tile_ranges");
+#else
+    (void)keyA; (void)keyB; (void)valA; (void)valB; (void)hist; (void)totals; (void)inv;
+#endif
     return DAS3R_OK;
 }
 

@@ -140,7 +140,8 @@ int64_t das3r_raster_forward(const das3r_raster_args *args, const das3r_raster_i
 int das3r_raster_backward(const das3r_raster_args *args, const das3r_raster_in *in, const das3r_raster_saved *saved,
                           const float *dL_dpix /* [3,H,W] */, const das3r_raster_grads *grads, das3r_stream_t stream);
 
-/* Bytes of device scratch das3r_raster_backward needs in grads->scratch for a forward with the given saved->capacity. */
+/* Bytes of device scratch das3r_raster_backward needs in grads->scratch for a forward with the given saved->capacity:
+ * 36 bytes (nine partial sums) per instance. */
 size_t das3r_raster_backward_scratch_bytes(int64_t capacity);
 
 /* das3r_raster_forward returns as soon as its kernels are enqueued.  Its binning kernels check themselves (a bounded wait on
@@ -262,6 +263,10 @@ void das3r_reload_switches(void);
 /* Process-wide counters since load: out[0] forwards, [1] binning self-check words examined by the host, [2] of those with the
  * "a stalled look-back poll was rescued by the atomic read path" note (granule.h; informational), [3] failed self-checks. */
 void das3r_get_stats(uint64_t out[4]);
+
+/* 1 when the library was built with the superseded experiment kernels (make EXPERIMENTS=1: DAS3R_RENDER_BWD=mfma | stream,
+ * DAS3R_SORT=classic), 0 for the shipped build; the parity tests of those kernels skip themselves on 0. */
+int das3r_has_experiments(void);
 
 int das3r_abi_version(void);
 const char *das3r_last_error(void);

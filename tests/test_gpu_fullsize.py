@@ -1,7 +1,7 @@
-"""GPU parity at BASELINE.json's full sizes, where the oracle is too slow to run inside a test, through
+"""GPU parity at BASELINE.json's full sizes: every benchmarked shape (c1, c2, c4 and the DAS3R shape) forward + backward against
+the CPU oracle with element-wise gradient checks (the oracle needs 0.1 - 11 s per scene on the GPU box's host cores), plus the
 size-independent properties of the algorithm (background linearity, permutation invariance, SH == precomputed colour,
-gradient consistency between the two colour paths, sortedness of the per-tile lists), plus one full-size oracle check
-of configs[1] (100k splats, 1080p — the oracle needs < 1 s for it on the GPU box's host cores)."""
+gradient consistency between the two colour paths, sortedness of the per-tile lists) and the densification stress."""
 import numpy as np
 import pytest
 import torch
@@ -25,22 +25,48 @@ def _view(buf, off, dtype, count):
     return buf[off:off + count * item].view(dtype)
 
 
-def test_c2_full_size_vs_oracle():
-    """BASELINE.json configs[1]: 100k splats, 1920x1080, SH degree 3, forward + backward."""
-    sc, scd, dev, Settings, Rasterizer = _setup("c2")
+def _full_size_vs_oracle(name, P=None):
+    """One forward + backward of workload `name` through the drop-in surface (default kernel selection) against the CPU oracle:
+    radii exactly, colours within the stated tolerance, every gradient in the max norm AND element by element."""
+    sc, scd, dev, Settings, Rasterizer = _setup(name, P)
     mode = dict(colors_precomp=False, cov3D_precomp=False, scale_modifier=1.0)
     ref_color, ref_radii, ref_g, S = util.run_oracle(sc, mode)
     leaves = {k: getattr(scd, k).clone().requires_grad_() for k in ("means3D", "opacities", "shs", "scales", "rotations")}
     m2 = torch.zeros(sc.P, 3, device=dev, requires_grad=True)
     color, radii = Rasterizer(Settings(**scd.settings_kwargs()))(means2D=m2, **leaves)
-    assert 0 < color.grad_fn.num_rendered <= S["num_rendered"]
+    num_rendered = color.grad_fn.num_rendered
+    assert 0 < num_rendered <= S["num_rendered"]
     color.backward(scd.dL_dpix)
     torch.cuda.synchronize()
     assert np.array_equal(radii.cpu().numpy(), ref_radii)
-    util.assert_color_close(color.detach().cpu().numpy(), ref_color, "c2 colour")
-    for k, t in leaves.items():
-        util.assert_grad_close(t.grad.cpu().numpy(), ref_g[k], f"c2 dL/d{k}")
-    util.assert_grad_close(m2.grad.cpu().numpy(), ref_g["means2D"], "c2 dL/dmeans2D")
+    util.assert_color_close(color.detach().cpu().numpy(), ref_color, f"{name} colour")
+    for k, t in list(leaves.items()) + [("means2D", m2)]:
+        g = t.grad.cpu().numpy()
+        util.assert_grad_close(g, ref_g[k], f"{name} dL/d{k}")
+        util.assert_grad_elementwise(g, ref_g[k], f"{name} dL/d{k}")
+    return sc, num_rendered
+
+
+def test_c2_full_size_vs_oracle():
+    """BASELINE.json configs[1]: 100k splats, 1920x1080, SH degree 3, forward + backward (quad forward, dpp backward)."""
+    _full_size_vs_oracle("c2")
+
+
+def test_c4_full_size_vs_oracle():
+    """BASELINE.json configs[3], the headline configuration: 1M splats, 1920x1080, SH degree 3.  By default selection this is the
+    rows forward kernel with the in-kernel local depth order of ~320-entry lists and the block-list backward kernel (VERDICT r2
+    item 1: the headline kernels held to the oracle at the headline size; the oracle needs ~2.4 s on the GPU box's host cores)."""
+    sc, I = _full_size_vs_oracle("c4")
+    tiles = ((sc.W + 15) // 16) * ((sc.H + 15) // 16)
+    assert 192 * tiles <= I < 512 * tiles, "the scene is meant to take the long-list kernels (mean tile list ~320)"
+
+
+def test_ds_full_size_vs_oracle():
+    """The DAS3R shape (SURVEY.md 8d "DS-like"): 5M tiny splats on 512x208, SH degree 0 — ~13 800-entry tile lists: six-pass radix
+    binning, rows forward with checkpoints, bucket-parallel backward replay, degree-0 per-Gaussian backward."""
+    sc, I = _full_size_vs_oracle("ds")
+    tiles = ((sc.W + 15) // 16) * ((sc.H + 15) // 16)
+    assert I >= 2048 * tiles, "the scene is meant to take the bucket-parallel backward"
 
 
 @pytest.mark.parametrize("name", ["c4"])
@@ -115,21 +141,8 @@ def test_gradient_consistency_between_colour_paths_c4():
 def test_c1_vs_oracle():
     """BASELINE.json configs[0]: 10k random Gaussians, 256x256, SH degree 0 — the reference's "CPU-runnable plumbing" case, here
     run on the HIP path (forward AND backward) against the CPU oracle."""
-    sc, scd, dev, Settings, Rasterizer = _setup("c1")
+    sc, _ = _full_size_vs_oracle("c1")
     assert (sc.P, sc.W, sc.H, sc.sh_degree) == (10_000, 256, 256, 0)
-    mode = dict(colors_precomp=False, cov3D_precomp=False, scale_modifier=1.0)
-    ref_color, ref_radii, ref_g, S = util.run_oracle(sc, mode)
-    leaves = {k: getattr(scd, k).clone().requires_grad_() for k in ("means3D", "opacities", "shs", "scales", "rotations")}
-    m2 = torch.zeros(sc.P, 3, device=dev, requires_grad=True)
-    color, radii = Rasterizer(Settings(**scd.settings_kwargs()))(means2D=m2, **leaves)
-    color.backward(scd.dL_dpix)
-    torch.cuda.synchronize()
-    assert np.array_equal(radii.cpu().numpy(), ref_radii)
-    util.assert_color_close(color.detach().cpu().numpy(), ref_color, "c1 colour")
-    for k, t in leaves.items():
-        util.assert_grad_close(t.grad.cpu().numpy(), ref_g[k], f"c1 dL/d{k}")
-        util.assert_grad_elementwise(t.grad.cpu().numpy(), ref_g[k], f"c1 dL/d{k}")
-    util.assert_grad_close(m2.grad.cpu().numpy(), ref_g["means2D"], "c1 dL/dmeans2D")
 
 
 def test_densification_growth_small_vs_oracle():
