@@ -54,7 +54,12 @@ static void load_switches() {
     w.no_sh_stage = getenv("DAS3R_NO_SH_STAGE") != nullptr;
     if ((e = env("DAS3R_RENDER"))) w.render_fwd = e[0] == 'q' ? 1 : (e[0] == 'r' ? 2 : 0);
     if ((e = env("DAS3R_RENDER_BWD"))) {   // dpp | mfma | scan[a][64|128|256|512]
-        w.render_bwd = e[0] == 'd' ? 1 : (e[0] == 'm' ? 2 : (strncmp(e, "stream", 6) == 0 ? 5 : (e[0] == 's' ? 3 : 0)));
+        w.render_bwd = e[0] == 'd' ? 1 : (e[0] == 'm' ? 2 : (strncmp(e, "stream", 6) == 0 ? 5 : (e[0] == 's' ? 3 : (e[0] == 'b' ? 6 : 0))));
+        if (w.render_bwd == 6) {
+            const char *d = e;
+            while (*d && (*d < '0' || *d > '9')) d++;
+            w.render_bwd_mb = *d ? atoi(d) : 128;
+        }
         if (w.render_bwd == 3) {
             const char *d = e;
             while (*d && (*d < '0' || *d > '9')) d++;

@@ -28,8 +28,8 @@ struct Switches {
     bool fused_emit_off;   // DAS3R_FUSED_EMIT=0
     bool no_sh_stage;      // DAS3R_NO_SH_STAGE
     int render_fwd;        // DAS3R_RENDER=quad | rows: 1 | 2 (0: by list length)
-    int render_bwd;        // DAS3R_RENDER_BWD=dpp | mfma | scan... | stream: 1 | 2 | 3 | 5 (0: by list length)
-    int render_bwd_mb;     // scan64 / scan128 / scan256: entries per round; scana256 / scana512: 1000 + entries, atomic flush
+    int render_bwd;        // DAS3R_RENDER_BWD=dpp | mfma | scan... | stream | blk...: 1 | 2 | 3 | 5 | 6 (0: by list length)
+    int render_bwd_mb;     // scan64 / scan128 / scan256, blk64 / blk128 / blk256: entries per round; scana256 / scana512: 1000 + entries, atomic flush
     bool bwd_reduce_set, bwd_reduce_shfl;   // DAS3R_BWD_REDUCE=shfl | dpp (reference reduction of the pixel-per-lane kernel)
     bool ablate_set;       // DAS3R_ABLATE (perf experiments on the pixel-per-lane kernel)
     int ablate;
@@ -200,6 +200,9 @@ int launch_render_backward_stream(const das3r_raster_args *a, const float *dL_dp
 // slices > 1: bucket-parallel replay (grid = tiles x slices; needs the forward's checkpoints)
 int launch_render_backward_scan(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
                                 float *partial, int mb, int slices, hipStream_t s);
+// 4x4 block per DPP row, pixel state in registers, fp32 accumulators (render_bwd_blk.hip)
+int launch_render_backward_blk(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
+                               float *partial, int mb, int slices, hipStream_t s);
 constexpr int LOCAL_MAX = 1024;   // longest tile list the forward kernels sort in LDS
 // chained kernels (scan, radix passes) order their workgroups by ticket unless every workgroup of the grid is resident at once
 // (api.hip: grid_is_resident)

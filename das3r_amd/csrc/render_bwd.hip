@@ -188,12 +188,13 @@ int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, cha
         return DAS3R_ERR_INVALID_ARG;
     }
 #endif
-    if (kind >= 3) {
+    if (kind == 3 || kind == 6) {
         // long lists are replayed bucket by bucket in parallel workgroups (checkpoints from the forward: common.h BUCKET); slices =
         // buckets of an average tile, so that a tile's workgroups take about one bucket each
         int slices = sw.bwd_buckets;
         if (slices < 0) slices = (int)std::min<int64_t>(32, std::max<int64_t>(1, num_rendered / ((int64_t)BUCKET * std::max(L.ntiles, 1))));
         if (slices > 1 && mb > 256) slices = 1;
+        if (kind == 6) return launch_render_backward_blk(a, dL_dpix, geom, binning, img, L, partial, mb, slices, s);
         return launch_render_backward_scan(a, dL_dpix, geom, binning, img, L, partial, mb, slices, s);
     }
     const bool use_dpp = !sw.bwd_reduce_shfl;   // "shfl" selects the ds_bpermute reference reduction (diagnostics)

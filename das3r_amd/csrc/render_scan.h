@@ -70,13 +70,14 @@ __device__ __forceinline__ void row_scan_add_x4(float &x0, float &x1, float &x2,
 // overlaps the quadrant — for elongated, rotated splats more than the ellipse itself does.  With d = centre - pixel,
 // q(d) = A dx^2 + 2 B dx dy + C dy^2 is convex; alpha >= 1/255  <=>  q <= 2 ln(255 o) =: tau.  min of q over the rectangle: 0 if the
 // centre is inside, else the smallest of the four edge minima (one coordinate fixed, the other = clamp of its stationary point).
-// tau comes back out of the stored extent hx = sqrt(tau' Sigma_xx) 1.0005 + 0.02 (preprocess.hip; tau' carries its own margin),
-// Sigma_xx = C / (A C - B^2).
-__device__ __forceinline__ bool rect_hit_tight(const float4 xyh, const float4 co, const float x0, const float y0) {
+// tau is taken from the opacity exactly as preprocess.hip takes it for the extents (2 ln(255 o) 1.0005 + 1e-3: its own margin) —
+// NOT recovered from the stored extent through Sigma_xx = C / (A C - B^2): for long thin splats A C - B^2 cancels in fp32 (6.6 %
+// error of tau at a 1000 px major sigma), and a pair the forward blended with alpha just above 1/255 could lose its
+// gradient.
+__device__ __forceinline__ float splat_tau(const float opacity) { return 2.0f * __logf(255.0f * opacity) * 1.0005f + 1e-3f; }
+__device__ __forceinline__ bool rect_hit_tight_tau(const float4 xyh, const float4 co, const float tau, const float x0, const float y0) {
     const float dxl = xyh.x - (x0 + 7.0f), dxh = xyh.x - x0, dyl = xyh.y - (y0 + 7.0f), dyh = xyh.y - y0;
     const float A = co.x, B = co.y, C = co.z;
-    const float e = (xyh.z - 0.02f) * (1.0f / 1.0005f);
-    const float tau = e * e * (A * C - B * B) * __builtin_amdgcn_rcpf(C);
     const float rA = __builtin_amdgcn_rcpf(A), rC = __builtin_amdgcn_rcpf(C);
     auto qf = [&](const float dx, const float dy) { return A * dx * dx + 2.0f * B * dx * dy + C * dy * dy; };
     const float q0 = qf(dxl, __builtin_amdgcn_fmed3f(-B * dxl * rC, dyl, dyh));
@@ -86,6 +87,9 @@ __device__ __forceinline__ bool rect_hit_tight(const float4 xyh, const float4 co
     const bool inside = (dxl <= 0.f) & (dxh >= 0.f) & (dyl <= 0.f) & (dyh >= 0.f);
     const float qmin = fminf(fminf(q0, q1), fminf(q2, q3));
     return (xyh.z > 0.f) & (inside | (qmin * 0.9999f - 1e-3f <= tau));
+}
+__device__ __forceinline__ bool rect_hit_tight(const float4 xyh, const float4 co, const float x0, const float y0) {
+    return rect_hit_tight_tau(xyh, co, splat_tau(co.w), x0, y0);
 }
 
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));

@@ -69,7 +69,7 @@ def main():
     print(f"{args.workload}: visible {len(idx)}, instances (tight rect model) {I_total}, mean list {I_total / (tx_n * ty_n):.0f}")
     ev = args.every
     tot = dict(inst=0, quad_bbox=0, quad_exact=0, blk_bbox=0, blk_exact=0, live=0, rowpriv_batches=0, seq_batches=0, quad_batches=0,
-               rowpriv_batches_bbox=0, half_exact=0)
+               rowpriv_batches_bbox=0, half_exact=0, rowpriv_batches_mixed=0, rowpriv64=0, rowpriv256=0, quad256=0, blk_oct=0, rowpriv_oct=0)
     MB = args.mb
     for ty in range(0, ty_n, ev):
         for tx in range(0, tx_n, ev):
@@ -93,6 +93,10 @@ def main():
             tot["live"] += int(live.sum())
             blk_b = np.zeros((n, 4, 4), bool)
             blk_e = np.zeros((n, 4, 4), bool)
+            blk_o = np.zeros((n, 4, 4), bool)
+            detk = a * c - b * b
+            hd1 = np.sqrt(tk * (a + c - 2 * b) / (2 * detk)) * 1.0005 + 0.02   # extent along (1, 1) / sqrt 2
+            hd2 = np.sqrt(tk * (a + c + 2 * b) / (2 * detk)) * 1.0005 + 0.02   # extent along (1, -1) / sqrt 2
             for byi in range(4):
                 for bxi in range(4):
                     x0, y0 = tx * 16 + 4 * bxi, ty * 16 + 4 * byi
@@ -100,6 +104,9 @@ def main():
                     qmin = min_q_rect(a, b, c, X - (x0 + 3), X - x0, Y - (y0 + 3), Y - y0)
                     blk_b[:, byi, bxi] = bb
                     blk_e[:, byi, bxi] = bb & (qmin * 0.9999 - 1e-3 <= tk)
+                    ddx, ddy = X - (x0 + 1.5), Y - (y0 + 1.5)
+                    r2 = 3.0 / math.sqrt(2.0)   # half extent of the block's pixel-centre square along a diagonal: (1.5 + 1.5) / sqrt 2
+                    blk_o[:, byi, bxi] = bb & (np.abs(ddx + ddy) / math.sqrt(2.0) <= hd1 + r2) & (np.abs(ddx - ddy) / math.sqrt(2.0) <= hd2 + r2)
             quad_b = np.zeros((n, 2, 2), bool)
             quad_e = np.zeros((n, 2, 2), bool)
             for qy in range(2):
@@ -113,6 +120,8 @@ def main():
             tot["quad_exact"] += int(quad_e.sum())
             tot["blk_bbox"] += int(blk_b.sum())
             tot["blk_exact"] += int(blk_e.sum())
+            tot["blk_oct"] += int((blk_o & quad_e.repeat(2, 1).repeat(2, 2)).sum())
+            assert not (blk_e & ~blk_o).any(), "octagon test must be conservative"
             # 8x4 halves of a quadrant (two blocks side by side)
             half_e = blk_e.reshape(n, 4, 2, 2).any(3)
             tot["half_exact"] += int(half_e.sum())
@@ -127,6 +136,19 @@ def main():
                         tot["rowpriv_batches"] += max(math.ceil(v / 16) for v in lens)
                         tot["rowpriv_batches_bbox"] += max(math.ceil(v / 16) for v in lens_b)
                         tot["seq_batches"] += sum(math.ceil(v / 16) for v in lens)
+                        lens_m = [int((blk_b[sl, 2 * qy + j, 2 * qx + i] & quad_e[sl, qy, qx]).sum()) for j in range(2) for i in range(2)]
+                        tot["rowpriv_batches_mixed"] += max(math.ceil(v / 16) for v in lens_m)
+                        lens_o = [int((blk_o[sl, 2 * qy + j, 2 * qx + i] & quad_e[sl, qy, qx]).sum()) for j in range(2) for i in range(2)]
+                        tot["rowpriv_oct"] += max(math.ceil(v / 16) for v in lens_o)
+            for mb2, key in ((64, "rowpriv64"), (256, "rowpriv256")):
+                for r0 in range(0, n, mb2):
+                    sl = slice(r0, min(n, r0 + mb2))
+                    for qy in range(2):
+                        for qx in range(2):
+                            lens = [int(blk_e[sl, 2 * qy + j, 2 * qx + i].sum()) for j in range(2) for i in range(2)]
+                            tot[key] += max(math.ceil(v / 16) for v in lens)
+                            if mb2 == 256:
+                                tot["quad256"] += math.ceil(int(quad_e[sl, qy, qx].sum()) / 16)
     t = tot
     print(f"sampled instances {t['inst']}; live pairs {t['live']} = {t['live'] / t['inst']:.1f} per instance")
     print(f"quadrant hits per instance: bbox {t['quad_bbox'] / t['inst']:.2f}, exact {t['quad_exact'] / t['inst']:.2f}"
@@ -138,6 +160,9 @@ def main():
     print(f"row-private (wave = 4 blocks in lockstep, exact): {1024 * t['rowpriv_batches'] / t['inst']:.0f} pairs per instance"
           f" (x{t['rowpriv_batches'] / t['quad_batches']:.2f} of today's batches), live {t['live'] / (1024 * t['rowpriv_batches']):.2f};"
           f" bbox only: x{t['rowpriv_batches_bbox'] / t['quad_batches']:.2f}")
+    print(f"  quadrant-exact + block-bbox lists: x{t['rowpriv_batches_mixed'] / t['quad_batches']:.2f};  exact lists with 64-entry rounds: "
+          f"x{t['rowpriv64'] / t['quad_batches']:.2f}, 256-entry rounds: x{t['rowpriv256'] / t['quad_batches']:.2f} (quadrant lists at 256: x{t['quad256'] / t['quad_batches']:.2f})")
+    print(f"  quadrant-exact + block octagon (bbox + two diagonal extents): {t['blk_oct'] / t['inst']:.2f} block hits per instance, x{t['rowpriv_oct'] / t['quad_batches']:.2f}")
     print(f"blocks one after the other (4-step batches): {256 * t['seq_batches'] / t['inst']:.0f} pairs per instance"
           f" (x{256 * t['seq_batches'] / (1024 * t['quad_batches']):.2f}), live {t['live'] / (256 * t['seq_batches']):.2f}")
 
