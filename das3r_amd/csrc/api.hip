@@ -59,6 +59,10 @@ static void load_switches() {
             const char *d = e;
             while (*d && (*d < '0' || *d > '9')) d++;
             w.render_bwd_mb = *d ? atoi(d) : 128;
+            const char *pp = strchr(e, 'p');
+            w.render_bwd_pix = pp ? atoi(pp + 1) : 0;
+            const char *po = strchr(e, 'o');
+            w.render_bwd_occ = po ? atoi(po + 1) : 5;
         }
         if (w.render_bwd == 3) {
             const char *d = e;

@@ -160,21 +160,24 @@ int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, cha
     *quad_rows = false;
     // Which decomposition (DAS3R_RENDER_BWD=dpp | mfma | scan<N> | scana<N> | stream forces one; measurements: DESIGN.md §4):
     //   dpp     pixel per lane, cross-lane reduction on the vector ALU (this file): lists of a few hundred entries per tile
-    //   scan    lanes = 4 pixels x 16 splats, recurrences as DPP row scans, sums as split-bf16 products on the matrix cores
-    //           (render_bwd_scan.hip): long lists (the DAS3R shape)
+    //   blk     every DPP row of a wave on its own 4x4 block: lanes = 16 splats of the block's culled list, time = its 16 pixels,
+    //           recurrences as DPP row scans, sums in fp32 registers (render_bwd_blk.hip): everything but short lists
+    //   scan    lanes = 4 pixels x 16 splats of the QUADRANT's list, sums as split-bf16 products on the matrix cores
+    //           (render_bwd_scan.hip): round 2's kernel for long lists, kept as the reference for blk
     //   stream  the same arithmetic, every wave streaming the tile's list on its own (render_bwd_stream.hip; experimental)
     //   mfma    pixel per lane + LDS-transposed slab -> fp32 matrix cores (render_bwd_mfma.hip; superseded by scan)
     const Switches &sw = switches();
     int kind = sw.render_bwd;
     int mb = sw.render_bwd_mb ? sw.render_bwd_mb : 256;
     if (kind == 0) {
-        // measured crossover at 1080p (render backward, ms; tools/gpu_perf.py --workloads c4:<P>): mean list 80: dpp 0.149 / scan 0.177,
-        // 128: 0.227 / 0.247, 192: 0.331 / 0.320, 320: 0.533 / 0.489, 640: 0.753 / 0.754, 1280: 0.810 / 0.827 (saturating pixels cut
-        // dpp's walk short); DAS3R shape (13 800, bucket-parallel from 2048): 1.91 / 0.81
+        // measured (render backward, ms; tools/gpu_perf.py): 100 k splats at 1080p, mean list 32: dpp 0.071 / blk64 0.068 / scan128 0.129;
+        // 1 M splats, mean 320: dpp 0.532 / scan128 0.476 / blk128p1 0.381; DAS3R shape (13 800, bucket-parallel): dpp 1.89 / scan128 0.78 /
+        // blk192 0.497.  Round 2's crossover between dpp and the quadrant walk was a mean list of 192; the block walk culls per 4x4
+        // block and is ahead from ~100 entries per tile on (tools/gpu_perf.py --workloads c4:<P>: DESIGN.md section 5).
         const int64_t mean_list = num_rendered / std::max(L.ntiles, 1);   // (the count, not the capacity: the same scene takes the same kernel however its buffer was sized)
-        const bool long_lists = (mean_list >= 192 && mean_list < 512) || mean_list >= 2048;
-        kind = (sw.bwd_reduce_set || sw.ablate_set || !long_lists) ? 1 : 3;
-        mb = 128;   // 4 workgroups per CU
+        const bool long_lists = mean_list >= 96;
+        kind = (sw.bwd_reduce_set || sw.ablate_set || !long_lists) ? 1 : 6;
+        mb = mean_list >= 1024 ? 192 : 128;
     }
 #ifdef DAS3R_EXPERIMENTS
     if (kind == 5) {

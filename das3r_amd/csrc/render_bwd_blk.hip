@@ -26,117 +26,9 @@
 //     round is written out.
 // Per 64 pairs: ~48 VALU + 2 transcendentals, 0 LDS, 0 MFMA; ~70 VGPRs, 27 KB of LDS per workgroup (5 workgroups per CU).
 // Bucket-parallel replay of long lists as in render_bwd_scan.hip (gridDim.y > 1).  CPU model: tests/test_blk_model.py.
-#include "render_scan.h"
+#include "render_blk.h"
 
 namespace das3r {
-
-// lane K of every 16-lane row, to all lanes of the row (DPP row_newbcast: gfx90a and later; folded into VOP2 consumers)
-template <int K>
-__device__ __forceinline__ float bc(const float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + K, 0xf, 0xf, true));
-}
-// acc += x[lane K of the row] * v as ONE v_fmac_f32_dpp.  (The compiler folds a broadcast into its consumer only when that is the
-// broadcast's single use; dL/dpixel is used twice per step — in c . dL/dpix and here — and came out as v_mov_b32_dpp + fmac.)
-// x is a per-pixel constant: never written inside the walk, so the DPP read needs no wait states.
-template <int K>
-__device__ __forceinline__ void fmac_bc(float &acc, const float x, const float v) {
-    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(v), "i"(K));
-}
-// Pixel lane K of every row takes the row's totals (lane 15) of `t15` and `r15`; the other lanes keep theirs.  One scalar move for
-// the lane mask + two v_cndmask_b32_dpp.  `order`: a value computed AFTER t15 / r15 in program order (>= 2 VALU instructions later):
-// a DPP read needs two wait states behind the VALU write of its source, and the assembler does not add them inside inline asm.
-template <int K>
-__device__ __forceinline__ void state_to_pixel_lane(float &stT, float &stR, const float t15, const float r15, const float order) {
-    constexpr unsigned long long keep = ~(0x0001000100010001ull << K);   // vcc = 1: keep the old value
-    asm("s_mov_b64 vcc, %5\n\t"
-        "v_cndmask_b32_dpp %0, %2, %0, vcc row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
-        "v_cndmask_b32_dpp %1, %3, %1, vcc row_newbcast:15 row_mask:0xf bank_mask:0xf"
-        : "+v"(stT), "+v"(stR)
-        : "v"(t15), "v"(r15), "v"(order), "s"(keep)
-        : "vcc");
-}
-
-// per-pixel registers of a pixel lane (lane s of row r owns pixel s of block r: x = s & 3, y = s >> 2)
-struct PixelRegs {
-    float pxf, pyf;            // pixel centre
-    float d0, d1, d2, tfbg;    // dL/dpixel, T_final * (bg . dL/dpixel)
-    float T, R;                // replay state
-    float lastrel;             // n_contrib relative to the round's staged window, as a float in [0, MB]
-};
-struct SplatRegs {
-    float x, y;                // centre
-    float A, B, C, o;          // conic, opacity (0 on lanes without an entry)
-    float c0, c1, c2;          // colour
-    float posrel;              // list position relative to the round's window (MB - 1 - j)
-};
-struct Sums {
-    float C0, C1, C2, M0, Mu, Mv, Muu, Muv, Mvv;
-};
-
-// One image row KY of the block: its four pixel steps K = 4 KY .. 4 KY + 3, interleaved.  pair_alpha's arithmetic, bit for bit
-// (render_common.h), so that every pair takes the decision the forward kernel took.
-template <int KY>
-__device__ __forceinline__ void block_row(const SplatRegs &sp, PixelRegs &px, Sums &acc) {
-    const float dy = sp.y - bc<4 * KY>(px.pyf);
-    const float cyy = __fmul_rn(__fmul_rn(sp.C, dy), dy);
-    float am[4], Gm[4], rinv[4], Pinc[4], T[4], cd[4], w[4], wc[4], Sinc[4], Rinc[4], g[4];
-#define ALPHA_STEP(U)                                                                                                         \
-    {                                                                                                                         \
-        constexpr int K = 4 * KY + U;                                                                                         \
-        const float dx = sp.x - bc<K>(px.pxf);                                                                                \
-        const float q = __fmaf_rn(__fmul_rn(sp.A, dx), dx, cyy);                                                              \
-        const float power = __fmaf_rn(-0.5f, q, -__fmul_rn(__fmul_rn(sp.B, dx), dy));                                         \
-        const float G = __expf(power);                                                                                        \
-        /* position < n_contrib  <=>  lastrel - posrel >= 1, else <= 0 (small integers): a third operand of the alpha clamp —  */ \
-        /* where the pair takes part the minimum is min(0.99, o G) as in pair_alpha, elsewhere it fails the 1/255 test         */ \
-        const float a1 = fminf(fminf(0.99f, __fmul_rn(sp.o, G)), bc<K>(px.lastrel) - sp.posrel);                              \
-        const bool active = (!(power > 0.0f)) & (a1 >= (1.0f / 255.0f));                                                      \
-        am[U] = active ? a1 : 0.f;                                                                                            \
-        Gm[U] = active ? G : 0.f;                                                                                             \
-        rinv[U] = __builtin_amdgcn_rcpf(1.f - am[U]);                                                                         \
-        Pinc[U] = rinv[U];                                                                                                    \
-    }
-    ALPHA_STEP(0) ALPHA_STEP(1) ALPHA_STEP(2) ALPHA_STEP(3)
-#undef ALPHA_STEP
-    row_scan_mul_x4(Pinc[0], Pinc[1], Pinc[2], Pinc[3]);   // lane s: product of 1 / (1 - alpha) over splats 0..s of the batch
-#define W_STEP(U)                                                                                                             \
-    {                                                                                                                         \
-        constexpr int K = 4 * KY + U;                                                                                         \
-        T[U] = bc<K>(px.T) * Pinc[U];               /* transmittance in front of splat s at pixel K */                        \
-        w[U] = am[U] * T[U];                                                                                                  \
-        cd[U] = sp.c0 * bc<K>(px.d0);                                                                                         \
-        fmac_bc<K>(cd[U], px.d1, sp.c1);                                                                                      \
-        fmac_bc<K>(cd[U], px.d2, sp.c2);                                                                                      \
-        wc[U] = cd[U] * w[U];                                                                                                 \
-        Sinc[U] = wc[U];                                                                                                      \
-    }
-    W_STEP(0) W_STEP(1) W_STEP(2) W_STEP(3)
-#undef W_STEP
-    row_scan_add_x4(Sinc[0], Sinc[1], Sinc[2], Sinc[3]);   // lane s: sum of w (c . dL/dpix) over splats 0..s of the batch
-#define G_STEP(U)                                                                                                             \
-    {                                                                                                                         \
-        constexpr int K = 4 * KY + U;                                                                                         \
-        Rinc[U] = bc<K>(px.R) + Sinc[U];            /* lane 15: the pixel's R behind the next batch */                        \
-        const float Rex = Rinc[U] - wc[U];          /* R behind splat s */                                                    \
-        const float dL_dalpha = T[U] * cd[U] - (Rex + bc<K>(px.tfbg)) * rinv[U];                                              \
-        g[U] = Gm[U] * dL_dalpha;                                                                                             \
-        fmac_bc<K>(acc.C0, px.d0, w[U]);                                                                                      \
-        fmac_bc<K>(acc.C1, px.d1, w[U]);                                                                                      \
-        fmac_bc<K>(acc.C2, px.d2, w[U]);                                                                                      \
-        acc.M0 += g[U];                                                                                                       \
-        if (U > 0) acc.Mu += (float)U * g[U];                                                                                 \
-        if (KY > 0) acc.Mv += (float)KY * g[U];                                                                               \
-        if (U > 0) acc.Muu += (float)(U * U) * g[U];                                                                          \
-        if (U > 0 && KY > 0) acc.Muv += (float)(U * KY) * g[U];                                                               \
-        if (KY > 0) acc.Mvv += (float)(KY * KY) * g[U];                                                                       \
-    }
-    G_STEP(0) G_STEP(1) G_STEP(2) G_STEP(3)
-#undef G_STEP
-    state_to_pixel_lane<4 * KY + 0>(px.T, px.R, T[0], Rinc[0], acc.M0);
-    state_to_pixel_lane<4 * KY + 1>(px.T, px.R, T[1], Rinc[1], acc.M0);
-    state_to_pixel_lane<4 * KY + 2>(px.T, px.R, T[2], Rinc[2], acc.M0);
-    state_to_pixel_lane<4 * KY + 3>(px.T, px.R, T[3], Rinc[3], acc.M0);
-}
 
 // Octagon test of a splat against the 4x4 block whose pixel centres span [cx - 1.5, cx + 1.5] x [cy - 1.5, cy + 1.5]: the
 // axis-aligned extents (hx, hy: preprocess.hip, with their margins) and the extents hd1, hd2 along (1, 1) / sqrt 2 and
@@ -149,23 +41,30 @@ __device__ __forceinline__ bool block_hit_oct(const float x, const float y, cons
            (fabsf(ddx - ddy) * RS2 <= hd2 + HALF_DIAG);
 }
 
-template <int MB>
-__global__ void __launch_bounds__(256, 5) render_backward_blk_kernel(
+// MB: staged list entries per round.  PIX: where the walk finds the per-pixel values (render_blk.h): 0 pixel lanes' registers (DPP
+// broadcasts), 1 constants from LDS, 2 constants and state from LDS.
+// ABL: timing experiments only (DAS3R_ABLATE with DAS3R_RENDER_BWD=blk128p1; results are wrong): 1 no batches at all (what the rounds
+// cost without them), 2 batches without the record add, 4 nothing written out, 8 bounding-box block test only, 16 no quadrant ellipse test
+template <int MB, int PIX, int ABL = 0, int OCC = 5>
+__global__ void __launch_bounds__(256, OCC) render_backward_blk_kernel(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int tiles_x, int ntiles_strip /*tiles | strip height << 24: render_common.h xcd_tile*/,
     const float4 *__restrict__ xyh, const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
     const float *__restrict__ bg, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
     const float *__restrict__ dL_dpix, const uint32_t *__restrict__ slot_list, float *__restrict__ partial /*[I,9]*/,
     uint32_t last_g, uint32_t cap /*bounds of the list contents: render_common.h safe_range*/,
     const float4 *__restrict__ ckpt /*forward's checkpoints of long lists (render_common.h); used when gridDim.y > 1*/) {
-    static_assert(MB == 64 || MB == 128 || MB == 256, "entries per round");
+    static_assert(MB >= 64 && MB <= 256 && MB % 8 == 0, "entries per round (one-byte list entries)");
     constexpr int LIST_STRIDE = MB + 4;                                  // bytes; the four rows of a wave read position e of their lists in one instruction
     constexpr int OFF_STAGE = 0;                                         // StagedSplat[MB]
-    constexpr int OFF_ACC = OFF_STAGE + MB * (int)sizeof(StagedSplat);   // float[4 waves][MB][8]: C0 C1 C2 M0 | Sgx Sgy Sxx Sxy
+    constexpr int OFF_ACC = OFF_STAGE + MB * (int)sizeof(StagedSplat);   // float4[2][4 waves][MB]: C0 C1 C2 M0 | Sgx Sgy Sxx Sxy — two arrays of
+                                                                         // 16-byte rows, not one of 32-byte rows: a row's 16 lanes (random entries) then spread over 16 bank groups instead of 8
     constexpr int OFF_ACC1 = OFF_ACC + 4 * MB * 8 * 4;                   // float[4 waves][MB]: Syy
     constexpr int OFF_SLOT = OFF_ACC1 + 4 * MB * 4;                      // uint32_t[MB]
     constexpr int OFF_LIST = OFF_SLOT + MB * 4;                          // uint8_t[4 waves][4 rows][LIST_STRIDE]
     constexpr int OFF_MAX = OFF_LIST + 16 * LIST_STRIDE;                 // uint32_t[4]
-    constexpr int LDS_BYTES = OFF_MAX + 16;
+    constexpr int OFF_CST = OFF_MAX + 16;                                // PIX > 0: float4[4 waves][4 rows][16 (+ pad)]: d0, d1, d2, lastrel
+    constexpr int OFF_ST = OFF_CST + (PIX > 0 ? 16 * PIX_CST_ROW : 0);   // PIX == 2: float2[4 waves][4 rows][16 (+ pad)]: T, R
+    constexpr int LDS_BYTES = OFF_ST + (PIX == 2 ? 16 * PIX_ST_ROW : 0);
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     StagedSplat *const stage = reinterpret_cast<StagedSplat *>(lds + OFF_STAGE);
     float *const acc8 = reinterpret_cast<float *>(lds + OFF_ACC);
@@ -191,7 +90,7 @@ __global__ void __launch_bounds__(256, 5) render_backward_blk_kernel(
     const bool inside = ppx < W && ppy < H;
     PixelRegs px;
     uint32_t last_contributor;
-    float my_T_final;
+    float my_T_final, my_tfbg;
     {
         const size_t pix = (size_t)ppy * W + ppx, plane = (size_t)H * W;
         my_T_final = inside ? final_T[pix] : 0.f;
@@ -202,13 +101,18 @@ __global__ void __launch_bounds__(256, 5) render_backward_blk_kernel(
             px.d1 = dL_dpix[plane + pix];
             px.d2 = dL_dpix[2 * plane + pix];
         }
-        px.pxf = (float)ppx;
-        px.pyf = (float)ppy;
-        px.tfbg = my_T_final * (bg[0] * px.d0 + bg[1] * px.d1 + bg[2] * px.d2);
+        my_tfbg = my_T_final * (bg[0] * px.d0 + bg[1] * px.d1 + bg[2] * px.d2);
+        px.pxf = PIX ? (float)(qx0 + ((row & 1) << 2)) : (float)ppx;
+        px.pyf = PIX ? (float)(qy0 + ((row >> 1) << 2)) : (float)ppy;
         px.T = my_T_final;
-        px.R = 0.f;
+        px.R = my_tfbg;   // the replay state R always travels with T_final (bg . dL/dpix): only their sum is used
         px.lastrel = 0.f;
     }
+    // PIX > 0: the lane's pixel record in LDS (it is pixel s of block row `row`), and the block row the lane walks
+    char *const cst_row = lds + OFF_CST + (wave * 4 + row) * PIX_CST_ROW;
+    char *const st_row = lds + OFF_ST + (wave * 4 + row) * PIX_ST_ROW;
+    if constexpr (PIX > 0) *reinterpret_cast<float4 *>(cst_row + s * 16) = make_float4(px.d0, px.d1, px.d2, 0.f);
+    if constexpr (PIX == 2) *reinterpret_cast<float2 *>(st_row + s * 8) = make_float2(px.T, px.R);
     // the accumulator regions are zero between rounds: whoever reads a record when the round is written out clears it
     for (int f = tid; f < 4 * MB * 8 / 4; f += TILE_PIX) reinterpret_cast<v4f *>(acc8)[f] = v4f{0.f, 0.f, 0.f, 0.f};
     for (int f = tid; f < 4 * MB; f += TILE_PIX) acc1[f] = 0.f;
@@ -247,7 +151,11 @@ __global__ void __launch_bounds__(256, 5) render_backward_blk_kernel(
                 R0 = px.d0 * (fin.y - far.y) + px.d1 * (fin.z - far.z) + px.d2 * (fin.w - far.w);   // (c . dL/dpix) alpha T of everything behind
             }
             px.T = T0;
-            px.R = R0;
+            px.R = R0 + my_tfbg;
+            if constexpr (PIX == 2) {
+                *reinterpret_cast<float2 *>(st_row + s * 8) = make_float2(px.T, px.R);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // (wave-private rows)
+            }
         }
         for (int i = 0; i < rounds; i++) {
             const int done_before = i * MB;
@@ -267,30 +175,31 @@ __global__ void __launch_bounds__(256, 5) render_backward_blk_kernel(
                 const long long base = (long long)lo + (long long)max_contrib - done_before - MB;
                 const long long rel = (long long)last_contributor - base;
                 px.lastrel = (float)(rel < 0 ? 0ll : (rel > MB ? (long long)MB : rel));
+                if constexpr (PIX > 0) *reinterpret_cast<float *>(cst_row + s * 16 + 12) = px.lastrel;
             }
             __syncthreads();
 
             // ---- the wave's four row lists (entries in staged order = reverse list order, kept) ----
             int len[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int k = 0; k < MB / 64; k++) {
+            for (int k = 0; k < (MB + 63) / 64; k++) {
                 const int j = k * 64 + lane;
                 const int jc = j < n ? j : 0;
                 const float4 p = stage[jc].xyh;
                 const float4 co = stage[jc].co;
-                // alpha >= 1/255  <=>  q <= 2 ln(255 o): taken from the opacity (as preprocess.hip takes it), not from the stored extents
-                const float tau = splat_tau(co.w);
-                const bool qhit = (j < n) & quadrant_hit(p, qcx, qcy) && rect_hit_tight_tau(p, co, tau, (float)qx0, (float)qy0);
+                // (no exact ellipse-vs-quadrant test in front of the block tests, as render_bwd_scan.hip has it: with the octagon test per
+                //  block behind it, it cost more than the few blocks it still removed were worth — 0.405 vs 0.390 ms at 1 M splats)
+                const bool qhit = (j < n) && ((ABL & 16) ? rect_hit_tight_tau(p, co, splat_tau(co.w), (float)qx0, (float)qy0) : true);
                 // extents along the two diagonals from the axis-aligned ones: tau Sxx = ex2, tau Syy = ey2, tau Sxy = -B ex2 / C
                 const float ex = (p.z - 0.02f) * (1.0f / 1.0005f), ey = (p.w - 0.02f) * (1.0f / 1.0005f);
                 const float ex2 = ex * ex, ey2 = ey * ey, txy = -co.y * ex2 * __builtin_amdgcn_rcpf(co.z);
                 const float half = 0.5f * (ex2 + ey2), slack = 2e-6f * (ex2 + ey2) + 1e-3f;   // (cancellation of long thin splats)
-                const float hd1 = sqrtf(fmaxf(half + txy, 0.f) + slack) * 1.0005f + 0.05f;
-                const float hd2 = sqrtf(fmaxf(half - txy, 0.f) + slack) * 1.0005f + 0.05f;
+                const float hd1 = __builtin_amdgcn_sqrtf(fmaxf(half + txy, 0.f) + slack) * 1.0005f + 0.05f;   // (v_sqrt_f32: 1 ulp, inside the margins)
+                const float hd2 = __builtin_amdgcn_sqrtf(fmaxf(half - txy, 0.f) + slack) * 1.0005f + 0.05f;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const bool hit = qhit && block_hit_oct(p.x, p.y, p.z, p.w, hd1, hd2, (float)(qx0 + ((r & 1) << 2)) + 1.5f,
-                                                           (float)(qy0 + ((r >> 1) << 2)) + 1.5f);
+                    const bool hit = qhit && block_hit_oct(p.x, p.y, p.z, p.w, (ABL & 8) ? 1e30f : hd1, (ABL & 8) ? 1e30f : hd2,
+                                                           (float)(qx0 + ((r & 1) << 2)) + 1.5f, (float)(qy0 + ((r >> 1) << 2)) + 1.5f);
                     const uint64_t m = __ballot(hit);
                     const int at = len[r] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                     if (hit) wave_lists[r * LIST_STRIDE + at] = (uint8_t)j;
@@ -298,9 +207,28 @@ __global__ void __launch_bounds__(256, 5) render_backward_blk_kernel(
                 }
             }
             const int my_len = row == 0 ? len[0] : (row == 1 ? len[1] : (row == 2 ? len[2] : len[3]));
-            const int longest = __builtin_amdgcn_readfirstlane(max(max(len[0], len[1]), max(len[2], len[3])));
+            const int longest = (ABL & 1) ? 0 : __builtin_amdgcn_readfirstlane(max(max(len[0], len[1]), max(len[2], len[3])));
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the wave reads its own lists back
 
+            // The rows of a wave add their (block, entry) sums to the entry's record ONE AFTER THE OTHER (two rows may hold the same
+            // entry at the same time): four dependent LDS round trips per batch, 0.079 of the kernel's 0.405 ms at 1 M splats.
+            // (Taking them for the PREVIOUS batch, one between each pair of image rows of the current one, so that the vector ALU
+            //  has work while a record is on its way, was slower: 0.421 -> 0.445 ms with the registers, and the twelve extra live
+            //  registers spill inside the loop with the constants in LDS: 0.403 -> 1.23 ms.)
+            v4f p_lo4 = {0.f, 0.f, 0.f, 0.f}, p_hi4 = p_lo4;
+            float p_syy = 0.f;
+            float *p_rec8 = acc8, *p_rec1 = acc1;
+            bool p_valid = false;
+            auto add_pass = [&](const int r) {
+                if (row == r && p_valid && !(ABL & 2)) {
+                    const v4f o0 = *reinterpret_cast<const v4f *>(p_rec8), o1 = *reinterpret_cast<const v4f *>(p_rec8 + 4 * MB * 4);
+                    const float o2 = *p_rec1;
+                    *reinterpret_cast<v4f *>(p_rec8) = o0 + p_lo4;
+                    *reinterpret_cast<v4f *>(p_rec8 + 4 * MB * 4) = o1 + p_hi4;
+                    *p_rec1 = o2 + p_syy;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (compiler only: the next row's read stays behind this write)
+            };
             for (int b = 0; b < longest; b += 16) {
                 const int e = b + s;
                 const bool valid = e < my_len;
@@ -317,29 +245,23 @@ __global__ void __launch_bounds__(256, 5) render_backward_blk_kernel(
                     sp.posrel = (float)(MB - 1 - j);
                 }
                 Sums a = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                block_row<0>(sp, px, a);
-                block_row<1>(sp, px, a);
-                block_row<2>(sp, px, a);
-                block_row<3>(sp, px, a);
+                block_row<0, PIX>(sp, px, a, cst_row, st_row);
+                block_row<1, PIX>(sp, px, a, cst_row, st_row);
+                block_row<2, PIX>(sp, px, a, cst_row, st_row);
+                block_row<3, PIX>(sp, px, a, cst_row, st_row);
                 // moments about the block's corner -> sums about the splat centre (dx = X - u, dy = Y - v)
                 const float X = sp.x - bx0f, Y = sp.y - by0f;
-                v4f lo4 = {a.C0, a.C1, a.C2, a.M0};
-                v4f hi4 = {X * a.M0 - a.Mu, Y * a.M0 - a.Mv, X * X * a.M0 - 2.f * X * a.Mu + a.Muu, X * Y * a.M0 - X * a.Mv - Y * a.Mu + a.Muv};
-                const float syy = Y * Y * a.M0 - 2.f * Y * a.Mv + a.Mvv;
-                // the rows of the wave add to the entry's record one after the other: two rows may hold the same entry
-                float *const rec8 = acc8 + ((size_t)wave * MB + j) * 8;
-                float *const rec1 = acc1 + wave * MB + j;
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    if (row == r && valid) {
-                        const v4f o0 = *reinterpret_cast<const v4f *>(rec8), o1 = *reinterpret_cast<const v4f *>(rec8 + 4);
-                        const float o2 = *rec1;
-                        *reinterpret_cast<v4f *>(rec8) = o0 + lo4;
-                        *reinterpret_cast<v4f *>(rec8 + 4) = o1 + hi4;
-                        *rec1 = o2 + syy;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                }
+                p_lo4 = v4f{a.C0, a.C1, a.C2, a.M0};
+                p_hi4 = v4f{X * a.M0 - a.Mu, Y * a.M0 - a.Mv, X * X * a.M0 - 2.f * X * a.Mu + a.Muu, X * Y * a.M0 - X * a.Mv - Y * a.Mu + a.Muv};
+                p_syy = Y * Y * a.M0 - 2.f * Y * a.Mv + a.Mvv;
+                p_rec8 = acc8 + ((size_t)wave * MB + j) * 4;
+                p_rec1 = acc1 + wave * MB + j;
+                p_valid = valid;
+                // a row whose list is exhausted has nothing to add (uniform branches)
+                if (len[0] > b) add_pass(0);
+                if (len[1] > b) add_pass(1);
+                if (len[2] > b) add_pass(2);
+                if (len[3] > b) add_pass(3);
             }
             __syncthreads();
             // ---- write the round out: the four waves' records of every staged entry -> the nine per-instance sums ----
@@ -351,19 +273,23 @@ __global__ void __launch_bounds__(256, 5) render_backward_blk_kernel(
                     for (int q = 0; q < 9; q++) a[q] = 0.f;
 #pragma unroll
                     for (int w = 0; w < 4; w++) {
-                        float *const r8 = acc8 + ((size_t)w * MB + t) * 8;
-                        const v4f lo4 = *reinterpret_cast<const v4f *>(r8), hi4 = *reinterpret_cast<const v4f *>(r8 + 4);
+                        float *const r8 = acc8 + ((size_t)w * MB + t) * 4;
+                        const v4f lo4 = *reinterpret_cast<const v4f *>(r8), hi4 = *reinterpret_cast<const v4f *>(r8 + 4 * MB * 4);
                         a[0] += lo4[0]; a[1] += lo4[1]; a[2] += lo4[2]; a[3] += lo4[3];
                         a[4] += hi4[0]; a[5] += hi4[1]; a[6] += hi4[2]; a[7] += hi4[3];
                         a[8] += acc1[w * MB + t];
                         *reinterpret_cast<v4f *>(r8) = v4f{0.f, 0.f, 0.f, 0.f};
-                        *reinterpret_cast<v4f *>(r8 + 4) = v4f{0.f, 0.f, 0.f, 0.f};
+                        *reinterpret_cast<v4f *>(r8 + 4 * MB * 4) = v4f{0.f, 0.f, 0.f, 0.f};
                         acc1[w * MB + t] = 0.f;
                     }
                     const float4 co = stage[t].co;
                     const float kh = -0.5f * co.w;
                     const float Sgx = kh * a[4], Sgy = kh * a[5];   // -1/2 o sum g dx, dy
                     float *rowp = partial + (size_t)s_slot[t] * NACC;
+                    if constexpr (ABL & 4) {
+                        if (a[0] == 123.456f) rowp[0] = a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7] + a[8];
+                        continue;
+                    }
                     rowp[0] = a[0];
                     rowp[1] = a[1];
                     rowp[2] = a[2];
@@ -388,10 +314,25 @@ int launch_render_backward_blk(const das3r_raster_args *a, const float *dL_dpix,
         (const float4 *)(geom + L.pub.rgbd), a->bg, (const float *)(img + L.pub.final_T),                                 \
         (const uint32_t *)(img + L.pub.n_contrib), dL_dpix, (const uint32_t *)(binning + L.b_slot), partial,              \
         (uint32_t)(a->P - 1), (uint32_t)L.capacity, (const float4 *)(binning + L.b_ckpt)
-#define GO(MBV) DAS3R_LAUNCH((render_backward_blk_kernel<MBV>), dim3(xcd_grid(L.ntiles), slices > 1 ? slices : 1), dim3(TILE_PIX), 0, s, ARGS)
-    if (mb == 64) GO(64);
-    else if (mb == 256) GO(256);
-    else GO(128);
+#define GO(MBV, PIX, OCC) DAS3R_LAUNCH((render_backward_blk_kernel<MBV, PIX, 0, OCC>), dim3(xcd_grid(L.ntiles), slices > 1 ? slices : 1), dim3(TILE_PIX), 0, s, ARGS)
+    // DAS3R_RENDER_BWD=blk<entries per round>[p<PIX>][o<workgroups per CU>]: blk128 (registers), blk128p1 (constants in LDS), blk160p1o4 ...
+    // default (no DAS3R_RENDER_BWD): constants in LDS for 128-entry rounds (1 M splats at 1080p: 0.381 vs 0.407 ms), registers for 192
+    // (DAS3R shape: 0.497 vs 0.534 ms)
+    const int pix = switches().render_bwd == 6 ? switches().render_bwd_pix : (mb == 128 ? 1 : 0), occ = switches().render_bwd_occ == 4 ? 4 : 5;
+#define BY_PIX(MBV, OCC) do { if (pix == 2) GO(MBV, 2, OCC); else if (pix == 1) GO(MBV, 1, OCC); else GO(MBV, 0, OCC); } while (0)
+    if (mb == 128 && pix == 1 && switches().ablate_set) {
+        const int abl = switches().ablate;
+#define GA(A) DAS3R_LAUNCH((render_backward_blk_kernel<128, 1, A>), dim3(xcd_grid(L.ntiles), slices > 1 ? slices : 1), dim3(TILE_PIX), 0, s, ARGS)
+        if (abl == 1) GA(1); else if (abl == 2) GA(2); else if (abl == 4) GA(4); else if (abl == 8) GA(8); else if (abl == 16) GA(16); else if (abl == 3) GA(3); else if (abl == 7) GA(7); else GA(0);
+#undef GA
+    } else if (mb == 64) BY_PIX(64, 5);
+    else if (mb == 256) BY_PIX(256, 5);
+    else if (mb == 120) BY_PIX(120, 5);
+    else if (mb == 160) BY_PIX(160, 4);
+    else if (mb == 192) BY_PIX(192, 4);
+    else if (occ == 4) BY_PIX(128, 4);
+    else BY_PIX(128, 5);
+#undef BY_PIX
 #undef GO
 #undef ARGS
     KERNEL_CHECK(s, a->debug, "render_backward_blk");

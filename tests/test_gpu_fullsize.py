@@ -54,7 +54,7 @@ def test_c2_full_size_vs_oracle():
 
 def test_c4_full_size_vs_oracle():
     """BASELINE.json configs[3], the headline configuration: 1M splats, 1920x1080, SH degree 3.  By default selection this is the
-    rows forward kernel with the in-kernel local depth order of ~320-entry lists and the block-list backward kernel (VERDICT r2
+    rows forward kernel with the in-kernel local depth order of ~320-entry lists and the block-walk backward kernel (render_bwd_blk.hip) (VERDICT r2
     item 1: the headline kernels held to the oracle at the headline size; the oracle needs ~2.4 s on the GPU box's host cores)."""
     sc, I = _full_size_vs_oracle("c4")
     tiles = ((sc.W + 15) // 16) * ((sc.H + 15) // 16)
