@@ -30,17 +30,6 @@
 
 namespace das3r {
 
-// Octagon test of a splat against the 4x4 block whose pixel centres span [cx - 1.5, cx + 1.5] x [cy - 1.5, cy + 1.5]: the
-// axis-aligned extents (hx, hy: preprocess.hip, with their margins) and the extents hd1, hd2 along (1, 1) / sqrt 2 and
-// (1, -1) / sqrt 2.  Conservative: outside any of the four slabs alpha < 1 / 255 on every pixel centre of the block.
-__device__ __forceinline__ bool block_hit_oct(const float x, const float y, const float hx, const float hy, const float hd1, const float hd2,
-                                              const float cx, const float cy) {
-    const float ddx = x - cx, ddy = y - cy;
-    constexpr float RS2 = 0.70710678f, HALF_DIAG = 2.1213204f + 1e-3f;   // (1.5 + 1.5) / sqrt 2
-    return (fabsf(ddx) <= hx + 1.5f) & (fabsf(ddy) <= hy + 1.5f) & (fabsf(ddx + ddy) * RS2 <= hd1 + HALF_DIAG) &
-           (fabsf(ddx - ddy) * RS2 <= hd2 + HALF_DIAG);
-}
-
 // MB: staged list entries per round.  PIX: where the walk finds the per-pixel values (render_blk.h): 0 pixel lanes' registers (DPP
 // broadcasts), 1 constants from LDS, 2 constants and state from LDS.
 // ABL: timing experiments only (DAS3R_ABLATE with DAS3R_RENDER_BWD=blk128p1; results are wrong): 1 no batches at all (what the rounds
@@ -190,12 +179,8 @@ __global__ void __launch_bounds__(256, OCC) render_backward_blk_kernel(
                 // (no exact ellipse-vs-quadrant test in front of the block tests, as render_bwd_scan.hip has it: with the octagon test per
                 //  block behind it, it cost more than the few blocks it still removed were worth — 0.405 vs 0.390 ms at 1 M splats)
                 const bool qhit = (j < n) && ((ABL & 16) ? rect_hit_tight_tau(p, co, splat_tau(co.w), (float)qx0, (float)qy0) : true);
-                // extents along the two diagonals from the axis-aligned ones: tau Sxx = ex2, tau Syy = ey2, tau Sxy = -B ex2 / C
-                const float ex = (p.z - 0.02f) * (1.0f / 1.0005f), ey = (p.w - 0.02f) * (1.0f / 1.0005f);
-                const float ex2 = ex * ex, ey2 = ey * ey, txy = -co.y * ex2 * __builtin_amdgcn_rcpf(co.z);
-                const float half = 0.5f * (ex2 + ey2), slack = 2e-6f * (ex2 + ey2) + 1e-3f;   // (cancellation of long thin splats)
-                const float hd1 = __builtin_amdgcn_sqrtf(fmaxf(half + txy, 0.f) + slack) * 1.0005f + 0.05f;   // (v_sqrt_f32: 1 ulp, inside the margins)
-                const float hd2 = __builtin_amdgcn_sqrtf(fmaxf(half - txy, 0.f) + slack) * 1.0005f + 0.05f;
+                float hd1, hd2;
+                diagonal_extents(p, co, hd1, hd2);
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const bool hit = qhit && block_hit_oct(p.x, p.y, p.z, p.w, (ABL & 8) ? 1e30f : hd1, (ABL & 8) ? 1e30f : hd2,
