@@ -139,6 +139,10 @@ __global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
         const float4 *src = reinterpret_cast<const float4 *>(shs) + blk4;
 #pragma unroll
         for (int i = 0; i < 12; i++) {
+            // GUARDED loads on purpose: each sits in its own basic block and the compiler waits for them two at a time, which throttles
+            // this bulk stream while the latency-critical chain of the kernel (tiles_touched -> rows of `partial`) is on its way.
+            // With a clamped index all twelve go out at once, as in preprocess.hip (where that is worth 13 %) — and this kernel gets
+            // SLOWER: 0.129 -> 0.165 ms at 1 M splats (r3, A-B-A-B on one box): the rows are not needed before the gather is done.
             const int f = i * 256 + threadIdx.x;
             sh_in[i] = (size_t)f < limit4 ? src[f] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
