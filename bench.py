@@ -78,6 +78,8 @@ class Ranks:
                              f"(or without torchrun: bench.py starts the ranks itself)")
         self.stub = args.stub
         self.dist = None
+        self.failed = None      # reason, once a step of this rank has raised
+        self.last_local_s = 0.0
         if self.stub:
             self.dev = torch.device("cpu")
         else:
@@ -116,16 +118,36 @@ class Ranks:
         return float(t.item())
 
     def timed(self, step, steps, warmup):
-        """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides; MAX over ranks.  -> seconds"""
+        """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides; MAX over ranks.  -> seconds.
+        A rank whose step raises keeps its appointments (barriers, reductions) so that the others' line still comes out; it is
+        reported through `ranks_ok` (self.failed holds the reason) and its units do not count."""
+        def guarded():
+            if self.failed is None:
+                try:
+                    step()
+                except Exception as ex:  # noqa: BLE001 - reported, not swallowed: ranks_ok / stderr
+                    self.failed = repr(ex)
+                    print(f"bench.py: rank {self.rank} failed: {self.failed}", file=sys.stderr, flush=True)
         for _ in range(warmup):
-            step()
+            guarded()
         self.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            step()
+            guarded()
         self.sync()
+        self.last_local_s = time.perf_counter() - t0   # this rank's own time, before the closing barrier
         self.barrier()
         return self.max_over_ranks(time.perf_counter() - t0)
+
+    def gather_all(self, x):
+        """-> [x of rank 0, x of rank 1, ...] on every rank"""
+        import torch
+        if self.dist is None:
+            return [float(x)]
+        t = torch.zeros(self.world, device=self.dev, dtype=torch.float64)
+        t[self.rank] = float(x)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [round(float(v), 4) for v in t.tolist()]
 
     def close(self):
         if self.dist is not None:
@@ -189,21 +211,48 @@ class RasterJob:
         self.steps_done += 1
         return color
 
+    def forward_only(self):
+        """The forward render alone (BASELINE.json's metric names "render fwd/bwd Msplats/s": this is the fwd figure)."""
+        L = self.leaves
+        with self._torch.no_grad():
+            color, radii = self.rast(means3D=L["means3D"], means2D=self.means2D, opacities=L["opacities"], shs=L["shs"], scales=L["scales"],
+                                     rotations=L["rotations"])
+        return color
 
-def kernel_table(job, steps, measured=None):
+
+def kernel_times(job, steps):
     """The same K steps again with every kernel launch bracketed by HIP events on its launch stream (das3r_profile_*), kept apart
-    from the timed region so that `value` is not perturbed.  -> (kernels dict, roofline dict)"""
-    import glob
+    from the timed region so that `value` is not perturbed — and taken RIGHT BEHIND it, while the device is still at the clocks of
+    the timed steps (r2: taken after the profiler's child passes, the compositing kernels came out 6 % slower than in the timed
+    region they had just run in).  -> ({kernel: (launches, total ms)}, pairs per step {kernel: count})"""
     import torch
     from das3r_amd import _lib
-    from das3r_amd.roofline import HBM_PEAK_GBS, algorithmic_bytes, group_kernel_times
-    sc = job.sc
     _lib.profile_enable(True)
+    for _ in range(10):   # the instrumented pass warms up too (event pool)
+        job.step()
+    torch.cuda.synchronize()
+    _lib.profile_report()
     for _ in range(steps):
         job.step()
     torch.cuda.synchronize()
     rep = _lib.profile_report()
     _lib.profile_enable(False)
+    # (pixel, splat) pairs the two compositing kernels evaluate per step: counted by the kernels themselves in a pass of their own
+    _lib.pair_counters(True)
+    for _ in range(3):
+        job.step()
+    pc = _lib.pair_counters(False)
+    return rep, {"render_forward_kernel": pc["fwd_pairs"] / 3.0, "render_backward_kernel": pc["bwd_pairs"] / 3.0}
+
+
+def kernel_table(job, steps, measured=None, timed=None):
+    """-> (kernels dict, roofline dict) from kernel_times() (taken now unless `timed` holds them) and the measured HBM traffic."""
+    import glob
+    import torch
+    from das3r_amd import _lib
+    from das3r_amd.roofline import HBM_PEAK_GBS, algorithmic_bytes, group_kernel_times
+    sc = job.sc
+    rep, pairs = timed if timed is not None else kernel_times(job, steps)
     I = job.num_rendered
     per_kernel, b_fwd, b_bwd = algorithmic_bytes(job.P, sc.sh_degree, sc.shs.shape[1], I, sc.W, sc.H)
     kernels = {}
@@ -213,6 +262,11 @@ def kernel_table(job, steps, measured=None):
         if name in per_kernel:
             ent["alg_bytes"] = per_kernel[name]
             ent["GBps"] = round(per_kernel[name] / (avg_ms * 1e-3) / 1e9, 1)
+        if name in pairs and pairs[name] > 0:
+            # "additionally report pairs/s so a shortfall can be attributed" — pairs the kernel EVALUATES (alpha computed)
+            ent["pairs_per_step"] = int(pairs[name])
+            ent["pairs_per_instance"] = round(pairs[name] / max(I, 1), 1)
+            ent["Gpairs_per_s"] = round(pairs[name] / (avg_ms * 1e-3) / 1e9, 2)
         kernels[name] = ent
     # dominant KERNEL = the single kernel with the largest time per step (the 'binning' entry is a group of small launches)
     dom = next(k for k in kernels if k in per_kernel and k != "binning")
@@ -226,15 +280,28 @@ def kernel_table(job, steps, measured=None):
     if measured is not None and measured[0]:
         for k, ent in kernels.items():
             if k in measured[0]:
-                ent["hbm_bytes"] = int(measured[0][k])
+                # FETCH_SIZE correction per kernel (profiles/r03_fetch_calibration.json, tools/fetch_calib.sh): x2 for wide coalesced
+                # streams (the per-Gaussian kernels, the radix passes), x1 for the compositing kernels, whose reads are 64-byte splat
+                # records gathered per list entry — the counter is exact for those (known / raw = 1.02)
+                gather = k in ("render_forward_kernel", "render_backward_kernel")
+                hb = measured[0][k] - (0.5 * measured[3].get(k, 0.0) if (gather and len(measured) > 3) else 0.0)
+                ent["hbm_bytes"] = int(hb)
+                ent["fetch_factor"] = 1.0 if gather else 2.0
                 if "alg_bytes" in ent:
-                    ent["traffic_over_alg"] = round(measured[0][k] / ent["alg_bytes"], 3)
+                    ent["traffic_over_alg"] = round(hb / ent["alg_bytes"], 3)
+            if len(measured) > 2 and measured[2] and k in measured[2]:
+                # vector-ALU issue: wave instructions x 2 cycles (SIMD-32: a wave64 instruction occupies the ALU for two cycles at
+                # best, MI355X_MICROARCH.md) over SIMDs x kernel cycles at the 2.4 GHz peak clock.  A lower bound on how busy the ALU
+                # is: DPP-modified and compare instructions cost twice that, transcendentals four times (profiles/r03_valu_rate_probe.txt)
+                ent["valu_insts"] = int(measured[2][k])
+                ent["valu_issue_frac"] = round(measured[2][k] * 2.0 / (1024.0 * ent["ms_per_step"] * 1e-3 * 2.4e9), 3)
         traffic, traffic_source = kernels[dom].get("hbm_bytes"), measured[1]
     pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc_{wname}.json")))
     if traffic is None and pmc:
         try:
             ent = json.load(open(pmc[-1]))
-            rec = ent.get(dom) or ent.get({"render_backward_kernel": "render_backward_scan_kernel"}.get(dom, dom)) or {}
+            rec = (ent.get(dom) or (dom == "render_backward_kernel" and (ent.get("render_backward_blk_kernel") or ent.get("render_backward_scan_kernel")))
+                   or (dom == "render_forward_kernel" and ent.get("render_forward_rows_kernel")) or {})
             traffic = rec.get("hbm_bytes_per_launch")
             if traffic is not None:
                 traffic_source = (f"{os.path.relpath(pmc[-1], ROOT)} (separate rocprofv3 --pmc passes of the same workload, committed; "
@@ -264,7 +331,7 @@ def pmc_rows(files, counter):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("das3r::", "").split("<")[0]
             if not (k in BINNING_KERNELS or k in ALIASES or k.startswith("render_") or k.startswith("preprocess_")):
                 continue
-            b = float(r["Counter_Value"]) * 1024.0 * (2.0 if counter == "FETCH_SIZE" else 1.0)
+            b = float(r["Counter_Value"]) * (1.0 if counter == "SQ_INSTS_VALU" else 1024.0 * (2.0 if counter == "FETCH_SIZE" else 1.0))
             yield ("binning" if k in BINNING_KERNELS else ALIASES.get(k, k)), k, b
 
 
@@ -289,7 +356,8 @@ def measure_traffic(workload, timeout_s=90):
     tot, raw = {}, {}
     work = tempfile.mkdtemp(prefix="das3r_pmc_", dir="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        valu, fetch2 = {}, {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
             d = os.path.join(work, counter)
             cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--", sys.executable,
                    os.path.abspath(__file__), "--pmc-child", "--workload", workload, "--steps", str(steps)]
@@ -304,6 +372,11 @@ def measure_traffic(workload, timeout_s=90):
             if not files:
                 return None, f"rocprofv3 --pmc {counter} pass wrote no counter file (rc {p.returncode})"
             for key, raw_name, b in pmc_rows(files, counter):
+                if counter == "SQ_INSTS_VALU":
+                    valu[key] = valu.get(key, 0.0) + b
+                    continue
+                if counter == "FETCH_SIZE":
+                    fetch2[key] = fetch2.get(key, 0.0) + b
                 tot[key] = tot.get(key, 0.0) + b
                 if key == "binning":
                     raw[raw_name] = raw.get(raw_name, 0.0) + b
@@ -312,7 +385,10 @@ def measure_traffic(workload, timeout_s=90):
     # the child ran one initialisation step + `steps` steps, every one of them counted
     print(json.dumps({"bench_binning_hbm_bytes_per_step": {k: int(v / (steps + 1)) for k, v in raw.items()}}), file=sys.stderr, flush=True)
     return ({k: v / (steps + 1) for k, v in tot.items()},
-            f"this run: rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE (separate passes, {steps + 1} steps), bytes = 2*FETCH + WRITE (gfx950)")
+            f"this run: rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE (separate passes, {steps + 1} steps), bytes = f*FETCH + WRITE with f = 2 for the "
+            f"streaming kernels (gfx950 undercounts wide coalesced reads by 2x) and f = 1 for the compositing kernels' 64-byte record "
+            f"gathers (calibrated: profiles/r03_fetch_calibration.json)",
+            {k: v / (steps + 1) for k, v in valu.items()}, {k: v / (steps + 1) for k, v in fetch2.items()})
 
 
 def pmc_child_main(args):
@@ -327,22 +403,33 @@ def pmc_child_main(args):
     torch.cuda.synchronize()
 
 
-def cpu_baseline_of(sc_cpu, name, budget_s=20.0):
-    """The oracle (plain C + OpenMP restatement of the reference algorithm) on the host cores, same scene; rank 0, N = 1 only."""
+def cpu_baseline_of(sc_cpu, name, budget_s=30.0):
+    """The oracle (plain C + OpenMP restatement of the reference algorithm) on the host cores, same scene; rank 0, N = 1 only.
+    SURVEY.md 8d: one warm-up, then the median of 5 runs, forward and forward + backward — as many of the 5 as fit in `budget_s`
+    (a 5 M-splat scene takes ~11 s per run: the sample then says how many were taken)."""
+    import statistics
     from oracle import c_oracle
     o = c_oracle.RasterOracle(**sc_cpu.settings_kwargs())
     np_in = dict(shs=sc_cpu.shs.numpy(), scales=sc_cpu.scales.numpy(), rotations=sc_cpu.rotations.numpy())
-    times, t_start = [], time.perf_counter()
-    while len(times) < 3 and (time.perf_counter() - t_start) < budget_s:
+    m3, op, dl = sc_cpu.means3D.numpy(), sc_cpu.opacities.numpy(), sc_cpu.dL_dpix.numpy()
+    t_start = time.perf_counter()
+    o.forward(m3, op, **np_in)   # warm-up (page faults of the oracle's buffers, OpenMP pool)
+    o.backward(dl)
+    fb, fw = [], []
+    while len(fb) < 5 and (not fb or (time.perf_counter() - t_start) < budget_s):
         t1 = time.perf_counter()
-        o.forward(sc_cpu.means3D.numpy(), sc_cpu.opacities.numpy(), **np_in)
-        o.backward(sc_cpu.dL_dpix.numpy())
-        times.append(time.perf_counter() - t1)
+        o.forward(m3, op, **np_in)
+        t2 = time.perf_counter()
+        o.backward(dl)
+        t3 = time.perf_counter()
+        fw.append(t2 - t1)
+        fb.append(t3 - t1)
     o.free()
-    best = min(times)
-    return {"value": round(sc_cpu.P / best / 1e6, 4), "unit": "Msplats/s", "cores": c_oracle.max_threads(), "kind": "port",
-            "sample": f"whole {name} scene ({sc_cpu.P} splats, {sc_cpu.W}x{sc_cpu.H}), fwd+bwd, best of {len(times)} runs, "
-                      f"{best * 1e3:.1f} ms per fwd+bwd", "ms_per_step": round(best * 1e3, 2)}
+    med, medf = statistics.median(fb), statistics.median(fw)
+    return {"value": round(sc_cpu.P / med / 1e6, 4), "unit": "Msplats/s", "cores": c_oracle.max_threads(), "kind": "port",
+            "sample": f"whole {name} scene ({sc_cpu.P} splats, {sc_cpu.W}x{sc_cpu.H}), fwd+bwd, median of {len(fb)} runs after 1 warm-up, "
+                      f"{med * 1e3:.1f} ms per fwd+bwd", "ms_per_step": round(med * 1e3, 2),
+            "fwd_only": {"value": round(sc_cpu.P / medf / 1e6, 4), "unit": "Msplats/s", "ms_per_step": round(medf * 1e3, 2)}}
 
 
 def train_step_timer(dev, fused, frames=20, W=512, H=208):
@@ -436,15 +523,21 @@ def main():
     out = None
     if args.stub:   # the launch contract without a GPU: N gloo ranks, stand-in step, the same timing protocol
         x = torch.zeros(1024)
+        fail_rank = int(os.environ.get("DAS3R_BENCH_STUB_FAIL_RANK", "-1"))   # tests: this rank's job dies half way
 
         def step():
             x.add_(1.0)
+            if rk.rank == fail_rank and float(x[0]) > args.warmup + args.steps // 2:
+                raise RuntimeError("stub job failure (DAS3R_BENCH_STUB_FAIL_RANK)")
         elapsed = rk.timed(step, args.steps, args.warmup)
+        ranks_ok = [int(round(v)) for v in rk.gather_all(0.0 if rk.failed else 1.0)]
+        per_rank_ms = rk.gather_all(rk.last_local_s / args.steps * 1e3)
         if rk.rank == 0:
-            out = {"metric": "stub steps/s (launch-logic dry run, no GPU work)", "value": round(rk.world * args.steps / elapsed, 3),
+            out = {"metric": "stub steps/s (launch-logic dry run, no GPU work)", "value": round(sum(ranks_ok) * args.steps / elapsed, 3),
                    "unit": "steps/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
                    "ms_per_step": round(elapsed / args.steps * 1e3, 6), "higher_is_better": True, "scaling": "weak",
-                   "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": "stub"}}
+                   "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": "stub"},
+                   "ranks_ok": ranks_ok, "per_rank_ms": per_rank_ms}
             print(json.dumps(out), flush=True)
         rk.close()
         return
@@ -461,13 +554,18 @@ def main():
     rk.barrier()
     elapsed = rk.timed(job.step, args.steps, args.warmup)
     ms_per_step = elapsed / args.steps * 1e3
+    timed_kernels = kernel_times(job, args.steps) if rk.rank == 0 else None   # right behind the timed region (same clocks)
+    per_rank_ms = rk.gather_all(rk.last_local_s / args.steps * 1e3) if rk.world > 1 else None   # a straggler shows here
+    ranks_ok = [int(round(v)) for v in rk.gather_all(0.0 if rk.failed else 1.0)]
+    # the forward render alone, same protocol (BASELINE.json metric: "render fwd/bwd Msplats/s")
+    fwd_elapsed = rk.timed(job.forward_only, args.steps, min(args.warmup, 5)) if args.workload != "c4d" else None
+    measured = measure_traffic(args.workload) if (rk.rank == 0 and rk.world == 1 and not args.no_pmc) else None
     P_report = job.sc_cpu.P                        # (c4d: P grows; the rate is quoted on the initial P, the growth is in config)
-    msplats = rk.world * P_report / (elapsed / args.steps) / 1e6
+    msplats = sum(ranks_ok) * P_report / (elapsed / args.steps) / 1e6   # (a rank whose job failed processed nothing)
 
     kernels, roofline = (None, None)
     if rk.rank == 0:
-        measured = measure_traffic(args.workload) if (rk.world == 1 and not args.no_pmc) else None
-        kernels, roofline = kernel_table(job, args.steps, measured)
+        kernels, roofline = kernel_table(job, args.steps, measured, timed_kernels)
 
     # ---- train-step ms (fused §8f path) -> scenes/hour of the farm.  N = 1: in the extras child (its rasterizer launches carry the
     # same kernel names as the benchmarked workload's: kept out of this process, a rocprofv3 --stats of this command averages the
@@ -498,6 +596,10 @@ def main():
                "value": round(msplats, 3), "unit": "Msplats/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
+               "fwd_only": (None if fwd_elapsed is None else
+                            {"value": round(rk.world * P_report / (fwd_elapsed / args.steps) / 1e6, 3), "unit": "Msplats/s",
+                             "ms_per_step": round(fwd_elapsed / args.steps * 1e3, 4), "what": "forward render alone (no_grad), same K / barrier protocol"}),
+               "per_rank_ms": per_rank_ms, "ranks_ok": ranks_ok,
                "config": {"workload": WORKLOAD_DESC[args.workload], "name": args.workload, "splats_per_gpu": P_report,
                           "splats_per_gpu_final": job.P, "init_steps": INIT_STEPS if args.workload != "c4d" else 1, "image": [sc.W, sc.H], "sh_degree": sc.sh_degree, "num_rendered": job.num_rendered,
                           "api": "GaussianRasterizer.forward + autograd backward (drop-in surface)",

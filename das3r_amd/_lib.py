@@ -52,7 +52,7 @@ EXPORTS = ("das3r_raster_forward", "das3r_raster_backward", "das3r_raster_check"
            "das3r_knn3_mean_dist2", "das3r_raster_get_layout", "das3r_abi_version", "das3r_last_error", "das3r_reload_switches", "das3r_get_stats",
            "das3r_profile_enable", "das3r_profile_report", "das3r_pretransform_forward", "das3r_pretransform_backward", "das3r_pose_matrices", "das3r_pose_chain",
            "das3r_adam_step", "das3r_adam_step_gated", "das3r_photometric_blocks", "das3r_photometric_forward", "das3r_photometric_backward",
-           "das3r_has_experiments")
+           "das3r_has_experiments", "das3r_pair_counters")
 
 _lib = None
 
@@ -130,6 +130,20 @@ def has_experiments():
     L.das3r_has_experiments.restype = C.c_int
     L.das3r_has_experiments.argtypes = []
     return bool(L.das3r_has_experiments())
+
+
+def pair_counters(enable):
+    """enable=True: zero the compositing kernels' pair counters and start counting; enable=False: stop and return
+    dict(fwd_pairs, bwd_pairs, fwd_wave_iterations, bwd_wave_iterations)."""
+    L = load()
+    L.das3r_pair_counters.restype = C.c_int
+    L.das3r_pair_counters.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
+    if enable:
+        check(L.das3r_pair_counters(1, None), "das3r_pair_counters")
+        return None
+    out = (C.c_uint64 * 4)()
+    check(L.das3r_pair_counters(0, out), "das3r_pair_counters")
+    return dict(fwd_pairs=int(out[0]), bwd_pairs=int(out[1]), fwd_wave_iterations=int(out[2]), bwd_wave_iterations=int(out[3]))
 
 
 def stats():

@@ -26,15 +26,25 @@ struct ProfRec {
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 bool profile_enabled() { return g_prof_on; }
+// (events come from a pool that survives reports: creating two events per launch made the instrumented pass slower than the
+//  timed one — the host fell behind the device and the gaps showed up inside the brackets: VERDICT r2 item 10)
+static std::vector<hipEvent_t> g_event_pool;
+static hipEvent_t pooled_event() {
+    if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+}
 void profile_begin(const char *name, hipStream_t s) {
     ProfRec r;
     r.name = name;
-    if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
-    hipEventRecord(r.start, s);
+    r.start = pooled_event();
+    r.stop = pooled_event();
+    if (!r.start || !r.stop) return;
+    (void)hipEventRecord(r.start, s);
     g_prof.push_back(r);
 }
 void profile_end(hipStream_t s) {
-    if (!g_prof.empty()) hipEventRecord(g_prof.back().stop, s);
+    if (!g_prof.empty()) (void)hipEventRecord(g_prof.back().stop, s);
 }
 
 static Switches g_sw;
@@ -569,6 +579,28 @@ extern "C" int das3r_mark_visible(int32_t P, const float *means3D, const float *
     return launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
 }
 
+// ---- pair counters ----
+static unsigned long long *g_pairs = nullptr;
+namespace das3r { unsigned long long *pair_counters() { return g_pairs; } }
+// enable != 0: (allocate and) zero the counters, the compositing kernels count from now on; enable == 0: read them into out[4] (may be
+// null), stop counting.  Single-threaded use (bench.py); synchronises the device.
+extern "C" int das3r_pair_counters(int enable, uint64_t out[4]) {
+    if (enable) {
+        if (!g_pairs) HIP_TRY(hipMalloc((void **)&g_pairs, 4 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(g_pairs, 0, 4 * sizeof(unsigned long long)));
+        return DAS3R_OK;
+    }
+    if (g_pairs) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (out) HIP_TRY(hipMemcpy(out, g_pairs, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipFree(g_pairs));
+        g_pairs = nullptr;
+    } else if (out) {
+        out[0] = out[1] = out[2] = out[3] = 0;
+    }
+    return DAS3R_OK;
+}
+
 // ---- profiling introspection ----
 extern "C" void das3r_profile_enable(int on) { g_prof_on = on != 0; }
 
@@ -585,8 +617,8 @@ extern "C" int das3r_profile_report(char *buf, size_t cap) {
                 if (strcmp(a.name, r.name) == 0) { a.n++; a.ms += ms; found = true; break; }
             if (!found) agg.push_back({r.name, 1, (double)ms});
         }
-        hipEventDestroy(r.start);
-        hipEventDestroy(r.stop);
+        g_event_pool.push_back(r.start);
+        g_event_pool.push_back(r.stop);
     }
     g_prof.clear();
     size_t off = 0;

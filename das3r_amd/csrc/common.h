@@ -81,6 +81,12 @@ struct ProfTimer {
     }
 };
 
+// Optional pair counters (das3r_pair_counters in the C-ABI; bench.py's pairs/s): a device array of four 64-bit words, or null.
+//   [0] (pixel, splat) pairs the forward compositing kernel evaluated   [1] the same for the backward kernel
+//   [2] forward wave iterations                                          [3] backward wave iterations (64 pairs each)
+// The compositing kernels take the pointer as their last argument; each wave adds its totals once, at its end.
+unsigned long long *pair_counters();
+
 // every kernel launch goes through this macro so that the optional profiler sees it (name = kernel symbol)
 #define DAS3R_LAUNCH(kernel, grid, block, shmem, stream, ...)                \
     do {                                                                     \

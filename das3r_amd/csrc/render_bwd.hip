@@ -23,7 +23,8 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
     const float4 *__restrict__ xyh, const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
     const float *__restrict__ bg, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
     const float *__restrict__ dL_dpix, const uint32_t *__restrict__ slot_list, float *__restrict__ partial /*[I,9]*/, int ablate,
-    uint32_t last_g, uint32_t cap /*bounds of the list contents: render_common.h safe_range*/) {
+    uint32_t last_g, uint32_t cap /*bounds of the list contents: render_common.h safe_range*/,
+    unsigned long long *__restrict__ pairs /*common.h pair_counters(): null unless bench.py counts*/) {
     __shared__ StagedSplat stage[TILE_PIX];
     __shared__ uint32_t s_slot[TILE_PIX];   // emission slot of every staged entry = its row of `partial`
     __shared__ float acc[TILE_PIX * NACC];
@@ -81,6 +82,7 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
     const int widx = USE_DPP ? ((lane & 15) == 15 ? 8 : (lane >> 3)) : lane;
     const unsigned widx4 = (unsigned)widx * 4u;
 
+    int visits = 0;   // (wave-uniform) (splat, quadrant) visits = 64 pairs each
     for (int i = 0; i < rounds; i++) {
         const int done_before = i * TILE_PIX;
         const int n = min(TILE_PIX, (int)max_contrib - done_before);
@@ -102,6 +104,7 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
         for (int k = 0; k < 4; k++) {
             const int s = k * 64 + lane;
             masks[k] = __ballot(s < n && quadrant_hit(stage[s].xyh, qcx, qcy));
+            visits += __popcll(masks[k]);
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -152,6 +155,10 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
             }
         }
         __syncthreads();
+    }
+    if (pairs != nullptr && lane == 0 && visits > 0) {
+        atomicAdd(pairs + 1, (unsigned long long)visits * 64ull);
+        atomicAdd(pairs + 3, (unsigned long long)visits);
     }
 }
 
@@ -207,7 +214,7 @@ int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, cha
         L.tiles_x, pack_tiles(L), (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),                \
         (const float4 *)(geom + L.pub.rgbd), a->bg, (const float *)(img + L.pub.final_T),                                    \
         (const uint32_t *)(img + L.pub.n_contrib), dL_dpix, (const uint32_t *)(binning + L.b_slot), partial, ablate, \
-        (uint32_t)(a->P - 1), (uint32_t)L.capacity
+        (uint32_t)(a->P - 1), (uint32_t)L.capacity, pair_counters()
     const int pad_lds = sw.bwd_pad_lds;   // occupancy experiments
     if (use_dpp) DAS3R_LAUNCH((render_backward_kernel<true>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), pad_lds, s, ARGS);
     else DAS3R_LAUNCH((render_backward_kernel<false>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS);

@@ -41,7 +41,8 @@ __global__ void __launch_bounds__(256, OCC) render_backward_blk_kernel(
     const float *__restrict__ bg, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
     const float *__restrict__ dL_dpix, const uint32_t *__restrict__ slot_list, float *__restrict__ partial /*[I,9]*/,
     uint32_t last_g, uint32_t cap /*bounds of the list contents: render_common.h safe_range*/,
-    const float4 *__restrict__ ckpt /*forward's checkpoints of long lists (render_common.h); used when gridDim.y > 1*/) {
+    const float4 *__restrict__ ckpt /*forward's checkpoints of long lists (render_common.h); used when gridDim.y > 1*/,
+    unsigned long long *__restrict__ pairs /*common.h pair_counters(): null unless bench.py counts*/) {
     static_assert(MB >= 64 && MB <= 256 && MB % 8 == 0, "entries per round (one-byte list entries)");
     constexpr int LIST_STRIDE = MB + 4;                                  // bytes; the four rows of a wave read position e of their lists in one instruction
     constexpr int OFF_STAGE = 0;                                         // StagedSplat[MB]
@@ -116,6 +117,7 @@ __global__ void __launch_bounds__(256, OCC) render_backward_blk_kernel(
     const int slices = (int)gridDim.y;
     const int nbuckets = slices > 1 ? max(ckpt_buckets(range), 1) : 1;
     const float bx0f = (float)(qx0 + ((row & 1) << 2)), by0f = (float)(qy0 + ((row >> 1) << 2));   // corner pixel of the lane's block: origin of its moments
+    int batches_done = 0;   // (wave-uniform) batches of 16 pixel steps = 1024 pairs each
 
     for (int bk = (int)blockIdx.y; bk < nbuckets; bk += slices) {
         const uint32_t lo = slices > 1 ? (uint32_t)bk * BUCKET : 0u;                     // the bucket's list positions [lo, hi)
@@ -214,6 +216,7 @@ __global__ void __launch_bounds__(256, OCC) render_backward_blk_kernel(
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (compiler only: the next row's read stays behind this write)
             };
+            batches_done += (longest + 15) >> 4;
             for (int b = 0; b < longest; b += 16) {
                 const int e = b + s;
                 const bool valid = e < my_len;
@@ -289,6 +292,10 @@ __global__ void __launch_bounds__(256, OCC) render_backward_blk_kernel(
             __syncthreads();   // stage / s_slot / the lists are free for the next round
         }
     }
+    if (pairs != nullptr && lane == 0 && batches_done > 0) {
+        atomicAdd(pairs + 1, (unsigned long long)batches_done * 1024ull);
+        atomicAdd(pairs + 3, (unsigned long long)batches_done * 16ull);
+    }
 }
 
 int launch_render_backward_blk(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
@@ -298,7 +305,7 @@ int launch_render_backward_blk(const das3r_raster_args *a, const float *dL_dpix,
         L.tiles_x, pack_tiles(L), (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),             \
         (const float4 *)(geom + L.pub.rgbd), a->bg, (const float *)(img + L.pub.final_T),                                 \
         (const uint32_t *)(img + L.pub.n_contrib), dL_dpix, (const uint32_t *)(binning + L.b_slot), partial,              \
-        (uint32_t)(a->P - 1), (uint32_t)L.capacity, (const float4 *)(binning + L.b_ckpt)
+        (uint32_t)(a->P - 1), (uint32_t)L.capacity, (const float4 *)(binning + L.b_ckpt), pair_counters()
 #define GO(MBV, PIX, OCC) DAS3R_LAUNCH((render_backward_blk_kernel<MBV, PIX, 0, OCC>), dim3(xcd_grid(L.ntiles), slices > 1 ? slices : 1), dim3(TILE_PIX), 0, s, ARGS)
     // DAS3R_RENDER_BWD=blk<entries per round>[p<PIX>][o<workgroups per CU>]: blk128 (registers), blk128p1 (constants in LDS), blk160p1o4 ...
     // default (no DAS3R_RENDER_BWD): constants in LDS for 128-entry rounds (1 M splats at 1080p: 0.381 vs 0.407 ms), registers for 192

@@ -40,7 +40,8 @@ __global__ void __launch_bounds__(256, (MB <= 128 ? 4 : 2)) render_backward_scan
     const float *__restrict__ bg, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
     const float *__restrict__ dL_dpix, const uint32_t *__restrict__ slot_list, float *__restrict__ partial /*[I,9]*/,
     uint32_t last_g, uint32_t cap /*bounds of the list contents: render_common.h safe_range*/,
-    const float4 *__restrict__ ckpt /*forward's checkpoints of long lists (render_common.h); used when gridDim.y > 1*/) {
+    const float4 *__restrict__ ckpt /*forward's checkpoints of long lists (render_common.h); used when gridDim.y > 1*/,
+    unsigned long long *__restrict__ pairs /*common.h pair_counters(): null unless bench.py counts*/) {
     // one LDS object (cdna_hip_programming.md: a second __shared__ array changes the waits the compiler emits)
     constexpr int NROW = ATOM ? 12 : 9;   // private regions: C0 C1 C2 M0 | Mu Mv Muu Muv (two 16-byte pieces) + Mvv in its own array; shared: + C0' C1' C2'
     constexpr int NROW8 = ATOM ? 12 : 8;
@@ -149,6 +150,7 @@ __global__ void __launch_bounds__(256, (MB <= 128 ? 4 : 2)) render_backward_scan
         Aop[half] = U4{pack_hi(wv[0], wv[1]), pack_hi(wv[2], wv[3]), pack_hi(wv[4], wv[5]), pack_hi(wv[6], wv[7])};
     }
 
+    int batches_done = 0;   // (wave-uniform) batches of 16 steps = 1024 pairs each
     for (int bk = (int)blockIdx.y; bk < nbuckets; bk += slices) {
     const uint32_t lo = slices > 1 ? (uint32_t)bk * BUCKET : 0u;                     // the bucket's list positions [lo, hi)
     const uint32_t hi = slices > 1 ? min(list_len, lo + BUCKET) : list_len;
@@ -209,6 +211,7 @@ __global__ void __launch_bounds__(256, (MB <= 128 ? 4 : 2)) render_backward_scan
         cnt = (ABL & 4) ? 0 : __builtin_amdgcn_readfirstlane(cnt);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the wave reads its own list back
 
+        batches_done += (cnt + 15) >> 4;
         for (int b = 0; b < cnt; b += 16) {
             const int e = b + s;
             const bool valid = e < cnt;
@@ -378,6 +381,10 @@ __global__ void __launch_bounds__(256, (MB <= 128 ? 4 : 2)) render_backward_scan
         __syncthreads();   // stage / s_slot / the accumulators are free for the next round
     }
     }
+    if (pairs != nullptr && lane == 0 && batches_done > 0) {
+        atomicAdd(pairs + 1, (unsigned long long)batches_done * 1024ull);
+        atomicAdd(pairs + 3, (unsigned long long)batches_done * 16ull);
+    }
 }
 
 int launch_render_backward_scan(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
@@ -387,7 +394,7 @@ int launch_render_backward_scan(const das3r_raster_args *a, const float *dL_dpix
         L.tiles_x, pack_tiles(L), (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),             \
         (const float4 *)(geom + L.pub.rgbd), a->bg, (const float *)(img + L.pub.final_T),                                 \
         (const uint32_t *)(img + L.pub.n_contrib), dL_dpix, (const uint32_t *)(binning + L.b_slot), partial,              \
-        (uint32_t)(a->P - 1), (uint32_t)L.capacity, (const float4 *)(binning + L.b_ckpt)
+        (uint32_t)(a->P - 1), (uint32_t)L.capacity, (const float4 *)(binning + L.b_ckpt), pair_counters()
 #define GO(MBV, AT, AB) DAS3R_LAUNCH((render_backward_scan_kernel<MBV, AT, AB>), dim3(xcd_grid(L.ntiles), slices > 1 ? slices : 1), dim3(TILE_PIX), 0, s, ARGS)
     const int abl = switches().ablate_set ? switches().ablate : 0;
     // mb: 64 / 128 / 256 private accumulator regions; 1256: 256 entries per round with the atomic flush

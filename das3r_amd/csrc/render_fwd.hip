@@ -9,7 +9,8 @@ __global__ void __launch_bounds__(256) render_forward_kernel(const uint2 *__rest
                                                              int W, int H, int tiles_x, int ntiles_strip /*tiles | strip height << 24: render_common.h xcd_tile*/, const float4 *__restrict__ xyh,
                                                              const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
                                                              const float *__restrict__ bg, float *__restrict__ final_T,
-                                                             uint32_t *__restrict__ n_contrib, float *__restrict__ out_color, const LocalBin lb) {
+                                                             uint32_t *__restrict__ n_contrib, float *__restrict__ out_color, const LocalBin lb,
+                                                             unsigned long long *__restrict__ pairs /*common.h pair_counters()*/) {
     __shared__ StagedSplat stage[TILE_PIX];
     __shared__ uint32_t s_gid[LOCAL_MAX];   // local depth order: the tile's sorted list
     const int ntiles = ntiles_strip & 0xFFFFFF;
@@ -42,6 +43,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(const uint2 *__rest
     const int nb = ckpt_buckets(range);                                 // (> 1: a long list, checkpointed for the bucket-parallel backward)
     const int cpix = ((py - by * TILE_Y) << 4) + (px - bx * TILE_X);      // pixel's place in a checkpoint slot
     int next_slot = 0;
+    int visits = 0;   // (wave-uniform) (splat, quadrant) visits = 64 pairs each
     for (int i = 0; i < rounds; i++, toDo -= TILE_PIX) {
         if (__syncthreads_count(live == 0.f) == TILE_PIX) break;
         if (nb > 1 && i > 0 && (i * TILE_PIX) % BUCKET == 0) ckpt_slot(lb.ckpt, range, tile, next_slot++)[cpix] = make_float4(T, C0, C1, C2);
@@ -65,6 +67,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(const uint2 *__rest
         for (int k = 0; k < 4; k++) {
             uint64_t m = masks[k];
             if (m != 0ull && __ballot(live != 0.f) == 0ull) break;   // every pixel of the quadrant has stopped (checked per 64 entries)
+            visits += __popcll(m);
             while (m != 0ull) {
                 const int j = k * 64 + __builtin_ctzll(m);
                 m &= m - 1ull;
@@ -99,6 +102,10 @@ __global__ void __launch_bounds__(256) render_forward_kernel(const uint2 *__rest
         out_color[plane + pix] = C1 + T * bg[1];
         out_color[2 * plane + pix] = C2 + T * bg[2];
     }
+    if (pairs != nullptr && lane == 0 && visits > 0) {
+        atomicAdd(pairs, (unsigned long long)visits * 64ull);
+        atomicAdd(pairs + 2, (unsigned long long)visits);
+    }
 }
 
 int launch_render_forward(const das3r_raster_args *a, const float *colors_precomp, float *out_color, char *geom, char *binning,
@@ -110,7 +117,7 @@ int launch_render_forward(const das3r_raster_args *a, const float *colors_precom
                  (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height, L.tiles_x, pack_tiles(L),
                  (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),
                  (const float4 *)(geom + L.pub.rgbd), a->bg, (float *)(img + L.pub.final_T), (uint32_t *)(img + L.pub.n_contrib),
-                 out_color, lb);
+                 out_color, lb, pair_counters());
     KERNEL_CHECK(s, a->debug, "render_forward");
     return DAS3R_OK;
 }

@@ -84,7 +84,8 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
                                                                   const float4 *__restrict__ conic_opacity,
                                                                   const float4 *__restrict__ rgbd, const float *__restrict__ bg,
                                                                   float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
-                                                                  float *__restrict__ out_color, const LocalBin lb) {
+                                                                  float *__restrict__ out_color, const LocalBin lb,
+                                                                  unsigned long long *__restrict__ pairs /*common.h pair_counters()*/) {
     // PREFETCH: two staging areas in turn — ONE barrier per batch (publish the batch); a wave that is done with batch i goes on
     // to stage batch i + 1 into the other area while slower waves still composite batch i (the barrier of batch i + 1 needs
     // everybody past batch i: the area being overwritten held batch i - 1).  The four quadrants of a tile rarely have equally long sub-lists, and with
@@ -123,6 +124,7 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
     // PREFETCH state: pf = record of this thread's entry of the batch about to be staged, g_ahead = its list word one batch further
     float4 pf0 = make_float4(0.f, 0.f, 0.f, 0.f), pf1 = pf0, pf2 = pf0;
     uint32_t g_ahead = 0u;
+    int positions = 0;   // (wave-uniform) list positions walked = 64 pairs each (four 4x4 blocks x 16 pixels)
     if (PREFETCH) {
         const uint32_t len = range.y - range.x;
         if ((uint32_t)tid < len) {
@@ -175,6 +177,7 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
         constexpr int UNROLL = 4;
         for (int t = 0; t < longest; t += UNROLL) {
             if ((t & 15) == 0 && __ballot(live != 0.f) == 0ull) break;   // every pixel of the quadrant has stopped
+            positions += UNROLL;
             int jj[UNROLL];
             float aa[UNROLL];
 #pragma unroll
@@ -221,6 +224,10 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
         out_color[plane + pix] = C1 + T * bg[1];
         out_color[2 * plane + pix] = C2 + T * bg[2];
     }
+    if (pairs != nullptr && lane == 0 && positions > 0) {
+        atomicAdd(pairs, (unsigned long long)positions * 64ull);
+        atomicAdd(pairs + 2, (unsigned long long)positions);
+    }
 }
 
 // The row lists cost ~200 instructions per wave and batch to build: worth it once a tile's list is long.  DAS3R_RENDER=quad /
@@ -237,7 +244,7 @@ int launch_render_forward_rows(const das3r_raster_args *a, float *out_color, cha
     (const uint2 *)(img + L.pub.ranges), (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height,  \
         L.tiles_x, pack_tiles(L), (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),         \
         (const float4 *)(geom + L.pub.rgbd), a->bg, (float *)(img + L.pub.final_T), (uint32_t *)(img + L.pub.n_contrib),   \
-        out_color, lb
+        out_color, lb, pair_counters()
     // globally sorted lists and fewer tiles than the chip has workgroup slots (4 per CU and more): see PREFETCH
     const bool prefetch = lb.point_list == nullptr && L.ntiles <= 1024 && !switches().fwd_no_prefetch;
     if (prefetch) DAS3R_LAUNCH((render_forward_rows_kernel<true>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS);

@@ -39,7 +39,8 @@ def algorithmic_bytes(P, D, M, I, W, H):
 
 ALIASES = {"render_forward_rows_kernel": "render_forward_kernel",     # two implementations of each compositing stage
            "render_backward_mfma_kernel": "render_backward_kernel",    # (render_rows.hip, render_bwd_mfma.hip,
-           "render_backward_scan_kernel": "render_backward_kernel"}    #  render_bwd_scan.hip)
+           "render_backward_scan_kernel": "render_backward_kernel",    #  render_bwd_scan.hip, render_bwd_blk.hip)
+           "render_backward_blk_kernel": "render_backward_kernel"}
 
 
 def group_kernel_times(report):

@@ -256,6 +256,12 @@ int das3r_raster_get_layout(int32_t P, int64_t capacity, int32_t W, int32_t H, d
 void das3r_profile_enable(int on);
 int das3r_profile_report(char *buf, size_t cap);
 
+/* Pair counters of the compositing kernels (bench.py: pairs per second).  enable != 0: zero the counters and count from now on;
+ * enable == 0: stop, and read into out (may be NULL): out[0] (pixel, splat) pairs the forward compositing kernel evaluated, [1] the
+ * same for the backward kernel, [2] / [3] their wave iterations (64 pairs each).  Costs one atomic per wave while enabled, nothing
+ * otherwise.  Single-threaded use; synchronises the device. */
+int das3r_pair_counters(int enable, uint64_t out[4]);
+
 /* The library reads its diagnostic / experiment switches (environment variables DAS3R_*) once, at the first
  * call; a process that changes them afterwards (tests, A-B tools) calls this to have them read again. */
 void das3r_reload_switches(void);

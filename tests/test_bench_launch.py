@@ -31,6 +31,22 @@ def test_gpus_flag_spawns_that_many_ranks():
         assert key in out
 
 
+def test_a_failing_rank_still_yields_the_line():
+    """a rank whose job dies keeps its appointments (barriers, reductions); the line comes out with ok = 0 for it,
+    its units do not count, and per_rank_ms shows every rank's own time."""
+    env = _env()
+    env["DAS3R_BENCH_STUB_FAIL_RANK"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--stub"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = _json_line(p.stdout)
+    assert out["n_gpus"] == 2 and out["ranks_ok"] == [1, 0] and len(out["per_rank_ms"]) == 2
+    assert "rank 1 failed" in p.stderr
+    ok = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--stub"],
+                        capture_output=True, text=True, timeout=300, env=_env(), cwd=ROOT)
+    assert _json_line(ok.stdout)["ranks_ok"] == [1, 1]
+
+
 def test_single_rank_stub_and_world_size_mismatch():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--stub"],
                        capture_output=True, text=True, timeout=300, env=_env(), cwd=ROOT)
@@ -69,3 +85,6 @@ def test_counter_csv_rows_are_grouped_and_converted(tmp_path):
                    ("render_forward_kernel", "render_forward_rows_kernel", 10.0 * 1024 * 2),
                    ("binning", "onesweep_pass_kernel", 3.0 * 1024 * 2), ("binning", "scan_emit_kernel", 1.0 * 1024 * 2)]
     assert list(bench.pmc_rows([str(f)], "WRITE_SIZE")) == [("preprocess_kernel", "preprocess_kernel", 7.0 * 1024)]
+    g = tmp_path / "valu_counter_collection.csv"
+    g.write_text(head + row(1, "void das3r::render_backward_blk_kernel<128, 1, 0, 5>(int)", "SQ_INSTS_VALU", 2.5e8))
+    assert list(bench.pmc_rows([str(g)], "SQ_INSTS_VALU")) == [("render_backward_kernel", "render_backward_blk_kernel", 2.5e8)]   # a count, not KiB
