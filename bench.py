@@ -212,11 +212,12 @@ class RasterJob:
         return color
 
     def forward_only(self):
-        """The forward render alone (BASELINE.json's metric names "render fwd/bwd Msplats/s": this is the fwd figure)."""
+        """The forward render alone (BASELINE.json's metric names "render fwd/bwd Msplats/s": this is the fwd figure): the same call as
+        in step(), graph and saved buffers included, without the backward.  (Under torch.no_grad the rasterizer would wait for the
+        forward's binning self-check on every call — what an evaluation render wants, not what a training forward does.)"""
         L = self.leaves
-        with self._torch.no_grad():
-            color, radii = self.rast(means3D=L["means3D"], means2D=self.means2D, opacities=L["opacities"], shs=L["shs"], scales=L["scales"],
-                                     rotations=L["rotations"])
+        color, radii = self.rast(means3D=L["means3D"], means2D=self.means2D, opacities=L["opacities"], shs=L["shs"], scales=L["scales"],
+                                 rotations=L["rotations"])
         return color
 
 
@@ -598,7 +599,7 @@ def main():
                "dtype": "f32", "data": "synthetic",
                "fwd_only": (None if fwd_elapsed is None else
                             {"value": round(rk.world * P_report / (fwd_elapsed / args.steps) / 1e6, 3), "unit": "Msplats/s",
-                             "ms_per_step": round(fwd_elapsed / args.steps * 1e3, 4), "what": "forward render alone (no_grad), same K / barrier protocol"}),
+                             "ms_per_step": round(fwd_elapsed / args.steps * 1e3, 4), "what": "forward render alone (training-mode call, no backward), same K / barrier protocol"}),
                "per_rank_ms": per_rank_ms, "ranks_ok": ranks_ok,
                "config": {"workload": WORKLOAD_DESC[args.workload], "name": args.workload, "splats_per_gpu": P_report,
                           "splats_per_gpu_final": job.P, "init_steps": INIT_STEPS if args.workload != "c4d" else 1, "image": [sc.W, sc.H], "sh_degree": sc.sh_degree, "num_rendered": job.num_rendered,

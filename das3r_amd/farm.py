@@ -99,8 +99,11 @@ def run_sequence_job(scene_id, iterations, device, frames=6, seq_dir=None, out_d
             from .io_formats import save_model_ply, save_poses_npy
             save_model_ply(os.path.join(out_dir, "point_cloud", f"iteration_{iterations}", "point_cloud.ply"), model)
             save_poses_npy(os.path.join(out_dir, "pose", f"pose_{iterations}.npy"), [model.get_RT(i) for i in range(len(cams))])
+        # a report over zero views (ground-truth masks exist for the sequence but none of the held-out views has one) is no result:
+        # ok = 0 keeps its NaN out of the table's mean
+        import math
         return dict(scene_id=scene_id, psnr=rep["psnr"], l1=rep["l1"], iters_per_s=stats["iters_per_s"],
-                    n_splats=model.get_xyz.shape[0], ok=1)
+                    n_splats=model.get_xyz.shape[0], ok=int(rep["views"] > 0 and math.isfinite(rep["psnr"])))
     except Exception as ex:  # noqa: BLE001 - keep the farm alive, report the failure in the table
         print(f"[farm] sequence {scene_id} failed: {ex!r}")
         return dict(scene_id=scene_id, psnr=float("nan"), l1=float("nan"), iters_per_s=0.0, n_splats=0, ok=0)

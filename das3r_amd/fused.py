@@ -93,6 +93,8 @@ class FusedAdam:
     with "lr_rest": one [P, 1 + K, 3] tensor holding DC + rest (no torch.cat in the render path, no split in its backward),
     DC stepping with "lr", the rest with "lr_rest"."""
 
+    is_fused = True   # das3r_amd.render: the DC-only SH shortcut needs an optimizer that counts the steps of a gradient-less f_rest
+
     def __init__(self, params, lr=0.0, betas=(0.9, 0.999), eps=1e-15):
         self.param_groups = []
         for g in params:

@@ -203,6 +203,34 @@ def load_sequence(seq_dir, device="cpu", gt_mask_dir=None, dataset="sintel"):
     return res
 
 
+def write_sequence_dir(seq, seq_dir):
+    """The inverse of load_sequence: write a sequence in the layout das3r_amd.train.synthetic_sequence / load_sequence use as the
+    preprocessed DAS3R directory utils/rearrange.py:44-133 produces (images/frame_%04d.png, sparse/0/{cameras,images}.txt,
+    pred_traj.txt (TUM), pred_intrinsics.txt, depth_maps/frame_%04d.npy, confidence_maps/conf_%04d.npy, dyna_avg/dyna_avg_%04d.npy).
+    Used by the tests and by tools/farm_davis_shape.py to run the farm on sequences of the reference's real sizes."""
+    from PIL import Image
+    os.makedirs(seq_dir, exist_ok=True)
+    for sub in ("images", "sparse/0", "depth_maps", "confidence_maps", "dyna_avg"):
+        os.makedirs(os.path.join(seq_dir, sub), exist_ok=True)
+    F = int(seq["images"].shape[0])
+    names = [f"frame_{i:04d}.png" for i in range(F)]
+    c2w = seq["cam2world"].detach().cpu().numpy().astype(np.float64)
+    # pred_traj.txt stores (qx, qy, qz, qw); DAS3R reads the rotation of the quaternion (real = qx, i = qy, j = qz, k = qw)
+    quat = np.stack([np.roll(rotation_to_quat_wxyz(m[:3, :3]), 1) for m in c2w])
+    write_tum_trajectory(os.path.join(seq_dir, "pred_traj.txt"), np.arange(F), c2w[:, :3, 3], quat)
+    K = seq["K"].detach().cpu().numpy()
+    np.savetxt(os.path.join(seq_dir, "pred_intrinsics.txt"), K.reshape(F, 9))
+    write_colmap_cameras_text(os.path.join(seq_dir, "sparse/0/cameras.txt"), (int(seq["W"]), int(seq["H"])), K)
+    write_colmap_images_text(os.path.join(seq_dir, "sparse/0/images.txt"), list(c2w), names)
+    for i in range(F):
+        img = (seq["images"][i].detach().permute(1, 2, 0).cpu().numpy() * 255).round().astype(np.uint8)
+        Image.fromarray(img).save(os.path.join(seq_dir, "images", names[i]))
+        np.save(os.path.join(seq_dir, "depth_maps", f"frame_{i:04d}.npy"), seq["depths"][i].detach().cpu().numpy())
+        np.save(os.path.join(seq_dir, "confidence_maps", f"conf_{i:04d}.npy"), seq["confs"][i].detach().cpu().numpy())
+        np.save(os.path.join(seq_dir, "dyna_avg", f"dyna_avg_{i:04d}.npy"), seq["dyna_avg"][i].detach().cpu().numpy())
+    return names
+
+
 # ---- extended 3DGS PLY ----------------------------------------------------------------------------------------------------
 def ply_attribute_names(n_dc, n_rest, n_scale=3, n_rot=4):
     """Property order of the reference's save_ply (scene/gaussian_model.py:326-341)."""

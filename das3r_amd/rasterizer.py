@@ -280,6 +280,9 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
                                      raster_settings)
 
 
+_last = threading.local()
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
@@ -305,6 +308,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
         ctx.capacity = capacity
+        _last.capacity = capacity   # GaussianRasterizer.forward: a render that no backward pass will follow checks itself
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities, geomBuffer,
                               binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii)
@@ -377,5 +381,12 @@ class GaussianRasterizer(nn.Module):
             rotations = e
         if cov3D_precomp is None:
             cov3D_precomp = e
-        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                   raster_settings)
+        _last.capacity = None
+        color, radii = rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                           raster_settings)
+        if not color.requires_grad and getattr(_last, "capacity", None) is not None:
+            # evaluation (torch.no_grad, or no input that takes a gradient): no backward pass will examine this forward's binning
+            # self-check, so it is examined here, before the image is used (include/das3r_raster.h: das3r_raster_check)
+            check_forward(_last.capacity, means3D.device)
+        _last.capacity = None
+        return color, radii

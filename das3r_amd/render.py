@@ -22,7 +22,7 @@ import math
 
 import torch
 
-from .camera import camera_from_tensor, quat_multiply
+from .camera import camera_from_tensor, projection_matrix, quat_multiply
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 _SH_C0 = 0.28209479177387814
@@ -69,7 +69,14 @@ def _settings(cam, pc, pipe, bg_color, scaling_modifier, device, model_fov=False
     # render_no_soft (gaussian_renderer/__init__.py:308-319) takes the field of view from the MODEL (pc.FoVx / FoVy, the two inert
     # optimizer groups of scene/gaussian_model.py:165-166,253-254) and rebuilds the projection from it
     fovx, fovy = (pc.FoVx, pc.FoVy) if model_fov else (cam.FoVx, cam.FoVy)
-    pm = cam.get_projection_matrix(fovx, fovy) if model_fov else cam.projection_matrix
+    if model_fov and (fovx is None or fovy is None):
+        raise RuntimeError("render_no_soft takes the field of view from the model: call SplatModel.init_fov(FoVx, FoVy) first "
+                           "(build_from_sequence does)")
+    if model_fov:   # rebuilt from the model's field of view; cameras that carry the reference's method keep theirs
+        pm = (cam.get_projection_matrix(fovx, fovy) if hasattr(cam, "get_projection_matrix")
+              else projection_matrix(0.01, 100.0, float(fovx), float(fovy)).transpose(0, 1))
+    else:
+        pm = cam.projection_matrix
     proj = ident.unsqueeze(0).bmm(pm.to(device).unsqueeze(0)).squeeze(0)
     return GaussianRasterizationSettings(
         image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=math.tan(float(fovx) * 0.5),
@@ -113,7 +120,10 @@ def rasterizer_inputs(cam, pc, pipe, bg_color, scaling_modifier=1.0, override_co
         # while the active SH degree is 0 (iterations < 3000 of DAS3R's 4000) only the DC coefficient is read: the rasterizer gets
         # the [P, 1, 3] DC tensor itself (M = 1) instead of cat(f_dc, f_rest) — same image bit for bit, 12 instead of 192 bytes of
         # SH per splat each way; f_rest then has no gradient (FusedAdam counts its steps all the same: fused.py)
-        shs = pc._features_dc if pc.active_sh_degree == 0 else pc.get_features
+        # — only with the fused optimizer: torch.optim.Adam skips a parameter without gradient, so its step count (and bias
+        # correction) for f_rest would restart at the degree bump, where the reference has counted 3000 zero-gradient steps
+        fused_opt = getattr(getattr(pc, "optimizer", None), "is_fused", False)
+        shs = pc._features_dc if (pc.active_sh_degree == 0 and fused_opt) else pc.get_features
         return settings, dict(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None, opacities=opacity, scales=scales,
                               rotations=rotations, cov3D_precomp=None)
 

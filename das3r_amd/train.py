@@ -150,7 +150,8 @@ def psnr_report(model, cameras, dynamic_masks=None, pipe=None, background=None, 
     lens = skipped = 0
     for cam in cameras:
         pose = model.get_RT_test(cam.uid) if test_poses else model.get_RT(cam.uid)
-        img = torch.clamp(das3r_render(cam, model, pipe, background, camera_pose=pose)["render"], 0.0, 1.0)
+        with torch.no_grad():   # evaluation: the rasterizer then examines the forward's self-check itself (no backward will)
+            img = torch.clamp(das3r_render(cam, model, pipe, background, camera_pose=pose)["render"], 0.0, 1.0)
         gt = torch.clamp(cam.original_image, 0.0, 1.0)
         if dynamic_masks is not None:
             m = dynamic_masks.get(cam.uid) if hasattr(dynamic_masks, "get") else dynamic_masks[cam.uid]

@@ -73,25 +73,12 @@ def test_farm_job_on_a_sequence_directory(tmp_path):
     from das3r_amd.train import synthetic_sequence
     seq = synthetic_sequence(frames=4, W=64, H=48, focal=70.0, n_splats=2500, seed=5)
     d = tmp_path / "data" / "scene_a"
-    for sub in ("images", "sparse/0", "depth_maps", "confidence_maps", "dyna_avg"):
-        (d / sub).mkdir(parents=True)
+    io.write_sequence_dir(seq, str(d))
     F = seq["images"].shape[0]
-    names = [f"frame_{i:04d}.png" for i in range(F)]
     c2w = seq["cam2world"].cpu().numpy().astype(np.float64)
-    # pred_traj.txt stores (qx, qy, qz, qw); DAS3R reads the rotation of the quaternion (real = qx, i = qy, j = qz, k = qw)
-    quat_wxyz = np.stack([np.roll(io.rotation_to_quat_wxyz(m[:3, :3]), 1) for m in c2w])
-    io.write_tum_trajectory(d / "pred_traj.txt", np.arange(F), c2w[:, :3, 3], quat_wxyz)
-    for i in range(F):
-        assert np.allclose(io.tumpose_to_c2w(np.concatenate([c2w[i, :3, 3], quat_wxyz[i]])), c2w[i], atol=1e-6)
-    K = seq["K"].cpu().numpy()
-    np.savetxt(d / "pred_intrinsics.txt", K.reshape(F, 9))
-    io.write_colmap_cameras_text(d / "sparse/0/cameras.txt", (seq["W"], seq["H"]), K)
-    io.write_colmap_images_text(d / "sparse/0/images.txt", list(c2w), names)
-    for i in range(F):
-        Image.fromarray((seq["images"][i].permute(1, 2, 0).cpu().numpy() * 255).round().astype(np.uint8)).save(d / "images" / names[i])
-        np.save(d / "depth_maps" / f"frame_{i:04d}.npy", seq["depths"][i].cpu().numpy())
-        np.save(d / "confidence_maps" / f"conf_{i:04d}.npy", seq["confs"][i].cpu().numpy())
-        np.save(d / "dyna_avg" / f"dyna_avg_{i:04d}.npy", seq["dyna_avg"][i].cpu().numpy())
+    for i in range(F):   # the TUM line of frame i reproduces its camera-to-world matrix
+        _, xyz, quat = io.read_tum_trajectory(d / "pred_traj.txt")
+        assert np.allclose(io.tumpose_to_c2w(np.concatenate([xyz[i], quat[i]])), c2w[i], atol=1e-6)
     assert sequence_cost(str(d)) == F * seq["W"] * seq["H"]
     out = tmp_path / "out" / "scene_a"
     rec = run_sequence_job(0, 12, torch.device("cuda:0"), seq_dir=str(d), out_dir=str(out), fused=True)

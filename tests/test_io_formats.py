@@ -131,6 +131,29 @@ def test_load_sequence_from_a_directory(tmp_path):
     assert s["dynamic_masks"][0] is not None and s["dynamic_masks"][1] is None and s["names"] == names
 
 
+def test_write_sequence_dir_round_trip(tmp_path):
+    """write_sequence_dir -> load_sequence gives the sequence back (images to 8 bits, everything else exactly / to fp32 text precision)."""
+    rng = np.random.default_rng(7)
+    F, H, W = 4, 10, 16
+    q = rng.normal(size=(F, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    c2w = np.stack([io.tumpose_to_c2w(np.concatenate([rng.normal(size=3), q[i]])) for i in range(F)]).astype(np.float32)
+    K = np.tile(np.array([[25.0, 0, W / 2], [0, 27.0, H / 2], [0, 0, 1]], dtype=np.float32), (F, 1, 1))
+    seq = dict(images=torch.from_numpy(rng.integers(0, 256, size=(F, 3, H, W)).astype(np.float32) / 255.0),
+               depths=torch.from_numpy(rng.uniform(1, 4, size=(F, H, W)).astype(np.float32)),
+               confs=torch.from_numpy(rng.uniform(0, 3, size=(F, H, W)).astype(np.float32)),
+               dyna_avg=torch.from_numpy(rng.uniform(0, 1, size=(F, H, W)).astype(np.float32)),
+               K=torch.from_numpy(K), cam2world=torch.from_numpy(c2w), W=W, H=H)
+    names = io.write_sequence_dir(seq, str(tmp_path / "seq"))
+    s = io.load_sequence(str(tmp_path / "seq"))
+    assert s["names"] == names and (s["W"], s["H"]) == (W, H)
+    assert np.array_equal((s["images"].numpy() * 255).round(), (seq["images"].numpy() * 255).round())
+    for k in ("depths", "confs", "dyna_avg"):
+        assert np.array_equal(s[k].numpy(), seq[k].numpy()), k
+    assert np.allclose(s["cam2world"].numpy(), c2w, atol=2e-6)
+    assert np.allclose(s["K"][:, 0, 0].numpy(), 25.0, rtol=1e-6) and np.allclose(s["K"][:, 1, 1].numpy(), 27.0, rtol=1e-6)
+
+
 def test_save_poses_npy(tmp_path):
     poses = torch.tensor([[1.0, 0, 0, 0, 0.1, 0.2, 0.3], [0.9, 0.1, -0.2, 0.3, 1, 2, 3]])
     m = io.save_poses_npy(tmp_path / "pose" / "pose_4000.npy", poses)
