@@ -472,6 +472,14 @@ def extras_main(main_workload):
     out["train_step_fused_ms"] = round(rk.timed(fs_step, 100, 10) / 100 * 1e3, 4)
     out["train_step_splats"] = fs_splats
     del fs_step
+    torch.cuda.empty_cache()
+    # the same step at the DAVIS size of the reference's held-out runs: 45 training frames of 512x288 = 6.6 M Gaussians
+    # (scripts/testing_psnr_davis.sh:35-59; the whole 4000-iteration job at that size: profiles/r03_farm_davis_shape.json)
+    ds_step, ds_splats = train_step_timer(dev, fused=True, frames=45, W=512, H=288)
+    for _ in range(10):
+        ds_step()
+    out["train_step_davis"] = {"fused_ms": round(rk.timed(ds_step, 50, 5) / 50 * 1e3, 4), "splats": ds_splats, "frames": 45, "image": [512, 288]}
+    del ds_step
     for w, k in (("c2", 300), ("ds", 50), ("c1", 300), ("c4d", 700), ("c4", 200)):
         if w == main_workload:
             continue
@@ -577,6 +585,8 @@ def main():
         if extras and "train_step_fused_ms" in extras:
             train = {"fused": extras.pop("train_step_fused_ms"), "splats": extras.pop("train_step_splats", None), "frames": 20,
                      "image": [512, 208], "iters": 100}
+            if "train_step_davis" in extras:
+                train["davis_shape"] = extras.pop("train_step_davis")
             if "train_step_unfused_ms" in extras:
                 train["unfused"] = extras.pop("train_step_unfused_ms")
     if train is None:
