@@ -87,6 +87,7 @@ static void load_switches() {
     if ((e = env("DAS3R_BWD_PAD_LDS"))) w.bwd_pad_lds = atoi(e);
     if ((e = env("DAS3R_FWD_PAD_LDS"))) w.fwd_pad_lds = atoi(e);
     if ((e = env("DAS3R_INJECT_FAULT"))) w.inject_fault = atoi(e);
+    w.deterministic = (e = env("DAS3R_DETERMINISTIC")) && e[0] != '0';
     w.bwd_buckets = -1;
     if ((e = env("DAS3R_BWD_BUCKETS"))) w.bwd_buckets = atoi(e);
     w.fwd_no_prefetch = (e = env("DAS3R_FWD_PREFETCH")) && e[0] == '0';

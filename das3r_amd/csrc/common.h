@@ -30,6 +30,8 @@ struct Switches {
     int render_fwd;        // DAS3R_RENDER=quad | rows: 1 | 2 (0: by list length)
     int render_bwd;        // DAS3R_RENDER_BWD=dpp | mfma | scan... | stream | blk...: 1 | 2 | 3 | 5 | 6 (0: by list length)
     int render_bwd_mb;     // scan64 / scan128 / scan256, blk64 / blk128 / blk256: entries per round; scana256 / scana512: 1000 + entries, atomic flush
+    bool deterministic;    // DAS3R_DETERMINISTIC=1: bit-identical gradients run to run (the block-walk backward for every list length:
+                           // the pixel-per-lane kernel meets its four waves with LDS float atomics, whose order varies)
     int render_bwd_occ;    // blk...o<4|5>: workgroups per CU the kernel is compiled for (register cap)
     int render_bwd_pix;    // blk...p<0|1|2>: where render_bwd_blk.hip keeps the per-pixel values (render_blk.h)
     bool bwd_reduce_set, bwd_reduce_shfl;   // DAS3R_BWD_REDUCE=shfl | dpp (reference reduction of the pixel-per-lane kernel)

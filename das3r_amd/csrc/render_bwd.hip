@@ -185,6 +185,10 @@ int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, cha
         const bool long_lists = mean_list >= 96;
         kind = (sw.bwd_reduce_set || sw.ablate_set || !long_lists) ? 1 : 6;
         mb = mean_list >= 1024 ? 192 : 128;
+        if (sw.deterministic && kind == 1) {   // short lists too on the block walk: every sum has a fixed order (rows 0..3 of a wave, waves 0..3)
+            kind = 6;
+            mb = 64;
+        }
     }
 #ifdef DAS3R_EXPERIMENTS
     if (kind == 5) {

@@ -309,6 +309,24 @@ def test_forward_kernels_agree_bit_for_bit(name, monkeypatch):
         util.assert_grad_close(gr[k].cpu().numpy(), gq[k].cpu().numpy(), f"rows vs quad forward dL/d{k}", tol=1e-5)
 
 
+def test_deterministic_switch_gives_bit_identical_gradients(monkeypatch):
+    """a bit-deterministic mode for tests.  DAS3R_DETERMINISTIC=1 takes the block-walk backward for every
+    list length (its sums have a fixed order; the pixel-per-lane kernel of short lists meets its four waves with LDS float atomics):
+    two runs of the same scene give the same bits in every gradient — short lists (the default would be the dpp kernel), long
+    lists and the bucket-parallel replay alike."""
+    monkeypatch.setenv("DAS3R_DETERMINISTIC", "1")   # (conftest.py: the library re-reads its switches)
+    for name in ("basic_deg3", "long_lists", "deep"):
+        sc, mode = util.scene_variant(name)
+        _, _, g0, _ = _run_hip(sc, mode)
+        for _ in range(3):
+            _, _, g1, _ = _run_hip(sc, mode)
+            for k in g0:
+                assert torch.equal(g0[k], g1[k]), (name, k)
+        _, _, ref_g, _ = util.run_oracle(sc, mode)
+        for k, t in g0.items():
+            util.assert_grad_close(t.cpu().numpy(), ref_g[k], f"{name} deterministic dL/d{k}")
+
+
 SCAN_KINDS = ("scan64", "scan128", "scan256", "scana256",   # render_bwd_scan.hip: entries per round, private / atomic flush
               "blk64", "blk128", "blk256")                  # render_bwd_blk.hip: 4x4 block per DPP row, entries per round
 EXPERIMENT_KINDS = ("mfma", "stream")                        # superseded kernels: only in `make EXPERIMENTS=1` builds of the library
