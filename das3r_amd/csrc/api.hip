@@ -580,6 +580,24 @@ extern "C" int das3r_mark_visible(int32_t P, const float *means3D, const float *
     return launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
 }
 
+// ---- test aid: fill every CU's LDS with a bit pattern ----
+// The compositing kernels leave parts of their LDS arrays unwritten (list tails, staged entries past a tile's list); what they
+// then read must not matter.  A test fills the LDS of every CU with NaNs / all-ones first (tests/test_gpu_raster.py).
+__global__ void __launch_bounds__(1024) poison_lds_kernel(uint32_t pattern, uint32_t *sink) {
+    extern __shared__ uint32_t lds_words[];
+    for (int i = threadIdx.x; i < 160 * 256 - 64; i += 1024) lds_words[i] = pattern;   // just under the CU's 160 KB
+    __syncthreads();
+    if (lds_words[(threadIdx.x * 37) % (160 * 256 - 64)] != pattern) *sink = 1u;       // (keeps the stores alive)
+}
+extern "C" int das3r_debug_poison_lds(uint32_t pattern, das3r_stream_t stream) {
+    static uint32_t *sink = nullptr;
+    if (!sink) HIP_TRY(hipMalloc((void **)&sink, 4));
+    HIP_TRY(hipFuncSetAttribute((const void *)poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (160 * 256 - 64) * 4));
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(1024), dim3(1024), (160 * 256 - 64) * 4, (hipStream_t)stream, pattern, sink);
+    HIP_TRY(hipGetLastError());
+    return DAS3R_OK;
+}
+
 // ---- pair counters ----
 static unsigned long long *g_pairs = nullptr;
 namespace das3r { unsigned long long *pair_counters() { return g_pairs; } }

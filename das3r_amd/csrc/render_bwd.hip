@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
                 float dx, dy, G, alpha;
                 const bool active = pair_alpha(p.x, p.y, co, pxf, pyf, dx, dy, G, alpha) & (position < last_contributor);
                 if (__ballot(active) == 0ull) continue;  // wave-uniform skip
-                const float4 c = stage[j].rgbd;
+                const float4 c = lds_read4(&stage[j].rgbd);   // (b128, not b96: half the LDS cycles)
                 float v[NACC];
                 replay_pair_moments(active, alpha, G, dx, dy, c, dLp0, dLp1, dLp2, tfbg, st, v);   // geometry sums as raw moments
                 float out;

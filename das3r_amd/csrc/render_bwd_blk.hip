@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(256, OCC) render_backward_blk_kernel(
                 {
                     const float4 p = stage[j].xyh;
                     const float4 co = stage[j].co;
-                    const float4 c = stage[j].rgbd;
+                    const float4 c = lds_read4(&stage[j].rgbd);   // (b128, not b96: half the LDS cycles)
                     sp.x = p.x; sp.y = p.y;
                     sp.A = co.x; sp.B = co.y; sp.C = co.z;
                     sp.o = valid ? co.w : 0.f;   // a lane without an entry: alpha = 0 on every pixel

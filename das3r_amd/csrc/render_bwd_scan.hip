@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(256, (MB <= 128 ? 4 : 2)) render_backward_scan
             const int j = list[valid ? e : cnt - 1];
             const float4 p = stage[j].xyh;
             float4 co = stage[j].co;
-            const float4 c = stage[j].rgbd;
+            const float4 c = lds_read4(&stage[j].rgbd);   // (b128, not b96: half the LDS cycles)
             co.w = valid ? co.w : 0.f;   // an empty slot of the last batch: alpha = 0 on every pixel
             const uint32_t position = lo + max_contrib - 1 - done_before - j;   // 0-based list position of the lane's splat
             v4f Dw = {0.f, 0.f, 0.f, 0.f}, Dg = {0.f, 0.f, 0.f, 0.f};

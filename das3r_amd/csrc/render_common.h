@@ -18,6 +18,25 @@ struct StagedSplat {   // one LDS-staged entry of a tile's splat list (48 B)
     float4 rgbd;       // r, g, b, (depth)
 };
 
+// A staged float4 of which only x, y, z are used is fetched with ds_read_b96 — 8 LDS cycles per wave instruction against 4 for
+// ds_read_b128 (MI355X_MICROARCH.md, LDS table).  Keeping the fourth component formally alive makes it the 128-bit read.
+__device__ __forceinline__ float4 lds_read4(const float4 *p) {
+    const float4 v = *p;
+    asm volatile("" ::"v"(v.w));
+    return v;
+}
+
+// The row walk of render_rows.hip reads a staged entry for EVERY position of its trips, also past the end of a row's list (the
+// list byte there is stale, the arithmetic makes the pair inert): the entry it lands on must hold finite numbers — 0 x NaN is NaN —
+// so the entries of a batch beyond the tile's list are filled with this one.
+__device__ __forceinline__ StagedSplat null_splat() {
+    StagedSplat z;
+    z.xyh = make_float4(0.f, 0.f, -1e30f, -1e30f);
+    z.co = make_float4(0.f, 0.f, 0.f, 0.f);
+    z.rgbd = make_float4(0.f, 0.f, 0.f, 0.f);
+    return z;
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() fences every address space: on gfx950 (one vmcnt for loads and
 // stores) that is s_waitcnt vmcnt(0) in front of s_barrier, i.e. global loads issued ahead of their use — a software prefetch —
 // are waited for at the very next barrier.  Fences restricted to the LDS address space leave them in flight (s_waitcnt lgkmcnt(0)
@@ -124,6 +143,106 @@ __device__ __forceinline__ float4 *ckpt_slot(float4 *ckpt, const uint2 range, co
 }
 __device__ __forceinline__ int ckpt_buckets(const uint2 range) { return (int)((range.y - range.x + BUCKET - 1) / BUCKET); }
 
+// ---- single-wave bitonic network in registers -----------------------------------------------------------------------------
+// Sorts N = 64 << G 64-bit words in LDS ascending, executed by ONE wave: every lane holds E = 1 << G words per pass in registers
+// and takes G levels of the always-ascending bitonic network (first level of every merge mirrors the block, the rest are plain
+// butterflies) before the words go back — 16 passes for 512 words (15 for 1024) against the 45 (55) LDS round trips of a
+// comparison per thread and level, and no workgroup barrier (LDS is in order per wave).  Round 2's network kept the CU's LDS
+// busy ~60 us of the 1 M-splat forward: 2 reads + 2 writes per comparison and level, 32 tiles per CU.
+// The words are (depth bits << 32 | position) of positive finite floats, i.e. read as DOUBLES they are positive, finite and in the
+// same order: a compare-exchange is v_min_f64 + v_max_f64 instead of a 64-bit compare + four selects.  Padding: the largest finite
+// double.  CPU model: tests/test_sort_network.py.
+__device__ __forceinline__ void ce64(double &lo, double &hi) {
+    // (as builtins the compiler first canonicalises both operands — v_max_f64 x, x, x — for signalling NaNs that cannot occur here)
+    double a, b;
+    asm("v_min_f64 %0, %2, %3\n\tv_max_f64 %1, %2, %3" : "=&v"(a), "=&v"(b) : "v"(lo), "v"(hi));
+    lo = a;
+    hi = b;
+}
+constexpr unsigned long long SORT_PAD = 0x7FEFFFFFFFFFFFFFull;   // DBL_MAX: above every (depth bits << 32 | position) word
+
+// levels R - 1 .. R - g of the current merge: plain butterflies on 2^g words at stride 2^(R - g); E >> g such groups per lane
+template <int g, int E>
+__device__ __forceinline__ void butterfly_group(double *key, const int lane, const int R) {
+    const int s = R - g;
+#pragma unroll
+    for (int c = 0; c < (E >> g); c++) {
+        const int gid = c * 64 + lane;
+        const int base = ((gid >> s) << R) | (gid & ((1 << s) - 1));
+        double e[1 << g];
+#pragma unroll
+        for (int m = 0; m < (1 << g); m++) e[m] = key[base + (m << s)];
+#pragma unroll
+        for (int t = g - 1; t >= 0; t--)
+#pragma unroll
+            for (int m = 0; m < (1 << g); m++)
+                if (!((m >> t) & 1)) ce64(e[m], e[m | (1 << t)]);
+#pragma unroll
+        for (int m = 0; m < (1 << g); m++) key[base + (m << s)] = e[m];
+    }
+}
+
+template <int G>
+__device__ __forceinline__ void wave_bitonic_sort(double *key, const int lane) {
+    constexpr int E = 1 << G, H = E / 2, LOGN = 6 + G;
+    {   // pass 0: merges 1 .. G — every lane sorts its E contiguous words
+        double v[E];
+#pragma unroll
+        for (int m = 0; m < E; m++) v[m] = key[lane * E + m];
+#pragma unroll
+        for (int lk = 1; lk <= G; lk++) {
+#pragma unroll
+            for (int i = 0; i < E; i++)
+                if (!(i & (1 << (lk - 1)))) ce64(v[i], v[i ^ ((1 << lk) - 1)]);   // mirror inside the 2^lk block
+#pragma unroll
+            for (int lj = lk - 2; lj >= 0; lj--)
+#pragma unroll
+                for (int i = 0; i < E; i++)
+                    if (!((i >> lj) & 1)) ce64(v[i], v[i | (1 << lj)]);
+        }
+#pragma unroll
+        for (int m = 0; m < E; m++) key[lane * E + m] = v[m];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int lk = G + 1; lk <= LOGN; lk++) {
+        {   // mirror level of merge lk + its butterflies on bits lk - 2 .. lk - G: H words of the lower half and their mirror images
+            const int sh = lk - G;
+            const int block = lane >> sh, hbase = lane & ((1 << sh) - 1);
+            const int lo0 = (block << lk) + hbase, hi0 = (block << lk) + ((1 << lk) - 1) - hbase;
+            double a[H], b[H];
+#pragma unroll
+            for (int m = 0; m < H; m++) {
+                a[m] = key[lo0 + (m << sh)];
+                b[m] = key[hi0 - (m << sh)];
+            }
+#pragma unroll
+            for (int m = 0; m < H; m++) ce64(a[m], b[m]);
+#pragma unroll
+            for (int t = G - 2; t >= 0; t--)
+#pragma unroll
+                for (int m = 0; m < H; m++)
+                    if (!((m >> t) & 1)) {
+                        ce64(a[m], a[m | (1 << t)]);
+                        ce64(b[m | (1 << t)], b[m]);   // (mirrored words: the larger m is the lower address)
+                    }
+#pragma unroll
+            for (int m = 0; m < H; m++) {
+                key[lo0 + (m << sh)] = a[m];
+                key[hi0 - (m << sh)] = b[m];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int R = lk - G; R > 0;) {   // the remaining butterflies, G levels at a time (the last group may be smaller)
+            const int g = R < G ? R : G;
+            if (g == 1) butterfly_group<1, E>(key, lane, R);
+            else if (g == 2) butterfly_group<2, E>(key, lane, R);
+            else if (g == 3) butterfly_group<3, E>(key, lane, R);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            R -= g;
+        }
+    }
+}
+
 // ---- local binning front-end (local_bin.hip) -------------------------------------------------------------------------------
 // Local depth order (common.h: LocalBin): the tile's list arrives in index order; put it in the exact (depth bits, index)
 // order the global radix path produces, in place (point_list / slot_list are read by the backward pass and the tests).
@@ -132,8 +251,9 @@ __device__ __forceinline__ int ckpt_buckets(const uint2 range) { return (int)((r
 //              one extra barrier and no extra trip to memory compared with reading a sorted list.  Returns true.
 //   n <= 1024  bitonic network on 64-bit words (depth bits << 32 | position in the list: positions follow the index order,
 //              so this is the (depth, index) order) in its always-ascending form (first step of every merge mirrors the
-//              block, the rest are plain butterflies): n needs no padding, a comparison whose partner lies beyond n is
-//              skipped.  The sorted indices stay in s_gid for the staging loop.  The words borrow the staging area.
+//              block, the rest are plain butterflies), padded to 512 or 1024 words and run by ONE wave with 8 / 16 words per
+//              lane in registers (wave_bitonic_sort).  The sorted indices stay in s_gid for the staging loop.  The words
+//              borrow the staging area.
 //   longer     the same network over global memory (slow; the host is told and goes back to the global sort for the next
 //              forwards); s_gid is not filled.
 __device__ __forceinline__ bool local_order_tile(const LocalBin &lb, const uint2 range, const float4 *__restrict__ xyh,
@@ -170,44 +290,55 @@ __device__ __forceinline__ bool local_order_tile(const LocalBin &lb, const uint2
             stage[rank].rgbd = r2;
             pl[rank] = g;
             sl[rank] = slot;
+        } else {
+            stage[tid] = null_splat();   // entries n .. 255: initialised (see null_splat)
         }
         return true;   // the compositing loop's barrier publishes the batch
     }
     if (n <= LOCAL_MAX) {
         unsigned long long *s_key = reinterpret_cast<unsigned long long *>(stage);
         uint32_t *s_slot = reinterpret_cast<uint32_t *>(stage) + 2 * LOCAL_MAX;
-        for (int i = tid; i < n; i += TILE_PIX) {
-            const uint32_t g = min(pl[i], lb.last_g);
-            s_gid[i] = g;
-            s_slot[i] = sl[i];
-            s_key[i] = ((unsigned long long)__float_as_uint(rgbd[(size_t)g * SPLAT_REC].w) << 32) | (unsigned long long)i;
+        const int N = n <= 2 * TILE_PIX ? 2 * TILE_PIX : LOCAL_MAX;   // (uniform) 512 or 1024 words, padded above n
+        for (int i = tid; i < N; i += TILE_PIX) {
+            unsigned long long k = SORT_PAD;
+            if (i < n) {
+                const uint32_t g = min(pl[i], lb.last_g);
+                s_gid[i] = g;
+                s_slot[i] = sl[i];
+                k = ((unsigned long long)__float_as_uint(rgbd[(size_t)g * SPLAT_REC].w) << 32) | (unsigned long long)i;
+            }
+            s_key[i] = k;
         }
         __syncthreads();
-        // One thread per comparison (not per element: half of those would only find that their partner is the lower one).
-        // Comparison pr touches words of the 128-word chunk pr / 64 only as long as the partner distance stays below 128, and
-        // the comparisons 64 w .. 64 w + 63 (+ 256) belong to wave w: those steps — 42 of the 45 for 512 words — need no
-        // workgroup barrier, LDS executes a wave's accesses in order.
-        int N = 2 * TILE_PIX;
-        while (N < n) N <<= 1;
-        bool wide_before = false;   // (the barrier behind the loads above covers the first step)
-        for (int lk = 1; (1 << (lk - 1)) < n; lk++)
-            for (int lj = lk - 1; lj >= 0; lj--) {
-                const bool wide = lj > 6;   // words of another wave's chunk
-                if (wide || wide_before) __syncthreads();
-                else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                wide_before = wide;
-                for (int pr = tid; pr < (N >> 1); pr += TILE_PIX) {
-                    const int i = ((pr >> lj) << (lj + 1)) | (pr & ((1 << lj) - 1));   // bit lj of i is clear
-                    const int q = (lj == lk - 1) ? (i ^ ((2 << lj) - 1)) : (i | (1 << lj));   // mirror in the block / butterfly
-                    if (q < n) {
-                        const unsigned long long a = s_key[i], b = s_key[q];
-                        if (a > b) {
-                            s_key[i] = b;
-                            s_key[q] = a;
+        if (N == 2 * TILE_PIX) {
+            // up to 512 words (the 1 M-splat 1080p benchmark: mean list 320): one wave sorts them with eight words per lane in
+            // registers (wave_bitonic_sort); the other three wait at the barrier below
+            if (tid < 64) wave_bitonic_sort<3>(reinterpret_cast<double *>(stage), tid);
+        } else {
+            // 513 .. 1024 words: round 2's network, one thread per comparison and level (sixteen words per lane in registers would
+            // cost the compositing loop behind it two waves of occupancy; these lists are rare where the local order is chosen).
+            // Comparison pr touches words of the 128-word chunk pr / 64 only as long as the partner distance stays below 128, and
+            // the comparisons 64 w .. 64 w + 63 (+ 256) belong to wave w: those steps need no workgroup barrier.
+            bool wide_before = false;   // (the barrier behind the loads above covers the first step)
+            for (int lk = 1; (1 << (lk - 1)) < n; lk++)
+                for (int lj = lk - 1; lj >= 0; lj--) {
+                    const bool wide = lj > 6;   // words of another wave's chunk
+                    if (wide || wide_before) __syncthreads();
+                    else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    wide_before = wide;
+                    for (int pr = tid; pr < (N >> 1); pr += TILE_PIX) {
+                        const int i = ((pr >> lj) << (lj + 1)) | (pr & ((1 << lj) - 1));   // bit lj of i is clear
+                        const int q = (lj == lk - 1) ? (i ^ ((2 << lj) - 1)) : (i | (1 << lj));   // mirror in the block / butterfly
+                        if (q < n) {
+                            const unsigned long long a = s_key[i], b = s_key[q];
+                            if (a > b) {
+                                s_key[i] = b;
+                                s_key[q] = a;
+                            }
                         }
                     }
                 }
-            }
+        }
         __syncthreads();
         uint32_t g[LOCAL_MAX / TILE_PIX], slot[LOCAL_MAX / TILE_PIX];
 #pragma unroll

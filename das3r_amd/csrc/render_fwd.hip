@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(const uint2 *__rest
                 m &= m - 1ull;
                 const float4 p = stage[j].xyh;
                 const float4 co = stage[j].co;
-                const float4 c = stage[j].rgbd;
+                const float4 c = lds_read4(&stage[j].rgbd);   // (b128, not b96: half the LDS cycles)
                 const float dx = p.x - pxf, dy = p.y - pyf;
                 const float q = __fmaf_rn(__fmul_rn(co.x, dx), dx, __fmul_rn(__fmul_rn(co.z, dy), dy));
                 const float power = __fmaf_rn(-0.5f, q, -__fmul_rn(__fmul_rn(co.y, dx), dy));   // (pair_alpha's arithmetic, its

@@ -147,6 +147,8 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
                 stage[tid].xyh = pf0;
                 stage[tid].co = pf1;
                 stage[tid].rgbd = pf2;
+            } else {
+                stage[tid] = null_splat();
             }
             if (progress + TILE_PIX < range.y) {       // batch i + 1: its list word arrived a batch ago
                 const uint32_t g = min(g_ahead, lb.last_g);
@@ -160,6 +162,8 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
             stage[tid].xyh = xyh[(size_t)g * SPLAT_REC];           // one 64-byte record: a single cache line per splat
             stage[tid].co = conic_opacity[(size_t)g * SPLAT_REC];
             stage[tid].rgbd = rgbd[(size_t)g * SPLAT_REC];
+        } else if (!prestaged) {
+            stage[tid] = null_splat();   // (every staged entry is initialised: see null_splat)
         }
         if (PREFETCH) lds_barrier();   // (the loads just issued stay in flight: render_common.h)
         else __syncthreads();
@@ -174,27 +178,36 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
         // r02 PMC on the DAS3R shape (1.6 waves per SIMD) showed 54 % of the wave cycles waiting, and removing every LDS wait
         // from the loop by software pipelining changed nothing — it was the ALU's own latency.  Measured, 1 / 2 / 4 / 8 positions
         // per trip: DAS3R shape 0.656 / 0.537 / 0.495 / 0.494 ms, 1 M splats at 1080p (7 waves per SIMD) 0.311 / 0.287 / 0.279 ms.
+        // Round 3: the three tests of a position (is there one, power <= 0, alpha >= 1/255) are taken by ARITHMETIC, not by compare +
+        // select pairs: on this chip v_cmp and v_cndmask issue at half the rate of a plain VALU instruction (1.76 vs 0.96 ns per
+        // wave instruction on a saturated SIMD: profiles/r03_valu_rate_probe.txt), and the loop spent 12 of them per position.
+        //   * "is there a position t + u in my list": rem - u is >= 1 where there is and <= 0 where not — a third operand of the
+        //     alpha clamp (where it decides, the minimum fails the 1/255 test); the list byte is read regardless (in bounds: the
+        //     row stride holds 260 bytes) and may name any staged entry, initialised or not: v_min3 / v_min drop a NaN operand;
+        //   * m = min(a1 - 1/255, -power) >= 0  <=>  both tests pass (a1 - 1/255 is exact near the threshold: Sterbenz);
+        //     a = max(min(a1, a1 + 1e30 m), 0): m >= 0 -> a1, m < 0 -> 0 (|m| >= 1e-21 whenever it is negative: the smallest positive
+        //     power fp32 pixel offsets can produce, and one ulp of 1/255 on the other side).
+        // Same decisions as pair_alpha, bit for bit (tests: image, n_contrib and final_T against the quad kernel and the oracle).
         constexpr int UNROLL = 4;
+        const float lenf = (float)my_len;
         for (int t = 0; t < longest; t += UNROLL) {
             if ((t & 15) == 0 && __ballot(live != 0.f) == 0ull) break;   // every pixel of the quadrant has stopped
             positions += UNROLL;
             int jj[UNROLL];
             float aa[UNROLL];
+            const float rem = lenf - (float)t;   // positions of my list from t on
 #pragma unroll
             for (int u = 0; u < UNROLL; u++) {
-                const bool has = t + u < my_len;
-                const int j = mine[has ? t + u : 0];
+                const int j = mine[t + u];
                 const float4 p = stage[j].xyh;
                 const float4 co = stage[j].co;
                 const float dx = p.x - pxf, dy = p.y - pyf;
                 const float q = __fmaf_rn(__fmul_rn(co.x, dx), dx, __fmul_rn(__fmul_rn(co.z, dy), dy));
-                const float power = __fmaf_rn(-0.5f, q, -__fmul_rn(__fmul_rn(co.y, dx), dy));   // (pair_alpha's arithmetic, its two
-                float a = fminf(0.99f, __fmul_rn(co.w, __expf(power)));                           // tests taken as selects)
-                a = power > 0.0f ? 0.f : a;
-                a = a >= (1.0f / 255.0f) ? a : 0.f;
-                a = has ? a : 0.f;
+                const float power = __fmaf_rn(-0.5f, q, -__fmul_rn(__fmul_rn(co.y, dx), dy));   // (pair_alpha's arithmetic)
+                const float a1 = fminf(fminf(0.99f, __fmul_rn(co.w, __expf(power))), rem - (float)u);
+                const float m = fminf(a1 - (1.0f / 255.0f), -power);
                 jj[u] = j;
-                aa[u] = a;
+                aa[u] = fmaxf(fminf(a1, __fmaf_rn(1e30f, m, a1)), 0.f);   // (not med3: a1 is negative where the list has no position)
             }
 #pragma unroll
             for (int u = 0; u < UNROLL; u++) {
@@ -202,7 +215,7 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
                 // (no wave-uniform skip here: a listed position nearly always has a taker among the four rows, and every such test is a
                 //  VALU -> SALU -> branch round trip)
                 const int j = jj[u];
-                const float4 c = stage[j].rgbd;
+                const float4 c = lds_read4(&stage[j].rgbd);   // (b128, not b96: half the LDS cycles)
                 const float test_T = T * (1.0f - a);
                 const bool stop = test_T < 0.0001f;   // (T >= 1e-4 on every live lane: only a contributing pair can stop a pixel)
                 const float w = stop ? 0.f : a;

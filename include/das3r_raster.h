@@ -256,6 +256,10 @@ int das3r_raster_get_layout(int32_t P, int64_t capacity, int32_t W, int32_t H, d
 void das3r_profile_enable(int on);
 int das3r_profile_report(char *buf, size_t cap);
 
+/* Test aid: one workgroup per CU (and a few more) fills the CU's whole LDS with `pattern` (e.g. 0x7FC00000 = NaN, 0xFFFFFFFF), so that
+ * a following kernel that reads LDS it has not written sees it (tests/test_gpu_raster.py). */
+int das3r_debug_poison_lds(uint32_t pattern, das3r_stream_t stream);
+
 /* Pair counters of the compositing kernels (bench.py: pairs per second).  enable != 0: zero the counters and count from now on;
  * enable == 0: stop, and read into out (may be NULL): out[0] (pixel, splat) pairs the forward compositing kernel evaluated, [1] the
  * same for the backward kernel, [2] / [3] their wave iterations (64 pairs each).  Costs one atomic per wave while enabled, nothing
