@@ -176,6 +176,7 @@ void compute_layout(int P, int64_t I, int W, int H, Layout *L) {
     L->b_totals = take(4 * RADIX_SIZE);
     L->b_gid_of = take(4 * In);
     L->b_slot = take(4 * In);
+    L->b_e2 = take(4 * In);
     L->b_ghist = take(4 * 4 * RADIX_SIZE);
     L->b_ticket = take(256);
     L->b_status = take(onesweep_status_bytes((int64_t)In, L->tile_passes));

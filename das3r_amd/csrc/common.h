@@ -135,6 +135,7 @@ struct Layout {
     // private scratch offsets
     size_t g_keyA, g_keyB, g_valA, g_valB, g_hist, g_totals, g_blocksums, g_count, g_off_by_gid, g_rect;   // g_rect: u32 per splat, binned tile rectangle x0 | x1 << 8 | y0 << 16 | y1 << 24 (0 = none)
     size_t b_keyA, b_keyB, b_valA, b_valB, b_hist, b_totals, b_gid_of, b_slot;
+    size_t b_e2;     // u32[capacity]: ping-pong partner of b_slot for the emission slots travelling through the partition passes
     size_t b_ckpt;   // float4[(capacity / BUCKET + ntiles + 2) * 256]: per-pixel (T, C) at the bucket boundaries of long tile lists
     // single-pass radix control words (sort_onesweep.hip): [global digit histograms][tickets][status granules], contiguous
     // so that one store loop / one memset zeroes them: geom side by preprocess_kernel, binning side by a memset before emit

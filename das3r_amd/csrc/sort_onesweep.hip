@@ -70,9 +70,11 @@ __global__ void __launch_bounds__(256) depth_hist_kernel(const uint32_t *__restr
 }
 
 // One digit of a stable LSD sort / partition.  keys_out may be null; vals_in null => payload = index.
-// gather_src / inv_out (FINAL): last pass of the tile partition (payload = emission slot e): vals_out = gather_src[e] (splat
-// id), inv_out = e (slot list: where the backward pass puts this instance's partial sums), both in list order.
-template <int IPL, bool FINAL>
+// TWO (the tile partition): a second payload travels with every key — the emission slot e of the instance (vals2_in null: e = the
+// input index, i.e. the first pass) beside the splat id; the last pass leaves the ids in point_list and the slots in slot_list
+// (where the backward pass puts the instance's partial sums), both in list order, all loads and stores coalesced.  Round 2
+// carried e alone and gathered gid_of[e] in the last pass: a 64-byte sector per 4-byte word, 167 of the pass's 240 MB at 1 M splats.
+template <int IPL, bool TWO>
 __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                             uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
                                                             uint32_t cap, const uint32_t *__restrict__ n_ptr, int shift, int bits,
@@ -80,7 +82,7 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
                                                             u64 *__restrict__ status /*[nblocks][256]*/,
                                                             u64 *__restrict__ group_status /*[ngroups][256]*/, int gs_log2,
                                                             uint32_t *__restrict__ ticket,
-                                                            const uint32_t *__restrict__ gather_src, uint32_t *__restrict__ inv_out,
+                                                            const uint32_t *__restrict__ vals2_in, uint32_t *__restrict__ vals2_out,
                                                             uint32_t *__restrict__ err, uint32_t *__restrict__ zero_ptr, uint32_t zero_words) {
     // side duty (last depth pass only): zero the control words of the binning buffer, which did not exist yet when the
     // preprocess kernel zeroed everything else; nothing in this kernel touches them
@@ -88,6 +90,7 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
     __shared__ uint32_t cnt[4][RADIX_SIZE];  // per-wave digit counts, then per-wave running offsets
     __shared__ uint32_t gdelta[RADIX_SIZE];
     __shared__ uint32_t sk[256 * IPL], sv[256 * IPL];  // staging: key, payload
+    __shared__ uint32_t sv2[TWO ? 256 * IPL : 1];      //          second payload
     __shared__ uint32_t ws[8];
     __shared__ uint32_t s_block;
     const int tid = threadIdx.x, lane = __lane_id(), wave = tid >> 6;
@@ -100,12 +103,13 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
     const uint32_t base = (b * 4u + (uint32_t)wave) * 64u * (uint32_t)IPL;
     const uint32_t mask = (1u << bits) - 1u;
 
-    uint32_t k[IPL], v[IPL], out[IPL];
+    uint32_t k[IPL], v[IPL], v2[TWO ? IPL : 1];
 #pragma unroll
     for (int s = 0; s < IPL; s++) {
         const uint32_t i = base + s * 64 + lane;
         k[s] = i < n ? keys_in[i] : 0u;
         v[s] = (vals_in && i < n) ? vals_in[i] : i;
+        if (TWO) v2[s] = (vals2_in && i < n) ? vals2_in[i] : i;
     }
     // Count AND rank in one sweep, without LDS atomics (ds_add costs ~12 cycles per active lane on this chip: 16 of them per lane
     // were the longest phase of the pass).  Per row of 64 keys: match-any over the digit bits -> every key knows its peers; the
@@ -117,7 +121,6 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
 #pragma unroll
         for (int s = 0; s < IPL; s++) {
             const uint32_t i = base + s * 64 + lane;
-            out[s] = v[s];   // FINAL: the staged payload stays the emission slot; the splat id is gathered at write-out
             const bool valid = i < n;
             const uint32_t digit = (k[s] >> shift) & mask;
             // match-any over the 8 digit bits (bits above `bits` are zero in every lane: harmless).  Kept in 32-bit halves so
@@ -184,7 +187,8 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
         if (i < n) {
             const uint32_t slot = cnt[wave][(k[s] >> shift) & mask] + local[s];
             sk[slot] = k[s];
-            sv[slot] = out[s];
+            sv[slot] = v[s];
+            if (TWO) sv2[slot] = v2[s];
         }
     }
     {
@@ -220,17 +224,8 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
                 continue;
             }
             if (keys_out) keys_out[dst] = key;
-            if (FINAL) {   // point_list[dst] = splat id of emission slot e, slot_list[dst] = e: both coalesced, no inverse scatter
-                const uint32_t e = sv[i];
-                if (e >= n) {
-                    atomicOr(err, ERR_RANGE);
-                    continue;
-                }
-                vals_out[dst] = gather_src[e];
-                inv_out[dst] = e;
-            } else {
-                vals_out[dst] = sv[i];
-            }
+            vals_out[dst] = sv[i];
+            if (TWO) vals2_out[dst] = sv2[i];
         }
     }
 }
@@ -238,18 +233,18 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
 static int onesweep_group_log2(int nblocks);
 
 static int onesweep_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t cap, const uint32_t *n_ptr,
-                         int shift, int bits, const uint32_t *ghist, u64 *status, uint32_t *ticket, const uint32_t *gather_src,
-                         uint32_t *inv_out, uint32_t *err, bool debug, hipStream_t s, uint32_t *zero_ptr = nullptr,
+                         int shift, int bits, const uint32_t *ghist, u64 *status, uint32_t *ticket, const uint32_t *v2in,
+                         uint32_t *v2out, uint32_t *err, bool debug, hipStream_t s, uint32_t *zero_ptr = nullptr,
                          uint32_t zero_words = 0) {
     const int ipl = sort_items_per_lane(cap);
     const int nblocks = div_up(cap, (int64_t)256 * ipl);
     const int gs_log2 = onesweep_group_log2(nblocks);
     u64 *group_status = status + (size_t)nblocks * RADIX_SIZE;
-#define PASS(IPL, FINAL)                                                                                                  \
-    DAS3R_LAUNCH((onesweep_pass_kernel<IPL, FINAL>), dim3(nblocks), dim3(256), 0, s, kin, vin, kout, vout, (uint32_t)cap, n_ptr, \
-                 shift, bits, ghist, status, group_status, gs_log2, grid_is_resident(nblocks) ? (uint32_t *)nullptr : ticket, gather_src, inv_out, \
+#define PASS(IPL, TWO)                                                                                                    \
+    DAS3R_LAUNCH((onesweep_pass_kernel<IPL, TWO>), dim3(nblocks), dim3(256), 0, s, kin, vin, kout, vout, (uint32_t)cap, n_ptr,   \
+                 shift, bits, ghist, status, group_status, gs_log2, grid_is_resident(nblocks) ? (uint32_t *)nullptr : ticket, v2in, v2out, \
                  err, zero_ptr, zero_words)
-    if (inv_out) {
+    if (v2out) {
         if (ipl == 4) PASS(4, true); else if (ipl == 8) PASS(8, true); else PASS(16, true);
     } else {
         if (ipl == 4) PASS(4, false); else if (ipl == 8) PASS(8, false); else PASS(16, false);
@@ -307,21 +302,25 @@ int launch_onesweep_partition(int64_t cap, char *geom, char *binning, const Layo
     uint32_t *err = err_override ? err_override : (uint32_t *)(geom + L.g_ticket) + 8;  // inside the zeroed control region
     uint32_t *keyA = (uint32_t *)(binning + L.b_keyA), *keyB = (uint32_t *)(binning + L.b_keyB);
     uint32_t *valA = (uint32_t *)(binning + L.b_valA), *valB = (uint32_t *)(binning + L.b_valB);
-    uint32_t *gid_of = (uint32_t *)(binning + L.b_gid_of), *inv = (uint32_t *)(binning + L.b_slot);
+    uint32_t *gid_of = (uint32_t *)(binning + L.b_gid_of), *slot_list = (uint32_t *)(binning + L.b_slot), *e_tmp = (uint32_t *)(binning + L.b_e2);
     uint32_t *ghist = ghist_override ? ghist_override : (uint32_t *)(binning + L.b_ghist), *ticket = (uint32_t *)(binning + L.b_ticket);
     u64 *status = (u64 *)(binning + L.b_status);
     const size_t per_pass = onesweep_status_bytes(cap, 1) / sizeof(u64);
-    uint32_t *kin = keyA, *vin = nullptr, *kout = keyB, *vout = valB;
+    // payloads: the splat id (read from gid_of by the first pass, then ping-pong B -> A ...) and the emission slot e (the input index
+    // in the first pass, then ping-pong so that the LAST pass writes slot_list)
+    uint32_t *kin = keyA, *kout = keyB, *vout = valB;
+    const uint32_t *vin = gid_of, *v2in = nullptr;
     int shift = 0, rc;
     for (int p = 0; p < L.tile_passes; p++) {
         const int dw = tile_digit_width(L.tbits), bits = (L.tbits - shift) < dw ? (L.tbits - shift) : dw;
-        const bool last = p == L.tile_passes - 1;
+        uint32_t *v2out = ((L.tile_passes - 1 - p) & 1) ? e_tmp : slot_list;
         if ((rc = onesweep_pass(kin, vin, kout, vout, cap, n_ptr, shift, bits, ghist + p * 256, status + p * per_pass, ticket + p,
-                                last ? gid_of : nullptr, last ? inv : nullptr, err, debug, s)))
+                                v2in, v2out, err, debug, s)))
             return rc;
         shift += bits;
         uint32_t *t = kin; kin = kout; kout = t;
         vin = vout;
+        v2in = v2out;
         vout = (vout == valB) ? valA : valB;
     }
     *keys_final = kin;
