@@ -87,6 +87,7 @@ static void load_switches() {
     if ((e = env("DAS3R_BWD_PAD_LDS"))) w.bwd_pad_lds = atoi(e);
     if ((e = env("DAS3R_FWD_PAD_LDS"))) w.fwd_pad_lds = atoi(e);
     if ((e = env("DAS3R_INJECT_FAULT"))) w.inject_fault = atoi(e);
+    if ((e = env("DAS3R_SCAN_ITEMS"))) { const int v = atoi(e); w.scan_items = (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? v : 0; }
     w.deterministic = (e = env("DAS3R_DETERMINISTIC")) && e[0] != '0';
     w.bwd_buckets = -1;
     if ((e = env("DAS3R_BWD_BUCKETS"))) w.bwd_buckets = atoi(e);

@@ -30,6 +30,7 @@ struct Switches {
     int render_fwd;        // DAS3R_RENDER=quad | rows: 1 | 2 (0: by list length)
     int render_bwd;        // DAS3R_RENDER_BWD=dpp | mfma | scan... | stream | blk...: 1 | 2 | 3 | 5 | 6 (0: by list length)
     int render_bwd_mb;     // scan64 / scan128 / scan256, blk64 / blk128 / blk256: entries per round; scana256 / scana512: 1000 + entries, atomic flush
+    int scan_items;        // DAS3R_SCAN_ITEMS = 1 | 2 | 4 | 8 | 16: ranks per thread of the scan + emission kernel (0: by size)
     bool deterministic;    // DAS3R_DETERMINISTIC=1: bit-identical gradients run to run (the block-walk backward for every list length:
                            // the pixel-per-lane kernel meets its four waves with LDS float atomics, whose order varies)
     int render_bwd_occ;    // blk...o<4|5>: workgroups per CU the kernel is compiled for (register cap)

@@ -52,6 +52,12 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
     __shared__ uint32_t ws[4];
     __shared__ uint32_t s_block, s_carry;
     __shared__ uint32_t h[EMIT ? 4 : 1][RADIX_SIZE];
+    // Emission through LDS (round 3): the instances of 256 consecutive ranks are one contiguous run of the output; written per lane
+    // they are 4-byte stores at a stride of the splats' tile counts (r02 PMC: 96 MB of HBM traffic for 21 MB of instances).  The
+    // run is assembled in LDS and leaves as unit-stride stores; a run longer than EMIT_LDS instances (huge splats) is written
+    // directly as before.
+    constexpr int EMIT_LDS = 3072;
+    __shared__ uint32_t e_key[EMIT ? EMIT_LDS : 1], e_gid[EMIT ? EMIT_LDS : 1];
     const int tid = threadIdx.x, lane = __lane_id(), wave = tid >> 6;
     // order of the chained scan: a ticket (arrival order) in general; the workgroup index when the whole grid is resident at
     // once (ticket == null: nobody can wait for a workgroup that has not started) — the returned atomic is ~2 us of every
@@ -79,7 +85,7 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
         // 5 M-splat DAS3R-shaped scene spent 0.31 ms here).  Without the array (more than 255 tiles per axis): tiles_touched
         // from the record.  In index order: the plain array, coalesced.
         rc[k] = 0u;
-        if (r < P && sorted_idx && rect32) {
+        if (r < P && rect32) {   // (in index order too: 4 coalesced bytes per splat instead of its 64-byte record for the emission)
             rc[k] = rect32[g[k]];
             v[k] = (((rc[k] >> 8) & 255u) - (rc[k] & 255u)) * ((rc[k] >> 24) - ((rc[k] >> 16) & 255u));
         } else {
@@ -106,23 +112,28 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
         const int r = base + k * 256 + tid;
         uint32_t tot;
         const uint32_t ex = block_exclusive_scan_256(v[k], ws, &tot);
+        const bool via_lds = EMIT && tot <= (uint32_t)EMIT_LDS;   // (uniform)
         if (r < P) {
             uint32_t o = carry + ex;
             offsets[r] = o;
             off_by_gid[g[k]] = o;   // first emission slot of splat g (its instances are emitted contiguously)
             if (EMIT && v[k] != 0u) {
                 int rminx, rminy, rmaxx, rmaxy;
-                if (sorted_idx && rect32) {
+                if (rect32) {
                     rminx = (int)(rc[k] & 255u), rmaxx = (int)((rc[k] >> 8) & 255u), rminy = (int)((rc[k] >> 16) & 255u), rmaxy = (int)(rc[k] >> 24);
                 } else {
                     const float4 p = xyh[(size_t)g[k] * SPLAT_REC];
                     const int radius = __float_as_int(xyh[(size_t)g[k] * SPLAT_REC + 3].x);
                     binned_rect(p, radius, tiles_x, tiles_y, tight_rect != 0, rminx, rminy, rmaxx, rmaxy);
                 }
+                uint32_t l = ex;   // place in the workgroup's run
                 for (int y = rminy; y < rmaxy; y++)
                     for (int x = rminx; x < rmaxx; x++) {
-                        if (o < cap) {   // cap < num_rendered only when the capacity hint was too small (the binning is then redone)
-                            const uint32_t t = (uint32_t)(y * tiles_x + x);
+                        const uint32_t t = (uint32_t)(y * tiles_x + x);
+                        if (via_lds) {
+                            e_key[EMIT ? l : 0] = t;
+                            e_gid[EMIT ? l : 0] = g[k];
+                        } else if (o < cap) {   // cap < num_rendered only when the capacity hint was too small (the binning is then redone)
                             tile_keys[o] = t;
                             gids[o] = g[k];   // gid_of[emission slot]
                             for (int q = 0, sh = 0, dw = tile_digit_width(tbits); sh < tbits; q++, sh += dw) {
@@ -131,8 +142,25 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
                             }
                         }
                         o++;
+                        l++;
                     }
             }
+        }
+        if (via_lds) {
+            __syncthreads();
+            for (uint32_t l = tid; l < tot; l += 256u) {   // unit stride: tile ids and splat ids of the run [carry, carry + tot)
+                const uint32_t o = carry + l;
+                if (o < cap) {
+                    const uint32_t t = e_key[EMIT ? l : 0];
+                    tile_keys[o] = t;
+                    gids[o] = e_gid[EMIT ? l : 0];
+                    for (int q = 0, sh = 0, dw = tile_digit_width(tbits); sh < tbits; q++, sh += dw) {
+                        const int bits = (tbits - sh) < dw ? (tbits - sh) : dw;
+                        atomicAdd(&h[EMIT ? q : 0][(t >> sh) & ((1u << bits) - 1u)], 1u);
+                    }
+                }
+            }
+            __syncthreads();   // the staging arrays are free for the next 256 ranks
         }
         carry += tot;
     }
@@ -158,10 +186,13 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
 }
 
 // ranks per thread: as many as keeps >= 256 workgroups in flight (the emission loop is the long pole, it wants parallelism;
-// the chain wants few workgroups), between 1 and 16
+// the chain wants few workgroups), between 1 and 8.  (r3, scan + emission, ms: 1 M splats 2 / 4 / 8 / 16 ranks per thread 0.067 /
+// 0.046 / 0.039 / 0.056; 2 M 0.091 (4) / 0.080 (8) / 0.112 (16); 5 M in depth order 0.171 (4) / 0.157 (8) / 0.196 (16): sixteen
+// leaves one workgroup per CU at these sizes — nobody covers its trips to memory.)
 static inline int scan_items(int P) {
+    if (switches().scan_items) return switches().scan_items;   // DAS3R_SCAN_ITEMS (A-B runs)
     int it = 1;
-    while (it < 16 && (int64_t)P >= (int64_t)256 * 256 * (it * 2)) it *= 2;
+    while (it < 8 && (int64_t)P >= (int64_t)256 * 256 * (it * 2)) it *= 2;
     return it;
 }
 static inline int scan_blocks(int P) { return div_up(P > 0 ? P : 1, 256 * scan_items(P)); }
