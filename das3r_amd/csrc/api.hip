@@ -607,8 +607,8 @@ namespace das3r { unsigned long long *pair_counters() { return g_pairs; } }
 // null), stop counting.  Single-threaded use (bench.py); synchronises the device.
 extern "C" int das3r_pair_counters(int enable, uint64_t out[4]) {
     if (enable) {
-        if (!g_pairs) HIP_TRY(hipMalloc((void **)&g_pairs, 4 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(g_pairs, 0, 4 * sizeof(unsigned long long)));
+        if (!g_pairs) HIP_TRY(hipMalloc((void **)&g_pairs, (4 + PHASE_WORDS * PHASE_COPIES) * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(g_pairs, 0, (4 + PHASE_WORDS * PHASE_COPIES) * sizeof(unsigned long long)));
         return DAS3R_OK;
     }
     if (g_pairs) {
@@ -621,6 +621,21 @@ extern "C" int das3r_pair_counters(int enable, uint64_t out[4]) {
     }
     return DAS3R_OK;
 }
+
+#ifdef DAS3R_EXPERIMENTS
+// Phase clocks (make EXPERIMENTS=1 only; tools/phase_clocks.py): while the pair counters are on, wave 0 of every workgroup of
+// render_forward_rows_kernel / render_backward_blk_kernel adds the shader clocks it spent in each phase of its tile to the words
+// behind the pair counters (common.h PHASE_*).  Read them BEFORE das3r_pair_counters(0, ..) frees the array.
+extern "C" int das3r_debug_phase_clocks(uint64_t out[16]) {
+    for (int i = 0; i < PHASE_WORDS; i++) out[i] = 0;
+    if (!g_pairs) return DAS3R_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<unsigned long long> all(PHASE_WORDS * PHASE_COPIES);
+    HIP_TRY(hipMemcpy(all.data(), g_pairs + 4, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < all.size(); i++) out[i % PHASE_WORDS] += all[i];
+    return DAS3R_OK;
+}
+#endif
 
 // ---- profiling introspection ----
 extern "C" void das3r_profile_enable(int on) { g_prof_on = on != 0; }

@@ -89,6 +89,33 @@ struct ProfTimer {
 //   [2] forward wave iterations                                          [3] backward wave iterations (64 pairs each)
 // The compositing kernels take the pointer as their last argument; each wave adds its totals once, at its end.
 unsigned long long *pair_counters();
+// behind the four counters: phase clocks of the compositing kernels (experiments build only: api.hip das3r_debug_phase_clocks)
+constexpr int PHASE_WORDS = 16, PHASE_COPIES = 64;   // (64 copies, picked by workgroup: thousands of atomics on ONE word serialise in L2)
+#ifdef DAS3R_EXPERIMENTS
+// wave 0's lane 0 adds the clocks since its previous mark to phase word k — in LDS (eight words per workgroup: one thread, no
+// atomics), flushed to the device words base .. base + 7 when the kernel ends.  (Marks that went straight to global atomics
+// queued ahead of the kernel's own loads and showed up as "staging".)
+#define PHASE_BEGIN()                                                                      \
+    __shared__ unsigned long long phase_w_[8];                                             \
+    unsigned long long phase_t_ = 0ull;                                                    \
+    if (pairs != nullptr && threadIdx.x == 0) {                                            \
+        for (int k_ = 0; k_ < 8; k_++) phase_w_[k_] = 0ull;                                \
+        phase_t_ = clock64();                                                              \
+    }
+#define PHASE_MARK(k)                                                                      \
+    if (pairs != nullptr && threadIdx.x == 0) {                                            \
+        const unsigned long long now_ = clock64();                                         \
+        phase_w_[(k) & 7] += now_ - phase_t_;                                              \
+        phase_t_ = now_;                                                                   \
+    }
+#define PHASE_END(base)                                                                    \
+    if (pairs != nullptr && threadIdx.x == 0)                                              \
+        for (int k_ = 0; k_ < 8; k_++) atomicAdd(pairs + 4 + (blockIdx.x % PHASE_COPIES) * PHASE_WORDS + (base) + k_, phase_w_[k_]);
+#else
+#define PHASE_MARK(k)
+#define PHASE_BEGIN()
+#define PHASE_END(base)
+#endif
 
 // every kernel launch goes through this macro so that the optional profiler sees it (name = kernel symbol)
 #define DAS3R_LAUNCH(kernel, grid, block, shmem, stream, ...)                \

@@ -65,6 +65,7 @@ __global__ void __launch_bounds__(256, OCC) render_backward_blk_kernel(
     const int ntiles = ntiles_strip & 0xFFFFFF;
     const int tile = xcd_tile(blockIdx.x, ntiles, tiles_x, ntiles_strip >> 24);
     if (tile < 0) return;
+    PHASE_BEGIN();   // (experiments build: common.h)
     const int tid = threadIdx.x, lane = __lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bx = tile % tiles_x, by = tile / tiles_x;
@@ -113,6 +114,7 @@ __global__ void __launch_bounds__(256, OCC) render_backward_blk_kernel(
     if (lane == 0) s_max[wave] = mx;
     __syncthreads();
     const uint32_t list_len = range.y - range.x;
+    PHASE_MARK(8)   // prologue
     const uint32_t tile_contrib = min(max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])), list_len);
     const int slices = (int)gridDim.y;
     const int nbuckets = slices > 1 ? max(ckpt_buckets(range), 1) : 1;
@@ -131,6 +133,7 @@ __global__ void __launch_bounds__(256, OCC) render_backward_blk_kernel(
                 partial[(size_t)min(slot_list[range.x + lo + max_contrib + t], cap - 1u) * NACC + q] = 0.f;
             }
         }
+        PHASE_MARK(14)   // zero rows of the tail
         if (max_contrib == 0u) continue;   // (uniform)
         if (slices > 1) {   // the pixels' state at the far end of the bucket
             float T0 = my_T_final, R0 = 0.f;
@@ -169,6 +172,7 @@ __global__ void __launch_bounds__(256, OCC) render_backward_blk_kernel(
                 if constexpr (PIX > 0) *reinterpret_cast<float *>(cst_row + s * 16 + 12) = px.lastrel;
             }
             __syncthreads();
+            PHASE_MARK(9)   // staging the round
 
             // ---- the wave's four row lists (entries in staged order = reverse list order, kept) ----
             int len[4] = {0, 0, 0, 0};
@@ -196,6 +200,7 @@ __global__ void __launch_bounds__(256, OCC) render_backward_blk_kernel(
             const int my_len = row == 0 ? len[0] : (row == 1 ? len[1] : (row == 2 ? len[2] : len[3]));
             const int longest = (ABL & 1) ? 0 : __builtin_amdgcn_readfirstlane(max(max(len[0], len[1]), max(len[2], len[3])));
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the wave reads its own lists back
+            PHASE_MARK(10)   // row lists
 
             // The rows of a wave add their (block, entry) sums to the entry's record ONE AFTER THE OTHER (two rows may hold the same
             // entry at the same time): four dependent LDS round trips per batch, 0.079 of the kernel's 0.405 ms at 1 M splats.
@@ -251,7 +256,9 @@ __global__ void __launch_bounds__(256, OCC) render_backward_blk_kernel(
                 if (len[2] > b) add_pass(2);
                 if (len[3] > b) add_pass(3);
             }
+            PHASE_MARK(11)   // batches
             __syncthreads();
+            PHASE_MARK(12)   // waiting for the slowest wave
             // ---- write the round out: the four waves' records of every staged entry -> the nine per-instance sums ----
             for (int t0 = 0; t0 < n; t0 += TILE_PIX) {
                 const int t = t0 + tid;
@@ -290,8 +297,10 @@ __global__ void __launch_bounds__(256, OCC) render_backward_blk_kernel(
                 }
             }
             __syncthreads();   // stage / s_slot / the lists are free for the next round
+            PHASE_MARK(13)   // write-out
         }
     }
+    PHASE_END(8)
     if (pairs != nullptr && lane == 0 && batches_done > 0) {
         atomicAdd(pairs + 1, (unsigned long long)batches_done * 1024ull);
         atomicAdd(pairs + 3, (unsigned long long)batches_done * 16ull);

@@ -94,6 +94,64 @@ __device__ __forceinline__ bool pair_alpha(const float x, const float y, const f
     return (!(power > 0.0f)) & (alpha >= (1.0f / 255.0f));
 }
 
+// ---- the forward kernels' per-pair decisions by arithmetic ---------------------------------------------------------------------
+// On this chip v_cmp and v_cndmask issue at half the rate of a plain VALU instruction (1.76 vs 0.96 ns per wave instruction on a
+// saturated SIMD: profiles/r03_valu_rate_probe.txt); a compare + select pair costs as much as four multiplies.  The helpers
+// below take the same decisions as the selects they replace, bit for bit, with fma / min / med3 and the clamp output modifier.
+
+// min(a, b) clamped to [0, 1] in ONE instruction (output modifier); a NaN comes out as 0 (DX10_CLAMP is on in compute kernels)
+__device__ __forceinline__ float min_clamp01(const float a, const float b) {
+    float r;
+    asm("v_min_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// clamp(a b + c, 0, 1) in one instruction
+__device__ __forceinline__ float fma_clamp01(const float a, const float b, const float c) {
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// alpha of a pair whose clamped opacity a1 = min(0.99, o G[, ...]) and exponent `power` are known: a1 where power <= 0 and
+// a1 >= 1/255 (pair_alpha's two tests), else 0.  m = min(a1 - 1/255, -power) >= 0 <=> both pass (a1 - 1/255 is exact near the
+// threshold: Sterbenz); min(a1, a1 + 1e30 m) is a1 for m >= 0 and hugely negative for m < 0 (|m| >= 1e-21 whenever it is
+// negative: the smallest positive power fp32 pixel offsets can produce, and one ulp of 1/255 on the other side).  a1 may be
+// negative (render_rows.hip: no such list position) — the clamp takes care of it.
+__device__ __forceinline__ float alpha_if_visible(const float a1, const float power) {
+    const float m = fminf(a1 - (1.0f / 255.0f), -power);
+    return min_clamp01(a1, __fmaf_rn(1e30f, m, a1));
+}
+// Per-pixel compositing state of the forward kernels.  live: 1 until the pixel stops (T would drop below 1e-4), then 0.
+// lastf: staged index of the pixel's last contributor in the CURRENT batch, -1 = none yet (batch_begin / batch_end).
+struct PixelBlend {
+    float T, C0, C1, C2, live, lastf;
+};
+// Blend staged entry j (jf = (float)j, colour c, alpha `a` from alpha_if_visible) into the pixel.  The reference's loop:
+//     test_T = T (1 - alpha);  if (test_T < 1e-4) { done; } else { C += c alpha T; T = test_T; last = position; }
+//   * s = 1 where test_T >= 1e-4f, else 0: clamp(test_T 2^100 - c' 2^100) with c' the float below 1e-4f — the product and the
+//     constant are exact (power-of-two scaling), so the sign is; one ulp of 1e-4 scaled by 2^100 is 2^63, far beyond the clamp;
+//   * w = alpha s;  T (1 - w) is test_T where the pair is taken and T where it is not (alpha = 0 or stop);
+//   * entries are visited in staged order, so `last` is a running maximum: med3(last, j, 1e30 w - 1) is j where w > 0
+//     (w >= 1/255 there) and last where w = 0 (last >= -1).
+// T never drops below 1e-4 while a lane is live, and a stopped lane has alpha = 0: s = 1 there, nothing changes.
+__device__ __forceinline__ void blend_pair(PixelBlend &px, const float alpha, const float4 c, const float jf) {
+    const float a = alpha * px.live;
+    const float test_T = px.T * (1.0f - a);
+    const float s = fma_clamp01(test_T, 0x1p100f, -__uint_as_float(0x6AD1B716u) /* (float below 1e-4f = 0x38D1B716) x 2^100 */);
+    const float w = a * s;
+    const float wT = w * px.T;
+    px.C0 = __fmaf_rn(c.x, wT, px.C0);
+    px.C1 = __fmaf_rn(c.y, wT, px.C1);
+    px.C2 = __fmaf_rn(c.z, wT, px.C2);
+    px.T = px.T * (1.0f - w);
+    px.live *= s;
+    px.lastf = __builtin_amdgcn_fmed3f(px.lastf, jf, __fmaf_rn(w, 1e30f, -1.0f));
+}
+__device__ __forceinline__ void blend_batch_begin(PixelBlend &px) { px.lastf = -1.0f; }
+// -> the pixel's last contributor as a 1-based list position, given the batch's first list position
+__device__ __forceinline__ uint32_t blend_batch_end(const PixelBlend &px, const uint32_t last_contributor, const uint32_t batch_first) {
+    return px.lastf >= 0.0f ? batch_first + (uint32_t)px.lastf + 1u : last_contributor;
+}
+
 // A failed binning (look-back timeout: reported through the self-check word, api.hip) may leave garbage in the tile lists.
 // Every index read from them is kept in bounds, so that the failure surfaces as the error it is and not as a memory fault.
 __device__ __forceinline__ uint2 safe_range(uint2 r, const uint32_t cap) {
@@ -256,9 +314,15 @@ __device__ __forceinline__ void wave_bitonic_sort(double *key, const int lane) {
 //              borrow the staging area.
 //   longer     the same network over global memory (slow; the host is told and goes back to the global sort for the next
 //              forwards); s_gid is not filled.
+struct NoMark {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+// mark(k): phase clocks of the experiments build (common.h PHASE_MARK; tools/phase_clocks.py), a no-op otherwise
+template <class Mark = NoMark>
 __device__ __forceinline__ bool local_order_tile(const LocalBin &lb, const uint2 range, const float4 *__restrict__ xyh,
                                                  const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
-                                                 StagedSplat *stage /*[TILE_PIX]*/, uint32_t *s_gid /*[LOCAL_MAX]*/, const int tid) {
+                                                 StagedSplat *stage /*[TILE_PIX]*/, uint32_t *s_gid /*[LOCAL_MAX]*/, const int tid,
+                                                 const Mark mark = Mark()) {
     const int n = (int)(range.y - range.x);
     uint32_t *pl = lb.point_list + range.x, *sl = lb.slot_list + range.x;
     if (n <= TILE_PIX) {   // (uniform)
@@ -310,6 +374,7 @@ __device__ __forceinline__ bool local_order_tile(const LocalBin &lb, const uint2
             s_key[i] = k;
         }
         __syncthreads();
+        mark(6);   // list words + depth keys in LDS
         if (N == 2 * TILE_PIX) {
             // up to 512 words (the 1 M-splat 1080p benchmark: mean list 320): one wave sorts them with eight words per lane in
             // registers (wave_bitonic_sort); the other three wait at the barrier below
@@ -340,6 +405,7 @@ __device__ __forceinline__ bool local_order_tile(const LocalBin &lb, const uint2
                 }
         }
         __syncthreads();
+        mark(7);   // the network
         uint32_t g[LOCAL_MAX / TILE_PIX], slot[LOCAL_MAX / TILE_PIX];
 #pragma unroll
         for (int u = 0; u < LOCAL_MAX / TILE_PIX; u++) {

@@ -36,8 +36,9 @@ __global__ void __launch_bounds__(256) render_forward_kernel(const uint2 *__rest
     // instructions spread over four SIMDs — it was bound by the scalar unit (1.8e7 SALU instructions per launch at 100 k splats =
     // 29 us of 45).  `live` (1 / 0) replaces the `done` flag; the transmittance itself says when a pixel stops:
     // T never drops below 1e-4 while a lane is live, so test_T < 1e-4 can only come from a pair that contributes.
-    float live = inside ? 1.f : 0.f;
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    // Round 3: not even selects — blend_pair (render_common.h) takes the decisions by arithmetic.
+    PixelBlend pb = {1.0f, 0.f, 0.f, 0.f, inside ? 1.f : 0.f, -1.0f};
+    float &live = pb.live, &T = pb.T, &C0 = pb.C0, &C1 = pb.C1, &C2 = pb.C2;
     uint32_t last_contributor = 0;
 
     const int nb = ckpt_buckets(range);                                 // (> 1: a long list, checkpointed for the bucket-parallel backward)
@@ -56,6 +57,7 @@ __global__ void __launch_bounds__(256) render_forward_kernel(const uint2 *__rest
         }
         __syncthreads();
         const int n = toDo < TILE_PIX ? toDo : TILE_PIX;
+        blend_batch_begin(pb);
         // wave-level cull of the batch against this wave's quadrant: 4 splats per lane, one ballot each
         uint64_t masks[4];
 #pragma unroll
@@ -77,21 +79,11 @@ __global__ void __launch_bounds__(256) render_forward_kernel(const uint2 *__rest
                 const float dx = p.x - pxf, dy = p.y - pyf;
                 const float q = __fmaf_rn(__fmul_rn(co.x, dx), dx, __fmul_rn(__fmul_rn(co.z, dy), dy));
                 const float power = __fmaf_rn(-0.5f, q, -__fmul_rn(__fmul_rn(co.y, dx), dy));   // (pair_alpha's arithmetic, its
-                float a = fminf(0.99f, __fmul_rn(co.w, __expf(power)));                           // two tests taken as selects)
-                a = power > 0.0f ? 0.f : a;
-                a = a >= (1.0f / 255.0f) ? a : 0.f;
-                a *= live;
-                const float test_T = T * (1.0f - a);
-                const bool stop = test_T < 0.0001f;
-                const float w = stop ? 0.f : a;
-                C0 += c.x * w * T;
-                C1 += c.y * w * T;
-                C2 += c.z * w * T;
-                T = stop ? T : test_T;
-                live = stop ? 0.f : live;
-                last_contributor = w > 0.f ? (uint32_t)(i * TILE_PIX + j + 1) : last_contributor;  // 1-based list position
+                const float a1 = fminf(0.99f, __fmul_rn(co.w, __expf(power)));                    // two tests by arithmetic)
+                blend_pair(pb, alpha_if_visible(a1, power), c, (float)j);
             }
         }
+        last_contributor = blend_batch_end(pb, last_contributor, (uint32_t)(i * TILE_PIX));
     }
     for (; nb > 1 && next_slot < nb; next_slot++) ckpt_slot(lb.ckpt, range, tile, next_slot)[cpix] = make_float4(T, C0, C1, C2);   // (early exit: nothing changes any more)
     if (inside) {

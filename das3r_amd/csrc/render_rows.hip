@@ -98,6 +98,7 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
     const int ntiles = ntiles_strip & 0xFFFFFF;
     const int tile = xcd_tile(blockIdx.x, ntiles, tiles_x, ntiles_strip >> 24);
     if (tile < 0) return;
+    PHASE_BEGIN();   // (experiments build: common.h)
     const int tid = threadIdx.x, lane = __lane_id(), wave = tid >> 6, row = lane >> 4;
     const int bx = tile % tiles_x, by = tile / tiles_x;
     int px, py;
@@ -108,14 +109,15 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
     const uint2 range = safe_range(ranges[tile], lb.cap);
     const bool sorted_here = lb.point_list != nullptr && (int)(range.y - range.x) <= LOCAL_MAX;   // (uniform)
     // local depth order: sort this tile's list first (a list of one batch is staged by the sort itself)
-    const bool prestaged = lb.point_list != nullptr && local_order_tile(lb, range, xyh, conic_opacity, rgbd, stage, s_gid, threadIdx.x);
+    const bool prestaged = lb.point_list != nullptr && local_order_tile(lb, range, xyh, conic_opacity, rgbd, stage, s_gid, threadIdx.x, [&](const int k) { (void)k; PHASE_MARK(k) });
     int toDo = (int)(range.y - range.x);
     const int rounds = (toDo + TILE_PIX - 1) / TILE_PIX;
+    PHASE_MARK(0)   // prologue + local sort
 
     // lane state in vector registers, decisions as compare + select pairs: see render_fwd.hip (this kernel issued 1.3e8 scalar
     // instructions per launch at 1 M splats — 211 us of the CU's one scalar ALU in a 277 us kernel)
-    float live = inside ? 1.f : 0.f;
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    PixelBlend pb = {1.0f, 0.f, 0.f, 0.f, inside ? 1.f : 0.f, -1.0f};   // (render_common.h blend_pair)
+    float &live = pb.live, &T = pb.T, &C0 = pb.C0, &C1 = pb.C1, &C2 = pb.C2;
     uint32_t last_contributor = 0;
 
     const int nb = ckpt_buckets(range);                                 // (> 1: a long list, checkpointed for the bucket-parallel backward)
@@ -140,6 +142,7 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
             stage = stage_all + (i % NBUF) * TILE_PIX;
             if ((i & 15) == 0 && __syncthreads_count(live == 0.f) == TILE_PIX) break;   // (rare on this path: checked every 16 batches)
         } else if (__syncthreads_count(live == 0.f) == TILE_PIX) break;
+        PHASE_MARK(1)   // waiting for the workgroup's slowest wave
         if (nb > 1 && i > 0 && (i * TILE_PIX) % BUCKET == 0) ckpt_slot(lb.ckpt, range, tile, next_slot++)[cpix] = make_float4(T, C0, C1, C2);
         const uint32_t progress = range.x + i * TILE_PIX + tid;
         if (PREFETCH) {
@@ -168,11 +171,14 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
         if (PREFETCH) lds_barrier();   // (the loads just issued stay in flight: render_common.h)
         else __syncthreads();
         const int n = toDo < TILE_PIX ? toDo : TILE_PIX;
+        PHASE_MARK(2)   // staging the batch
         int len[4];
+        blend_batch_begin(pb);
         build_row_lists<!PREFETCH>(stage, n, q0x, q0y, lane, lists[wave], len);
         const int my_len = row == 0 ? len[0] : (row == 1 ? len[1] : (row == 2 ? len[2] : len[3]));
         const int longest = max(max(len[0], len[1]), max(len[2], len[3]));
         const uint8_t *mine = lists[wave][row];
+        PHASE_MARK(3)   // row lists
         // Four list positions per trip: their alpha chains (subtract .. exp .. compare, ~20 dependent instructions each) are
         // independent and interleave; blending stays in list order.  A lone dependent chain leaves the SIMD idle most of the time:
         // r02 PMC on the DAS3R shape (1.6 waves per SIMD) showed 54 % of the wave cycles waiting, and removing every LDS wait
@@ -184,9 +190,8 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
         //   * "is there a position t + u in my list": rem - u is >= 1 where there is and <= 0 where not — a third operand of the
         //     alpha clamp (where it decides, the minimum fails the 1/255 test); the list byte is read regardless (in bounds: the
         //     row stride holds 260 bytes) and may name any staged entry, initialised or not: v_min3 / v_min drop a NaN operand;
-        //   * m = min(a1 - 1/255, -power) >= 0  <=>  both tests pass (a1 - 1/255 is exact near the threshold: Sterbenz);
-        //     a = max(min(a1, a1 + 1e30 m), 0): m >= 0 -> a1, m < 0 -> 0 (|m| >= 1e-21 whenever it is negative: the smallest positive
-        //     power fp32 pixel offsets can produce, and one ulp of 1/255 on the other side).
+        //   * the two tests of pair_alpha and the blend itself (stop at T < 1e-4, last contributor): alpha_if_visible / blend_pair
+        //     (render_common.h) — 14 full-rate instructions per position where the compare + select version had 22 issue slots.
         // Same decisions as pair_alpha, bit for bit (tests: image, n_contrib and final_T against the quad kernel and the oracle).
         constexpr int UNROLL = 4;
         const float lenf = (float)my_len;
@@ -196,37 +201,30 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
             int jj[UNROLL];
             float aa[UNROLL];
             const float rem = lenf - (float)t;   // positions of my list from t on
+            const uint32_t packed = *reinterpret_cast<const uint32_t *>(mine + t);   // four list bytes (t is a multiple of 4, the row stride too)
 #pragma unroll
             for (int u = 0; u < UNROLL; u++) {
-                const int j = mine[t + u];
+                const int j = (int)((packed >> (8 * u)) & 0xFFu);
                 const float4 p = stage[j].xyh;
                 const float4 co = stage[j].co;
                 const float dx = p.x - pxf, dy = p.y - pyf;
                 const float q = __fmaf_rn(__fmul_rn(co.x, dx), dx, __fmul_rn(__fmul_rn(co.z, dy), dy));
                 const float power = __fmaf_rn(-0.5f, q, -__fmul_rn(__fmul_rn(co.y, dx), dy));   // (pair_alpha's arithmetic)
                 const float a1 = fminf(fminf(0.99f, __fmul_rn(co.w, __expf(power))), rem - (float)u);
-                const float m = fminf(a1 - (1.0f / 255.0f), -power);
                 jj[u] = j;
-                aa[u] = fmaxf(fminf(a1, __fmaf_rn(1e30f, m, a1)), 0.f);   // (not med3: a1 is negative where the list has no position)
+                aa[u] = alpha_if_visible(a1, power);   // (a1 is negative where the list has no position)
             }
 #pragma unroll
             for (int u = 0; u < UNROLL; u++) {
-                const float a = aa[u] * live;   // (live may have changed with the position before)
                 // (no wave-uniform skip here: a listed position nearly always has a taker among the four rows, and every such test is a
                 //  VALU -> SALU -> branch round trip)
                 const int j = jj[u];
                 const float4 c = lds_read4(&stage[j].rgbd);   // (b128, not b96: half the LDS cycles)
-                const float test_T = T * (1.0f - a);
-                const bool stop = test_T < 0.0001f;   // (T >= 1e-4 on every live lane: only a contributing pair can stop a pixel)
-                const float w = stop ? 0.f : a;
-                C0 += c.x * w * T;
-                C1 += c.y * w * T;
-                C2 += c.z * w * T;
-                T = stop ? T : test_T;
-                live = stop ? 0.f : live;
-                last_contributor = w > 0.f ? (uint32_t)(i * TILE_PIX + j + 1) : last_contributor;  // 1-based list position
+                blend_pair(pb, aa[u], c, (float)((packed >> (8 * u)) & 0xFFu));   // (v_cvt_f32_ubyte<u>: straight from the list word)
             }
         }
+        last_contributor = blend_batch_end(pb, last_contributor, (uint32_t)(i * TILE_PIX));
+        PHASE_MARK(4)   // the walk
     }
     for (; nb > 1 && next_slot < nb; next_slot++) ckpt_slot(lb.ckpt, range, tile, next_slot)[cpix] = make_float4(T, C0, C1, C2);   // (early exit: nothing changes any more)
     if (inside) {
@@ -237,6 +235,8 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
         out_color[plane + pix] = C1 + T * bg[1];
         out_color[2 * plane + pix] = C2 + T * bg[2];
     }
+    PHASE_MARK(5)   // output
+    PHASE_END(0)
     if (pairs != nullptr && lane == 0 && positions > 0) {
         atomicAdd(pairs, (unsigned long long)positions * 64ull);
         atomicAdd(pairs + 2, (unsigned long long)positions);
