@@ -130,8 +130,9 @@ struct PixelBlend {
 //   * s = 1 where test_T >= 1e-4f, else 0: clamp(test_T 2^100 - c' 2^100) with c' the float below 1e-4f — the product and the
 //     constant are exact (power-of-two scaling), so the sign is; one ulp of 1e-4 scaled by 2^100 is 2^63, far beyond the clamp;
 //   * w = alpha s;  T (1 - w) is test_T where the pair is taken and T where it is not (alpha = 0 or stop);
-//   * entries are visited in staged order, so `last` is a running maximum: med3(last, j, 1e30 w - 1) is j where w > 0
-//     (w >= 1/255 there) and last where w = 0 (last >= -1).
+//   * contributing entries are visited in staged order, so `last` is a running maximum: max(last, min(j, 1e30 w - 1)) is j where
+//     w > 0 (w >= 1/255 there) and last where w = 0 (last >= -1).  (NOT med3(last, j, 1e30 w - 1): render_rows.hip reads a stale
+//     list byte past the end of a row's list — an inert pair, but its j may be below `last`, and the median would take it.)
 // T never drops below 1e-4 while a lane is live, and a stopped lane has alpha = 0: s = 1 there, nothing changes.
 __device__ __forceinline__ void blend_pair(PixelBlend &px, const float alpha, const float4 c, const float jf) {
     const float a = alpha * px.live;
@@ -144,7 +145,7 @@ __device__ __forceinline__ void blend_pair(PixelBlend &px, const float alpha, co
     px.C2 = __fmaf_rn(c.z, wT, px.C2);
     px.T = px.T * (1.0f - w);
     px.live *= s;
-    px.lastf = __builtin_amdgcn_fmed3f(px.lastf, jf, __fmaf_rn(w, 1e30f, -1.0f));
+    px.lastf = fmaxf(px.lastf, fminf(jf, __fmaf_rn(w, 1e30f, -1.0f)));
 }
 __device__ __forceinline__ void blend_batch_begin(PixelBlend &px) { px.lastf = -1.0f; }
 // -> the pixel's last contributor as a 1-based list position, given the batch's first list position

@@ -309,12 +309,13 @@ def test_forward_kernels_agree_bit_for_bit(name, monkeypatch):
         util.assert_grad_close(gr[k].cpu().numpy(), gq[k].cpu().numpy(), f"rows vs quad forward dL/d{k}", tol=1e-5)
 
 
-@pytest.mark.parametrize("pattern", [0x7FC00000, 0xFFFFFFFF, 0x7F800000, 0x7FA00000])
+@pytest.mark.parametrize("pattern", [0x7FC00000, 0xFFFFFFFF, 0x7F800000, 0x7FA00000, 0x00000000, 0x01010101])
 def test_unwritten_lds_does_not_reach_the_image(pattern):
     """The compositing kernels leave parts of their LDS arrays unwritten (list tails, staged entries past a tile's list) and the
     row walk reads a staged entry for every position of a trip, also past the end of a row's list: whatever the LDS held before
     must not matter (r3: 0 x NaN from an uninitialised staged colour turned a few tiles into garbage, once in ~15 fresh
-    processes).  Every CU's LDS is filled with quiet NaNs / all-ones / +inf / signalling NaNs, then a scene whose second forward
+    processes; a stale list byte naming an EARLIER entry pulled a pixel's last contributor back, which only small bytes show:
+    hence the zero and 0x01 patterns).  Every CU's LDS is filled with quiet NaNs / all-ones / +inf / signalling NaNs / zeros, then a scene whose second forward
     takes the speculative path (rows kernel on short lists: deg1 and deg2 share P, W, H) is rendered and held to the oracle."""
     from das3r_amd import _lib
     for name in ("deg1", "deg2", "ragged_image", "long_lists", "deep", "single"):
