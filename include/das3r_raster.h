@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define DAS3R_ABI_VERSION 7
+#define DAS3R_ABI_VERSION 8
 
 typedef enum {
     DAS3R_OK = 0,
