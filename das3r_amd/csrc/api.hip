@@ -623,6 +623,25 @@ extern "C" int das3r_pair_counters(int enable, uint64_t out[4]) {
 }
 
 #ifdef DAS3R_EXPERIMENTS
+static unsigned long long *g_trace = nullptr;
+namespace das3r { unsigned long long *wg_trace() { return g_trace; } }
+// enable != 0: (allocate and) zero the trace, the partition passes stamp from now on; enable == 0: copy it to out (TRACE_PASSES x
+// TRACE_WGS x TRACE_STAMPS words) and stop.
+extern "C" int das3r_debug_wg_trace(int enable, uint64_t *out) {
+    const size_t words = (size_t)TRACE_PASSES * TRACE_WGS * TRACE_STAMPS;
+    if (enable) {
+        if (!g_trace) HIP_TRY(hipMalloc((void **)&g_trace, words * 8));
+        HIP_TRY(hipMemset(g_trace, 0, words * 8));
+        return DAS3R_OK;
+    }
+    if (g_trace) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (out) HIP_TRY(hipMemcpy(out, g_trace, words * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipFree(g_trace));
+        g_trace = nullptr;
+    }
+    return DAS3R_OK;
+}
 // Phase clocks (make EXPERIMENTS=1 only; tools/phase_clocks.py): while the pair counters are on, wave 0 of every workgroup of
 // render_forward_rows_kernel / render_backward_blk_kernel adds the shader clocks it spent in each phase of its tile to the words
 // behind the pair counters (common.h PHASE_*).  Read them BEFORE das3r_pair_counters(0, ..) frees the array.

@@ -111,10 +111,17 @@ constexpr int PHASE_WORDS = 16, PHASE_COPIES = 64;   // (64 copies, picked by wo
 #define PHASE_END(base)                                                                    \
     if (pairs != nullptr && threadIdx.x == 0)                                              \
         for (int k_ = 0; k_ < 8; k_++) atomicAdd(pairs + 4 + (blockIdx.x % PHASE_COPIES) * PHASE_WORDS + (base) + k_, phase_w_[k_]);
+// Workgroup trace of the partition passes (tools/wg_trace.py): eight 100 MHz timestamps per workgroup and pass, by ticket.
+constexpr int TRACE_WGS = 4096, TRACE_PASSES = 8, TRACE_STAMPS = 8;
+unsigned long long *wg_trace();   // null unless das3r_debug_wg_trace(1) (api.hip)
+#define WG_STAMP(k)                                                                                   \
+    if (trace != nullptr && threadIdx.x == 0 && s_block < (uint32_t)TRACE_WGS)                        \
+        trace[((size_t)(shift >> 3) * TRACE_WGS + s_block) * TRACE_STAMPS + (k)] = wall_clock64();
 #else
 #define PHASE_MARK(k)
 #define PHASE_BEGIN()
 #define PHASE_END(base)
+#define WG_STAMP(k)
 #endif
 
 // every kernel launch goes through this macro so that the optional profiler sees it (name = kernel symbol)

@@ -83,11 +83,17 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
                                                             u64 *__restrict__ group_status /*[ngroups][256]*/, int gs_log2,
                                                             uint32_t *__restrict__ ticket,
                                                             const uint32_t *__restrict__ vals2_in, uint32_t *__restrict__ vals2_out,
-                                                            uint32_t *__restrict__ err, uint32_t *__restrict__ zero_ptr, uint32_t zero_words) {
+                                                            uint32_t *__restrict__ err, uint32_t *__restrict__ zero_ptr, uint32_t zero_words
+#ifdef DAS3R_EXPERIMENTS
+                                                            , unsigned long long *__restrict__ trace /*common.h WG_STAMP*/
+#endif
+                                                            ) {
     // side duty (last depth pass only): zero the control words of the binning buffer, which did not exist yet when the
     // preprocess kernel zeroed everything else; nothing in this kernel touches them
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < zero_words; i += gridDim.x * 256u) zero_ptr[i] = 0u;
-    __shared__ uint32_t cnt[4][RADIX_SIZE];  // per-wave digit counts, then per-wave running offsets
+    // (16-bit: a workgroup holds at most 4096 keys — with 32-bit counters the 16-key instantiation needs 54 308 B, a few hundred bytes
+    //  past a third of the CU's 160 KB once the allocation is rounded up: two workgroups per CU instead of three)
+    __shared__ uint16_t cnt[4][RADIX_SIZE];  // per-wave digit counts, then per-wave running offsets
     __shared__ uint32_t gdelta[RADIX_SIZE];
     __shared__ uint32_t sk[256 * IPL], sv[256 * IPL];  // staging: key, payload
     __shared__ uint32_t sv2[TWO ? 256 * IPL : 1];      //          second payload
@@ -100,6 +106,12 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
     for (int w = 0; w < 4; w++) cnt[w][tid] = 0;
     __syncthreads();
     const uint32_t b = s_block;
+    // A workgroup past the end of the list has nothing to sort and nobody behind it that has: it leaves at once.  (The grid is
+    // sized for the CAPACITY of the binning buffer — 25 % over the last count on the speculative path: at 1 M splats 799
+    // workgroups for 639 with keys, and 768 fit the chip at a time; the idle ones used to run every phase, look-back included.)
+    const uint32_t last_block = n > 0u ? (n - 1u) / (256u * (uint32_t)IPL) : 0u;
+    if (b > last_block) return;
+    WG_STAMP(0)   // ticket taken
     const uint32_t base = (b * 4u + (uint32_t)wave) * 64u * (uint32_t)IPL;
     const uint32_t mask = (1u << bits) - 1u;
 
@@ -115,9 +127,13 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
     // were the longest phase of the pass).  Per row of 64 keys: match-any over the digit bits -> every key knows its peers; the
     // first peer reads the wave's running count of the digit and adds the group's size (plain read + write: one writer per digit
     // and row, rows in program order, LDS in order per wave).  local[s] = (same-digit keys of this wave before this one).
+#ifdef DAS3R_EXPERIMENTS
+    if (trace != nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WG_STAMP(1)   // keys and payloads arrived
+#endif
     uint32_t local[IPL];
     {
-        volatile uint32_t *cw = cnt[wave];
+        volatile uint16_t *cw = cnt[wave];
 #pragma unroll
         for (int s = 0; s < IPL; s++) {
             const uint32_t i = base + s * 64 + lane;
@@ -139,12 +155,13 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
             uint32_t before = 0;
             if (valid) before = cw[digit];
             __builtin_amdgcn_wave_barrier();
-            if (valid && rank == 0) cw[digit] = before + count;
+            if (valid && rank == 0) cw[digit] = (uint16_t)(before + count);
             __builtin_amdgcn_wave_barrier();
             local[s] = before + rank;
         }
     }
     __syncthreads();
+    WG_STAMP(2)   // counted and ranked
 
     // thread d owns digit d.  Publish this workgroup's count first, then do everything that needs only LOCAL information
     // (ranking + staging, ~3 us); the look-back over the earlier workgroups' counts comes after it, when their words have
@@ -172,10 +189,10 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
             }
         lstart = lbase + lincl - total;
         digit_base = wbase + incl - g;
-        cnt[0][tid] = lstart;
-        cnt[1][tid] = lstart + c0;
-        cnt[2][tid] = lstart + c0 + c1;
-        cnt[3][tid] = lstart + c0 + c1 + c2;
+        cnt[0][tid] = (uint16_t)lstart;
+        cnt[1][tid] = (uint16_t)(lstart + c0);
+        cnt[2][tid] = (uint16_t)(lstart + c0 + c1);
+        cnt[3][tid] = (uint16_t)(lstart + c0 + c1 + c2);
     }
     __syncthreads();
 
@@ -191,6 +208,7 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
             if (TWO) sv2[slot] = v2[s];
         }
     }
+    WG_STAMP(3)   // published, staged
     {
         // Two-level look-back.  Workgroups are grouped GS = 2^gs_log2 at a time; the last workgroup of a group also
         // publishes the group's total.  Every workgroup then needs (its predecessors inside its group) + (the totals of
@@ -200,13 +218,19 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
         // 0.1-4 M keys on 256 CUs: nobody owns a prefix yet, so workgroup b walks over all b predecessors.)
         const uint32_t gs_mask = (1u << gs_log2) - 1u;
         const uint32_t grp = b >> gs_log2, r = b & gs_mask;
+        // (Reading both columns in one sweep — the earlier groups' totals do not depend on this group's words — does not shorten
+        //  the look-back: 8.8 vs 8.4 us median at 1 M splats, tools/wg_trace.py.  What a workgroup waits for is the total of the
+        //  group just before its own, which that group's last workgroup publishes only after staging and summing its own group;
+        //  and the 55 rows of 2 KB every workgroup reads are 70 MB per pass, more than the keys.)
         const uint32_t in_group = sum_published(status + (size_t)(b - r) * RADIX_SIZE + tid, (int)r, err);
         if (r == gs_mask) granule_store(group_status + (size_t)grp * RADIX_SIZE + tid, TAG_AGG | (u64)(in_group + total));
-        const uint32_t excl = in_group + sum_published(group_status + tid, (int)grp, err);
-        if (b == gridDim.x - 1 && excl + total != g) atomicOr(err, ERR_COUNTS);   // self-check: all counts add up to the histogram
+        const uint32_t before_group = sum_published(group_status + tid, (int)grp, err);
+        const uint32_t excl = in_group + before_group;
+        if (b == last_block && excl + total != g) atomicOr(err, ERR_COUNTS);   // self-check: all counts add up to the histogram
         gdelta[tid] = digit_base + excl - lstart;   // destination of staged slot i holding digit d: i + gdelta[d]
     }
     __syncthreads();
+    WG_STAMP(4)   // look-back done (the whole workgroup)
 
     // write out in staged order: neighbouring lanes hold neighbouring slots of the same digit => every digit's run of this
     // workgroup goes out as contiguous, coalesced stores (a direct scatter issues 64 separate 4-byte writes per
@@ -228,10 +252,23 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
             if (TWO) vals2_out[dst] = sv2[i];
         }
     }
+    WG_STAMP(5)   // stores issued
+#ifdef DAS3R_EXPERIMENTS
+    if (trace != nullptr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WG_STAMP(6)   // stores acknowledged
+        if (threadIdx.x == 0 && s_block < (uint32_t)TRACE_WGS) trace[((size_t)(shift >> 3) * TRACE_WGS + s_block) * TRACE_STAMPS + 7] = blockIdx.x;
+    }
+#endif
 }
 
 static int onesweep_group_log2(int nblocks);
 
+#ifdef DAS3R_EXPERIMENTS
+#define TRACE_ARG , wg_trace()
+#else
+#define TRACE_ARG
+#endif
 static int onesweep_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t cap, const uint32_t *n_ptr,
                          int shift, int bits, const uint32_t *ghist, u64 *status, uint32_t *ticket, const uint32_t *v2in,
                          uint32_t *v2out, uint32_t *err, bool debug, hipStream_t s, uint32_t *zero_ptr = nullptr,
@@ -243,7 +280,7 @@ static int onesweep_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kou
 #define PASS(IPL, TWO)                                                                                                    \
     DAS3R_LAUNCH((onesweep_pass_kernel<IPL, TWO>), dim3(nblocks), dim3(256), 0, s, kin, vin, kout, vout, (uint32_t)cap, n_ptr,   \
                  shift, bits, ghist, status, group_status, gs_log2, grid_is_resident(nblocks) ? (uint32_t *)nullptr : ticket, v2in, v2out, \
-                 err, zero_ptr, zero_words)
+                 err, zero_ptr, zero_words TRACE_ARG)
     if (v2out) {
         if (ipl == 4) PASS(4, true); else if (ipl == 8) PASS(8, true); else PASS(16, true);
     } else {

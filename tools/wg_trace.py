@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Timeline of the workgroups of the tile-partition passes (make EXPERIMENTS=1 builds only): when each took its ticket, had its
+keys, had counted, had published and staged, finished its look-back, issued and completed its stores (100 MHz stamps).
+
+    python tools/wg_trace.py --workload c4"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+NAMES = ["ticket", "keys here", "ranked", "published+staged", "look-back done", "stores issued", "stores done"]
+PASSES, WGS, STAMPS = 8, 4096, 8
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="c4")
+    args = ap.parse_args()
+    from das3r_amd import GaussianRasterizationSettings, _lib
+    from das3r_amd.rasterizer import _forward_full
+    from das3r_amd.synth import make_workload
+    if not _lib.has_experiments():
+        sys.exit("the trace needs the experiments build: make -C das3r_amd/csrc EXPERIMENTS=1")
+    L = _lib.load()
+    L.das3r_debug_wg_trace.restype = C.c_int
+    L.das3r_debug_wg_trace.argtypes = [C.c_int, C.c_void_p]
+    dev = torch.device("cuda:0")
+    sc = make_workload(args.workload).to(dev)
+    rs = GaussianRasterizationSettings(**sc.settings_kwargs())
+    e = torch.empty(0, device=dev)
+
+    def fwd():
+        return _forward_full(rs, sc.means3D, sc.shs, e, sc.opacities, sc.scales, sc.rotations, e)
+    for _ in range(5):
+        fwd()
+    torch.cuda.synchronize()
+    _lib.check(L.das3r_debug_wg_trace(1, None), "trace on")
+    fwd()
+    torch.cuda.synchronize()
+    buf = np.zeros(PASSES * WGS * STAMPS, dtype=np.uint64)
+    _lib.check(L.das3r_debug_wg_trace(0, buf.ctypes.data_as(C.c_void_p)), "trace off")
+    t = buf.reshape(PASSES, WGS, STAMPS).astype(np.int64)
+    for p in range(PASSES):
+        used = t[p, :, 0] != 0
+        n = int(used.sum())
+        if n == 0:
+            continue
+        w = t[p, used]
+        worked = w[:, 1] != 0            # (a workgroup past the end of the list returns before its first stamp-1)
+        t0 = w[:, 0].min()
+        us = lambda x: (x - t0) / 100.0   # noqa: E731
+        span = us(w[worked][:, 6].max())
+        print(f"== pass {p} (shift {8 * p}): {n} workgroups stamped, {int(worked.sum())} with work, first ticket -> last store done {span:.1f} us")
+        ww = w[worked]
+        order = np.argsort(ww[:, 0])
+        q = lambda a: " ".join(f"{v:7.1f}" for v in np.percentile(a, [0, 10, 50, 90, 100]))  # noqa: E731
+        print(f"   ticket time (us)                 min/10/50/90/max: {q(us(ww[:, 0]))}")
+        for k in range(1, 7):
+            print(f"   {NAMES[k]:20s} - {NAMES[k - 1]:18s} min/10/50/90/max: {q((ww[:, k] - ww[:, k - 1]) / 100.0)}")
+        print(f"   lifetime (ticket -> stores done)  min/10/50/90/max: {q((ww[:, 6] - ww[:, 0]) / 100.0)}")
+        print(f"   end time (us)                     min/10/50/90/max: {q(us(ww[:, 6]))}")
+        # does ticket order follow block order?
+        tick = np.nonzero(used)[0][worked]
+        print(f"   corr(ticket, blockIdx) = {np.corrcoef(tick, ww[:, 7])[0, 1]:.3f}")
+
+
+if __name__ == "__main__":
+    main()
