@@ -48,7 +48,11 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
     // emission (EMIT only)
     int tiles_x, int tiles_y, const float4 *__restrict__ xyh, const int32_t *__restrict__ radii, uint32_t *__restrict__ tile_keys,
     uint32_t *__restrict__ gids, uint32_t cap, uint32_t *__restrict__ ghist /*[passes][256]*/, int tbits, int tight_rect,
-    const uint32_t *__restrict__ rect32 /*packed binned rectangles by splat (common.h g_rect) or null*/) {
+    const uint32_t *__restrict__ rect32 /*packed binned rectangles by splat (common.h g_rect) or null*/
+#ifdef DAS3R_EXPERIMENTS
+    , unsigned long long *__restrict__ wg_trace_ptr /*common.h SCAN_STAMP*/
+#endif
+    ) {
     __shared__ uint32_t ws[4];
     __shared__ uint32_t s_block, s_carry;
     __shared__ uint32_t h[EMIT ? 4 : 1][RADIX_SIZE];
@@ -69,6 +73,7 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
     }
     __syncthreads();
     const uint32_t b = s_block;
+    SCAN_STAMP(0)   // ticket
     const int base = (int)b * 256 * SCAN_ITEMS;
 
     uint32_t g[SCAN_ITEMS], v[SCAN_ITEMS], rc[SCAN_ITEMS], sum = 0;
@@ -95,6 +100,7 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
     }
     uint32_t total;
     block_exclusive_scan_256(sum, ws, &total);
+    SCAN_STAMP(1)   // rectangles read, workgroup total known
 
     if (wave == 0) {   // one wave publishes and looks back for the whole workgroup
         const uint32_t grp = b >> SCAN_GROUP_LOG2, r = b & ((1u << SCAN_GROUP_LOG2) - 1u);
@@ -106,6 +112,7 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
     }
     __syncthreads();
     uint32_t carry = s_carry;
+    SCAN_STAMP(2)   // look-back done
 
 #pragma unroll 1
     for (int k = 0; k < SCAN_ITEMS; k++) {
@@ -164,6 +171,7 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
         }
         carry += tot;
     }
+    SCAN_STAMP(3)   // offsets and instances written (stores issued)
     if (b == gridDim.x - 1 && tid == 0) {
         const uint32_t flags = *err;   // look-back timeout flags of the depth sort / this scan travel with the count
         count[0] = carry;
@@ -183,8 +191,18 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
             if (c) atomicAdd(&ghist[q * RADIX_SIZE + tid], c);
         }
     }
+#ifdef DAS3R_EXPERIMENTS
+    if (wg_trace_ptr != nullptr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SCAN_STAMP(4)   // everything acknowledged
+    }
+#endif
 }
 
+// (Round 3, tried and dropped: BLOCKED ranks — thread t owns SCAN_ITEMS consecutive ranks, one block-wide scan, the workgroup's whole
+//  run assembled in one LDS window — instead of a scan + emission + write-out per stripe of 256 ranks: 39 -> 35 us at 1 M splats
+//  (tools/wg_trace.py: emission 20.7 -> 16.5 us of a workgroup's 31), but 157 -> 177 us on the 5 M-splat DAS3R shape.  Counting the
+//  digit histograms with ballot matches + wave-private counters instead of LDS integer atomics: 35 -> 44 us.)
 // ranks per thread: as many as keeps >= 256 workgroups in flight (the emission loop is the long pole, it wants parallelism;
 // the chain wants few workgroups), between 1 and 8.  (r3, scan + emission, ms: 1 M splats 2 / 4 / 8 / 16 ranks per thread 0.067 /
 // 0.046 / 0.039 / 0.056; 2 M 0.091 (4) / 0.080 (8) / 0.112 (16); 5 M in depth order 0.171 (4) / 0.157 (8) / 0.196 (16): sixteen
@@ -202,6 +220,11 @@ size_t scan_status_bytes(int P) {
     return (size_t)(nblocks + div_up(nblocks, 1 << SCAN_GROUP_LOG2)) * sizeof(u64);
 }
 
+#ifdef DAS3R_EXPERIMENTS
+#define SCAN_TRACE_ARG , wg_trace()
+#else
+#define SCAN_TRACE_ARG
+#endif
 #define RECT32 ((L.tiles_x <= 255 && L.tiles_y <= 255) ? (const uint32_t *)(geom + L.g_rect) : (const uint32_t *)nullptr)
 #define SCAN_COMMON                                                                                                           \
     P, order, (const uint32_t *)(geom + L.pub.tiles_touched),                          \
@@ -216,7 +239,7 @@ int launch_scan(int P, char *geom, const Layout &L, uint32_t *host_out, uint32_t
 #define GO(IT)                                                                                                               \
     DAS3R_LAUNCH((scan_emit_kernel<false, IT>), dim3(nblocks), dim3(256), 0, s, SCAN_COMMON, 0, 0,                            \
                  (const float4 *)(geom + L.pub.xy),                                                                           \
-                 (const int32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (uint32_t *)nullptr, 0, 0, RECT32)
+                 (const int32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (uint32_t *)nullptr, 0, 0, RECT32 SCAN_TRACE_ARG)
     switch (scan_items(P)) { case 1: GO(1); break; case 2: GO(2); break; case 4: GO(4); break; case 8: GO(8); break; default: GO(16); }
 #undef GO
     KERNEL_CHECK(s, debug, "scan");
@@ -230,7 +253,7 @@ int launch_scan_emit(int P, int64_t cap, const int32_t *radii, char *geom, char 
 #define GO(IT)                                                                                                               \
     DAS3R_LAUNCH((scan_emit_kernel<true, IT>), dim3(nblocks), dim3(256), 0, s, SCAN_COMMON, L.tiles_x, L.tiles_y,              \
                  (const float4 *)(geom + L.pub.xy), radii, (uint32_t *)(binning + L.b_keyA), (uint32_t *)(binning + L.b_gid_of), \
-                 (uint32_t)cap, (uint32_t *)(binning + L.b_ghist), L.tbits, use_tight_rect() ? 1 : 0, RECT32)
+                 (uint32_t)cap, (uint32_t *)(binning + L.b_ghist), L.tbits, use_tight_rect() ? 1 : 0, RECT32 SCAN_TRACE_ARG)
     switch (scan_items(P)) { case 1: GO(1); break; case 2: GO(2); break; case 4: GO(4); break; case 8: GO(8); break; default: GO(16); }
 #undef GO
     KERNEL_CHECK(s, debug, "scan_emit");

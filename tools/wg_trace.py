@@ -46,7 +46,17 @@ def main():
     buf = np.zeros(PASSES * WGS * STAMPS, dtype=np.uint64)
     _lib.check(L.das3r_debug_wg_trace(0, buf.ctypes.data_as(C.c_void_p)), "trace off")
     t = buf.reshape(PASSES, WGS, STAMPS).astype(np.int64)
-    for p in range(PASSES):
+    # scan + emission: region PASSES - 1, five stamps
+    sw = t[PASSES - 1][t[PASSES - 1, :, 0] != 0]
+    if len(sw):
+        t0 = sw[:, 0].min()
+        q = lambda a: " ".join(f"{v:7.1f}" for v in np.percentile(a, [0, 10, 50, 90, 100]))  # noqa: E731
+        print(f"== scan + emission: {len(sw)} workgroups, first ticket -> last acknowledged {(sw[:, 4].max() - t0) / 100.0:.1f} us")
+        print(f"   ticket time (us)                   min/10/50/90/max: {q((sw[:, 0] - t0) / 100.0)}")
+        for k, name in ((1, "rectangles read + block total"), (2, "look-back"), (3, "offsets + instances written"), (4, "acknowledged")):
+            print(f"   {name:34s} min/10/50/90/max: {q((sw[:, k] - sw[:, k - 1]) / 100.0)}")
+        print(f"   lifetime                           min/10/50/90/max: {q((sw[:, 4] - sw[:, 0]) / 100.0)}")
+    for p in range(PASSES - 1):
         used = t[p, :, 0] != 0
         n = int(used.sum())
         if n == 0:
