@@ -557,14 +557,15 @@ extern "C" int das3r_raster_backward(const das3r_raster_args *a, const das3r_ras
     return launch_preprocess_backward(a, in, saved->geom, saved->binning, L, g, partial, s, quad_rows);
 }
 
-// One 36-byte row of partial sums per instance.  (The experimental stream kernel — EXPERIMENTS=1 builds, DAS3R_RENDER_BWD=stream —
+// One 36-byte row of partial sums per instance + 16 bytes (the per-Gaussian backward reads the rows of a workgroup as 16-byte
+// words up to the boundary above the last row).  (The experimental stream kernel — EXPERIMENTS=1 builds, DAS3R_RENDER_BWD=stream —
 // needs up to four 48-byte rows per instance: only then is the larger figure returned.)
 extern "C" size_t das3r_raster_backward_scratch_bytes(int64_t capacity) {
     const size_t c = capacity > 0 ? (size_t)capacity : 1;
 #ifdef DAS3R_EXPERIMENTS
-    if (switches().render_bwd == 5) return std::max(c * 9 * sizeof(float), stream_scratch_bytes(capacity));
+    if (switches().render_bwd == 5) return std::max(c * 9 * sizeof(float) + 16, stream_scratch_bytes(capacity));
 #endif
-    return c * 9 * sizeof(float);
+    return c * 9 * sizeof(float) + 16;
 }
 
 extern "C" int das3r_has_experiments(void) {

@@ -121,12 +121,17 @@ unsigned long long *wg_trace();   // null unless das3r_debug_wg_trace(1) (api.hi
 #define SCAN_STAMP(k)                                                                                 \
     if (wg_trace_ptr != nullptr && threadIdx.x == 0 && s_block < (uint32_t)TRACE_WGS)                 \
         wg_trace_ptr[((size_t)(TRACE_PASSES - 1) * TRACE_WGS + s_block) * TRACE_STAMPS + (k)] = wall_clock64();
+// the same for any kernel whose workgroups are numbered by blockIdx.x: region r of the trace
+#define BLK_STAMP(ptr, r, k)                                                                          \
+    if ((ptr) != nullptr && threadIdx.x == 0 && blockIdx.x < (uint32_t)TRACE_WGS)                      \
+        (ptr)[((size_t)(r) * TRACE_WGS + blockIdx.x) * TRACE_STAMPS + (k)] = wall_clock64();
 #else
 #define PHASE_MARK(k)
 #define PHASE_BEGIN()
 #define PHASE_END(base)
 #define WG_STAMP(k)
 #define SCAN_STAMP(k)
+#define BLK_STAMP(ptr, r, k)
 #endif
 
 // every kernel launch goes through this macro so that the optional profiler sees it (name = kernel symbol)

@@ -102,7 +102,15 @@ __global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
     const uint8_t *__restrict__ row_exists /*[I][4] or null*/, const uint32_t *__restrict__ off_by_gid,
     float *__restrict__ dL_dmeans2D /*[P,3] out*/, float *__restrict__ dL_dopacity /*[P] out*/,
     float *__restrict__ dL_dcolors_precomp /*[P,3] out, precomp mode*/, float *__restrict__ dL_dmeans3D,
-    float *__restrict__ dL_dscales, float *__restrict__ dL_drot, float *__restrict__ dL_dsh, float *__restrict__ dL_dcov3D) {
+    float *__restrict__ dL_dscales, float *__restrict__ dL_drot, float *__restrict__ dL_dsh, float *__restrict__ dL_dcov3D
+#ifdef DAS3R_EXPERIMENTS
+    , unsigned long long *__restrict__ trace /*common.h BLK_STAMP (tools/wg_trace.py), region 6*/
+#endif
+    ) {
+#ifndef DAS3R_EXPERIMENTS
+    constexpr unsigned long long *trace = nullptr;
+#endif
+    BLK_STAMP(trace, 6, 0)
     // one 208-byte (13 x float4) LDS row per lane: SH coefficients in (STAGE_IN), dL_dsh out (STAGE_OUT)
     __shared__ float4 sh_lds[(STAGE_IN || STAGE_OUT) ? 256 * 13 : 1];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -130,23 +138,25 @@ __global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
     // with coalesced loads, 1024 rows at a time, and each lane then adds its own rows out of LDS in the same order as before
     // (bit-identical sums).  A lane used to walk its rows with one trip to L2 per row: the longest walk of 64 lanes set the pace.
     constexpr bool LDS_GATHER = STAGE_OUT;
-    constexpr int CHUNK_ROWS = 1024;                                      // 36 KB of the 52 KB region
+    constexpr int CHUNK_ROWS = 1020;                                      // 36 KB of the 52 KB region: 2304 float4 = 9 per thread with the 3 + 3 floats of alignment slack
     float acc[9];
 #pragma unroll
     for (int q = 0; q < 9; q++) acc[q] = 0.f;
     float4 sh_in[STAGE_IN ? 12 : 1];
-    if (STAGE_IN) {   // requested now, parked in registers while the region serves the gather
-        const float4 *src = reinterpret_cast<const float4 *>(shs) + blk4;
+    // The SH rows of the workgroup (48 KB): requested with a clamped index, i.e. all twelve loads of a thread in flight at once, but
+    // only BEHIND the loads of the gather (loads return in order: ahead of them they delayed the rows the kernel is waiting for —
+    // r3: 0.129 -> 0.165 ms; after the gather was done their latency was exposed: 0.136 -> 0.150 ms).  Parked in registers while the
+    // LDS region serves the gather.
+    auto request_sh = [&]() {
+        if (STAGE_IN) {
+            const float4 *src = reinterpret_cast<const float4 *>(shs) + blk4;
 #pragma unroll
-        for (int i = 0; i < 12; i++) {
-            // GUARDED loads on purpose: each sits in its own basic block and the compiler waits for them two at a time, which throttles
-            // this bulk stream while the latency-critical chain of the kernel (tiles_touched -> rows of `partial`) is on its way.
-            // With a clamped index all twelve go out at once, as in preprocess.hip (where that is worth 13 %) — and this kernel gets
-            // SLOWER: 0.129 -> 0.165 ms at 1 M splats (r3, A-B-A-B on one box): the rows are not needed before the gather is done.
-            const int f = i * 256 + threadIdx.x;
-            sh_in[i] = (size_t)f < limit4 ? src[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < 12; i++) {
+                const size_t f = (size_t)(i * 256 + threadIdx.x);
+                sh_in[i] = limit4 ? src[f < limit4 ? f : limit4 - 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
-    }
+    };
     bool gathered = false;
     uint32_t run0 = 0u, run1 = 0u;
     if (LDS_GATHER && !row_exists) {
@@ -171,26 +181,61 @@ __global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
         run1 = max(max(s_run[0][1], s_run[1][1]), max(s_run[2][1], s_run[3][1]));
         const uint32_t rows = s_run[0][2] + s_run[1][2] + s_run[2][2] + s_run[3][2];
         gathered = rows == 0u || rows == run1 - run0;   // (workgroup-uniform)
+        BLK_STAMP(trace, 6, 1)   // the splats' own words are here, run known
     }
     if (gathered) {
+        // Round 3: the run comes in as float4 words, ALL of a thread's loads of a chunk in flight at once (it used to be 4-byte loads,
+        // four at a time: six trips to memory in a row for the ~670 rows of a workgroup at 1 M splats — and this kernel runs three
+        // waves per SIMD, nobody covers a trip).  A run starts at a multiple of 36 bytes: the words are taken from the 16-byte
+        // boundary below it (head = 0..3 floats that are not ours, skipped when the rows are read back) to the one above its end
+        // (the scratch buffer carries 16 bytes of slack: das3r_raster_backward_scratch_bytes).
         float *const buf = reinterpret_cast<float *>(sh_lds);
+        float4 *const buf4 = sh_lds;
         const uint32_t mine0 = e0_in, mine1 = e0_in + ntiles_g;
+        const bool aligned_base = (reinterpret_cast<uintptr_t>(partial) & 15u) == 0;   // (uniform; torch's allocations are)
+        bool sh_requested = false;
         for (uint32_t c0 = run0; c0 < run1; c0 += CHUNK_ROWS) {
             const uint32_t nrows = min((uint32_t)CHUNK_ROWS, run1 - c0);
             const float *src = partial + (size_t)c0 * 9;
             const int n9 = (int)nrows * 9;
+            int head = 0;
+            if (aligned_base) {
+                head = (int)((reinterpret_cast<uintptr_t>(src) & 15u) >> 2);
+                const float4 *src4 = reinterpret_cast<const float4 *>(src - head);
+                const int n4 = (head + n9 + 3) >> 2;   // <= 2304 = 9 x 256 (CHUNK_ROWS)
+                float4 w[9];
+#pragma unroll
+                for (int i = 0; i < 9; i++) {
+                    const int f = i * 256 + (int)threadIdx.x;
+                    w[i] = src4[f < n4 ? f : n4 - 1];
+                }
+                if (!sh_requested) request_sh();
+#pragma unroll
+                for (int i = 0; i < 9; i++) {
+                    const int f = i * 256 + (int)threadIdx.x;
+                    if (f < n4) buf4[f] = w[i];
+                }
+            } else {
+                if (!sh_requested) request_sh();
 #pragma unroll 4
-            for (int f = threadIdx.x; f < n9; f += 256) buf[f] = src[f];
+                for (int f = threadIdx.x; f < n9; f += 256) buf[f] = src[f];
+            }
+            sh_requested = true;
             __syncthreads();
+            BLK_STAMP(trace, 6, 2)   // the chunk's rows are in LDS
             const uint32_t k0 = max(mine0, c0), k1 = min(mine1, c0 + nrows);
             for (uint32_t k = k0; k < k1; k++) {
-                const float *row = buf + (k - c0) * 9;   // (stride 9 words: consecutive rows fall in different banks)
+                const float *row = buf + head + (k - c0) * 9;   // (stride 9 words: consecutive rows fall in different banks)
 #pragma unroll
                 for (int q = 0; q < 9; q++) acc[q] += row[q];
             }
             __syncthreads();
         }
+        if (!sh_requested) request_sh();   // (an empty run)
+    } else {
+        request_sh();
     }
+    BLK_STAMP(trace, 6, 3)   // rows added
     if (STAGE_IN) {
 #pragma unroll
         for (int i = 0; i < 12; i++) {
@@ -199,6 +244,7 @@ __global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
         }
         __syncthreads();
     }
+    BLK_STAMP(trace, 6, 4)   // SH rows in LDS
 
     // unstaged variants: AoS gradient rows leave through a wave-private LDS scratch (wave_store_rows); the staged ones (M == 16)
     // keep their direct stores — their LDS is spoken for and their 12-byte rows are a small share next to the 192-byte SH rows
@@ -486,6 +532,7 @@ __global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
         if (!HAS_SH) wave_store_rows<3>(dL_dcolors_precomp + 3 * (size_t)wave_first, rows_valid, o_col, xp, lane);
         else if (M == 1) wave_store_rows<3>(dL_dsh + 3 * (size_t)wave_first, rows_valid, o_sh0, xp, lane);
     }
+    BLK_STAMP(trace, 6, 5)   // per-Gaussian arithmetic done, small rows stored
     if (STAGE_OUT) {
         __syncthreads();
         float4 *dst = reinterpret_cast<float4 *>(dL_dsh) + blk4;
@@ -495,6 +542,13 @@ __global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
             if ((size_t)f < limit4) dst[f] = sh_lds[(f / 12) * 13 + (f % 12)];
         }
     }
+#ifdef DAS3R_EXPERIMENTS
+    if (trace != nullptr) {
+        BLK_STAMP(trace, 6, 6)   // dL_dsh rows issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BLK_STAMP(trace, 6, 7)   // acknowledged
+    }
+#endif
 }
 
 int launch_preprocess_backward(const das3r_raster_args *a, const das3r_raster_in *in, char *geom, char *binning, const Layout &L,
@@ -508,12 +562,17 @@ int launch_preprocess_backward(const das3r_raster_args *a, const das3r_raster_in
     const uint8_t *exists = quad_rows ? reinterpret_cast<const uint8_t *>(partial) + align_up(cap_rows * 4 * 12 * sizeof(float)) : nullptr;
     const bool stage_out = has_sh && a->M == 16 && ((uintptr_t)g->dL_dshs & 15) == 0 && !nostage;
     const bool stage_in = stage_out && a->sh_degree >= 2 && ((uintptr_t)in->shs & 15) == 0;
+#ifdef DAS3R_EXPERIMENTS
+#define PB_TRACE_ARG , wg_trace()
+#else
+#define PB_TRACE_ARG
+#endif
 #define ARGS                                                                                                                 \
     P, a->sh_degree, a->M, in->means3D, in->scales, a->scale_modifier, in->rotations, in->shs, in->cov3D_precomp,            \
         a->viewmatrix, a->projmatrix, a->campos, a->image_width, a->image_height, a->tanfovx, a->tanfovy,                    \
         (const uint32_t *)(geom + L.pub.tiles_touched), (const uint8_t *)(geom + L.pub.clamped), partial, exists,        \
         (const uint32_t *)(geom + L.g_off_by_gid), g->dL_dmeans2D, g->dL_dopacities, g->dL_dcolors_precomp, g->dL_dmeans3D,  \
-        g->dL_dscales, g->dL_drotations, g->dL_dshs, g->dL_dcov3D
+        g->dL_dscales, g->dL_drotations, g->dL_dshs, g->dL_dcov3D PB_TRACE_ARG
 #define LAUNCH(SH, COV, SI, SO) DAS3R_LAUNCH((preprocess_backward_kernel<SH, COV, SI, SO>), grid, block, 0, s, ARGS)
 #define LAUNCH0(SH, COV) DAS3R_LAUNCH((preprocess_backward_kernel<SH, COV, false, false, true>), grid, block, 0, s, ARGS)
     const bool deg0 = a->sh_degree == 0 && !stage_out;

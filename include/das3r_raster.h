@@ -141,7 +141,8 @@ int das3r_raster_backward(const das3r_raster_args *args, const das3r_raster_in *
                           const float *dL_dpix /* [3,H,W] */, const das3r_raster_grads *grads, das3r_stream_t stream);
 
 /* Bytes of device scratch das3r_raster_backward needs in grads->scratch for a forward with the given saved->capacity:
- * 36 bytes (nine partial sums) per instance. */
+ * 36 bytes (nine partial sums) per instance + 16 (the rows are read back as 16-byte words).  16-byte alignment of the buffer
+ * lets the per-Gaussian backward do that; any other alignment falls back to 4-byte loads. */
 size_t das3r_raster_backward_scratch_bytes(int64_t capacity);
 
 /* das3r_raster_forward returns as soon as its kernels are enqueued.  Its binning kernels check themselves (a bounded wait on

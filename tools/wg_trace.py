@@ -40,8 +40,10 @@ def main():
     for _ in range(5):
         fwd()
     torch.cuda.synchronize()
+    from das3r_amd.rasterizer import _backward_impl
     _lib.check(L.das3r_debug_wg_trace(1, None), "trace on")
-    fwd()
+    I, color, radii, geom, binning, img, cap = fwd()
+    _backward_impl(rs, I, sc.dL_dpix, sc.means3D, sc.shs, e, sc.opacities, sc.scales, sc.rotations, e, geom, binning, img, cap)
     torch.cuda.synchronize()
     buf = np.zeros(PASSES * WGS * STAMPS, dtype=np.uint64)
     _lib.check(L.das3r_debug_wg_trace(0, buf.ctypes.data_as(C.c_void_p)), "trace off")
@@ -56,7 +58,21 @@ def main():
         for k, name in ((1, "rectangles read + block total"), (2, "look-back"), (3, "offsets + instances written"), (4, "acknowledged")):
             print(f"   {name:34s} min/10/50/90/max: {q((sw[:, k] - sw[:, k - 1]) / 100.0)}")
         print(f"   lifetime                           min/10/50/90/max: {q((sw[:, 4] - sw[:, 0]) / 100.0)}")
-    for p in range(PASSES - 1):
+    # per-Gaussian backward: region PASSES - 2, eight stamps, by blockIdx
+    pb = t[PASSES - 2][t[PASSES - 2, :, 0] != 0]
+    if len(pb):
+        t0 = pb[:, 0].min()
+        q = lambda a: " ".join(f"{v:7.1f}" for v in np.percentile(a, [0, 10, 50, 90, 100]))  # noqa: E731
+        print(f"== preprocess backward: {len(pb)} workgroups traced (of P / 256), first start -> last acknowledged {(pb[:, 7].max() - t0) / 100.0:.1f} us")
+        print(f"   start time (us)                    min/10/50/90/max: {q((pb[:, 0] - t0) / 100.0)}")
+        names = ["own words + run known", "first chunk of rows in LDS", "rows added", "SH rows in LDS", "arithmetic + small rows", "dL_dsh issued", "acknowledged"]
+        for k, name in enumerate(names, start=1):
+            d = (pb[:, k] - pb[:, k - 1]) / 100.0
+            d = d[(pb[:, k] != 0) & (pb[:, k - 1] != 0)]
+            if len(d):
+                print(f"   {name:34s} min/10/50/90/max: {q(d)}")
+        print(f"   lifetime                           min/10/50/90/max: {q((pb[:, 7] - pb[:, 0]) / 100.0)}")
+    for p in range(PASSES - 2):
         used = t[p, :, 0] != 0
         n = int(used.sum())
         if n == 0:
