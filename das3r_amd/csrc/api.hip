@@ -93,6 +93,8 @@ static void load_switches() {
     if ((e = env("DAS3R_BWD_BUCKETS"))) w.bwd_buckets = atoi(e);
     w.fwd_no_prefetch = (e = env("DAS3R_FWD_PREFETCH")) && e[0] == '0';
     w.tile_strip = 8;
+    w.tile_chunk = -1;
+    if ((e = env("DAS3R_TILE_CHUNK"))) { const int v = atoi(e); w.tile_chunk = (v >= 0 && v <= 64 && (v & (v - 1)) == 0) ? v : -1; }
     if ((e = env("DAS3R_TILE_STRIP"))) w.tile_strip = std::max(0, std::min(64, atoi(e)));
     g_sw = w;
     __atomic_store_n(&g_sw_loaded, true, __ATOMIC_RELEASE);

@@ -30,6 +30,7 @@ struct Switches {
     int render_fwd;        // DAS3R_RENDER=quad | rows: 1 | 2 (0: by list length)
     int render_bwd;        // DAS3R_RENDER_BWD=dpp | mfma | scan... | stream | blk...: 1 | 2 | 3 | 5 | 6 (0: by list length)
     int render_bwd_mb;     // scan64 / scan128 / scan256, blk64 / blk128 / blk256: entries per round; scana256 / scana512: 1000 + entries, atomic flush
+    int tile_chunk;        // DAS3R_TILE_CHUNK: tiles per chunk of the XCD round robin (render_common.h); -1 = default, 0 = contiguous eighths
     int scan_items;        // DAS3R_SCAN_ITEMS = 1 | 2 | 4 | 8 | 16: ranks per thread of the scan + emission kernel (0: by size)
     bool deterministic;    // DAS3R_DETERMINISTIC=1: bit-identical gradients run to run (the block-walk backward for every list length:
                            // the pixel-per-lane kernel meets its four waves with LDS float atomics, whose order varies)
@@ -112,8 +113,20 @@ constexpr int PHASE_WORDS = 16, PHASE_COPIES = 64;   // (64 copies, picked by wo
     if (pairs != nullptr && threadIdx.x == 0)                                              \
         for (int k_ = 0; k_ < 8; k_++) atomicAdd(pairs + 4 + (blockIdx.x % PHASE_COPIES) * PHASE_WORDS + (base) + k_, phase_w_[k_]);
 // Workgroup trace of the partition passes (tools/wg_trace.py): eight 100 MHz timestamps per workgroup and pass, by ticket.
-constexpr int TRACE_WGS = 4096, TRACE_PASSES = 8, TRACE_STAMPS = 8;
+constexpr int TRACE_WGS = 16384, TRACE_PASSES = 8, TRACE_STAMPS = 8;
 unsigned long long *wg_trace();   // null unless das3r_debug_wg_trace(1) (api.hip)
+// The compositing kernels have one diagnostic pointer argument (`pairs`): while the workgroup trace is on and the pair counters
+// are off it carries the trace buffer instead, marked by its lowest bit.
+static inline unsigned long long *pairs_or_trace() {
+    unsigned long long *p = pair_counters();
+    if (p == nullptr && wg_trace() != nullptr) p = reinterpret_cast<unsigned long long *>(reinterpret_cast<uintptr_t>(wg_trace()) | 1u);
+    return p;
+}
+#define DECODE_PAIRS_OR_TRACE(arg)                                                                                         \
+    unsigned long long *const trace = (reinterpret_cast<uintptr_t>(arg) & 1u)                                              \
+                                          ? reinterpret_cast<unsigned long long *>(reinterpret_cast<uintptr_t>(arg) & ~(uintptr_t)1) \
+                                          : nullptr;                                                                       \
+    unsigned long long *const pairs = trace ? nullptr : (arg);
 #define WG_STAMP(k)                                                                                   \
     if (trace != nullptr && threadIdx.x == 0 && s_block < (uint32_t)TRACE_WGS)                        \
         trace[((size_t)(shift >> 3) * TRACE_WGS + s_block) * TRACE_STAMPS + (k)] = wall_clock64();
@@ -125,7 +138,9 @@ unsigned long long *wg_trace();   // null unless das3r_debug_wg_trace(1) (api.hi
 #define BLK_STAMP(ptr, r, k)                                                                          \
     if ((ptr) != nullptr && threadIdx.x == 0 && blockIdx.x < (uint32_t)TRACE_WGS)                      \
         (ptr)[((size_t)(r) * TRACE_WGS + blockIdx.x) * TRACE_STAMPS + (k)] = wall_clock64();
+#define PAIRS_ARG pairs_or_trace()
 #else
+#define PAIRS_ARG pair_counters()
 #define PHASE_MARK(k)
 #define PHASE_BEGIN()
 #define PHASE_END(base)

@@ -19,7 +19,7 @@ constexpr int NACC = 9;  // dcolor[3], dmean2D[2], dconic[3], dopacity
 
 template <bool USE_DPP>
 __global__ void __launch_bounds__(256) render_backward_kernel(
-    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int tiles_x, int ntiles_strip /*tiles | strip height << 24: render_common.h xcd_tile*/,
+    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int tiles_x, int ntiles_strip /*render_common.h pack_tiles*/,
     const float4 *__restrict__ xyh, const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
     const float *__restrict__ bg, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
     const float *__restrict__ dL_dpix, const uint32_t *__restrict__ slot_list, float *__restrict__ partial /*[I,9]*/, int ablate,
@@ -30,8 +30,8 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
     __shared__ float acc[TILE_PIX * NACC];
     __shared__ uint32_t s_max[4];
 
-    const int ntiles = ntiles_strip & 0xFFFFFF;
-    const int tile = xcd_tile(blockIdx.x, ntiles, tiles_x, ntiles_strip >> 24);
+    const int ntiles = packed_ntiles(ntiles_strip);
+    const int tile = xcd_tile(blockIdx.x, ntiles_strip, tiles_x);
     if (tile < 0) return;
     const int tid = threadIdx.x, lane = __lane_id(), wave = tid >> 6;
     const int bx = tile % tiles_x, by = tile / tiles_x;
@@ -220,8 +220,8 @@ int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, cha
         (const uint32_t *)(img + L.pub.n_contrib), dL_dpix, (const uint32_t *)(binning + L.b_slot), partial, ablate, \
         (uint32_t)(a->P - 1), (uint32_t)L.capacity, pair_counters()
     const int pad_lds = sw.bwd_pad_lds;   // occupancy experiments
-    if (use_dpp) DAS3R_LAUNCH((render_backward_kernel<true>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), pad_lds, s, ARGS);
-    else DAS3R_LAUNCH((render_backward_kernel<false>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS);
+    if (use_dpp) DAS3R_LAUNCH((render_backward_kernel<true>), dim3(xcd_grid(L)), dim3(TILE_PIX), pad_lds, s, ARGS);
+    else DAS3R_LAUNCH((render_backward_kernel<false>), dim3(xcd_grid(L)), dim3(TILE_PIX), 0, s, ARGS);
 #undef ARGS
     KERNEL_CHECK(s, a->debug, "render_backward");
     return DAS3R_OK;

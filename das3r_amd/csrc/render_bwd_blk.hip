@@ -36,13 +36,18 @@ namespace das3r {
 // cost without them), 2 batches without the record add, 4 nothing written out, 8 bounding-box block test only, 16 no quadrant ellipse test
 template <int MB, int PIX, int ABL = 0, int OCC = 5>
 __global__ void __launch_bounds__(256, OCC) render_backward_blk_kernel(
-    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int tiles_x, int ntiles_strip /*tiles | strip height << 24: render_common.h xcd_tile*/,
+    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int tiles_x, int ntiles_strip /*render_common.h pack_tiles*/,
     const float4 *__restrict__ xyh, const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
     const float *__restrict__ bg, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
     const float *__restrict__ dL_dpix, const uint32_t *__restrict__ slot_list, float *__restrict__ partial /*[I,9]*/,
     uint32_t last_g, uint32_t cap /*bounds of the list contents: render_common.h safe_range*/,
     const float4 *__restrict__ ckpt /*forward's checkpoints of long lists (render_common.h); used when gridDim.y > 1*/,
-    unsigned long long *__restrict__ pairs /*common.h pair_counters(): null unless bench.py counts*/) {
+    unsigned long long *__restrict__ pairs_arg /*common.h pair_counters(): null unless bench.py counts*/) {
+#ifdef DAS3R_EXPERIMENTS
+    DECODE_PAIRS_OR_TRACE(pairs_arg)   // (tools/wg_trace.py)
+#else
+    unsigned long long *const pairs = pairs_arg;
+#endif
     static_assert(MB >= 64 && MB <= 256 && MB % 8 == 0, "entries per round (one-byte list entries)");
     constexpr int LIST_STRIDE = MB + 4;                                  // bytes; the four rows of a wave read position e of their lists in one instruction
     constexpr int OFF_STAGE = 0;                                         // StagedSplat[MB]
@@ -62,10 +67,13 @@ __global__ void __launch_bounds__(256, OCC) render_backward_blk_kernel(
     uint32_t *const s_slot = reinterpret_cast<uint32_t *>(lds + OFF_SLOT);
     uint32_t *const s_max = reinterpret_cast<uint32_t *>(lds + OFF_MAX);
 
-    const int ntiles = ntiles_strip & 0xFFFFFF;
-    const int tile = xcd_tile(blockIdx.x, ntiles, tiles_x, ntiles_strip >> 24);
+    const int ntiles = packed_ntiles(ntiles_strip);
+    const int tile = xcd_tile(blockIdx.x, ntiles_strip, tiles_x);
     if (tile < 0) return;
     PHASE_BEGIN();   // (experiments build: common.h)
+#ifdef DAS3R_EXPERIMENTS
+    BLK_STAMP(trace, 5, 0)
+#endif
     const int tid = threadIdx.x, lane = __lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bx = tile % tiles_x, by = tile / tiles_x;
@@ -301,6 +309,14 @@ __global__ void __launch_bounds__(256, OCC) render_backward_blk_kernel(
         }
     }
     PHASE_END(8)
+#ifdef DAS3R_EXPERIMENTS
+    BLK_STAMP(trace, 5, 1)   // stores issued
+    if (trace != nullptr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BLK_STAMP(trace, 5, 2)
+        if (threadIdx.x == 0 && blockIdx.x < (uint32_t)TRACE_WGS) trace[((size_t)5 * TRACE_WGS + blockIdx.x) * TRACE_STAMPS + 3] = range.y - range.x;
+    }
+#endif
     if (pairs != nullptr && lane == 0 && batches_done > 0) {
         atomicAdd(pairs + 1, (unsigned long long)batches_done * 1024ull);
         atomicAdd(pairs + 3, (unsigned long long)batches_done * 16ull);
@@ -314,8 +330,8 @@ int launch_render_backward_blk(const das3r_raster_args *a, const float *dL_dpix,
         L.tiles_x, pack_tiles(L), (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),             \
         (const float4 *)(geom + L.pub.rgbd), a->bg, (const float *)(img + L.pub.final_T),                                 \
         (const uint32_t *)(img + L.pub.n_contrib), dL_dpix, (const uint32_t *)(binning + L.b_slot), partial,              \
-        (uint32_t)(a->P - 1), (uint32_t)L.capacity, (const float4 *)(binning + L.b_ckpt), pair_counters()
-#define GO(MBV, PIX, OCC) DAS3R_LAUNCH((render_backward_blk_kernel<MBV, PIX, 0, OCC>), dim3(xcd_grid(L.ntiles), slices > 1 ? slices : 1), dim3(TILE_PIX), 0, s, ARGS)
+        (uint32_t)(a->P - 1), (uint32_t)L.capacity, (const float4 *)(binning + L.b_ckpt), PAIRS_ARG
+#define GO(MBV, PIX, OCC) DAS3R_LAUNCH((render_backward_blk_kernel<MBV, PIX, 0, OCC>), dim3(xcd_grid(L), slices > 1 ? slices : 1), dim3(TILE_PIX), 0, s, ARGS)
     // DAS3R_RENDER_BWD=blk<entries per round>[p<PIX>][o<workgroups per CU>]: blk128 (registers), blk128p1 (constants in LDS), blk160p1o4 ...
     // default (no DAS3R_RENDER_BWD): constants in LDS for 128-entry rounds (1 M splats at 1080p: 0.381 vs 0.407 ms), registers for 192
     // (DAS3R shape: 0.497 vs 0.534 ms)
@@ -323,7 +339,7 @@ int launch_render_backward_blk(const das3r_raster_args *a, const float *dL_dpix,
 #define BY_PIX(MBV, OCC) do { if (pix == 2) GO(MBV, 2, OCC); else if (pix == 1) GO(MBV, 1, OCC); else GO(MBV, 0, OCC); } while (0)
     if (mb == 128 && pix == 1 && switches().ablate_set) {
         const int abl = switches().ablate;
-#define GA(A) DAS3R_LAUNCH((render_backward_blk_kernel<128, 1, A>), dim3(xcd_grid(L.ntiles), slices > 1 ? slices : 1), dim3(TILE_PIX), 0, s, ARGS)
+#define GA(A) DAS3R_LAUNCH((render_backward_blk_kernel<128, 1, A>), dim3(xcd_grid(L), slices > 1 ? slices : 1), dim3(TILE_PIX), 0, s, ARGS)
         if (abl == 1) GA(1); else if (abl == 2) GA(2); else if (abl == 4) GA(4); else if (abl == 8) GA(8); else if (abl == 16) GA(16); else if (abl == 3) GA(3); else if (abl == 7) GA(7); else GA(0);
 #undef GA
     } else if (mb == 64) BY_PIX(64, 5);

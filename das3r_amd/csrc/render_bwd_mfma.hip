@@ -30,7 +30,7 @@ constexpr int MB = 256;     // splats per staged batch (smaller than the other k
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(256) render_backward_mfma_kernel(
-    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int tiles_x, int ntiles_strip /*tiles | strip height << 24: render_common.h xcd_tile*/,
+    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int tiles_x, int ntiles_strip /*render_common.h pack_tiles*/,
     const float4 *__restrict__ xyh, const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
     const float *__restrict__ bg, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
     const float *__restrict__ dL_dpix, const uint32_t *__restrict__ slot_list, float *__restrict__ partial /*[I,9]*/,
@@ -45,8 +45,8 @@ __global__ void __launch_bounds__(256) render_backward_mfma_kernel(
     __shared__ uint32_t chunk_j[4][CHUNK];    // staged index of every pair of the wave's current chunk
     __shared__ uint32_t s_max[4];
 
-    const int ntiles = ntiles_strip & 0xFFFFFF;
-    const int tile = xcd_tile(blockIdx.x, ntiles, tiles_x, ntiles_strip >> 24);
+    const int ntiles = packed_ntiles(ntiles_strip);
+    const int tile = xcd_tile(blockIdx.x, ntiles_strip, tiles_x);
     if (tile < 0) return;
     const int tid = threadIdx.x, lane = __lane_id(), wave = tid >> 6;
     const int bx = tile % tiles_x, by = tile / tiles_x;
@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(256) render_backward_mfma_kernel(
 
 int launch_render_backward_mfma(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
                                 float *partial, hipStream_t s) {
-    DAS3R_LAUNCH(render_backward_mfma_kernel, dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, (const uint2 *)(img + L.pub.ranges),
+    DAS3R_LAUNCH(render_backward_mfma_kernel, dim3(xcd_grid(L)), dim3(TILE_PIX), 0, s, (const uint2 *)(img + L.pub.ranges),
                  (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height, L.tiles_x, pack_tiles(L),
                  (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),
                  (const float4 *)(geom + L.pub.rgbd), a->bg, (const float *)(img + L.pub.final_T),

@@ -35,7 +35,7 @@ namespace das3r {
 // all (what the rounds cost without them), 8 bounding-box cull only
 template <int MB, bool ATOM, int ABL = 0>
 __global__ void __launch_bounds__(256, (MB <= 128 ? 4 : 2)) render_backward_scan_kernel(
-    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int tiles_x, int ntiles_strip /*tiles | strip height << 24: render_common.h xcd_tile*/,
+    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int tiles_x, int ntiles_strip /*render_common.h pack_tiles*/,
     const float4 *__restrict__ xyh, const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
     const float *__restrict__ bg, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
     const float *__restrict__ dL_dpix, const uint32_t *__restrict__ slot_list, float *__restrict__ partial /*[I,9]*/,
@@ -64,8 +64,8 @@ __global__ void __launch_bounds__(256, (MB <= 128 ? 4 : 2)) render_backward_scan
     uint64_t *const s_hit = reinterpret_cast<uint64_t *>(lds + OFF_HIT);
     uint32_t *const s_max = reinterpret_cast<uint32_t *>(lds + OFF_MAX);
 
-    const int ntiles = ntiles_strip & 0xFFFFFF;
-    const int tile = xcd_tile(blockIdx.x, ntiles, tiles_x, ntiles_strip >> 24);
+    const int ntiles = packed_ntiles(ntiles_strip);
+    const int tile = xcd_tile(blockIdx.x, ntiles_strip, tiles_x);
     if (tile < 0) return;
     const int tid = threadIdx.x, lane = __lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -395,7 +395,7 @@ int launch_render_backward_scan(const das3r_raster_args *a, const float *dL_dpix
         (const float4 *)(geom + L.pub.rgbd), a->bg, (const float *)(img + L.pub.final_T),                                 \
         (const uint32_t *)(img + L.pub.n_contrib), dL_dpix, (const uint32_t *)(binning + L.b_slot), partial,              \
         (uint32_t)(a->P - 1), (uint32_t)L.capacity, (const float4 *)(binning + L.b_ckpt), pair_counters()
-#define GO(MBV, AT, AB) DAS3R_LAUNCH((render_backward_scan_kernel<MBV, AT, AB>), dim3(xcd_grid(L.ntiles), slices > 1 ? slices : 1), dim3(TILE_PIX), 0, s, ARGS)
+#define GO(MBV, AT, AB) DAS3R_LAUNCH((render_backward_scan_kernel<MBV, AT, AB>), dim3(xcd_grid(L), slices > 1 ? slices : 1), dim3(TILE_PIX), 0, s, ARGS)
     const int abl = switches().ablate_set ? switches().ablate : 0;
     // mb: 64 / 128 / 256 private accumulator regions; 1256: 256 entries per round with the atomic flush
     if (mb == 128 && abl == 1) GO(128, false, 1);

@@ -32,14 +32,14 @@ constexpr int WAVE_LDS = Q_OUT + 16 * 48;   // + the batch's 16 x 12 sums on the
 // WPS: waves per SIMD the register allocation is held to (= workgroups per CU; 4: 128 VGPRs, no spills)
 template <int ABL, int WPS = 4>
 __global__ void __launch_bounds__(256, WPS) render_backward_stream_kernel(
-    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int tiles_x, int ntiles_strip /*tiles | strip height << 24: render_common.h xcd_tile*/,
+    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int tiles_x, int ntiles_strip /*render_common.h pack_tiles*/,
     const float4 *__restrict__ xyh, const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
     const float *__restrict__ bg, const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
     const float *__restrict__ dL_dpix, const uint32_t *__restrict__ slot_list, float *__restrict__ rows /*[cap][4][12]*/,
     uint8_t *__restrict__ row_exists /*[cap][4], zero on entry*/, uint32_t last_g, uint32_t cap) {
     __shared__ __attribute__((aligned(16))) char lds[4 * WAVE_LDS];
-    const int ntiles = ntiles_strip & 0xFFFFFF;
-    const int tile = xcd_tile(blockIdx.x, ntiles, tiles_x, ntiles_strip >> 24);
+    const int ntiles = packed_ntiles(ntiles_strip);
+    const int tile = xcd_tile(blockIdx.x, ntiles_strip, tiles_x);
     if (tile < 0) return;
     const int lane = __lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -333,15 +333,15 @@ int launch_render_backward_stream(const das3r_raster_args *a, const float *dL_dp
         (const float4 *)(geom + L.pub.rgbd), a->bg, (const float *)(img + L.pub.final_T),                                 \
         (const uint32_t *)(img + L.pub.n_contrib), dL_dpix, (const uint32_t *)(binning + L.b_slot), scratch, exists,     \
         (uint32_t)(a->P - 1), (uint32_t)L.capacity
-#define GO(AB) DAS3R_LAUNCH((render_backward_stream_kernel<AB>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS)
+#define GO(AB) DAS3R_LAUNCH((render_backward_stream_kernel<AB>), dim3(xcd_grid(L)), dim3(TILE_PIX), 0, s, ARGS)
     const int abl = switches().ablate_set ? switches().ablate : 0;
     if (abl == 1) GO(1);
     else if (abl == 2) GO(2);
     else if (abl == 3) GO(3);
     else if (abl == 4) GO(4);
     else if (abl == 8) GO(8);
-    else if (abl == 103) DAS3R_LAUNCH((render_backward_stream_kernel<0, 3>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS);
-    else if (abl == 105) DAS3R_LAUNCH((render_backward_stream_kernel<0, 5>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS);
+    else if (abl == 103) DAS3R_LAUNCH((render_backward_stream_kernel<0, 3>), dim3(xcd_grid(L)), dim3(TILE_PIX), 0, s, ARGS);
+    else if (abl == 105) DAS3R_LAUNCH((render_backward_stream_kernel<0, 5>), dim3(xcd_grid(L)), dim3(TILE_PIX), 0, s, ARGS);
     else GO(0);
 #undef GO
 #undef ARGS

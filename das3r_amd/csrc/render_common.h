@@ -47,16 +47,28 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// XCD-aware block -> tile map.  The dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md): every XCD gets one contiguous
-// piece of a LOCALITY ORDER of the tiles, so that the tiles a splat touches (2.6 on average at 1080p, mostly a 2 x 2 or 1 x 2
-// patch) are composited on the same XCD at about the same time and find the splat's record in that XCD's 4 MiB L2.  The order:
-// strips of 8 tile rows, column by column inside a strip, top to bottom inside a column — vertical neighbours are 1 apart,
-// horizontal neighbours 8 apart, against 1 / tiles_x in row-major order (where ~200 tiles in flight per XCD x 320 entries x
-// 64 B already fill the L2 before the row below comes up).
-// SH = strip height (0: plain row-major order), handed to the kernels in the top byte of their tile count (pack_tiles).
-__device__ __forceinline__ int xcd_tile(const int block, const int ntiles, const int tiles_x, const int SH) {
-    const int per = (ntiles + 7) >> 3;
-    const int k = (block & 7) * per + (block >> 3);
+// XCD-aware block -> tile map.  The dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md).  The tiles are put in a LOCALITY
+// ORDER — strips of 8 tile rows, column by column inside a strip, top to bottom inside a column: vertical neighbours are 1
+// apart, horizontal neighbours 8 apart, against 1 / tiles_x in row-major order (where ~200 tiles in flight per XCD x 320 entries
+// x 64 B already fill the L2 before the row below comes up) — so that the tiles a splat touches (2.6 on average at 1080p, mostly
+// a 2 x 2 or 1 x 2 patch) are composited on the same XCD at about the same time and find the splat's record in that XCD's 4 MiB L2.
+// Round 3: the order is dealt to the XCDs in CHUNKS of up to 64 tiles (an 8 x 8 tile square of the strip order), round robin,
+// instead of one contiguous eighth each: a contiguous eighth of a 1080p frame is one band of the image, and an image whose
+// density varies from top to bottom (sky over ground) leaves whole XCDs idle while others still work.  Fewer than 4096 tiles:
+// smaller chunks, so that every XCD still gets at least eight of them.
+// Packed (pack_tiles): bits 0-21 tiles, 22-24 chunk code (0 = contiguous eighths, else log2(chunk) + 1), 25-31 strip height
+// (0: plain row-major order).
+__device__ __forceinline__ int packed_ntiles(const int packed) { return packed & 0x3FFFFF; }
+__device__ __forceinline__ int xcd_tile(const int block, const int packed, const int tiles_x) {
+    const int ntiles = packed & 0x3FFFFF, code = (packed >> 22) & 7, SH = (int)((unsigned)packed >> 25);
+    int k;
+    if (code == 0) {
+        const int per = (ntiles + 7) >> 3;
+        k = (block & 7) * per + (block >> 3);
+    } else {
+        const int lg = code - 1, j = block >> 3;   // j-th block of XCD (block & 7): its (j >> lg)-th chunk, tile (j & mask) of it
+        k = ((((j >> lg) << 3) + (block & 7)) << lg) + (j & ((1 << lg) - 1));
+    }
     if (k >= ntiles) return -1;
     if (SH == 0) return k;
     const int tiles_y = ntiles / tiles_x;
@@ -66,14 +78,31 @@ __device__ __forceinline__ int xcd_tile(const int block, const int ntiles, const
     const int bx = rem / h, by = SH * strip + (rem - bx * h);
     return by * tiles_x + bx;
 }
+// chunk code of a launch (host): DAS3R_TILE_CHUNK = 0 contiguous eighths, 1 .. 64 a fixed chunk, default: 64, halved until there
+// are at least 64 chunks
+static inline int tile_chunk_code(const int ntiles) {
+    const int forced = switches().tile_chunk;
+    if (forced == 0) return 0;
+    int c = 64;
+    if (forced > 0) c = forced;
+    else while (c > 1 && ntiles / c < 64) c >>= 1;
+    int lg = 0;
+    while ((1 << lg) < c) lg++;
+    return lg + 1;
+}
 // Strips pay when the splat records dominate a tile's traffic (measured at 1 M splats / 1080p, mean list 320: L2 misses of the
 // forward 1.83 -> 1.51 x and of the backward 3.48 -> 2.97 x the algorithmic bytes, time unchanged); with short lists (100 k
 // splats, mean list 32) the image rows dominate and vertically stacked tiles hit the same memory channels: 3 % slower — row-major.
 static inline int pack_tiles(const Layout &L) {
     const int sh = (L.capacity >= (int64_t)128 * L.ntiles) ? switches().tile_strip : 0;
-    return L.ntiles | (sh << 24);
+    return L.ntiles | (tile_chunk_code(L.ntiles) << 22) | (sh << 25);
 }
-static inline int xcd_grid(int ntiles) { return ((ntiles + 7) / 8) * 8; }
+static inline int xcd_grid(const Layout &L) {
+    const int code = tile_chunk_code(L.ntiles);
+    if (code == 0) return ((L.ntiles + 7) / 8) * 8;
+    const int ch = 1 << (code - 1), nchunks = (L.ntiles + ch - 1) / ch;
+    return ((nchunks + 7) / 8) * 8 * ch;
+}
 
 // pixel owned by lane `lane` of wave `wave` inside tile (bx, by): wave -> 8x8 quadrant, lane -> pixel of the quadrant
 __device__ __forceinline__ void quadrant_pixel(const int bx, const int by, const int wave, const int lane, int &px, int &py) {

@@ -6,15 +6,15 @@
 namespace das3r {
 
 __global__ void __launch_bounds__(256) render_forward_kernel(const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
-                                                             int W, int H, int tiles_x, int ntiles_strip /*tiles | strip height << 24: render_common.h xcd_tile*/, const float4 *__restrict__ xyh,
+                                                             int W, int H, int tiles_x, int ntiles_strip /*render_common.h pack_tiles*/, const float4 *__restrict__ xyh,
                                                              const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
                                                              const float *__restrict__ bg, float *__restrict__ final_T,
                                                              uint32_t *__restrict__ n_contrib, float *__restrict__ out_color, const LocalBin lb,
                                                              unsigned long long *__restrict__ pairs /*common.h pair_counters()*/) {
     __shared__ StagedSplat stage[TILE_PIX];
     __shared__ uint32_t s_gid[LOCAL_MAX];   // local depth order: the tile's sorted list
-    const int ntiles = ntiles_strip & 0xFFFFFF;
-    const int tile = xcd_tile(blockIdx.x, ntiles, tiles_x, ntiles_strip >> 24);
+    const int ntiles = packed_ntiles(ntiles_strip);
+    const int tile = xcd_tile(blockIdx.x, ntiles_strip, tiles_x);
     if (tile < 0) return;
     const int tid = threadIdx.x, lane = __lane_id(), wave = tid >> 6;
     const int bx = tile % tiles_x, by = tile / tiles_x;
@@ -105,7 +105,7 @@ int launch_render_forward(const das3r_raster_args *a, const float *colors_precom
     (void)colors_precomp;  // precomputed colours were copied into rgbd by the preprocess kernel
     if (use_row_private(L.capacity, L.ntiles)) return launch_render_forward_rows(a, out_color, geom, binning, img, L, lb, s);
     const int pad_lds = switches().fwd_pad_lds;   // occupancy experiments
-    DAS3R_LAUNCH(render_forward_kernel, dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), pad_lds, s, (const uint2 *)(img + L.pub.ranges),
+    DAS3R_LAUNCH(render_forward_kernel, dim3(xcd_grid(L)), dim3(TILE_PIX), pad_lds, s, (const uint2 *)(img + L.pub.ranges),
                  (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height, L.tiles_x, pack_tiles(L),
                  (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),
                  (const float4 *)(geom + L.pub.rgbd), a->bg, (float *)(img + L.pub.final_T), (uint32_t *)(img + L.pub.n_contrib),

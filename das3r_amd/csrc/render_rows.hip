@@ -80,12 +80,17 @@ __device__ __forceinline__ void build_row_lists(const StagedSplat *stage, const 
 // composites; a batch used to start with two trips in a row (list word -> record) behind the barrier.
 template <bool PREFETCH>
 __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
-                                                                  int W, int H, int tiles_x, int ntiles_strip /*tiles | strip height << 24: render_common.h xcd_tile*/, const float4 *__restrict__ xyh,
+                                                                  int W, int H, int tiles_x, int ntiles_strip /*render_common.h pack_tiles*/, const float4 *__restrict__ xyh,
                                                                   const float4 *__restrict__ conic_opacity,
                                                                   const float4 *__restrict__ rgbd, const float *__restrict__ bg,
                                                                   float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                                                                   float *__restrict__ out_color, const LocalBin lb,
-                                                                  unsigned long long *__restrict__ pairs /*common.h pair_counters()*/) {
+                                                                  unsigned long long *__restrict__ pairs_arg /*common.h pair_counters()*/) {
+#ifdef DAS3R_EXPERIMENTS
+    DECODE_PAIRS_OR_TRACE(pairs_arg)   // (tools/wg_trace.py)
+#else
+    unsigned long long *const pairs = pairs_arg;
+#endif
     // PREFETCH: two staging areas in turn — ONE barrier per batch (publish the batch); a wave that is done with batch i goes on
     // to stage batch i + 1 into the other area while slower waves still composite batch i (the barrier of batch i + 1 needs
     // everybody past batch i: the area being overwritten held batch i - 1).  The four quadrants of a tile rarely have equally long sub-lists, and with
@@ -95,10 +100,13 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
     StagedSplat *stage = stage_all;
     __shared__ uint32_t s_gid[LOCAL_MAX];   // local depth order: the tile's sorted list
     __shared__ uint8_t lists[4][4][ROW_LIST_STRIDE];   // [wave][row][position]
-    const int ntiles = ntiles_strip & 0xFFFFFF;
-    const int tile = xcd_tile(blockIdx.x, ntiles, tiles_x, ntiles_strip >> 24);
+    const int ntiles = packed_ntiles(ntiles_strip);
+    const int tile = xcd_tile(blockIdx.x, ntiles_strip, tiles_x);
     if (tile < 0) return;
     PHASE_BEGIN();   // (experiments build: common.h)
+#ifdef DAS3R_EXPERIMENTS
+    BLK_STAMP(trace, 4, 0)
+#endif
     const int tid = threadIdx.x, lane = __lane_id(), wave = tid >> 6, row = lane >> 4;
     const int bx = tile % tiles_x, by = tile / tiles_x;
     int px, py;
@@ -237,6 +245,14 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
     }
     PHASE_MARK(5)   // output
     PHASE_END(0)
+#ifdef DAS3R_EXPERIMENTS
+    BLK_STAMP(trace, 4, 1)
+    if (trace != nullptr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BLK_STAMP(trace, 4, 2)
+        if (threadIdx.x == 0 && blockIdx.x < (uint32_t)TRACE_WGS) trace[((size_t)4 * TRACE_WGS + blockIdx.x) * TRACE_STAMPS + 3] = range.y - range.x;
+    }
+#endif
     if (pairs != nullptr && lane == 0 && positions > 0) {
         atomicAdd(pairs, (unsigned long long)positions * 64ull);
         atomicAdd(pairs + 2, (unsigned long long)positions);
@@ -257,11 +273,11 @@ int launch_render_forward_rows(const das3r_raster_args *a, float *out_color, cha
     (const uint2 *)(img + L.pub.ranges), (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height,  \
         L.tiles_x, pack_tiles(L), (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity),         \
         (const float4 *)(geom + L.pub.rgbd), a->bg, (float *)(img + L.pub.final_T), (uint32_t *)(img + L.pub.n_contrib),   \
-        out_color, lb, pair_counters()
+        out_color, lb, PAIRS_ARG
     // globally sorted lists and fewer tiles than the chip has workgroup slots (4 per CU and more): see PREFETCH
     const bool prefetch = lb.point_list == nullptr && L.ntiles <= 1024 && !switches().fwd_no_prefetch;
-    if (prefetch) DAS3R_LAUNCH((render_forward_rows_kernel<true>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS);
-    else DAS3R_LAUNCH((render_forward_rows_kernel<false>), dim3(xcd_grid(L.ntiles)), dim3(TILE_PIX), 0, s, ARGS);
+    if (prefetch) DAS3R_LAUNCH((render_forward_rows_kernel<true>), dim3(xcd_grid(L)), dim3(TILE_PIX), 0, s, ARGS);
+    else DAS3R_LAUNCH((render_forward_rows_kernel<false>), dim3(xcd_grid(L)), dim3(TILE_PIX), 0, s, ARGS);
 #undef ARGS
     KERNEL_CHECK(s, a->debug, "render_forward_rows");
     return DAS3R_OK;

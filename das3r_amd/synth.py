@@ -16,6 +16,9 @@ WORKLOADS = {
     "c2": dict(P=100_000, W=1920, H=1080, focal=1200.0, sh_degree=3, seed=2),
     "c4": dict(P=1_000_000, W=1920, H=1080, focal=1200.0, sh_degree=3, seed=4),
     "ds": dict(P=5_000_000, W=512, H=208, focal=600.0, sh_degree=0, seed=5, s_px=(0.3, 1.5), opacity=0.02),
+    # c4 with the splats crowded towards the top of the frame (density ~ 1 / sqrt(height)): what an image with a busy band does to a
+    # tile order that hands every XCD one contiguous band (tools/gpu_perf.py --workloads c4s; not a bench line)
+    "c4s": dict(P=1_000_000, W=1920, H=1080, focal=1200.0, sh_degree=3, seed=4, y_skew=2.0),
 }
 
 
@@ -56,7 +59,7 @@ def _logu(g, n, lo, hi):
     return torch.exp(torch.rand(n, generator=g) * (math.log(hi) - math.log(lo)) + math.log(lo))
 
 
-def make_scene(P, W, H, focal, sh_degree, seed, s_px=(0.5, 4.0), opacity=None, max_sh_degree=3, bg=(0.0, 0.0, 0.0)):
+def make_scene(P, W, H, focal, sh_degree, seed, s_px=(0.5, 4.0), opacity=None, max_sh_degree=3, bg=(0.0, 0.0, 0.0), y_skew=1.0):
     """Camera at the origin looking down +z (DAS3R convention: viewmatrix = I, campos = 0,
     projmatrix = I @ P^T — /root/reference/gaussian_renderer/__init__.py:57-61)."""
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -66,7 +69,7 @@ def make_scene(P, W, H, focal, sh_degree, seed, s_px=(0.5, 4.0), opacity=None, m
     proj = view @ projection_matrix(0.01, 100.0, fovx, fovy).transpose(0, 1)
     z = torch.rand(P, generator=g) * 9.0 + 1.0
     x = z * tanfovx * (torch.rand(P, generator=g) * 2.2 - 1.1)
-    y = z * tanfovy * (torch.rand(P, generator=g) * 2.2 - 1.1)
+    y = z * tanfovy * (torch.rand(P, generator=g) ** y_skew * 2.2 - 1.1)   # (y_skew > 1: crowded towards the top)
     means3D = torch.stack([x, y, z], 1).contiguous()
     spx = _logu(g, P, *s_px)
     aniso = torch.stack([_logu(g, P, 0.5, 2.0) for _ in range(3)], 1)

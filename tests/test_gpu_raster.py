@@ -309,6 +309,23 @@ def test_forward_kernels_agree_bit_for_bit(name, monkeypatch):
         util.assert_grad_close(gr[k].cpu().numpy(), gq[k].cpu().numpy(), f"rows vs quad forward dL/d{k}", tol=1e-5)
 
 
+@pytest.mark.parametrize("chunk", ["0", "1", "8", "64"])
+def test_tile_order_does_not_change_results(chunk, monkeypatch):
+    """The block -> tile map of the compositing kernels (contiguous eighths per XCD / chunks dealt round robin: render_common.h
+    xcd_tile, CPU model in tests/test_tile_map.py) decides WHEN a tile is composited, nothing else: image, radii and every
+    gradient are the same bits as with the default map (short lists: quad + dpp kernels; long lists: rows + block walk)."""
+    for name in ("ragged_image", "long_lists", "deep"):
+        sc, mode = util.scene_variant(name)
+        monkeypatch.setenv("DAS3R_DETERMINISTIC", "1")   # (the dpp backward's LDS float atomics are order-dependent on their own)
+        monkeypatch.delenv("DAS3R_TILE_CHUNK", raising=False)
+        c0, r0, g0, _ = _run_hip(sc, mode)
+        monkeypatch.setenv("DAS3R_TILE_CHUNK", chunk)
+        c1, r1, g1, _ = _run_hip(sc, mode)
+        assert torch.equal(c0, c1) and torch.equal(r0, r1), (name, chunk)
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), (name, chunk, k)
+
+
 @pytest.mark.parametrize("pattern", [0x7FC00000, 0xFFFFFFFF, 0x7F800000, 0x7FA00000, 0x00000000, 0x01010101])
 def test_unwritten_lds_does_not_reach_the_image(pattern):
     """The compositing kernels leave parts of their LDS arrays unwritten (list tails, staged entries past a tile's list) and the

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 NAMES = ["ticket", "keys here", "ranked", "published+staged", "look-back done", "stores issued", "stores done"]
-PASSES, WGS, STAMPS = 8, 4096, 8
+PASSES, WGS, STAMPS = 8, 16384, 8
 
 
 def main():
@@ -58,6 +58,29 @@ def main():
         for k, name in ((1, "rectangles read + block total"), (2, "look-back"), (3, "offsets + instances written"), (4, "acknowledged")):
             print(f"   {name:34s} min/10/50/90/max: {q((sw[:, k] - sw[:, k - 1]) / 100.0)}")
         print(f"   lifetime                           min/10/50/90/max: {q((sw[:, 4] - sw[:, 0]) / 100.0)}")
+    # compositing kernels: regions 4 (rows forward) and 5 (block-walk backward): start, stores issued, acknowledged, list length
+    for region, name in ((4, "render forward (rows)"), (5, "render backward (blk)")):
+        cw = t[region][t[region, :, 0] != 0]
+        if not len(cw):
+            continue
+        t0 = cw[:, 0].min()
+        q = lambda a: " ".join(f"{v:7.1f}" for v in np.percentile(a, [0, 10, 50, 90, 100]))  # noqa: E731
+        start, end = (cw[:, 0] - t0) / 100.0, (cw[:, 2] - t0) / 100.0
+        life = end - start
+        span = end.max()
+        # workgroups in flight over time
+        ev = np.concatenate([np.stack([start, np.ones_like(start)], 1), np.stack([end, -np.ones_like(end)], 1)])
+        ev = ev[np.argsort(ev[:, 0])]
+        conc = np.cumsum(ev[:, 1])
+        peak = conc.max()
+        dt = np.diff(ev[:, 0], append=span)
+        mean_conc = float((conc * dt).sum() / span)
+        print(f"== {name}: {len(cw)} workgroups, first start -> last acknowledged {span:.1f} us; in flight: peak {int(peak)}, time-average {mean_conc:.0f}")
+        print(f"   start time (us)                    min/10/50/90/max: {q(start)}")
+        print(f"   lifetime (us)                      min/10/50/90/max: {q(life)}")
+        print(f"   list length                        min/10/50/90/max: {q(cw[:, 3].astype(float))}")
+        print(f"   lifetime vs list length: corr {np.corrcoef(life, cw[:, 3])[0, 1]:.2f};  us per 100 entries (median) {np.median(life / np.maximum(cw[:, 3], 1)) * 100:.1f}")
+        print(f"   last start at {start.max():.1f} us; time with fewer than half the peak in flight: {float(dt[conc < peak / 2].sum()):.1f} us")
     # per-Gaussian backward: region PASSES - 2, eight stamps, by blockIdx
     pb = t[PASSES - 2][t[PASSES - 2, :, 0] != 0]
     if len(pb):
