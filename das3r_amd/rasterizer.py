@@ -230,7 +230,7 @@ def _forward_full(rs, means3D, sh, colors_precomp, opacities, scales, rotations,
 
 
 def _backward_impl(rs, num_rendered, grad_out_color, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                   geom, binning, img, capacity=None):
+                   geom, binning, img, capacity=None, _scratch_misalign=0):
     ticket = capacity
     capacity = int(num_rendered) if capacity is None else int(capacity)
     lib = _lib.load()
@@ -248,7 +248,8 @@ def _backward_impl(rs, num_rendered, grad_out_color, means3D, sh, colors_precomp
     if P == 0:
         return g_means2D, g_colors, g_opac, g_means3D, g_cov, g_sh, g_scales, g_rot
     # per-instance partial sums, written by the render backward and added per Gaussian (no atomics, no memset by the caller)
-    scratch = torch.empty(int(lib.das3r_raster_backward_scratch_bytes(max(capacity, 1))), dtype=torch.uint8, device=device)
+    # (_scratch_misalign: tests hand the library a scratch buffer that is only 4-byte aligned — a C caller may)
+    scratch = torch.empty(int(lib.das3r_raster_backward_scratch_bytes(max(capacity, 1))) + int(_scratch_misalign), dtype=torch.uint8, device=device)
     keep = []
     a = _fill_args(rs, P, M, device, keep)
     i = _fill_in(means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp)
@@ -264,7 +265,7 @@ def _backward_impl(rs, num_rendered, grad_out_color, means3D, sh, colors_precomp
     g.dL_dcolors_precomp = _ptr(g_colors)
     g.dL_dscales, g.dL_drotations = _ptr(g_scales), _ptr(g_rot)
     g.dL_dcov3D = _ptr(g_cov)
-    g.scratch = scratch.data_ptr()
+    g.scratch = scratch.data_ptr() + int(_scratch_misalign)
     dL = grad_out_color.contiguous()
     if dL.dtype != torch.float32:
         dL = dL.float()

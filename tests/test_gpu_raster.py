@@ -309,6 +309,31 @@ def test_forward_kernels_agree_bit_for_bit(name, monkeypatch):
         util.assert_grad_close(gr[k].cpu().numpy(), gq[k].cpu().numpy(), f"rows vs quad forward dL/d{k}", tol=1e-5)
 
 
+def test_scratch_alignment_does_not_matter(monkeypatch):
+    """The per-Gaussian backward reads a workgroup's run of partial rows as 16-byte words when the caller's scratch buffer is 16-byte
+    aligned and as 4-byte words otherwise (preprocess_bwd.hip): same rows, same order of the sums — the gradients are the same bits
+    (deterministic backward, so that the comparison can be exact)."""
+    from das3r_amd import GaussianRasterizationSettings, rasterizer
+    monkeypatch.setenv("DAS3R_DETERMINISTIC", "1")
+    for name in ("basic_deg3", "long_lists", "ragged_image"):
+        sc, mode = util.scene_variant(name)
+        dev = _dev()
+        kw = {k: v.to(dev) for k, v in util.raster_inputs(sc, mode).items()}
+        skw = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in util.settings_kwargs(sc, mode).items()}
+        rs = GaussianRasterizationSettings(**skw)
+        e = torch.empty(0, device=dev)
+        args = (rs, kw["means3D"], kw["shs"], e, kw["opacities"], kw["scales"], kw["rotations"], e)
+        I, c, r, g, b, i, cap = rasterizer._forward_full(*args, exact=True)
+        dL = sc.dL_dpix.to(dev)
+        ref = rasterizer._backward_impl(rs, I, dL, *args[1:], g, b, i, cap)
+        for off in (4, 8, 12):
+            got = rasterizer._backward_impl(rs, I, dL, *args[1:], g, b, i, cap, _scratch_misalign=off)
+            for x, y in zip(ref, got):
+                assert (x is None) == (y is None)
+                if x is not None:
+                    assert torch.equal(x, y), (name, off)
+
+
 @pytest.mark.parametrize("chunk", ["0", "1", "8", "64"])
 def test_tile_order_does_not_change_results(chunk, monkeypatch):
     """The block -> tile map of the compositing kernels (contiguous eighths per XCD / chunks dealt round robin: render_common.h
