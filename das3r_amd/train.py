@@ -84,7 +84,7 @@ def train(model, cameras, opt: OptimParams, iterations, pipe=None, background=No
         cam = stack.pop(rng.randint(0, len(stack) - 1))
         loss, p, _ = train_step(model, cam, opt, it, pipe, background, fused=fused)
         if not stack and test_cameras and model.enable_test:
-            test_pose_pass(model, test_cameras, gt_dynamic_masks, opt, pipe, background, rng)
+            test_pose_pass(model, test_cameras, gt_dynamic_masks, opt, pipe, background, rng, fused=fused)
         ema = 0.4 * loss + 0.6 * ema          # stays on the device: a float() here would stall the host every iteration
         last_psnr = p
         if log_every and it % log_every == 0:
@@ -106,25 +106,35 @@ def resize_mask_nearest(mask, H, W):
     return torch.nn.functional.interpolate(m, size=(H, W), mode="nearest")[0]
 
 
-def test_pose_pass(model, test_cams, gt_dynamic_masks, opt: OptimParams, pipe, background, rng):
+def test_pose_pass(model, test_cams, gt_dynamic_masks, opt: OptimParams, pipe, background, rng, fused=False):
     """The pass over the held-out views train_test_psnr.py runs whenever the training stack runs empty (:109-147): every test
     view, in random order, is rendered with its test pose, the loss against the ground truth under (1 - gt_dynamic_mask) is
     back-propagated, the Gaussian optimizer's gradients are dropped WITHOUT a step, and optimizer_cam is stepped when the frame
     PSNR exceeds the gate.  optimizer_cam holds the TRAINING poses, whose gradients are None here, so no parameter changes
-     — the pass costs time and nothing else; it is reproduced for the iterations/s of configs[4]."""
+     — the pass costs time and nothing else; it is reproduced for the iterations/s of configs[4].
+    fused: the same render + loss kernels as the training step (round 3: with the PyTorch glue this pass was more than half of a
+    DAVIS-shaped job — five 6.6 M-Gaussian views at ~40 ms each per 45 iterations of 3.7 ms), and no host sync on the gate."""
     stack = list(test_cams)
     while stack:
         cam = stack.pop(rng.randint(0, len(stack) - 1))
-        pkg = das3r_render(cam, model, pipe, background, camera_pose=model.get_RT_test(cam.uid))
+        pkg = das3r_render(cam, model, pipe, background, camera_pose=model.get_RT_test(cam.uid), fused=fused)
         m = gt_dynamic_masks.get(cam.uid) if gt_dynamic_masks else None
-        static = 1 - resize_mask_nearest(m, cam.image_height, cam.image_width) if m is not None else 1.0
-        image, gt = pkg["render"] * static, cam.original_image * static
-        psnr_frame = psnr(image, gt).mean()
-        loss = ((1.0 - opt.lambda_dssim) * l1_loss(image, gt, reduce=False) + opt.lambda_dssim * (1.0 - ssim(image, gt, size_average=False))).mean()
+        if fused:
+            from .fused import masked_photometric_loss
+            H, W = cam.image_height, cam.image_width
+            static_hw = (1 - resize_mask_nearest(m, H, W)[0]) if m is not None else torch.ones(H, W, device=pkg["render"].device)
+            loss, mse = masked_photometric_loss(pkg["render"], cam.original_image, static_hw, opt.lambda_dssim)
+            psnr_frame = (20 * torch.log10(1.0 / torch.sqrt(mse))).mean()
+        else:
+            static = 1 - resize_mask_nearest(m, cam.image_height, cam.image_width) if m is not None else 1.0
+            image, gt = pkg["render"] * static, cam.original_image * static
+            psnr_frame = psnr(image, gt).mean()
+            loss = ((1.0 - opt.lambda_dssim) * l1_loss(image, gt, reduce=False) + opt.lambda_dssim * (1.0 - ssim(image, gt, size_average=False))).mean()
         loss.backward(retain_graph=True)
         with torch.no_grad():
             model.optimizer.zero_grad(set_to_none=True)
-            if psnr_frame > opt.psnr_threshold and not hasattr(model.optimizer_cam, "_gate_state"):
+            # (FusedAdam evaluates the gate on the device and owns no gradient here: nothing to do, and no host sync on psnr_frame)
+            if not hasattr(model.optimizer_cam, "_gate_state") and psnr_frame > opt.psnr_threshold:
                 model.optimizer_cam.step()   # every gradient it owns is None: a no-op, as in the reference
             model.optimizer_cam.zero_grad(set_to_none=True)
             if model.test_Q.grad is not None:   # (test_Q / test_T do get gradients; nothing ever consumes them)

@@ -63,6 +63,39 @@ def test_train_step_improves_psnr():
     assert lrs["xyz"] < opt.position_lr_init and 3e-4 < lrs["conf_static"] < 3e-3
 
 
+@pytest.mark.parametrize("fused", [False, True])
+def test_held_out_pose_pass_changes_nothing(fused):
+    """train_test_psnr.py's pass over the held-out views (train.test_pose_pass): renders and back-propagates every test view and
+    changes no parameter and no optimizer state — with the PyTorch glue and with the fused kernels (the form the farm runs:
+    round 3, it used to take the unfused path and more than half of a DAVIS-shaped job)."""
+    import random
+    from types import SimpleNamespace
+    from das3r_amd.model import OptimParams
+    from das3r_amd.train import build_from_sequence, synthetic_sequence, test_pose_pass, train
+    seq = synthetic_sequence(frames=12, W=64, H=48, focal=70.0, n_splats=2500, seed=7)
+    model, cams, test_cams = build_from_sequence(seq, heldout=True)
+    assert len(test_cams) >= 1 and model.enable_test
+    opt = OptimParams(iterations=20)
+    model.training_setup(opt, fused=fused)
+    train(model, cams, opt, 5, seed=1, fused=fused)   # a few steps so that the optimizer has state
+    def params():   # (SplatModel is not an nn.Module: its parameters are the optimizers' — Gaussians, conf_static, poses, FoV)
+        out = {}
+        for oi, o in enumerate((model.optimizer, model.optimizer_cam)):
+            for g in o.param_groups:
+                for k, p in enumerate(g["params"]):
+                    out[f"{oi}:{g.get('name', '?')}:{k}"] = p
+        return out
+    before = {n: p.detach().clone() for n, p in params().items()}
+    dev = model.get_xyz.device
+    masks = {c.uid: (torch.rand(48, 64, device=dev) > 0.7) for c in test_cams}
+    pipe = SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
+    for gt_masks in (None, masks):
+        test_pose_pass(model, test_cams, gt_masks, opt, pipe, torch.zeros(3, device=dev), random.Random(0), fused=fused)
+    for n, p in params().items():
+        assert torch.equal(p.detach(), before[n]), n
+        assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+
+
 def test_farm_job_on_a_sequence_directory(tmp_path):
     """§8(f)-4 end to end: a preprocessed sequence directory on disk -> load_sequence -> per-pixel Gaussian model -> a few
     optimisation steps (fused kernels) -> the reference's output files, read back."""
