@@ -243,23 +243,44 @@ def save_gaussians_ply(path, xyz, features_dc, features_rest, opacity_raw, scali
     element: features as [P,K,3] tensors are stored channel-major (transpose(1,2).flatten), `opacity_ori` is the raw logit,
     `opacity` = inverse_sigmoid(sigmoid(opacity_ori) * conf_static), normals are zero."""
     to = lambda t: np.asarray(t.detach().cpu().numpy() if hasattr(t, "detach") else t, dtype=np.float32)
-    xyz, opacity_raw, scaling, rotation = to(xyz), to(opacity_raw).reshape(-1, 1), to(scaling), to(rotation)
-    conf = to(conf_static_per_gaussian).reshape(-1, 1)
-    f_dc = to(features_dc).transpose(0, 2, 1).reshape(xyz.shape[0], -1)
-    f_rest = to(features_rest).transpose(0, 2, 1).reshape(xyz.shape[0], -1)
-    sig = 1.0 / (1.0 + np.exp(-opacity_raw.astype(np.float32)))
-    o = (sig * conf).astype(np.float32)
+    on_device = hasattr(xyz, "is_cuda") and xyz.is_cuda
+    opacity_raw_np = to(opacity_raw).reshape(-1, 1)
+    conf_np = to(conf_static_per_gaussian).reshape(-1, 1)
+    sig = 1.0 / (1.0 + np.exp(-opacity_raw_np.astype(np.float32)))
+    o = (sig * conf_np).astype(np.float32)
     with np.errstate(divide="ignore", invalid="ignore"):
-        opacity = np.log(o / (1 - o)).astype(np.float32)
-    table = np.concatenate([xyz, np.zeros_like(xyz), f_dc, f_rest, opacity_raw, opacity, conf, scaling, rotation], axis=1).astype("<f4")
-    names = ply_attribute_names(f_dc.shape[1], f_rest.shape[1], scaling.shape[1], rotation.shape[1])
-    assert table.shape[1] == len(names)
+        opacity_np = np.log(o / (1 - o)).astype(np.float32)
+    P = opacity_raw_np.shape[0]
+    if on_device:
+        # The 62-column table is interleaved ON THE DEVICE (pure copies: the same bytes) and comes over in one piece: on the host
+        # the strided concatenate of 1.7 GB was the largest part of a DAVIS-shaped job outside its training loop.  The two opacity
+        # columns are computed on the host as before (numpy float32: the file's bytes do not depend on where the tensors live).
+        import torch
+        with torch.no_grad():
+            dev, f32 = xyz.device, torch.float32
+            t = lambda a: a.detach().to(f32)
+            up = lambda a: torch.from_numpy(a).to(dev)
+            f_dc_t = t(features_dc).transpose(1, 2).reshape(P, -1)
+            f_rest_t = t(features_rest).transpose(1, 2).reshape(P, -1)
+            cols = [t(xyz), torch.zeros(P, 3, device=dev, dtype=f32), f_dc_t, f_rest_t, up(opacity_raw_np), up(opacity_np), up(conf_np),
+                    t(scaling), t(rotation)]
+            n_dc, n_rest, n_sc, n_rot = f_dc_t.shape[1], f_rest_t.shape[1], cols[7].shape[1], cols[8].shape[1]
+            table = torch.cat(cols, dim=1).contiguous().cpu().numpy()
+    else:
+        xyz_np, scaling_np, rotation_np = to(xyz), to(scaling), to(rotation)
+        f_dc = to(features_dc).transpose(0, 2, 1).reshape(P, -1)
+        f_rest = to(features_rest).transpose(0, 2, 1).reshape(P, -1)
+        n_dc, n_rest, n_sc, n_rot = f_dc.shape[1], f_rest.shape[1], scaling_np.shape[1], rotation_np.shape[1]
+        table = np.concatenate([xyz_np, np.zeros_like(xyz_np), f_dc, f_rest, opacity_raw_np, opacity_np, conf_np, scaling_np, rotation_np], axis=1)
+    table = np.ascontiguousarray(table, dtype="<f4")
+    names = ply_attribute_names(n_dc, n_rest, n_sc, n_rot)
+    assert table.shape == (P, len(names))
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-    header = "ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % xyz.shape[0]
+    header = "ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % P
     header += "".join(f"property float {n}\n" for n in names) + "end_header\n"
     with open(path, "wb") as f:
         f.write(header.encode("ascii"))
-        f.write(np.ascontiguousarray(table).tobytes())
+        table.tofile(f)   # (no second copy of the table in memory)
 
 
 def read_ply_vertices(path):
