@@ -22,7 +22,7 @@ struct AdamTable {
     float *m[ADAM_MAX_TENSORS];
     float *v[ADAM_MAX_TENSORS];
     long long n_active[ADAM_MAX_TENSORS];     // rows * active_len
-    int row_len[ADAM_MAX_TENSORS], active_len[ADAM_MAX_TENSORS];
+    int row_len[ADAM_MAX_TENSORS], active_len[ADAM_MAX_TENSORS], grad_row_len[ADAM_MAX_TENSORS];
     int first_chunk[ADAM_MAX_TENSORS + 1];    // prefix of chunk counts
     float step_size[ADAM_MAX_TENSORS], bc2_sqrt[ADAM_MAX_TENSORS], step_size_tail[ADAM_MAX_TENSORS];
     int head_len[ADAM_MAX_TENSORS];
@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(256) adam_kernel(const AdamTable T, float beta
     float *__restrict__ m = T.m[t];
     float *__restrict__ v = T.v[t];
     const long long n = T.n_active[t];
-    const int row_len = T.row_len[t], active_len = T.active_len[t];
+    const int row_len = T.row_len[t], active_len = T.active_len[t], grad_row_len = T.grad_row_len[t];
     const float step_size = GATED ? T.step_size[t] / gate_bc1 : T.step_size[t], bc2_sqrt = GATED ? gate_bc2_sqrt : T.bc2_sqrt[t];
     const float step_size_tail = GATED ? T.step_size_tail[t] / gate_bc1 : T.step_size_tail[t];
     const int head_len = T.head_len[t];
@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256) adam_kernel(const AdamTable T, float beta
         if (e < n) {
             const int col = (int)(e % active_len);
             const long long off = (row_len == active_len) ? e : (e / active_len) * row_len + col;
-            const float gr = g[off];
+            const float gr = g[(grad_row_len == row_len) ? off : (e / active_len) * grad_row_len + col];   // (a compact gradient: its own row stride)
             float mm = m[off], vv = v[off];
             mm = mm + (gr - mm) * (1.0f - beta1);
             vv = vv * beta2 + (1.0f - beta2) * gr * gr;
@@ -95,14 +95,16 @@ static int adam_launch(int32_t n, const das3r_adam_tensor *tensors, float beta1,
     int chunks = 0, k = 0;
     for (int i = 0; i < n; i++) {
         const das3r_adam_tensor &a = tensors[i];
-        if (a.rows < 0 || a.row_len <= 0 || a.active_len < 0 || a.active_len > a.row_len || !a.param || !a.grad || !a.exp_avg || !a.exp_avg_sq) {
+        const int grl = a.grad_row_len > 0 ? a.grad_row_len : a.row_len;
+        if (a.rows < 0 || a.row_len <= 0 || a.active_len < 0 || a.active_len > a.row_len || a.active_len > grl || !a.param || !a.grad || !a.exp_avg ||
+            !a.exp_avg_sq) {
             set_error("das3r_adam_step: bad tensor %d", i);
             return DAS3R_ERR_INVALID_ARG;
         }
         const long long na = (long long)a.rows * a.active_len;
         if (na == 0) continue;   // nothing active in this tensor (e.g. f_rest while the SH degree is 0)
         T.p[k] = a.param; T.g[k] = a.grad; T.m[k] = a.exp_avg; T.v[k] = a.exp_avg_sq;
-        T.n_active[k] = na; T.row_len[k] = a.row_len; T.active_len[k] = a.active_len;
+        T.n_active[k] = na; T.row_len[k] = a.row_len; T.active_len[k] = a.active_len; T.grad_row_len[k] = grl;
         T.step_size[k] = a.step_size; T.bc2_sqrt[k] = a.bc2_sqrt;
         const bool split = a.head_len > 0 && a.head_len < a.active_len;   // otherwise one rate for the whole row
         T.head_len[k] = split ? a.head_len : a.row_len;

@@ -16,7 +16,7 @@ from . import _lib
 class AdamTensor(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("rows", C.c_int64),
                 ("row_len", C.c_int32), ("active_len", C.c_int32), ("step_size", C.c_float), ("bc2_sqrt", C.c_float),
-                ("head_len", C.c_int32), ("step_size_tail", C.c_float)]
+                ("head_len", C.c_int32), ("step_size_tail", C.c_float), ("grad_row_len", C.c_int32)]
 
 
 def _stream(device):
@@ -86,6 +86,28 @@ def pretransform(xyz, rot, scaling, opacity_raw, conf, mask_index, pose):
     return _PreTransform.apply(xyz, rot, scaling, opacity_raw, conf, mask_index, pose)
 
 
+class _ShPrefix(torch.autograd.Function):
+    """cat(f_dc, f_rest[:, :K - 1]) -> [P, K, 3]: the coefficients of the ACTIVE degree only (K = (degree + 1)^2).  Its backward
+    hands f_dc its slice and leaves f_rest.grad None: the [P, K - 1, 3] gradient of the active prefix is parked on the parameter
+    (`_das3r_compact_grad`) for FusedAdam, which reads it with its own row stride — a dense [P, 15, 3] gradient would be 180
+    bytes per Gaussian of zeros written and read back every iteration."""
+
+    @staticmethod
+    def forward(ctx, f_dc, f_rest, K):
+        ctx.rest = f_rest
+        return torch.cat((f_dc, f_rest[:, :K - 1]), dim=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.rest._das3r_compact_grad = g[:, 1:].contiguous()
+        return g[:, :1].contiguous(), None, None
+
+
+def active_sh_prefix(f_dc, f_rest, degree):
+    """The SH tensor the fused render hands the rasterizer while 0 < degree < max (das3r_amd.render); FusedAdam only."""
+    return _ShPrefix.apply(f_dc, f_rest, (int(degree) + 1) ** 2)
+
+
 class FusedAdam:
     """torch.optim.Adam(lr=0.0, eps=1e-15)-compatible optimizer for lists of fp32 device tensors: same param_groups / step() /
     zero_grad() surface as the reference uses, one HIP launch per step.  A group may carry "sh_rest": True — its tensor is
@@ -113,6 +135,8 @@ class FusedAdam:
     def zero_grad(self, set_to_none=True):
         for g in self.param_groups:
             for p in g["params"]:
+                if getattr(p, "_das3r_compact_grad", None) is not None:
+                    p._das3r_compact_grad = None
                 if set_to_none:
                     p.grad = None
                 elif p.grad is not None:
@@ -128,7 +152,8 @@ class FusedAdam:
         entries, keep, dev = [], [], None
         for g in self.param_groups:
             for p in g["params"]:
-                if p.grad is None:
+                compact = getattr(p, "_das3r_compact_grad", None) if g.get("sh_rest") else None   # (_ShPrefix: gradient of the active prefix)
+                if p.grad is None and compact is None:
                     # The higher-order SH coefficients get no gradient while the fused render hands the rasterizer the DC tensor
                     # alone (render.py).  In the reference they receive an all-zero gradient from iteration 1, so torch.optim.Adam
                     # counts those steps (moments stay 0): keep the same count, or the bias corrections would restart at 1 when
@@ -147,9 +172,12 @@ class FusedAdam:
                     st = self.state[p] = dict(step=0, exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p))
                 st["step"] += 1
                 t = st["step"]
-                grad = p.grad.contiguous()
+                if p.grad is None and (self.active_sh_degree is None or p.dim() != 3):
+                    raise RuntimeError("FusedAdam: a compact SH gradient needs set_active_sh_degree() and a [P, K, 3] parameter")
+                grad = (p.grad if p.grad is not None else compact).contiguous()
                 keep.append(grad)
                 e = AdamTensor()
+                e.grad_row_len = 0
                 e.param, e.grad, e.exp_avg, e.exp_avg_sq = p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
                 e.head_len, e.step_size_tail = 0, 0.0
                 if g.get("sh_all") and p.dim() == 3:     # one [P, K, 3] tensor: DC coefficient (lr) + the rest (lr_rest)
@@ -161,6 +189,10 @@ class FusedAdam:
                 elif g.get("sh_rest") and self.active_sh_degree is not None and p.dim() == 3:
                     e.rows, e.row_len = p.shape[0], p.shape[1] * p.shape[2]
                     e.active_len = min(e.row_len, 3 * ((self.active_sh_degree + 1) ** 2 - 1))
+                    if p.grad is None:   # the compact gradient [P, K - 1, 3] of _ShPrefix
+                        e.grad_row_len = grad.shape[1] * grad.shape[2]
+                        if e.grad_row_len < e.active_len:
+                            raise RuntimeError("FusedAdam: the compact SH gradient is shorter than the active degree")
                 else:
                     e.rows, e.row_len, e.active_len = 1, p.numel(), p.numel()
                     if p.numel() >= 2 ** 31:

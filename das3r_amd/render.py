@@ -123,7 +123,16 @@ def rasterizer_inputs(cam, pc, pipe, bg_color, scaling_modifier=1.0, override_co
         # — only with the fused optimizer: torch.optim.Adam skips a parameter without gradient, so its step count (and bias
         # correction) for f_rest would restart at the degree bump, where the reference has counted 3000 zero-gradient steps
         fused_opt = getattr(getattr(pc, "optimizer", None), "is_fused", False)
-        shs = pc._features_dc if (pc.active_sh_degree == 0 and fused_opt) else pc.get_features
+        if fused_opt and pc.active_sh_degree == 0:
+            shs = pc._features_dc
+        elif fused_opt and pc.active_sh_degree < pc.max_sh_degree:
+            # round 3: between degree 0 and the maximum (iterations 3000 .. of DAS3R's 4000 run at degree 1) the rasterizer gets the
+            # coefficients of the ACTIVE degree only — [P, 4, 3] at degree 1 instead of [P, 16, 3]: same image, and the gradient of
+            # the active prefix goes to FusedAdam as it is (fused._ShPrefix)
+            from .fused import active_sh_prefix
+            shs = active_sh_prefix(pc._features_dc, pc._features_rest, pc.active_sh_degree)
+        else:
+            shs = pc.get_features
         return settings, dict(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None, opacities=opacity, scales=scales,
                               rotations=rotations, cov3D_precomp=None)
 

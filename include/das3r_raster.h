@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define DAS3R_ABI_VERSION 8
+#define DAS3R_ABI_VERSION 9
 
 typedef enum {
     DAS3R_OK = 0,
@@ -202,6 +202,8 @@ typedef struct {
     float bc2_sqrt;   /* sqrt(1 - beta2^t) */
     int32_t head_len;
     float step_size_tail;
+    int32_t grad_row_len; /* ABI 9: floats per row of `grad` when it is more compact than the parameter (>= active_len: e.g. the
+                             gradient of the first 3 of 15 SH coefficients as [P, 3, 3]); 0 = row_len */
 } das3r_adam_tensor;
 int das3r_adam_step(int32_t n, const das3r_adam_tensor *tensors, float beta1, float beta2, float eps, das3r_stream_t stream);
 /* The same step taken iff the DEVICE scalar gate[0] > threshold (DAS3R's camera optimizer steps only when the frame PSNR exceeds

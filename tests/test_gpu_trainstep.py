@@ -108,6 +108,40 @@ def test_first_adam_steps_match_the_float64_restatement(fused):
                 assert float(g[far].max()) <= 1e-3 * float(g.max()), (k, float(g[far].max()) / float(g.max()))
 
 
+@pytest.mark.parametrize("degree", [1, 2])
+def test_active_sh_prefix_steps_like_the_full_tensor(degree):
+    """Between SH degree 0 and the maximum the fused render hands the rasterizer the coefficients of the active degree only
+    ([P, 4, 3] at degree 1: fused._ShPrefix) and FusedAdam takes the compact gradient of that prefix with its own row stride
+    (das3r_adam_tensor.grad_row_len, ABI 9).  Two identical models take the same three fused steps, one with the prefix, one
+    with cat(f_dc, f_rest) (as at the maximum degree): losses, every parameter and the Adam moments of f_rest agree."""
+    from das3r_amd.train import train_step
+    out = []
+    for full in (False, True):
+        model, cams, _, opt, _dense = _pair(frames=3, W=32, H=24, seed=9, heldout=False, iterations=100, fused=True, generic=True)
+        model.active_sh_degree = degree
+        model.optimizer.set_active_sh_degree(degree)
+        with torch.no_grad():   # (coefficients above DC start at zero: give them values, the same in both models)
+            g = torch.Generator(device="cpu").manual_seed(11)
+            model._features_rest.copy_((torch.randn(model._features_rest.shape, generator=g) * 0.05).to(model._features_rest.device))
+        if full:
+            model.max_sh_degree = degree   # render.py: at the maximum degree the full tensor is passed
+        bg = torch.zeros(3, device="cuda")
+        losses = [float(train_step(model, cams[u], opt, it, PIPE, bg, fused=True)[0]) for it, u in enumerate([0, 2, 1], start=1)]
+        st = model.optimizer.state[model._features_rest]
+        out.append((losses, {k: getattr(model, a).detach().clone() for k, a in NAMES.items()}, st["exp_avg"].clone(), st["exp_avg_sq"].clone(), st["step"]))
+    (l0, p0, m0, v0, s0), (l1, p1, m1, v1, s1) = out
+    assert s0 == s1 == 3
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 1e-6 * abs(b), (l0, l1)
+    K = (degree + 1) ** 2 - 1
+    assert float(m0[:, K:].abs().max()) == 0.0 and float(v0[:, K:].abs().max()) == 0.0   # nothing above the active degree moved
+    assert torch.allclose(m0, m1, rtol=1e-4, atol=1e-9) and torch.allclose(v0, v1, rtol=1e-4, atol=1e-12)
+    for k in p0:
+        lr = 1e-2   # (an Adam step moves an element by at most its learning rate: a sign flip of a noise-level gradient is the bound)
+        far = (p0[k] - p1[k]).abs() > 1e-5 + 1e-4 * p1[k].abs()
+        assert float(far.double().mean()) <= 1e-3, (k, float(far.double().mean()))
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_full_schedule_psnr_matches_the_float64_restatement(fused):
     """fused=True (VERDICT r2 item 5 / ADVICE r1): the same schedule on the opt-in fused kernels — the path train_step_ms and
