@@ -52,7 +52,7 @@ EXPORTS = ("das3r_raster_forward", "das3r_raster_backward", "das3r_raster_check"
            "das3r_knn3_mean_dist2", "das3r_raster_get_layout", "das3r_abi_version", "das3r_last_error", "das3r_reload_switches", "das3r_get_stats",
            "das3r_profile_enable", "das3r_profile_report", "das3r_pretransform_forward", "das3r_pretransform_backward", "das3r_pose_matrices", "das3r_pose_chain",
            "das3r_adam_step", "das3r_adam_step_gated", "das3r_photometric_blocks", "das3r_photometric_forward", "das3r_photometric_backward",
-           "das3r_has_experiments", "das3r_pair_counters", "das3r_debug_poison_lds")
+           "das3r_has_experiments", "das3r_pair_counters", "das3r_debug_poison_lds", "das3r_debug_inject_fault")
 
 _lib = None
 
@@ -130,6 +130,14 @@ def has_experiments():
     L.das3r_has_experiments.restype = C.c_int
     L.das3r_has_experiments.argtypes = []
     return bool(L.das3r_has_experiments())
+
+
+def inject_fault(bits):
+    """Test aid: OR `bits` into the binning self-check word of every forward from now on; 0 switches it off (include/das3r_raster.h)."""
+    L = load()
+    L.das3r_debug_inject_fault.restype = None
+    L.das3r_debug_inject_fault.argtypes = [C.c_uint32]
+    L.das3r_debug_inject_fault(int(bits))
 
 
 def poison_lds(pattern=0x7FC00000):

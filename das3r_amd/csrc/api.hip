@@ -49,19 +49,31 @@ void profile_end(hipStream_t s) {
 
 static Switches g_sw;
 static bool g_sw_loaded = false;
+static int g_inject_fault = 0;
 static void load_switches() {
     Switches w;
     memset(&w, 0, sizeof(w));
     auto env = [](const char *k) -> const char * { const char *e = getenv(k); return (e && e[0]) ? e : nullptr; };
     const char *e;
+    // Switches that select between CORRECT code paths (tests force each of them) are read in every build.  Those that exist for
+    // timing experiments only — some of them produce wrong results by design (DAS3R_ABLATE) — are read only by an experiments
+    // build (make EXPERIMENTS=1): a stray environment variable cannot change what the shipped library computes.  Fault injection
+    // for the self-check tests is a call (das3r_debug_inject_fault), not an environment variable.
+#ifdef DAS3R_EXPERIMENTS
     if ((e = env("DAS3R_SORT_IPL"))) { const int v = atoi(e); w.sort_ipl = (v == 4 || v == 8 || v == 16) ? v : 0; }
     w.sort_classic = (e = env("DAS3R_SORT")) && e[0] == 'c';
+    w.no_sh_stage = getenv("DAS3R_NO_SH_STAGE") != nullptr;
+    if ((e = env("DAS3R_ABLATE"))) { w.ablate_set = true; w.ablate = atoi(e); }
+    if ((e = env("DAS3R_BWD_PAD_LDS"))) w.bwd_pad_lds = atoi(e);
+    if ((e = env("DAS3R_FWD_PAD_LDS"))) w.fwd_pad_lds = atoi(e);
+    if ((e = env("DAS3R_SCAN_ITEMS"))) { const int v = atoi(e); w.scan_items = (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? v : 0; }
+    w.fwd_no_prefetch = (e = env("DAS3R_FWD_PREFETCH")) && e[0] == '0';
+#endif
     w.rect_upstream = (e = env("DAS3R_RECT")) && e[0] == 'u';
     w.verbose = env("DAS3R_VERBOSE") != nullptr;
     if ((e = env("DAS3R_BINNING"))) w.binning = e[0] == 'l' ? 1 : (e[0] == 'r' ? -1 : 0);
     w.capacity_exact = (e = env("DAS3R_CAPACITY")) && e[0] == 'e';
     w.fused_emit_off = (e = env("DAS3R_FUSED_EMIT")) && e[0] == '0';
-    w.no_sh_stage = getenv("DAS3R_NO_SH_STAGE") != nullptr;
     if ((e = env("DAS3R_RENDER"))) w.render_fwd = e[0] == 'q' ? 1 : (e[0] == 'r' ? 2 : 0);
     if ((e = env("DAS3R_RENDER_BWD"))) {   // dpp | mfma | scan[a][64|128|256|512]
         w.render_bwd = e[0] == 'd' ? 1 : (e[0] == 'm' ? 2 : (strncmp(e, "stream", 6) == 0 ? 5 : (e[0] == 's' ? 3 : (e[0] == 'b' ? 6 : 0))));
@@ -81,21 +93,16 @@ static void load_switches() {
         }
     }
     if ((e = env("DAS3R_BWD_REDUCE"))) { w.bwd_reduce_set = true; w.bwd_reduce_shfl = e[0] == 's'; }
-    if ((e = env("DAS3R_ABLATE"))) { w.ablate_set = true; w.ablate = atoi(e); }
     w.tickets = -1;
     if ((e = env("DAS3R_TICKETS"))) w.tickets = e[0] == 'a' ? 0 : (e[0] == 'n' ? 1 << 30 : ((e[0] >= '1' && e[0] <= '9') ? atoi(e) : -1));
-    if ((e = env("DAS3R_BWD_PAD_LDS"))) w.bwd_pad_lds = atoi(e);
-    if ((e = env("DAS3R_FWD_PAD_LDS"))) w.fwd_pad_lds = atoi(e);
-    if ((e = env("DAS3R_INJECT_FAULT"))) w.inject_fault = atoi(e);
-    if ((e = env("DAS3R_SCAN_ITEMS"))) { const int v = atoi(e); w.scan_items = (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? v : 0; }
     w.deterministic = (e = env("DAS3R_DETERMINISTIC")) && e[0] != '0';
     w.bwd_buckets = -1;
     if ((e = env("DAS3R_BWD_BUCKETS"))) w.bwd_buckets = atoi(e);
-    w.fwd_no_prefetch = (e = env("DAS3R_FWD_PREFETCH")) && e[0] == '0';
     w.tile_strip = 8;
     w.tile_chunk = -1;
     if ((e = env("DAS3R_TILE_CHUNK"))) { const int v = atoi(e); w.tile_chunk = (v >= 0 && v <= 64 && (v & (v - 1)) == 0) ? v : -1; }
-    if ((e = env("DAS3R_TILE_STRIP"))) w.tile_strip = std::max(0, std::min(64, atoi(e)));
+    if ((e = env("DAS3R_TILE_STRIP"))) w.tile_strip = std::max(0, std::min(63, atoi(e)));   // (7-bit field of render_common.h pack_tiles, kept below its sign bit)
+    w.inject_fault = g_inject_fault;   // (not an environment variable: das3r_debug_inject_fault)
     g_sw = w;
     __atomic_store_n(&g_sw_loaded, true, __ATOMIC_RELEASE);
 }
@@ -199,6 +206,10 @@ void compute_layout(int P, int64_t I, int W, int H, Layout *L) {
 static int validate(const das3r_raster_args *a, const das3r_raster_in *in) {
     if (!a || !in) { set_error("null args"); return DAS3R_ERR_INVALID_ARG; }
     if (a->P < 0 || a->image_width <= 0 || a->image_height <= 0) { set_error("bad extents P=%d W=%d H=%d", a->P, a->image_width, a->image_height); return DAS3R_ERR_INVALID_ARG; }
+    if ((int64_t)((a->image_width + TILE_X - 1) / TILE_X) * ((a->image_height + TILE_Y - 1) / TILE_Y) >= (1ll << 22)) {   // render_common.h pack_tiles
+        set_error("image of %d x %d pixels has 2^22 tiles or more", a->image_width, a->image_height);
+        return DAS3R_ERR_INVALID_ARG;
+    }
     if (a->P == 0) return DAS3R_OK;
     if (!a->bg || !a->viewmatrix || !a->projmatrix || !a->campos) { set_error("bg/viewmatrix/projmatrix/campos must be device pointers"); return DAS3R_ERR_INVALID_ARG; }
     if (!in->means3D || !in->opacities) { set_error("means3D/opacities are required"); return DAS3R_ERR_INVALID_ARG; }
@@ -222,6 +233,10 @@ using namespace das3r;
 
 extern "C" int das3r_abi_version(void) { return DAS3R_ABI_VERSION; }
 extern "C" void das3r_reload_switches(void) { load_switches(); }
+extern "C" void das3r_debug_inject_fault(uint32_t bits) {
+    g_inject_fault = (int)bits;
+    load_switches();
+}
 extern "C" const char *das3r_last_error(void) { return g_err; }
 
 extern "C" int das3r_raster_get_layout(int32_t P, int64_t num_rendered, int32_t W, int32_t H, das3r_raster_layout *out) {

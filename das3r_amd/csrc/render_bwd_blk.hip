@@ -337,12 +337,15 @@ int launch_render_backward_blk(const das3r_raster_args *a, const float *dL_dpix,
     // (DAS3R shape: 0.497 vs 0.534 ms)
     const int pix = switches().render_bwd == 6 ? switches().render_bwd_pix : (mb == 128 ? 1 : 0), occ = switches().render_bwd_occ == 4 ? 4 : 5;
 #define BY_PIX(MBV, OCC) do { if (pix == 2) GO(MBV, 2, OCC); else if (pix == 1) GO(MBV, 1, OCC); else GO(MBV, 0, OCC); } while (0)
+#ifdef DAS3R_EXPERIMENTS
     if (mb == 128 && pix == 1 && switches().ablate_set) {
         const int abl = switches().ablate;
 #define GA(A) DAS3R_LAUNCH((render_backward_blk_kernel<128, 1, A>), dim3(xcd_grid(L), slices > 1 ? slices : 1), dim3(TILE_PIX), 0, s, ARGS)
         if (abl == 1) GA(1); else if (abl == 2) GA(2); else if (abl == 4) GA(4); else if (abl == 8) GA(8); else if (abl == 16) GA(16); else if (abl == 3) GA(3); else if (abl == 7) GA(7); else GA(0);
 #undef GA
-    } else if (mb == 64) BY_PIX(64, 5);
+    } else
+#endif
+    if (mb == 64) BY_PIX(64, 5);
     else if (mb == 256) BY_PIX(256, 5);
     else if (mb == 120) BY_PIX(120, 5);
     else if (mb == 160) BY_PIX(160, 4);

@@ -93,9 +93,11 @@ static inline int tile_chunk_code(const int ntiles) {
 // Strips pay when the splat records dominate a tile's traffic (measured at 1 M splats / 1080p, mean list 320: L2 misses of the
 // forward 1.83 -> 1.51 x and of the backward 3.48 -> 2.97 x the algorithmic bytes, time unchanged); with short lists (100 k
 // splats, mean list 32) the image rows dominate and vertically stacked tiles hit the same memory channels: 3 % slower — row-major.
+// (built as an unsigned word: strip heights up to 63 keep the sign bit clear, and das3r_raster_forward refuses images of 2^22 tiles
+//  or more — the tile count would run into the chunk code)
 static inline int pack_tiles(const Layout &L) {
-    const int sh = (L.capacity >= (int64_t)128 * L.ntiles) ? switches().tile_strip : 0;
-    return L.ntiles | (tile_chunk_code(L.ntiles) << 22) | (sh << 25);
+    const uint32_t sh = (L.capacity >= (int64_t)128 * L.ntiles) ? (uint32_t)std::min(switches().tile_strip, 63) : 0u;
+    return (int)(((uint32_t)L.ntiles & 0x3FFFFFu) | ((uint32_t)tile_chunk_code(L.ntiles) << 22) | (sh << 25));
 }
 static inline int xcd_grid(const Layout &L) {
     const int code = tile_chunk_code(L.ntiles);

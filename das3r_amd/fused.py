@@ -99,7 +99,18 @@ class _ShPrefix(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        ctx.rest._das3r_compact_grad = g[:, 1:].contiguous()
+        # accumulates like .grad does: a second backward before the optimizer's step (gradient accumulation, two renders per
+        # step, a retain_graph re-run as train_gui.py:579 permits) adds to the parked gradient instead of replacing it; a parked
+        # gradient of another width (the degree went up in between without a step) cannot be added to and is an error
+        new = g[:, 1:].contiguous()
+        old = getattr(ctx.rest, "_das3r_compact_grad", None)
+        if old is None:
+            ctx.rest._das3r_compact_grad = new
+        elif old.shape == new.shape:
+            ctx.rest._das3r_compact_grad = old + new
+        else:
+            raise RuntimeError(f"fused._ShPrefix: a compact SH gradient of shape {tuple(old.shape)} is still parked on f_rest while one "
+                               f"of shape {tuple(new.shape)} arrives: step() or zero_grad() the optimizer before changing the SH degree")
         return g[:, :1].contiguous(), None, None
 
 
@@ -132,6 +143,12 @@ class FusedAdam:
     def set_active_sh_degree(self, d):
         self.active_sh_degree = d
 
+    def handles_compact_sh(self, p):
+        """True iff `p` sits in an "sh_rest" group of this optimizer, i.e. a gradient parked on it by fused._ShPrefix (or no
+        gradient at all while only the DC tensor is rendered) is consumed / counted by step().  das3r_amd.render gates its SH
+        shortcuts on this: with any other optimizer f_rest would silently never be updated."""
+        return any(g.get("sh_rest") and any(q is p for q in g["params"]) for g in self.param_groups)
+
     def zero_grad(self, set_to_none=True):
         for g in self.param_groups:
             for p in g["params"]:
@@ -152,7 +169,18 @@ class FusedAdam:
         entries, keep, dev = [], [], None
         for g in self.param_groups:
             for p in g["params"]:
-                compact = getattr(p, "_das3r_compact_grad", None) if g.get("sh_rest") else None   # (_ShPrefix: gradient of the active prefix)
+                compact = getattr(p, "_das3r_compact_grad", None)   # (_ShPrefix: gradient of the active prefix)
+                if compact is not None:
+                    if not g.get("sh_rest"):
+                        raise RuntimeError('FusedAdam: a parameter carries a compact SH gradient but its group is not marked "sh_rest"')
+                    p._das3r_compact_grad = None   # consumed by this step (a stale one must not be applied again)
+                    K1 = (self.active_sh_degree + 1) ** 2 - 1 if self.active_sh_degree is not None else -1
+                    if compact.shape[1] != K1:
+                        raise RuntimeError(f"FusedAdam: compact SH gradient has {compact.shape[1]} coefficients per Gaussian, the active "
+                                           f"degree {self.active_sh_degree} needs {K1}")
+                    if p.grad is not None:   # both a dense and a compact gradient arrived (mixed render paths): they add up
+                        p.grad[:, :K1] += compact
+                        compact = None
                 if p.grad is None and compact is None:
                     # The higher-order SH coefficients get no gradient while the fused render hands the rasterizer the DC tensor
                     # alone (render.py).  In the reference they receive an all-zero gradient from iteration 1, so torch.optim.Adam

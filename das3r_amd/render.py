@@ -122,10 +122,12 @@ def rasterizer_inputs(cam, pc, pipe, bg_color, scaling_modifier=1.0, override_co
         # SH per splat each way; f_rest then has no gradient (FusedAdam counts its steps all the same: fused.py)
         # — only with the fused optimizer: torch.optim.Adam skips a parameter without gradient, so its step count (and bias
         # correction) for f_rest would restart at the degree bump, where the reference has counted 3000 zero-gradient steps
-        fused_opt = getattr(getattr(pc, "optimizer", None), "is_fused", False)
+        optimizer = getattr(pc, "optimizer", None)
+        fused_opt = (getattr(optimizer, "is_fused", False) and hasattr(optimizer, "handles_compact_sh")
+                     and optimizer.handles_compact_sh(pc._features_rest))   # (f_rest must sit in an "sh_rest" group: ADVICE r3)
         if fused_opt and pc.active_sh_degree == 0:
             shs = pc._features_dc
-        elif fused_opt and pc.active_sh_degree < pc.max_sh_degree:
+        elif fused_opt and pc.active_sh_degree < pc.max_sh_degree and getattr(pc, "sh_prefix", True):
             # round 3: between degree 0 and the maximum (iterations 3000 .. of DAS3R's 4000 run at degree 1) the rasterizer gets the
             # coefficients of the ACTIVE degree only — [P, 4, 3] at degree 1 instead of [P, 16, 3]: same image, and the gradient of
             # the active prefix goes to FusedAdam as it is (fused._ShPrefix)

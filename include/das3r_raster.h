@@ -263,6 +263,11 @@ int das3r_profile_report(char *buf, size_t cap);
  * a following kernel that reads LDS it has not written sees it (tests/test_gpu_raster.py). */
 int das3r_debug_poison_lds(uint32_t pattern, das3r_stream_t stream);
 
+/* Test aid: OR `bits` into the binning self-check word of every forward from now on (0 switches it off again) — how the tests
+ * prove that a failed binning is reported before the backward pass launches anything.  A call, not an environment variable:
+ * nothing in the environment can make the shipped library report or compute anything else than it should. */
+void das3r_debug_inject_fault(uint32_t bits);
+
 /* Pair counters of the compositing kernels (bench.py: pairs per second).  enable != 0: zero the counters and count from now on;
  * enable == 0: stop, and read into out (may be NULL): out[0] (pixel, splat) pairs the forward compositing kernel evaluated, [1] the
  * same for the backward kernel, [2] / [3] their wave iterations (64 pairs each).  Costs one atomic per wave while enabled, nothing

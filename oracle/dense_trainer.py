@@ -51,8 +51,12 @@ class DenseTrainer:
     conf_static [F,H,W], Q [F,4], T [F,3] + `mask` (bool [F*H*W], the confident pixels that became Gaussians).
     cameras: list of dicts gt [3,H,W], fovx, fovy, proj_T [4,4] (the transposed projection matrix), indexed by uid."""
 
-    def __init__(self, params, cameras, iterations=4000, lambda_dssim=0.2, psnr_threshold=26.0, spatial_lr_scale=1.0):
-        f64 = lambda t: t.detach().to(torch.float64).clone().requires_grad_(True)
+    def __init__(self, params, cameras, iterations=4000, lambda_dssim=0.2, psnr_threshold=26.0, spatial_lr_scale=1.0, dtype=torch.float64):
+        """dtype: float64 is the restatement the product is held against; float32 exists for ONE purpose — measuring how far two
+        arithmetics of the same optimisation drift apart over a schedule (tools/schedule_psnr.py: the noise floor under the PSNR
+        bounds of tests/test_gpu_trainstep.py)."""
+        self.dtype = dtype
+        f64 = lambda t: t.detach().to(dtype).clone().requires_grad_(True)
         self.p = {k: f64(v) for k, v in params.items() if k != "mask"}
         self.mask = params["mask"].clone()
         self.cams = cameras
@@ -92,20 +96,20 @@ class DenseTrainer:
         shs = torch.cat([p["f_dc"], p["f_rest"]], 1)
         dev = p["xyz"].device
         H, W = cam["gt"].shape[1:]
-        eye = torch.eye(4, dtype=torch.float64, device=dev)
-        means2D = torch.zeros(p["xyz"].shape[0], 3, dtype=torch.float64, device=dev, requires_grad=True)
+        eye = torch.eye(4, dtype=self.dtype, device=dev)
+        means2D = torch.zeros(p["xyz"].shape[0], 3, dtype=self.dtype, device=dev, requires_grad=True)
         color, radii, _ = rasterize_dense(means3D, means2D, opac, shs=shs, scales=torch.exp(p["scaling"]), rotations=rot,
                                           image_height=H, image_width=W, tanfovx=math.tan(cam["fovx"] * 0.5),
                                           tanfovy=math.tan(cam["fovy"] * 0.5), bg=bg, scale_modifier=1.0, viewmatrix=eye,
-                                          projmatrix=cam["proj_T"].to(torch.float64), sh_degree=self.active_deg,
-                                          campos=torch.zeros(3, dtype=torch.float64, device=dev))
+                                          projmatrix=cam["proj_T"].to(self.dtype), sh_degree=self.active_deg,
+                                          campos=torch.zeros(3, dtype=self.dtype, device=dev), dtype=self.dtype)
         return color, means2D
 
     def loss_of(self, uid, bg):
         cam = self.cams[uid]
         image, means2D = self.render(uid, bg)
         static = self.p["conf_static"][uid]
-        img, gt = image * static, cam["gt"].to(torch.float64) * static
+        img, gt = image * static, cam["gt"].to(self.dtype) * static
         loss = ((1.0 - self.lam) * (img - gt).abs() + self.lam * (1.0 - ssim_map(img, gt))).mean()
         return loss, psnr_channels(img, gt).mean(), means2D
 
@@ -134,8 +138,8 @@ class DenseTrainer:
     @torch.no_grad()
     def heldout_psnr(self, gt, pose, cam_uid_for_intrinsics, bg, static_mask=None):
         """train_test_psnr.py:262-289 for one held-out view: clamp, optional (1 - gt_dynamic_mask), mean over channels."""
-        image, _ = self.render(cam_uid_for_intrinsics, bg, pose=pose.to(torch.float64))
-        img, g = image.clamp(0.0, 1.0), gt.to(torch.float64).clamp(0.0, 1.0)
+        image, _ = self.render(cam_uid_for_intrinsics, bg.to(self.dtype), pose=pose.to(self.dtype))
+        img, g = image.clamp(0.0, 1.0), gt.to(self.dtype).clamp(0.0, 1.0)
         if static_mask is not None:
             img, g = img * static_mask, g * static_mask
         return float(psnr_channels(img, g).mean()), float((img - g).abs().mean())

@@ -465,7 +465,7 @@ def test_bucket_parallel_backward(name, kind, slices, monkeypatch):
 
 def test_failed_binning_is_reported_before_the_backward_pass(monkeypatch):
     """A forward whose binning kernels fail their self-check (here: a look-back timeout forced into the word the last binning
-    kernel hands to the host, DAS3R_INJECT_FAULT) must not get as far as a parameter update: the backward pass examines the
+    kernel hands to the host, das3r_debug_inject_fault) must not get as far as a parameter update: the backward pass examines the
     forward's word before it launches anything and raises; `check_forward` does the same for callers without a backward; a debug
     forward raises by itself.  The next clean forward works again."""
     from das3r_amd import GaussianRasterizationSettings, GaussianRasterizer
@@ -484,16 +484,22 @@ def test_failed_binning_is_reported_before_the_backward_pass(monkeypatch):
         (color * scd.dL_dpix).sum().backward()
         return m3.grad
 
+    from das3r_amd import _lib
     good = fwd_bwd(rs)
-    monkeypatch.setenv("DAS3R_INJECT_FAULT", "1")   # ERR_TIMEOUT
-    with pytest.raises(RuntimeError, match="self-check"):
-        fwd_bwd(rs)                                  # the forward returns, the backward refuses
-    out = _forward_full(rs, scd.means3D, scd.shs, e, scd.opacities, scd.scales, scd.rotations, e)
-    with pytest.raises(RuntimeError, match="self-check"):
-        check_forward(out[6], dev)                   # explicit check of a forward without a backward
-    with pytest.raises(RuntimeError, match="self-check"):
-        fwd_bwd(rs._replace(debug=True))             # debug: the forward itself waits for the word
+    monkeypatch.setenv("DAS3R_INJECT_FAULT", "1")    # the shipped library does not read this (round 4): nothing may happen
+    assert torch.allclose(fwd_bwd(rs), good, rtol=1e-4, atol=1e-9)
     monkeypatch.delenv("DAS3R_INJECT_FAULT")
+    _lib.inject_fault(1)                             # ERR_TIMEOUT
+    try:
+        with pytest.raises(RuntimeError, match="self-check"):
+            fwd_bwd(rs)                                  # the forward returns, the backward refuses
+        out = _forward_full(rs, scd.means3D, scd.shs, e, scd.opacities, scd.scales, scd.rotations, e)
+        with pytest.raises(RuntimeError, match="self-check"):
+            check_forward(out[6], dev)                   # explicit check of a forward without a backward
+        with pytest.raises(RuntimeError, match="self-check"):
+            fwd_bwd(rs._replace(debug=True))             # debug: the forward itself waits for the word
+    finally:
+        _lib.inject_fault(0)
     for _ in range(20):                              # every slot of the self-check ring is examined and reused cleanly
         again = fwd_bwd(rs)
     assert torch.allclose(again, good, rtol=1e-4, atol=1e-9)
