@@ -603,29 +603,47 @@ extern "C" int das3r_mark_visible(int32_t P, const float *means3D, const float *
 // ---- test aid: fill every CU's LDS with a bit pattern ----
 // The compositing kernels leave parts of their LDS arrays unwritten (list tails, staged entries past a tile's list); what they
 // then read must not matter.  A test fills the LDS of every CU with NaNs / all-ones first (tests/test_gpu_raster.py).
-__global__ void __launch_bounds__(1024) poison_lds_kernel(uint32_t pattern, uint32_t *sink) {
+__global__ void __launch_bounds__(1024) poison_lds_kernel(uint32_t pattern, uint32_t *sink, int words) {
     extern __shared__ uint32_t lds_words[];
-    for (int i = threadIdx.x; i < 160 * 256 - 64; i += 1024) lds_words[i] = pattern;   // just under the CU's 160 KB
+    for (int i = threadIdx.x; i < words; i += 1024) lds_words[i] = pattern;
     __syncthreads();
-    if (lds_words[(threadIdx.x * 37) % (160 * 256 - 64)] != pattern) *sink = 1u;       // (keeps the stores alive)
+    if (lds_words[(threadIdx.x * 37) % words] != pattern) *sink = 1u;       // (keeps the stores alive)
 }
 extern "C" int das3r_debug_poison_lds(uint32_t pattern, das3r_stream_t stream) {
-    static uint32_t *sink = nullptr;
-    if (!sink) HIP_TRY(hipMalloc((void **)&sink, 4));
-    HIP_TRY(hipFuncSetAttribute((const void *)poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (160 * 256 - 64) * 4));
-    hipLaunchKernelGGL(poison_lds_kernel, dim3(1024), dim3(1024), (160 * 256 - 64) * 4, (hipStream_t)stream, pattern, sink);
+    // per device: the sink lives on the device the call runs on, and the fill is as large as that device lets one workgroup have
+    static uint32_t *sinks[MAX_DEVICES] = {};
+    int dev = 0, lds_bytes = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEVICES) { set_error("device ordinal %d not supported", dev); return DAS3R_ERR_INVALID_ARG; }
+    HIP_TRY(hipDeviceGetAttribute(&lds_bytes, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+    const int words = lds_bytes / 4 - 64;   // just under the limit (160 KB per CU on MI355X)
+    if (words <= 0) { set_error("das3r_debug_poison_lds: no LDS"); return DAS3R_ERR_HIP; }
+    if (!sinks[dev]) HIP_TRY(hipMalloc((void **)&sinks[dev], 4));
+    HIP_TRY(hipFuncSetAttribute((const void *)poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, words * 4));
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(1024), dim3(1024), words * 4, (hipStream_t)stream, pattern, sinks[dev], words);
     HIP_TRY(hipGetLastError());
     return DAS3R_OK;
 }
 
 // ---- pair counters ----
 static unsigned long long *g_pairs = nullptr;
-namespace das3r { unsigned long long *pair_counters() { return g_pairs; } }
+static int g_pairs_dev = -1;   // the counters live on ONE device (bench.py counts on its own GPU); launches on any other get none
+namespace das3r {
+unsigned long long *pair_counters() {
+    if (!g_pairs) return nullptr;
+    int dev = -1;
+    return (hipGetDevice(&dev) == hipSuccess && dev == g_pairs_dev) ? g_pairs : nullptr;
+}
+}  // namespace das3r
 // enable != 0: (allocate and) zero the counters, the compositing kernels count from now on; enable == 0: read them into out[4] (may be
 // null), stop counting.  Single-threaded use (bench.py); synchronises the device.
 extern "C" int das3r_pair_counters(int enable, uint64_t out[4]) {
     if (enable) {
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        if (g_pairs && dev != g_pairs_dev) { set_error("das3r_pair_counters: already counting on device %d", g_pairs_dev); return DAS3R_ERR_INVALID_ARG; }
         if (!g_pairs) HIP_TRY(hipMalloc((void **)&g_pairs, (4 + PHASE_WORDS * PHASE_COPIES) * sizeof(unsigned long long)));
+        g_pairs_dev = dev;
         HIP_TRY(hipMemset(g_pairs, 0, (4 + PHASE_WORDS * PHASE_COPIES) * sizeof(unsigned long long)));
         return DAS3R_OK;
     }

@@ -9,7 +9,10 @@ the reference's own farm for the predictor stage (/root/reference/dynamic_predic
         --sequences 8 --iterations 200
 """
 import argparse
+import json
 import os
+import threading
+import time
 
 import torch
 import torch.distributed as dist
@@ -58,6 +61,118 @@ def gather_records(local_records, n_sequences, device):
         sid = int(row[0])
         if 0 <= sid < n_sequences:
             table[sid] = row
+    return table
+
+
+class Rendezvous:
+    """File-based guard around the one collective of the farm: a rank that dies with a HIP fault must not
+    leave the others blocked in all_reduce / all_gather until the RCCL timeout.
+
+    Every rank keeps a heartbeat file fresh from a daemon thread (it stops with the process) and, when its sequences are done,
+    publishes its records as records_<rank>.json (written atomically).  Rank 0 DECIDES how the table is assembled and writes the
+    decision down; the others wait for it:
+      "collective"  every rank has published: all of them are alive and about to enter the gather — the collective cannot hang;
+      "files"       a rank's heartbeat went stale (dead) or it never published within the deadline (hung): nobody enters a
+                    collective; the table is assembled from the record files, and a sequence nobody reported is looked up in
+                    its own <out>/<sequence>/test_log.txt (train.scrape_test_logs — what the reference's scripts scrape,
+                    scripts/get_testing_psnr_davis.py:8-17) before it is marked failed.
+    A rank that cannot get a decision (rank 0 died) falls back to "files" on its own after the same deadline.  Single node: the
+    directory is on the node's file system (the farm is one node by definition)."""
+
+    def __init__(self, root, rank, world, beat_s=2.0):
+        self.root, self.rank, self.world, self.beat_s = root, rank, world, beat_s
+        os.makedirs(root, exist_ok=True)
+        self.t0 = time.time()
+        self._stop = threading.Event()
+        self._touch()
+        self._thread = threading.Thread(target=self._beat, daemon=True)
+        self._thread.start()
+
+    def _path(self, kind, rank=None):
+        return os.path.join(self.root, f"{kind}_{self.rank if rank is None else rank}.json")
+
+    def _touch(self):
+        with open(self._path("beat"), "w") as f:
+            f.write(str(time.time()))
+
+    def _beat(self):
+        while not self._stop.wait(self.beat_s):
+            try:
+                self._touch()
+            except OSError:
+                pass
+
+    def close(self):
+        self._stop.set()
+
+    def publish(self, records):
+        tmp = self._path("records") + ".tmp"
+        with open(tmp, "w") as f:
+            json.dump(records, f)
+        os.replace(tmp, self._path("records"))
+
+    def _state(self, r, stale_s):
+        if os.path.exists(self._path("records", r)):
+            return "done"
+        try:
+            age = time.time() - os.path.getmtime(self._path("beat", r))
+        except OSError:
+            age = time.time() - self.t0          # never seen: counts from our own start
+        return "dead" if age > stale_s else "working"
+
+    def decide(self, stale_s=30.0, hung_s=None):
+        """-> "collective" | "files" (see the class docstring).  hung_s: how long a live rank may still work after this rank has
+        published; default: as long again as this rank took, plus two minutes."""
+        mine = time.time() - self.t0
+        hung_s = (mine + 120.0) if hung_s is None else hung_s
+        deadline = time.time() + hung_s
+        decision = os.path.join(self.root, "decision.json")
+        while True:
+            if os.path.exists(decision):
+                try:
+                    with open(decision) as f:
+                        return json.load(f)["mode"]
+                except (OSError, ValueError, KeyError):
+                    pass                                  # being written: look again
+            if self.rank == 0:
+                states = [self._state(r, stale_s) for r in range(self.world)]
+                mode = "collective" if all(s == "done" for s in states) else ("files" if "dead" in states or time.time() > deadline else None)
+                if mode:
+                    tmp = decision + ".tmp"
+                    with open(tmp, "w") as f:
+                        json.dump(dict(mode=mode, states=states), f)
+                    os.replace(tmp, decision)
+                    return mode
+            elif self._state(0, stale_s) == "dead" or time.time() > deadline + stale_s:
+                return "files"                            # nobody left to decide
+            time.sleep(0.05)
+
+    def records_from_files(self):
+        out = []
+        for r in range(self.world):
+            try:
+                with open(self._path("records", r)) as f:
+                    out += json.load(f)
+            except (OSError, ValueError):
+                pass
+        return out
+
+
+def table_from_files(rdv, n_sequences, names=None, out_root=None):
+    """The table gather_records returns, assembled without any collective from the record files of the ranks that published;
+    sequences nobody reported are looked up in <out_root>/<name>/test_log.txt (the reference's own channel) and otherwise stay ok = 0."""
+    table = torch.zeros(n_sequences, len(RECORD_FIELDS), dtype=torch.float64)
+    table[:, 0] = torch.arange(n_sequences, dtype=torch.float64)
+    for rec in rdv.records_from_files():
+        sid = int(rec["scene_id"])
+        if 0 <= sid < n_sequences:
+            table[sid] = torch.tensor([float(rec[f]) for f in RECORD_FIELDS], dtype=torch.float64)
+    if out_root and names and os.path.isdir(out_root):
+        from .train import scrape_test_logs
+        logged = scrape_test_logs(out_root, "")
+        for sid, name in enumerate(names):
+            if table[sid, 5] == 0 and name in logged and logged[name] == logged[name]:
+                table[sid, 1], table[sid, 5] = logged[name], 1.0
     return table
 
 
@@ -119,6 +234,7 @@ def main():
     ap.add_argument("--fused", action="store_true", help="use the fused pre-transform / Adam / loss kernels")
     ap.add_argument("--gt-dynamic-mask", default=None, help="root of the ground-truth dynamic masks, <root>/<sequence>/... (train_test_psnr.py --gt_dynamic_mask)")
     ap.add_argument("--dataset", default="sintel", choices=("sintel", "davis"))
+    ap.add_argument("--rendezvous", default=None, help="directory of the ranks' heartbeat / record files (default: <out>/.farm or /tmp/das3r_farm_<port>)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -131,6 +247,15 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=args.backend or ("nccl" if use_gpu else "gloo"))
+    rdv = None
+    if world > 1:   # (file guard around the gather: a dead rank must not hang the others — Rendezvous)
+        root = args.rendezvous or (os.path.join(args.out, ".farm") if args.out else f"/tmp/das3r_farm_{os.environ.get('MASTER_PORT', '0')}")
+        if rank == 0:   # a previous run's files must not be mistaken for this one's
+            for f in (os.listdir(root) if os.path.isdir(root) else []):
+                os.remove(os.path.join(root, f))
+        dist.barrier()  # (start of the run: every rank is alive here, and nothing of this run has been written yet)
+        rdv = Rendezvous(root, rank, world)
+    dirs = None
     if args.data:   # real sequences: every rank lists the same sorted directory, longest first across ranks
         dirs = sorted(d for d in os.listdir(args.data) if os.path.isfile(os.path.join(args.data, d, "sparse/0/cameras.txt")))
         args.sequences = len(dirs)
@@ -142,17 +267,31 @@ def main():
     else:
         mine = assign(args.sequences, rank, world)
         records = [run_sequence_job(s, args.iterations, device, fused=args.fused) for s in mine]
-    table = gather_records(records, args.sequences, device)
-    if rank == 0:
+    names = dirs if args.data else [f"seq_{i}" for i in range(args.sequences)]
+    mode = "collective"
+    if rdv is not None:
+        rdv.publish(records)
+        mode = rdv.decide()
+    if mode == "collective":
+        table = gather_records(records, args.sequences, device)
+    else:
+        print(f"[farm] rank {rank}: a rank is missing — table assembled from the record files, no collective")
+        table = table_from_files(rdv, args.sequences, names, args.out)
+    if rdv is not None:
+        rdv.close()
+    if rank == 0 or (mode == "files" and rdv is not None and rdv._state(0, 30.0) == "dead" and rank == min(
+            r for r in range(world) if rdv._state(r, 30.0) != "dead")):
         from .train import latex_rows
         good = table[table[:, 5] > 0]
-        names = dirs if args.data else [f"seq_{i}" for i in range(args.sequences)]
         head, row = latex_rows({names[int(r[0])]: float(r[1]) for r in good})   # the rows get_testing_psnr_davis.py:19-22 prints
         print(head)
         print(row)
         print(f"mean PSNR {good[:, 1].mean().item():.2f} over {good.shape[0]}/{args.sequences} sequences")
     if world > 1:
-        dist.destroy_process_group()
+        if mode == "collective":
+            dist.destroy_process_group()
+        else:
+            os._exit(0)   # a peer is gone: tearing the process group down would wait for it
 
 
 if __name__ == "__main__":

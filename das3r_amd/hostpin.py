@@ -46,7 +46,10 @@ def gpu_numa_nodes(sysfs_root="/"):
             nodes.append(int(numa))
         except (TypeError, ValueError):
             nodes.append(-1)
-    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):   # (the runtime applies ROCR's filter first, then HIP's)
+    # (the runtime applies ROCR's filter first, then HIP's; CUDA_VISIBLE_DEVICES is HIP's alias on ROCm — HIP and torch honour it
+    #  when HIP_VISIBLE_DEVICES is not set)
+    hip_var = "HIP_VISIBLE_DEVICES" if os.environ.get("HIP_VISIBLE_DEVICES") else "CUDA_VISIBLE_DEVICES"
+    for var in ("ROCR_VISIBLE_DEVICES", hip_var):
         sel = os.environ.get(var)
         if sel:
             try:

@@ -120,3 +120,53 @@ def test_mask_resize_is_nearest_neighbour():
     assert out[0].sum() == 8 and out[0, 2:4, 4:6].sum() == 4 and out[0, 6:8, 10:12].sum() == 4
     down = resize_mask_nearest(m, 2, 3)       # source pixel = floor(dst * scale)
     assert down[0].tolist() == [[0.0, 0.0, 0.0], [0.0, 0.0, 0.0]]
+
+
+def _guarded_worker(rank, world, port, n_seq, out_dir, die):
+    """farm.main()'s end game: publish, let rank 0 decide, gather by collective or from the files."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.barrier()
+    rdv = farm.Rendezvous(os.path.join(out_dir, ".farm"), rank, world, beat_s=0.1)
+    if die and rank == 1:
+        os._exit(3)                                  # a HIP fault: no record file, no more heartbeats, no goodbye
+    recs = [dict(scene_id=s, psnr=20.0 + s, l1=0.01 * s, iters_per_s=100.0 + rank, n_splats=1000 * (s + 1), ok=1)
+            for s in farm.assign(n_seq, rank, world)]
+    rdv.publish(recs)
+    mode = rdv.decide(stale_s=1.0)
+    names = [f"seq_{i}" for i in range(n_seq)]
+    table = farm.gather_records(recs, n_seq, torch.device("cpu")) if mode == "collective" else farm.table_from_files(rdv, n_seq, names, out_dir)
+    rdv.close()
+    torch.save((mode, table), os.path.join(out_dir, f"guarded_{rank}.pt"))
+    os._exit(0)                                      # (no destroy_process_group: with a dead peer it would wait for it)
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("die", [False, True])
+def test_one_dead_rank_does_not_hang_the_gather(tmp_path, die):
+    """a rank that dies leaves the others in all_gather until the RCCL timeout.  With the file guard rank 0
+    notices the stale heartbeat within seconds, nobody enters a collective, the table comes from the record files and — for a
+    sequence of the dead rank that had already written its test_log.txt — from the log the reference's scripts scrape."""
+    import time
+    n_seq, world = 4, 2
+    os.makedirs(tmp_path / "seq_1")
+    (tmp_path / "seq_1" / "test_log.txt").write_text("[ITER 4000] Evaluating test: L1 0.01 PSNR 31.25\n")
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_guarded_worker, args=(r, world, port, n_seq, str(tmp_path), die)) for r in range(world)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(60)
+    assert all(not p.is_alive() for p in procs), "a rank is still blocked"
+    assert time.time() - t0 < 45
+    mode, table = torch.load(tmp_path / "guarded_0.pt")
+    if not die:
+        assert mode == "collective" and procs[1].exitcode == 0
+        assert table[:, 1].tolist() == [20.0, 21.0, 22.0, 23.0] and table[:, 5].tolist() == [1, 1, 1, 1]
+    else:
+        assert mode == "files" and procs[1].exitcode == 3
+        assert table[[0, 2], 1].tolist() == [20.0, 22.0] and table[[0, 2], 5].tolist() == [1, 1]     # rank 0's own sequences
+        assert table[1, 1] == 31.25 and table[1, 5] == 1                                              # from seq_1/test_log.txt
+        assert table[3, 5] == 0                                                                       # lost with its rank

@@ -168,6 +168,52 @@ def test_fused_adam_device_gate_matches_host_gated_torch_adam():
     assert not torch.equal(qa.detach(), q0)
 
 
+def test_compact_sh_gradient_accumulates_like_dot_grad():
+    """fused._ShPrefix parks the gradient of the active SH prefix on f_rest for FusedAdam (ADVICE r3 / VERDICT r3 item 8).  Two
+    backwards before one step must ADD (gradient accumulation, a retain_graph re-run: train_gui.py:579 permits it), exactly as
+    .grad does: two backwards + one step == torch.optim.Adam on the dense tensors; step() consumes the parked gradient, a wrong
+    width or a group that is not "sh_rest" is an error, and render.py only takes the shortcut with an optimizer that owns f_rest."""
+    from das3r_amd.fused import FusedAdam, active_sh_prefix
+    g = torch.Generator().manual_seed(21)
+    P, degree = 777, 1
+    K = (degree + 1) ** 2
+    dc0, rest0 = torch.randn(P, 1, 3, generator=g).cuda(), torch.randn(P, 15, 3, generator=g).cuda()
+    w1, w2 = torch.randn(P, K, 3, generator=g).cuda(), torch.randn(P, K, 3, generator=g).cuda()
+    dca, resta = torch.nn.Parameter(dc0.clone()), torch.nn.Parameter(rest0.clone())
+    dcb, restb = torch.nn.Parameter(dc0.clone()), torch.nn.Parameter(rest0.clone())
+    fa = FusedAdam([dict(params=[dca], lr=2.5e-3, name="f_dc"), dict(params=[resta], lr=1.25e-4, name="f_rest", sh_rest=True)], lr=0.0, eps=1e-15)
+    fa.set_active_sh_degree(degree)
+    assert fa.handles_compact_sh(resta) and not fa.handles_compact_sh(dca)
+    tb = torch.optim.Adam([dict(params=[dcb], lr=2.5e-3), dict(params=[restb], lr=1.25e-4)], lr=0.0, eps=1e-15)
+    for step in range(3):
+        for w in (w1, w2 * (step + 1)):
+            (active_sh_prefix(dca, resta, degree) * w).sum().backward()
+            (torch.cat((dcb, restb), 1)[:, :K] * w).sum().backward()
+        assert resta.grad is None and tuple(resta._das3r_compact_grad.shape) == (P, K - 1, 3)
+        assert torch.allclose(resta._das3r_compact_grad, restb.grad[:, :K - 1], rtol=1e-6, atol=1e-7)
+        fa.step()
+        tb.step()
+        assert getattr(resta, "_das3r_compact_grad", None) is None     # consumed: a stale gradient cannot be applied twice
+        fa.zero_grad(set_to_none=True)
+        tb.zero_grad(set_to_none=True)
+    assert float((resta - restb).abs().max()) <= ADAM_TOL * float(restb.abs().max())
+    assert float((dca - dcb).abs().max()) <= ADAM_TOL * float(dcb.abs().max())
+    assert torch.equal(resta.detach()[:, K - 1:], rest0[:, K - 1:])
+    # a parked gradient of another width (degree changed without a step) is refused, not silently replaced
+    (active_sh_prefix(dca, resta, 1) * w1).sum().backward()
+    with pytest.raises(RuntimeError, match="compact SH gradient"):
+        (active_sh_prefix(dca, resta, 2) * torch.ones(P, 9, 3, device="cuda")).sum().backward()
+    fa.zero_grad()
+    # an optimizer whose group is not marked sh_rest must not swallow it
+    other = FusedAdam([dict(params=[resta], lr=1e-4, name="f_rest")], lr=0.0, eps=1e-15)
+    other.set_active_sh_degree(1)
+    assert not other.handles_compact_sh(resta)
+    (active_sh_prefix(dca, resta, 1) * w1).sum().backward()
+    with pytest.raises(RuntimeError, match="sh_rest"):
+        other.step()
+    resta._das3r_compact_grad = None
+
+
 def test_fused_adam_skips_params_without_grad_and_rejects_cpu():
     from das3r_amd.fused import FusedAdam
     p, q = torch.nn.Parameter(torch.ones(5).cuda()), torch.nn.Parameter(torch.ones(5).cuda())
