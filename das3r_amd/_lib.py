@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdas3r_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
@@ -52,7 +52,8 @@ EXPORTS = ("das3r_raster_forward", "das3r_raster_backward", "das3r_raster_check"
            "das3r_knn3_mean_dist2", "das3r_raster_get_layout", "das3r_abi_version", "das3r_last_error", "das3r_reload_switches", "das3r_get_stats",
            "das3r_profile_enable", "das3r_profile_report", "das3r_pretransform_forward", "das3r_pretransform_backward", "das3r_pose_matrices", "das3r_pose_chain",
            "das3r_adam_step", "das3r_adam_step_gated", "das3r_photometric_blocks", "das3r_photometric_forward", "das3r_photometric_backward",
-           "das3r_has_experiments", "das3r_pair_counters", "das3r_debug_poison_lds", "das3r_debug_inject_fault")
+           "das3r_has_experiments", "das3r_pair_counters", "das3r_debug_poison_lds", "das3r_debug_inject_fault",
+           "das3r_pose_matrices_qt", "das3r_pose_chain_qt", "das3r_photometric_finish")
 
 _lib = None
 
@@ -105,6 +106,12 @@ def load():
     L.das3r_photometric_backward.restype = C.c_int
     L.das3r_photometric_backward.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p]
+    L.das3r_pose_matrices_qt.restype = C.c_int
+    L.das3r_pose_matrices_qt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.das3r_pose_chain_qt.restype = C.c_int
+    L.das3r_pose_chain_qt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.das3r_photometric_finish.restype = C.c_int
+    L.das3r_photometric_finish.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
     L.das3r_adam_step_gated.restype = C.c_int
     L.das3r_adam_step_gated.argtypes = [C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
     L.das3r_adam_step.restype = C.c_int

@@ -71,7 +71,7 @@ static void load_switches() {
 #endif
     w.rect_upstream = (e = env("DAS3R_RECT")) && e[0] == 'u';
     w.verbose = env("DAS3R_VERBOSE") != nullptr;
-    if ((e = env("DAS3R_BINNING"))) w.binning = e[0] == 'l' ? 1 : (e[0] == 'r' ? -1 : 0);
+    if ((e = env("DAS3R_BINNING"))) w.binning = e[0] == 'l' ? 1 : (e[0] == 'r' ? -1 : (e[0] == 's' ? 2 : 0));
     w.capacity_exact = (e = env("DAS3R_CAPACITY")) && e[0] == 'e';
     w.fused_emit_off = (e = env("DAS3R_FUSED_EMIT")) && e[0] == '0';
     if ((e = env("DAS3R_RENDER"))) w.render_fwd = e[0] == 'q' ? 1 : (e[0] == 'r' ? 2 : 0);
@@ -146,6 +146,8 @@ void compute_layout(int P, int64_t I, int W, int H, Layout *L) {
     L->ntiles = L->tiles_x * L->tiles_y;
     L->tbits = tile_bits(L->ntiles);
     L->tile_passes = (L->tbits + 7) / 8;
+    L->dbits = 0;
+    L->kbits = L->tbits;
     L->chunksP = sort_num_chunks(P);
     L->chunksI = sort_num_chunks(I);
     size_t o = 0;
@@ -170,6 +172,7 @@ void compute_layout(int P, int64_t I, int W, int H, Layout *L) {
     L->g_count = take(256);
     L->g_off_by_gid = take(4 * Pn);
     L->g_rect = take(4 * Pn);
+    L->g_dhist = take(4 * 256);
     L->g_ghist = take(4 * 4 * RADIX_SIZE);
     L->g_ticket = take(256);
     L->g_status = take(onesweep_status_bytes((int64_t)Pn, 4));
@@ -420,8 +423,19 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         verdict.radix_left = verdict.backoff;   // global sort for a while; longer every time it happens again
         if (verdict.backoff < 4096) verdict.backoff *= 2;
     }
-    const int forced = switches().binning;   // DAS3R_BINNING=local | radix: force one (diagnostics, tests)
-    bool local = use_onesweep() && (forced > 0 || (forced == 0 && verdict.radix_left == 0 && verdict.last_I <= LOCAL_AVG * L.ntiles));
+    const int forced = switches().binning;   // DAS3R_BINNING=local | radix | seg: force one (diagnostics, tests)
+    bool local = use_onesweep() && (forced == 1 || (forced == 0 && verdict.radix_left == 0 && verdict.last_I <= LOCAL_AVG * L.ntiles));
+    // Long lists (round 4): the segmented path — no global depth sort; the tile partition's passes carry a depth bucket in the key bits
+    // the tile ids leave free, and every (tile, bucket) segment is sorted inside LDS (segkey.h, segsort.hip).  Needs free key bits
+    // and segments that stay short on average; a segment that did not fit in LDS sends the shape back to the global sort for a
+    // while, like a list too long for the local order does (the same mailbox word and back-off).
+    constexpr int64_t SEG_AVG = 384;         // mean entries per segment up to which it is taken
+    const int seg_bits = use_onesweep() ? seg_dbits(L) : 0;
+    bool seg = !local && seg_bits > 0 && (forced == 2 || (forced == 0 && verdict.radix_left == 0 && verdict.last_I >= 0 &&
+                                                           (verdict.last_I >> seg_bits) <= SEG_AVG * L.ntiles));
+    auto apply_seg = [&]() {   // (compute_layout starts every layout without buckets)
+        if (seg) { L.dbits = seg_bits; L.kbits = L.tbits + seg_bits; }
+    };
     if (forced == 0 && verdict.radix_left > 0) verdict.radix_left--;
     const uint32_t count_tag = ++mb->seq ? mb->seq : ++mb->seq;
     unsigned long long *arrive = arrive_ring + (size_t)(count_tag % ARRIVE_SLOTS) * ARRIVE_WORDS;
@@ -430,10 +444,11 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
                               uint32_t *emit_slot = nullptr /*the preprocess kernel has emitted the instances already*/) -> int {
         int r;
         const bool fused_scan = use_onesweep();   // scan + emission in one kernel; the classic path scans, then emits
+        const bool seg = L.dbits > 0;             // segmented path: index-order emission with depth buckets, lists sorted by segment_sort_kernel
         if (!emit_slot) {
             if (fused_scan) {
                 if ((r = launch_binning_scan_emit(P, cap, out->radii, saved->geom, saved->binning, L, ctrl_zeroed, count_out, count_out_tag, a->debug != 0,
-                                                  s, local_order))) return r;
+                                                  s, local_order || seg))) return r;
             } else if ((r = launch_scan(P, saved->geom, L, nullptr, 0, a->debug != 0, s))) return r;
         }
         uint32_t *host_late = nullptr;
@@ -448,7 +463,7 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         }
         uint32_t *dead_keys = nullptr;
         if ((r = launch_binning(P, cap, W, H, out->radii, saved->geom, saved->binning, saved->img, L, fused_scan, host_late, late_tag,
-                                a->debug != 0, s, &dead_keys, emit_slot))) return r;
+                                a->debug != 0, s, &dead_keys, emit_slot, mb->dev + 10, verdict.gen))) return r;
         LocalBin lb = {(float4 *)(saved->binning + L.b_ckpt), nullptr, nullptr, nullptr, nullptr, verdict.gen, (uint32_t)(P - 1), (uint32_t)cap};
         if (local_order && cap > 0) {
             lb.point_list = (uint32_t *)(saved->binning + L.pub.point_list);
@@ -520,8 +535,13 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
             if ((rc = bin_and_render(cap, true, false))) return rc;
         }
     } else {
-        if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, nullptr, 0, L, arrive, mb->dev, count_tag, s))) return rc;
-        if (!local && (rc = launch_depth_sort(P, saved->geom, L, 0, nullptr, 0, a->debug != 0, s))) return rc;
+        uint32_t *dhist = nullptr;
+        if (seg) {   // the depth histogram of this forward (segkey.h): zeroed here, filled by the preprocess kernel, read by the emission
+            dhist = (uint32_t *)(saved->geom + L.g_dhist);
+            HIP_TRY(hipMemsetAsync(dhist, 0, 4 * 256, s));
+        }
+        if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, nullptr, 0, L, arrive, mb->dev, count_tag, s, nullptr, dhist))) return rc;
+        if (!local && !seg && (rc = launch_depth_sort(P, saved->geom, L, 0, nullptr, 0, a->debug != 0, s))) return rc;
         if ((rc = mailbox_wait(mb, 2, count_tag, s))) return rc;    // usually there already: preprocess finished long ago
         I = cap = (int64_t)mb->host[0];
         if (cap > (int64_t)0x7FFFFF00) { set_error("num_rendered %lld exceeds 2^31", (long long)cap); return DAS3R_ERR_OVERFLOW; }
@@ -532,10 +552,11 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
             if ((rc = launch_depth_sort(P, saved->geom, L, 0, nullptr, 0, a->debug != 0, s))) return rc;
         }
         compute_layout(P, cap, W, H, &L);
+        apply_seg();
         saved->binning = alloc_binning(user, L.pub.binning_bytes);
         if (!saved->binning) { set_error("scratch allocation failed (binning %zu B)", L.pub.binning_bytes); return DAS3R_ERR_ALLOC; }
-        if (!local && (rc = launch_depth_sort(P, saved->geom, L, 1, saved->binning + L.b_ghist, L.b_ctrl_bytes, a->debug != 0, s))) return rc;
-        if ((rc = bin_and_render(cap, local, !local))) return rc;
+        if (!local && !seg && (rc = launch_depth_sort(P, saved->geom, L, 1, saved->binning + L.b_ghist, L.b_ctrl_bytes, a->debug != 0, s))) return rc;
+        if ((rc = bin_and_render(cap, local, !local && !seg))) return rc;
     }
     if (a->debug && late_tag && (rc = check_slot(late_tag % CHECK_SLOTS, true))) return rc;   // debug: report this forward's self-check word right away
     saved->num_rendered = I;

@@ -23,7 +23,7 @@ struct Switches {
     bool sort_classic;     // DAS3R_SORT=classic: histogram + row scan + scatter per digit instead of the one-sweep passes
     bool rect_upstream;    // DAS3R_RECT=upstream: bin over upstream's 3-sigma square (bit-exact list tests)
     bool verbose;          // DAS3R_VERBOSE
-    int binning;           // DAS3R_BINNING=local | radix: 1 | -1 (0: chosen per scene)
+    int binning;           // DAS3R_BINNING=local | radix | seg: 1 | -1 | 2 (0: chosen per scene)
     bool capacity_exact;   // DAS3R_CAPACITY=exact: never lay the binning buffer out speculatively
     bool fused_emit_off;   // DAS3R_FUSED_EMIT=0
     bool no_sh_stage;      // DAS3R_NO_SH_STAGE
@@ -204,7 +204,14 @@ struct Layout {
     size_t b_ghist, b_ticket, b_status, b_ctrl_bytes;
     int tiles_x, tiles_y, ntiles, tbits, tile_passes;
     int chunksP, chunksI;
+    // segmented binning path (segkey.h): the partition key is (tile id << dbits | depth bucket), kbits = tbits + dbits wide, in the
+    // SAME number of passes the tile ids alone need (the backward pass lays the buffers out without knowing the path).  dbits = 0
+    // everywhere else.  g_dhist: u32[256] depth histogram of the forward
+    int dbits, kbits;
+    size_t g_dhist;
 };
+// depth-bucket bits the tile partition's passes have room for (0: none — the tile ids fill their passes)
+static inline int seg_dbits(const Layout &L) { return 8 * L.tile_passes - L.tbits; }
 
 // Local depth order (short tile lists): the binning skips the global depth sort, the tile lists arrive in index order and
 // the forward compositing kernel sorts each one by (depth bits, index) itself (render_common.h: local_sort_tile) — in LDS up
@@ -241,7 +248,7 @@ constexpr int EMIT_STATUS_GRANULES = 1024;             // >= resident grid + its
 // arrive: a zeroed 64-bit device word (self re-arming); host_out / tag: pinned mailbox that receives num_rendered
 int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int32_t *radii, char *geom, char *img, char *binning_ctrl,
                       size_t binning_ctrl_bytes, const Layout &L, unsigned long long *arrive, uint32_t *host_out, uint32_t tag,
-                      hipStream_t s, const EmitArgs *emit = nullptr);
+                      hipStream_t s, const EmitArgs *emit = nullptr, uint32_t *dhist = nullptr);
 int launch_mark_visible(int P, const float *means3D, const float *viewmatrix, uint8_t *present, hipStream_t s);
 // part 0: everything that can be enqueued before num_rendered is known; part 1: the rest, which also zeroes the binning buffer's
 // control words (binning_ctrl may be null)
@@ -283,7 +290,12 @@ bool use_tight_rect();  // DAS3R_RECT=upstream bins over upstream's 3-sigma squa
 // host_late / tag: pinned mailbox the last binning kernel copies the self-check word to (see api.hip)
 int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *geom, char *binning, char *img, const Layout &L,
                    bool fused_scan, uint32_t *host_late, uint32_t tag, bool debug, hipStream_t s, uint32_t **dead_keys = nullptr,
-                   uint32_t *emit_slot = nullptr /*fused emission: {err, pad, ghist} ring slot, re-armed by the last kernel*/);
+                   uint32_t *emit_slot = nullptr /*fused emission: {err, pad, ghist} ring slot, re-armed by the last kernel*/,
+                   uint32_t *seg_host_flag = nullptr, uint32_t seg_flag_value = 0 /*segmented path (L.dbits > 0): mailbox word for a segment too long for LDS*/);
+// segsort.hip: exact (depth bits, index) order inside every (tile, depth bucket) segment of the partitioned list, in place
+int launch_segment_sort(int64_t cap, const uint32_t *n_ptr, const uint32_t *keys_final, uint32_t *point_list, uint32_t *slot_list,
+                        const uint32_t *depth_key, uint32_t last_g, uint32_t *scratch_keys, uint32_t *host_flag, uint32_t flag_value, bool debug,
+                        hipStream_t s);
 // lb.point_list != null: the tile lists are in index order and the kernel sorts them by depth first
 int launch_render_forward(const das3r_raster_args *a, const float *colors_precomp, float *out_color, char *geom, char *binning,
                           char *img, const Layout &L, const LocalBin &lb, hipStream_t s);

@@ -153,6 +153,41 @@ __global__ void __launch_bounds__(256) photometric_backward_kernel(int H, int W,
     if (inside) d_static[pix] = ds;
 }
 
+// the few hundred rows of tile sums -> {loss, mse_r, mse_g, mse_b, psnr_frame} (what the host side of round 3 did with ~12 tiny
+// PyTorch kernels per iteration); one workgroup, rows added in a fixed order: deterministic
+__global__ void __launch_bounds__(256) photometric_finish_kernel(int nblocks, const float *__restrict__ partials, float npix, float lambda,
+                                                                 float *__restrict__ out /*[8]*/) {
+    __shared__ float red[4][5];
+    const int tid = threadIdx.x, lane = __lane_id(), wave = tid >> 6;
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = tid; b < nblocks; b += 256)
+#pragma unroll
+        for (int q = 0; q < 5; q++) acc[q] += partials[(size_t)b * 8 + q];
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+        float v = acc[q];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[wave][q] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float s[5];
+#pragma unroll
+        for (int q = 0; q < 5; q++) s[q] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
+        out[0] = ((1.f - lambda) * s[0] + lambda * s[1]) / (3.f * npix);
+        float psnr = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float mse = s[2 + c] / npix;
+            out[1 + c] = mse;
+            psnr += 20.f * log10f(1.f / sqrtf(mse));   // utils/image_utils.py:17-19
+        }
+        out[4] = psnr / 3.f;
+        out[5] = out[6] = out[7] = 0.f;
+    }
+}
+
 static GaussWin make_window() {
     GaussWin g;
     double v[2 * PR + 1], sum = 0.0;
@@ -183,6 +218,14 @@ extern "C" int das3r_photometric_forward(int32_t H, int32_t W, const float *rend
     DAS3R_LAUNCH(photometric_forward_kernel, dim3(div_up(W, PT), div_up(H, PT)), dim3(PT * PT), 0, s, H, W, render, gt, static_mask, lambda,
                  make_window(), partials, dmaps);
     KERNEL_CHECK(s, false, "photometric_forward");
+    return DAS3R_OK;
+}
+
+extern "C" int das3r_photometric_finish(int32_t H, int32_t W, const float *partials, float lambda, float *out8, das3r_stream_t stream) {
+    if (H <= 0 || W <= 0 || !partials || !out8) { set_error("das3r_photometric_finish: invalid argument"); return DAS3R_ERR_INVALID_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    DAS3R_LAUNCH(photometric_finish_kernel, dim3(1), dim3(256), 0, s, (int)das3r_photometric_blocks(H, W), partials, (float)H * (float)W, lambda, out8);
+    KERNEL_CHECK(s, false, "photometric_finish");
     return DAS3R_OK;
 }
 

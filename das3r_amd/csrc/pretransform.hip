@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256) pretransform_backward_kernel(
 
 // pose (qw,qx,qy,qz,tx,ty,tz) -> mats[28] = R (9, row-major; rotation of the NORMALISED quaternion, like get_camera_from_tensor),
 // t (3), Lq (16, row-major; left-multiplication matrix of the RAW quaternion, like quadmultiply).  One lane.
-__global__ void pose_matrices_kernel(const float *__restrict__ pose, float *__restrict__ mats) {
+__global__ void pose_matrices_kernel(const float *__restrict__ pose, const float *__restrict__ trans, float *__restrict__ mats) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const float w = pose[0], x = pose[1], y = pose[2], z = pose[3];
     const float inv = 1.0f / sqrtf(w * w + x * x + y * y + z * z);
@@ -112,12 +112,14 @@ __global__ void pose_matrices_kernel(const float *__restrict__ pose, float *__re
                         2 * (j * k - r * i), 2 * (i * k - r * j), 2 * (j * k + r * i), 1 - 2 * (i * i + j * j)};
     const float L[16] = {w, -x, -y, -z, x, w, -z, y, y, z, w, -x, z, -y, x, w};
     for (int a = 0; a < 9; a++) mats[a] = R[a];
-    for (int a = 0; a < 3; a++) mats[9 + a] = pose[4 + a];
+    for (int a = 0; a < 3; a++) mats[9 + a] = trans[a];
     for (int a = 0; a < 16; a++) mats[12 + a] = L[a];
 }
 
 // chain rule of pose_matrices: g[28] = dL/d(R, t, Lq) -> g_pose[7].  One lane.
-__global__ void pose_chain_kernel(const float *__restrict__ pose, const float *__restrict__ g, float *__restrict__ g_pose) {
+// g_t: where dL/dt goes (g_pose + 4 for the 7-vector form); rearm: zero g[0 .. 28) afterwards (the sums of the next backward are
+// accumulated into it with atomics: das3r_pose_chain_qt keeps the caller's buffer zero at rest)
+__global__ void pose_chain_kernel(const float *__restrict__ pose, float *__restrict__ g, float *__restrict__ g_pose, float *__restrict__ g_t, int rearm) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const float w = pose[0], x = pose[1], y = pose[2], z = pose[3];
     const float n = sqrtf(w * w + x * x + y * y + z * z), inv = 1.0f / n;
@@ -137,7 +139,9 @@ __global__ void pose_chain_kernel(const float *__restrict__ pose, const float *_
     gq[2] += -H[2] + H[7] + H[8] - H[13];
     gq[3] += -H[3] - H[6] + H[9] + H[12];
     for (int a = 0; a < 4; a++) g_pose[a] = gq[a];
-    for (int a = 0; a < 3; a++) g_pose[4 + a] = g[9 + a];
+    for (int a = 0; a < 3; a++) g_t[a] = g[9 + a];
+    if (rearm)
+        for (int a = 0; a < 28; a++) g[a] = 0.f;
 }
 
 }  // namespace das3r
@@ -147,15 +151,31 @@ using namespace das3r;
 extern "C" int das3r_pose_matrices(const float *pose, float *mats, das3r_stream_t stream) {
     if (!pose || !mats) { set_error("das3r_pose_matrices: invalid argument"); return DAS3R_ERR_INVALID_ARG; }
     hipStream_t s = (hipStream_t)stream;
-    DAS3R_LAUNCH(pose_matrices_kernel, dim3(1), dim3(64), 0, s, pose, mats);
+    DAS3R_LAUNCH(pose_matrices_kernel, dim3(1), dim3(64), 0, s, pose, pose + 4, mats);
     KERNEL_CHECK(s, false, "pose_matrices");
+    return DAS3R_OK;
+}
+
+extern "C" int das3r_pose_matrices_qt(const float *q, const float *t, float *mats, das3r_stream_t stream) {
+    if (!q || !t || !mats) { set_error("das3r_pose_matrices_qt: invalid argument"); return DAS3R_ERR_INVALID_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    DAS3R_LAUNCH(pose_matrices_kernel, dim3(1), dim3(64), 0, s, q, t, mats);
+    KERNEL_CHECK(s, false, "pose_matrices");
+    return DAS3R_OK;
+}
+
+extern "C" int das3r_pose_chain_qt(const float *q, float *g_mats, float *g_q, float *g_t, das3r_stream_t stream) {
+    if (!q || !g_mats || !g_q || !g_t) { set_error("das3r_pose_chain_qt: invalid argument"); return DAS3R_ERR_INVALID_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    DAS3R_LAUNCH(pose_chain_kernel, dim3(1), dim3(64), 0, s, q, g_mats, g_q, g_t, 1);
+    KERNEL_CHECK(s, false, "pose_chain");
     return DAS3R_OK;
 }
 
 extern "C" int das3r_pose_chain(const float *pose, const float *g_mats, float *g_pose, das3r_stream_t stream) {
     if (!pose || !g_mats || !g_pose) { set_error("das3r_pose_chain: invalid argument"); return DAS3R_ERR_INVALID_ARG; }
     hipStream_t s = (hipStream_t)stream;
-    DAS3R_LAUNCH(pose_chain_kernel, dim3(1), dim3(64), 0, s, pose, g_mats, g_pose);
+    DAS3R_LAUNCH(pose_chain_kernel, dim3(1), dim3(64), 0, s, pose, const_cast<float *>(g_mats), g_pose, g_pose + 4, 0);
     KERNEL_CHECK(s, false, "pose_chain");
     return DAS3R_OK;
 }

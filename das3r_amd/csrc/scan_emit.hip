@@ -8,6 +8,7 @@
 // lanes of one wave polling 64 words at a time, so the wait is ~3 round trips for any grid size.  Granules, tickets and the
 // histograms are zeroed earlier in the same forward (preprocess_kernel / the binning memset).
 #include "granule.h"
+#include "segkey.h"
 #include "splat_math.h"
 
 namespace das3r {
@@ -47,8 +48,10 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
     uint32_t *__restrict__ ticket, uint32_t *__restrict__ err, uint32_t *__restrict__ host_out /*pinned host mailbox*/, uint32_t tag,
     // emission (EMIT only)
     int tiles_x, int tiles_y, const float4 *__restrict__ xyh, const int32_t *__restrict__ radii, uint32_t *__restrict__ tile_keys,
-    uint32_t *__restrict__ gids, uint32_t cap, uint32_t *__restrict__ ghist /*[passes][256]*/, int tbits, int tight_rect,
-    const uint32_t *__restrict__ rect32 /*packed binned rectangles by splat (common.h g_rect) or null*/
+    uint32_t *__restrict__ gids, uint32_t cap, uint32_t *__restrict__ ghist /*[passes][256]*/, int tbits /*bits of the partition key*/, int tight_rect,
+    const uint32_t *__restrict__ rect32 /*packed binned rectangles by splat (common.h g_rect) or null*/,
+    // segmented path (segkey.h; index order only): partition key = tile id << dbits | depth bucket of the splat
+    int dbits, const uint32_t *__restrict__ depth_keys /*[P] by splat*/, const uint32_t *__restrict__ dhist /*[256] depth histogram of this forward*/
 #ifdef DAS3R_EXPERIMENTS
     , unsigned long long *__restrict__ wg_trace_ptr /*common.h SCAN_STAMP*/
 #endif
@@ -75,12 +78,29 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
     const uint32_t b = s_block;
     SCAN_STAMP(0)   // ticket
     const int base = (int)b * 256 * SCAN_ITEMS;
+    // depth buckets (segkey.h): every workgroup turns the forward's 256-bin depth histogram into the same monotone map
+    __shared__ float s_cnt[EMIT ? DBINS : 1], s_cdf[EMIT ? DBINS : 1];
+    float dscale = 0.f;
+    if (EMIT && dbits > 0) {   // (uniform)
+        const uint32_t c = dhist[tid];
+        uint32_t tot, tot2;
+        block_exclusive_scan_256(c, ws, &tot);
+        int sh = 0;
+        while ((tot >> sh) >= (1u << 24)) sh++;   // counts below 2^24: exact as floats
+        const uint32_t cs = c >> sh;
+        const uint32_t ex = block_exclusive_scan_256(cs, ws, &tot2);
+        s_cnt[EMIT ? tid : 0] = (float)cs;
+        s_cdf[EMIT ? tid : 0] = (float)ex;
+        dscale = tot2 ? (float)(1u << dbits) / (float)tot2 : 0.f;
+        __syncthreads();
+    }
 
-    uint32_t g[SCAN_ITEMS], v[SCAN_ITEMS], rc[SCAN_ITEMS], sum = 0;
+    uint32_t g[SCAN_ITEMS], v[SCAN_ITEMS], rc[SCAN_ITEMS], dkv[SCAN_ITEMS], sum = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
         const int r = base + k * 256 + tid;
         g[k] = r < P ? (sorted_idx ? sorted_idx[r] : (uint32_t)r) : 0u;   // sorted_idx == null: index order (local depth order)
+        dkv[k] = (EMIT && dbits > 0 && r < P) ? depth_keys[g[k]] : 0u;    // (segmented path: requested with everything else, up front)
     }
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
@@ -134,9 +154,10 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
                     binned_rect(p, radius, tiles_x, tiles_y, tight_rect != 0, rminx, rminy, rmaxx, rmaxy);
                 }
                 uint32_t l = ex;   // place in the workgroup's run
+                const uint32_t bucket = (EMIT && dbits > 0) ? depth_bucket(dkv[k], s_cnt, s_cdf, dscale, 1u << dbits) : 0u;
                 for (int y = rminy; y < rmaxy; y++)
                     for (int x = rminx; x < rmaxx; x++) {
-                        const uint32_t t = (uint32_t)(y * tiles_x + x);
+                        const uint32_t t = ((uint32_t)(y * tiles_x + x) << dbits) | bucket;
                         if (via_lds) {
                             e_key[EMIT ? l : 0] = t;
                             e_gid[EMIT ? l : 0] = g[k];
@@ -239,7 +260,8 @@ int launch_scan(int P, char *geom, const Layout &L, uint32_t *host_out, uint32_t
 #define GO(IT)                                                                                                               \
     DAS3R_LAUNCH((scan_emit_kernel<false, IT>), dim3(nblocks), dim3(256), 0, s, SCAN_COMMON, 0, 0,                            \
                  (const float4 *)(geom + L.pub.xy),                                                                           \
-                 (const int32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (uint32_t *)nullptr, 0, 0, RECT32 SCAN_TRACE_ARG)
+                 (const int32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (uint32_t *)nullptr, 0, 0, RECT32, 0,              \
+                 (const uint32_t *)nullptr, (const uint32_t *)nullptr SCAN_TRACE_ARG)
     switch (scan_items(P)) { case 1: GO(1); break; case 2: GO(2); break; case 4: GO(4); break; case 8: GO(8); break; default: GO(16); }
 #undef GO
     KERNEL_CHECK(s, debug, "scan");
@@ -253,7 +275,8 @@ int launch_scan_emit(int P, int64_t cap, const int32_t *radii, char *geom, char 
 #define GO(IT)                                                                                                               \
     DAS3R_LAUNCH((scan_emit_kernel<true, IT>), dim3(nblocks), dim3(256), 0, s, SCAN_COMMON, L.tiles_x, L.tiles_y,              \
                  (const float4 *)(geom + L.pub.xy), radii, (uint32_t *)(binning + L.b_keyA), (uint32_t *)(binning + L.b_gid_of), \
-                 (uint32_t)cap, (uint32_t *)(binning + L.b_ghist), L.tbits, use_tight_rect() ? 1 : 0, RECT32 SCAN_TRACE_ARG)
+                 (uint32_t)cap, (uint32_t *)(binning + L.b_ghist), L.kbits, use_tight_rect() ? 1 : 0, RECT32, index_order ? L.dbits : 0,      \
+                 (const uint32_t *)(geom + L.pub.depth_key), (const uint32_t *)(geom + L.g_dhist) SCAN_TRACE_ARG)
     switch (scan_items(P)) { case 1: GO(1); break; case 2: GO(2); break; case 4: GO(4); break; case 8: GO(8); break; default: GO(16); }
 #undef GO
     KERNEL_CHECK(s, debug, "scan_emit");

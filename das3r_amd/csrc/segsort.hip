@@ -1,0 +1,234 @@
+// segsort.hip — the per-tile sort of the segmented binning path (round 4): every (tile, depth bucket) segment of
+// the partitioned instance list is put into exact (depth bits, index) order inside LDS; the keys never leave the CU.
+// Replaces, for scenes with long tile lists, the global depth sort of the P splats in front of the tile partition
+// (depth_hist + 4 onesweep passes; upstream: the upper 32 bits of cub::DeviceRadixSort's 64-bit keys).
+// See segkey.h for how the segments come about.
+//
+// A workgroup owns the segments that START inside its window of SEG_CH list positions and holds them — the window plus up to
+// SEG_OVER positions of overhang — in LDS.  Segment boundaries come from the partition keys (flags + one block-wide running
+// maximum), then every owned entry counts the keys of its own segment below its own 64-bit word (depth bits << 32 | position:
+// positions follow the index order, the partition passes being stable) with broadcast LDS reads — neighbouring lanes sit in the
+// same segment — and stores its (splat id, emission slot) at that rank, in place: a segment is read and written by its owner only.
+// A segment that does not end inside the LDS span (a wall parallel to the image plane: thousands of equal depths in one tile) is
+// sorted by the same workgroup with a bitonic network over global memory — slow, exact — and the host is told through the mailbox
+// word the local depth order uses, so that the next forwards of this shape take the global sort for a while (api.hip).
+#include "granule.h"
+#include "segkey.h"
+
+namespace das3r {
+
+constexpr int SEG_CH = 2048;                  // list positions whose segment starts a workgroup owns
+constexpr int SEG_OVER = 1024;                // overhang: an owned segment may reach this far past the window
+constexpr int SEG_CAP = SEG_CH + SEG_OVER;    // entries in LDS
+constexpr int SEG_PAIRS = SEG_CAP / 512;      // pairs of neighbouring entries per thread
+constexpr int SEG_BLK = (SEG_CAP + 1 + 255) / 256;   // flag positions per thread (blocked), SEG_CAP + 1 of them
+constexpr uint32_t SEG_NONE = 0xFFFFu;
+
+// exclusive running maximum across the 256 threads of (v + 1) style values (0 = none)
+__device__ __forceinline__ uint32_t block_exclusive_max_256(const uint32_t v, uint32_t *ws /*[4]*/) {
+    const int lane = __lane_id(), wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t nb = __shfl_up(incl, o, 64);
+        if (lane >= o) incl = max(incl, nb);
+    }
+    uint32_t ex = __shfl_up(incl, 1, 64);
+    if (lane == 0) ex = 0u;
+    __syncthreads();
+    if (lane == 63) ws[wave] = incl;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+        if (w < wave) ex = max(ex, ws[w]);
+    return ex;
+}
+
+__global__ void __launch_bounds__(256) segment_sort_kernel(uint32_t cap, const uint32_t *__restrict__ n_ptr, const uint32_t *__restrict__ kk /*partition keys, final order*/,
+                                                           uint32_t *__restrict__ pl, uint32_t *__restrict__ sl, const uint32_t *__restrict__ depth_key /*[P] by splat*/,
+                                                           uint32_t last_g, uint32_t *__restrict__ dk /*u32[cap] scratch (the dead key buffer)*/,
+                                                           uint32_t *__restrict__ host_flag, uint32_t flag_value) {
+    const uint32_t n = n_ptr ? min(*n_ptr, cap) : cap;
+    const uint32_t w0 = blockIdx.x * (uint32_t)SEG_CH;
+    if (w0 >= n) return;
+    __shared__ unsigned long long s_key[SEG_CAP];          // first: the partition keys of positions w0 - 1 .. w0 + SEG_CAP (u32[SEG_CAP + 2])
+    __shared__ uint16_t s_start[SEG_CAP + 1], s_end[SEG_CAP + 1];
+    __shared__ uint32_t ws[4];
+    __shared__ uint32_t s_long;                            // start (relative) of the owned segment that leaves the LDS span, or SEG_NONE
+    uint32_t *skk = reinterpret_cast<uint32_t *>(s_key);   // skk[r] = kk[w0 - 1 + r]
+    const int tid = threadIdx.x;
+    static_assert(SEG_CAP + 2 <= 2 * SEG_CAP, "the partition keys borrow the sort words' array");
+    for (int r = tid; r < SEG_CAP + 2; r += 256) {
+        const long long idx = (long long)w0 - 1 + r;
+        skk[r] = (idx >= 0 && idx < (long long)n) ? kk[idx] : 0u;
+    }
+    for (int r = tid; r < SEG_CAP + 1; r += 256) s_end[r] = (uint16_t)SEG_NONE;
+    if (tid == 0) s_long = SEG_NONE;
+    __syncthreads();
+    // position p (0 .. SEG_CAP) starts a segment iff its key differs from the one before it; the position just behind the list
+    // counts as a start (it ends the last segment), nothing beyond it does
+    auto flag = [&](const int p) -> bool {
+        const uint32_t idx = w0 + (uint32_t)p;
+        if (idx > n) return false;
+        if (idx == n || idx == 0u) return true;
+        return skk[p] != skk[p + 1];
+    };
+    uint32_t last = 0u;   // (last start of this thread's positions) + 1, 0 = none
+#pragma unroll
+    for (int u = 0; u < SEG_BLK; u++) {
+        const int p = tid * SEG_BLK + u;
+        if (p <= SEG_CAP && flag(p)) last = (uint32_t)p + 1u;
+    }
+    uint32_t running = block_exclusive_max_256(last, ws);
+#pragma unroll
+    for (int u = 0; u < SEG_BLK; u++) {
+        const int p = tid * SEG_BLK + u;
+        if (p <= SEG_CAP) {
+            if (flag(p)) {
+                if (running) s_end[running - 1u] = (uint16_t)p;   // the segment before this one ends here
+                running = (uint32_t)p + 1u;
+            }
+            s_start[p] = running ? (uint16_t)(running - 1u) : (uint16_t)SEG_NONE;
+        }
+    }
+    __syncthreads();   // (the partition keys are dead from here on: s_key takes the array)
+    // owned in LDS: a true start inside the window whose end is known.  Thread t holds the PAIRS of neighbouring positions
+    // 2 t + 512 u, + 1 (u < SEG_PAIRS): neighbours nearly always share their segment, and then every key of it is read from LDS once
+    // for both of them (r4, first version: one position per lane and 64-bit compares — 0.20 ms on the 5 M-splat DAS3R shape, the
+    // LDS reads and v_cmp_lt_u64 in equal parts).
+    uint32_t g[SEG_PAIRS][2], slot[SEG_PAIRS][2];
+    bool own[SEG_PAIRS][2];
+#pragma unroll
+    for (int u = 0; u < SEG_PAIRS; u++)
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int p = 2 * tid + 512 * u + e;
+            const uint32_t s = s_start[p];
+            const bool cand = w0 + (uint32_t)p < n && s != SEG_NONE && s < (uint32_t)SEG_CH;
+            own[u][e] = cand && s_end[s] != SEG_NONE;
+            if (cand && s_end[s] == SEG_NONE && (uint32_t)p == s) s_long = s;   // (one writer at most)
+            g[u][e] = slot[u][e] = 0u;
+        }
+    __syncthreads();   // (s_long published; nobody reads the partition keys any more: s_key takes the array)
+#pragma unroll
+    for (int u = 0; u < SEG_PAIRS; u++) {
+        const int p0 = 2 * tid + 512 * u;
+        if (own[u][0] || own[u][1]) {   // (8-byte loads: w0 and p0 are even; an odd n leaves the last word unread)
+            uint2 gv = make_uint2(0u, 0u), sv = make_uint2(0u, 0u);
+            if (w0 + (uint32_t)p0 + 1u < n) {
+                gv = *reinterpret_cast<const uint2 *>(pl + w0 + p0);
+                sv = *reinterpret_cast<const uint2 *>(sl + w0 + p0);
+            } else {
+                gv.x = pl[w0 + p0];
+                sv.x = sl[w0 + p0];
+            }
+            g[u][0] = min(gv.x, last_g); g[u][1] = min(gv.y, last_g);
+            slot[u][0] = sv.x; slot[u][1] = sv.y;
+#pragma unroll
+            for (int e = 0; e < 2; e++)
+                if (own[u][e]) s_key[p0 + e] = ((unsigned long long)depth_key[g[u][e]] << 32) | (unsigned long long)(p0 + e);
+        }
+    }
+    __syncthreads();   // (also: every load of pl / sl above has arrived — the stores below may overwrite them)
+    // rank of a position = keys of its segment below its own word (depth bits << 32 | position).  [key_j < key_i] is the borrow of the
+    // 64-bit subtraction: v_sub_co + v_subb_co + v_addc_co, three full-rate instructions (v_cmp_lt_u64 is not)
+    auto count_below = [](uint32_t &rank, const uint2 kj, const uint2 ki) {
+        uint32_t tmp;
+        asm("v_sub_co_u32 %1, vcc, %2, %4\n\t"
+            "v_subb_co_u32 %1, vcc, %3, %5, vcc\n\t"
+            "v_addc_co_u32 %0, vcc, 0, %0, vcc"
+            : "+v"(rank), "=&v"(tmp)
+            : "v"(kj.x), "v"(kj.y), "v"(ki.x), "v"(ki.y)
+            : "vcc");
+    };
+    const uint2 *keys2 = reinterpret_cast<const uint2 *>(s_key);
+#pragma unroll
+    for (int u = 0; u < SEG_PAIRS; u++) {   // (unrolled: own / g / slot are registers)
+        const int p0 = 2 * tid + 512 * u;
+        if (!(own[u][0] || own[u][1])) continue;
+        const uint32_t s0 = own[u][0] ? s_start[p0] : s_start[p0 + 1], s1 = own[u][1] ? s_start[p0 + 1] : s0;
+        if (s0 == s1) {   // the pair shares its segment (or one of the two is not owned: its rank is computed and dropped)
+            const uint32_t t = s_end[s0];
+            const uint2 k0 = keys2[own[u][0] ? p0 : p0 + 1], k1 = keys2[own[u][1] ? p0 + 1 : p0];
+            uint32_t r0 = 0, r1 = 0, j = s0;
+            for (; j + 4 <= t; j += 4) {
+                const uint2 a = keys2[j], b = keys2[j + 1], c = keys2[j + 2], d = keys2[j + 3];
+                count_below(r0, a, k0); count_below(r1, a, k1);
+                count_below(r0, b, k0); count_below(r1, b, k1);
+                count_below(r0, c, k0); count_below(r1, c, k1);
+                count_below(r0, d, k0); count_below(r1, d, k1);
+            }
+            for (; j < t; j++) {
+                const uint2 a = keys2[j];
+                count_below(r0, a, k0); count_below(r1, a, k1);
+            }
+            if (own[u][0]) { pl[w0 + s0 + r0] = g[u][0]; sl[w0 + s0 + r0] = slot[u][0]; }
+            if (own[u][1]) { pl[w0 + s0 + r1] = g[u][1]; sl[w0 + s0 + r1] = slot[u][1]; }
+        } else {          // a segment boundary between the two
+#pragma unroll
+            for (int e = 0; e < 2; e++)
+                if (own[u][e]) {
+                    const uint32_t s = e ? s1 : s0, t = s_end[s];
+                    const uint2 k = keys2[p0 + e];
+                    uint32_t r = 0;
+                    for (uint32_t j = s; j < t; j++) count_below(r, keys2[j], k);
+                    pl[w0 + s + r] = g[u][e];
+                    sl[w0 + s + r] = slot[u][e];
+                }
+        }
+    }
+    // ---- a segment that leaves the LDS span (rare; uniform branch) ----
+    const uint32_t sl0 = s_long;
+    if (sl0 == SEG_NONE) return;
+    const uint32_t S = w0 + sl0;
+    const uint32_t key = kk[S];
+    __shared__ uint32_t s_T;
+    if (tid == 0) {
+        s_T = n;
+        __hip_atomic_store(host_flag, flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+    for (uint32_t base = w0 + (uint32_t)SEG_CAP; base < n; base += 256u) {   // its end: the first position with another key
+        const uint32_t idx = base + tid;
+        if (idx < n && kk[idx] != key) atomicMin(&s_T, idx);
+        __syncthreads();
+        if (s_T != n) break;   // (uniform: read behind the barrier)
+        __syncthreads();
+    }
+    __syncthreads();
+    const uint32_t T = s_T;
+    const int m = (int)(T - S);
+    uint32_t *dkk = dk + S, *plk = pl + S, *slk = sl + S;
+    for (int i = tid; i < m; i += 256) dkk[i] = depth_key[min(plk[i], last_g)];
+    __syncthreads();
+    for (int k = 2; (k >> 1) < m; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int flip = (j == (k >> 1)) ? k - 1 : j;
+            for (int i = tid; i < m; i += 256) {
+                const int q = i ^ flip;
+                if (q > i && q < m) {
+                    const uint32_t da = dkk[i], db = dkk[q], ga = plk[i], gb = plk[q];
+                    if (da > db || (da == db && ga > gb)) {   // (within a segment the index order is the splat-id order)
+                        dkk[i] = db; dkk[q] = da;
+                        plk[i] = gb; plk[q] = ga;
+                        const uint32_t t = slk[i];
+                        slk[i] = slk[q];
+                        slk[q] = t;
+                    }
+                }
+            }
+            __syncthreads();   // same workgroup, same CU: its write-through L1 keeps the exchanged words coherent
+        }
+}
+
+int launch_segment_sort(int64_t cap, const uint32_t *n_ptr, const uint32_t *keys_final, uint32_t *point_list, uint32_t *slot_list,
+                        const uint32_t *depth_key, uint32_t last_g, uint32_t *scratch_keys, uint32_t *host_flag, uint32_t flag_value, bool debug,
+                        hipStream_t s) {
+    if (cap <= 0) return DAS3R_OK;
+    DAS3R_LAUNCH(segment_sort_kernel, dim3(div_up(cap, SEG_CH)), dim3(256), 0, s, (uint32_t)cap, n_ptr, keys_final, point_list, slot_list, depth_key, last_g,
+                 scratch_keys, host_flag, flag_value);
+    KERNEL_CHECK(s, debug, "segment_sort");
+    return DAS3R_OK;
+}
+
+}  // namespace das3r

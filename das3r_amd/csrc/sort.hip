@@ -245,7 +245,8 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(uint32_t cap, const ui
                                                           const uint32_t *__restrict__ tile_keys, uint2 *__restrict__ ranges,
                                                           uint32_t *__restrict__ err, uint32_t *__restrict__ host_late, uint32_t tag,
                                                           uint32_t rearm_words /*fused emission: err[0 .. rearm_words) back to zero*/,
-                                                          uint32_t inject /*DAS3R_INJECT_FAULT: bits forced into the word (tests)*/) {
+                                                          uint32_t inject /*das3r_debug_inject_fault: bits forced into the word (tests)*/,
+                                                          int dbits /*segmented path: the keys are tile id << dbits | depth bucket*/) {
     const uint32_t I = n_ptr ? min(*n_ptr, cap) : cap;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0 && host_late) {   // last binning kernel: hand the self-check word of this forward to the host mailbox
@@ -254,10 +255,10 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(uint32_t cap, const ui
     }
     if (i < rearm_words) err[i] = 0u;   // (thread 0 has read err[0] just above) the ring slot is zero at rest again
     if (i >= I) return;
-    const uint32_t t = tile_keys[i];
+    const uint32_t t = tile_keys[i] >> dbits;
     if (i == 0) ranges[t].x = 0;
     else {
-        const uint32_t prev = tile_keys[i - 1];
+        const uint32_t prev = tile_keys[i - 1] >> dbits;
         if (prev != t) {
             ranges[prev].y = i;
             ranges[t].x = i;
@@ -298,7 +299,8 @@ int launch_binning_scan_emit(int P, int64_t I, const int32_t *radii, char *geom,
 
 // I = capacity of the binning buffer; the true instance count is read by the kernels from geom + L.g_count
 int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *geom, char *binning, char *img, const Layout &L,
-                   bool fused_scan, uint32_t *host_late, uint32_t tag, bool debug, hipStream_t s, uint32_t **dead_keys, uint32_t *emit_slot) {
+                   bool fused_scan, uint32_t *host_late, uint32_t tag, bool debug, hipStream_t s, uint32_t **dead_keys, uint32_t *emit_slot,
+                   uint32_t *seg_host_flag, uint32_t seg_flag_value) {
     const uint32_t *n_ptr = (const uint32_t *)(geom + L.g_count);
     (void)W; (void)H;
     uint2 *ranges = (uint2 *)(img + L.pub.ranges);  // zeroed by preprocess_kernel
@@ -326,9 +328,15 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
         int rc1 = launch_onesweep_partition(I, geom, binning, L, &kfinal, debug, s, emit_slot ? emit_slot + 64 : nullptr, emit_slot);
         if (rc1) return rc1;
         if (dead_keys) *dead_keys = kfinal;   // the tile keys are dead once tile_ranges_kernel has run
+        if (L.dbits > 0) {   // segmented path: exact depth order inside every (tile, bucket) segment, in place (segsort.hip)
+            uint32_t *other = kfinal == keyA ? keyB : keyA;   // the previous pass's keys: dead, scratch for a segment too long for LDS
+            rc1 = launch_segment_sort(I, n_ptr, kfinal, (uint32_t *)(binning + L.pub.point_list), (uint32_t *)(binning + L.b_slot),
+                                      (const uint32_t *)(geom + L.pub.depth_key), (uint32_t)(P - 1), other, seg_host_flag, seg_flag_value, debug, s);
+            if (rc1) return rc1;
+        }
         const int rearm = emit_slot ? EMIT_SLOT_WORDS : 0;
         DAS3R_LAUNCH(tile_ranges_kernel, dim3(div_up(std::max<int64_t>(I, rearm), 256)), dim3(256), 0, s, (uint32_t)I, n_ptr, kfinal, ranges,
-                     emit_slot ? emit_slot : (uint32_t *)(geom + L.g_ticket) + 8, host_late, tag, (uint32_t)rearm, (uint32_t)switches().inject_fault);
+                     emit_slot ? emit_slot : (uint32_t *)(geom + L.g_ticket) + 8, host_late, tag, (uint32_t)rearm, (uint32_t)switches().inject_fault, L.dbits);
         KERNEL_CHECK(s, debug, "tile_ranges");
         return DAS3R_OK;
     }
@@ -350,7 +358,7 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
     // kin/vin now hold the partitioned (tile id, gaussian id) lists; vin == binning + pub.point_list by construction
     if (dead_keys) *dead_keys = kin;
     DAS3R_LAUNCH(tile_ranges_kernel, dim3(div_up(I, 256)), dim3(256), 0, s, (uint32_t)I, n_ptr, kin, ranges,
-                 (uint32_t *)(geom + L.g_ticket) + 8, host_late, tag, 0u, (uint32_t)switches().inject_fault);
+                 (uint32_t *)(geom + L.g_ticket) + 8, host_late, tag, 0u, (uint32_t)switches().inject_fault, 0);
     KERNEL_CHECK(s, debug, "tile_ranges");
 #else
     (void)keyA; (void)keyB; (void)valA; (void)valB; (void)hist; (void)totals; (void)inv;

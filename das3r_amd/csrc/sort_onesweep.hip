@@ -349,7 +349,7 @@ int launch_onesweep_partition(int64_t cap, char *geom, char *binning, const Layo
     const uint32_t *vin = gid_of, *v2in = nullptr;
     int shift = 0, rc;
     for (int p = 0; p < L.tile_passes; p++) {
-        const int dw = tile_digit_width(L.tbits), bits = (L.tbits - shift) < dw ? (L.tbits - shift) : dw;
+        const int dw = tile_digit_width(L.kbits), bits = (L.kbits - shift) < dw ? (L.kbits - shift) : dw;   // (kbits = tbits unless segmented: common.h)
         uint32_t *v2out = ((L.tile_passes - 1 - p) & 1) ? e_tmp : slot_list;
         if ((rc = onesweep_pass(kin, vin, kout, vout, cap, n_ptr, shift, bits, ghist + p * 256, status + p * per_pass, ticket + p,
                                 v2in, v2out, err, debug, s)))

@@ -1,0 +1,205 @@
+"""The fused iteration without autograd (round 4): one pass of DAS3R's hot loop — render, masked L1 + SSIM
+loss, backward, both Adam steps (/root/reference/train_gui.py:532-589) — as a straight sequence of calls into the C-ABI.
+
+Round 3's fused iteration still went through torch.autograd and the reference's Python: 163 kernel launches per step of which 22
+were this library's — boolean-mask indexing just to shape the dummy means2D (a nonzero + gather over 2 M splats), eye / bmm /
+inverse for the settings of every render, cat / index for the pose and their index_put backward, select_backward + add over the
+whole conf_static tensor for one frame's mask gradient, a dozen scalar kernels for loss / PSNR / the EMA, zero fills.  Here:
+
+    pose row of Q, row of T  -> das3r_pose_matrices_qt -> das3r_pretransform_forward
+    cached settings (identity view, projection, zero campos: built once per camera)
+    das3r_raster_forward -> das3r_photometric_forward -> das3r_photometric_finish  {loss, mse, psnr_frame} on the device
+    das3r_photometric_backward -> das3r_raster_backward -> das3r_pretransform_backward -> das3r_pose_chain_qt
+    FusedAdam.step (one launch), FusedAdam.step(gate = psnr_frame) for the poses
+
+Gradients land where FusedAdam expects them (`p.grad`, or the compact SH gradient of fused._ShPrefix's contract); the pose gradient
+is written into row `uid` of two dense, otherwise zero buffers (torch's index backward produces exactly that dense gradient, and
+Adam's moments of the other rows decay with it).  Semantics are those of das3r_amd.train.train_step(fused=True) — the tests hold
+both to the float64 trainer and to each other — and nothing here is reachable unless the caller opted into the fused kernels.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from .rasterizer import GaussianRasterizationSettings, _backward_impl, _forward_full, _stream
+
+_p = lambda t: C.c_void_p(t.data_ptr())
+
+
+class _Pkg(dict):
+    """render package; `visibility_filter` (radii > 0: one kernel over P) is computed when somebody asks for it."""
+
+    def __missing__(self, k):
+        if k == "visibility_filter":
+            v = self["radii"] > 0
+            self[k] = v
+            return v
+        raise KeyError(k)
+
+
+def available(model, pipe):
+    """The direct path covers the configuration the farm trains in: fused optimizers on both parameter sets, the default `pipe`."""
+    return (getattr(model, "fast_step", True) and getattr(model.optimizer, "is_fused", False) and hasattr(model.optimizer_cam, "_gate_state")
+            and model.optimizer.handles_compact_sh(model._features_rest)
+            and not getattr(pipe, "compute_cov3D_python", False) and not getattr(pipe, "convert_SHs_python", False)
+            and not getattr(pipe, "debug", False) and model._xyz.device.type == "cuda")
+
+
+class _State:
+    """Per-model buffers that live across iterations (all zero at rest where zero matters)."""
+
+    def __init__(self, model):
+        dev = model._xyz.device
+        P = model._xyz.shape[0]
+        self.dev, self.P = dev, P
+        self.mats = torch.empty(28, device=dev)
+        self.g_small = torch.zeros(28, device=dev)            # re-armed by das3r_pose_chain_qt
+        self.one = torch.ones(1, device=dev)
+        self.Qg, self.Tg = torch.zeros_like(model.Q), torch.zeros_like(model.T)
+        self.tQg, self.tTg = (torch.zeros_like(model.test_Q), torch.zeros_like(model.test_T)) if model.test_Q is not None else (None, None)
+        self.means2D = torch.zeros(P, 3, device=dev, requires_grad=True)   # the reference's dummy leaf: only its .grad is ever used
+        self.e = torch.empty(0, device=dev)
+        idx = getattr(model, "_mask_index", None)
+        if idx is None:
+            idx = model._mask_index = torch.nonzero(model.aggregated_mask.reshape(-1), as_tuple=False).reshape(-1).contiguous()
+        self.mask_index = idx
+        self.mask_is_everything = int(idx.numel()) == int(model._conf_static.numel())
+        self.settings = {}
+
+
+def _state(model):
+    st = getattr(model, "_fast_state", None)
+    if st is None or st.P != model._xyz.shape[0] or st.Qg.shape != model.Q.shape:
+        st = model._fast_state = _State(model)
+    return st
+
+
+def _settings(st, cam, model, bg):
+    """GaussianRasterizationSettings of render() for this camera (gaussian_renderer/__init__.py:53-78): identity view matrix,
+    projmatrix = I @ P^T, campos = 0.  Built once per (camera, SH degree, background tensor)."""
+    key = (id(cam), model.active_sh_degree, bg.data_ptr())
+    rs = st.settings.get(key)
+    if rs is None:
+        dev = st.dev
+        ident = torch.eye(4, device=dev)
+        proj = ident @ cam.projection_matrix.to(dev)
+        rs = GaussianRasterizationSettings(
+            image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=math.tan(float(cam.FoVx) * 0.5),
+            tanfovy=math.tan(float(cam.FoVy) * 0.5), bg=bg, scale_modifier=1.0, viewmatrix=ident.contiguous(), projmatrix=proj.contiguous(),
+            sh_degree=model.active_sh_degree, campos=torch.zeros(3, device=dev), prefiltered=False, debug=False)
+        if len(st.settings) > 4096:
+            st.settings.clear()
+        st.settings[key] = rs
+    return rs
+
+
+def forward_backward(model, cam, q_row, t_row, gq_row, gt_row, static_hw, lambda_dssim, bg):
+    """Render `cam` with the pose (q_row, t_row: views of one row of Q / T), masked photometric loss against cam.original_image
+    under `static_hw` [H, W], and the complete backward.  Gradients: model parameters' .grad (f_rest: compact or none, as in
+    das3r_amd.render), the pose gradient into gq_row / gt_row, d loss / d static_hw returned.
+    -> (out8 = {loss, mse x 3, psnr_frame, ...} device tensor, d_static [H, W], package)"""
+    lib = _lib.load()
+    st = _state(model)
+    dev, P = st.dev, st.P
+    H, W = int(cam.image_height), int(cam.image_width)
+    s = _stream(dev)
+    # ---- pre-transform
+    means3D, rotations = torch.empty_like(model._xyz), torch.empty_like(model._rotation)
+    scales, opac = torch.empty_like(model._scaling), torch.empty(P, 1, device=dev)
+    conf_flat = model._conf_static.view(-1)
+    mats = st.mats
+    _lib.check(lib.das3r_pose_matrices_qt(_p(q_row), _p(t_row), _p(mats), s), "das3r_pose_matrices_qt")
+    _lib.check(lib.das3r_pretransform_forward(P, _p(model._xyz), _p(model._rotation), _p(model._scaling), _p(model._opacity), _p(conf_flat),
+                                              _p(st.mask_index), _p(mats), C.c_void_p(mats.data_ptr() + 36), C.c_void_p(mats.data_ptr() + 48),
+                                              _p(means3D), _p(rotations), _p(scales), _p(opac), s), "das3r_pretransform_forward")
+    # ---- the SH tensor of the active degree (das3r_amd.render: DC alone at degree 0, the active prefix below the maximum)
+    deg = model.active_sh_degree
+    K = (deg + 1) ** 2
+    if deg == 0:
+        shs = model._features_dc
+    elif deg < model.max_sh_degree and getattr(model, "sh_prefix", True):
+        shs = torch.cat((model._features_dc, model._features_rest[:, :K - 1]), dim=1)
+    else:
+        shs = torch.cat((model._features_dc, model._features_rest), dim=1)
+    rs = _settings(st, cam, model, bg)
+    e = st.e
+    I, image, radii, geom, binning, img, cap = _forward_full(rs, means3D, shs, e, opac, scales, rotations, e)
+    # ---- loss
+    gt = cam.original_image
+    nb = int(lib.das3r_photometric_blocks(H, W))
+    partials = torch.empty(nb, 8, device=dev)
+    dmaps = torch.empty(4, 3, H, W, device=dev)
+    out8 = torch.empty(8, device=dev)
+    lam = float(lambda_dssim)
+    _lib.check(lib.das3r_photometric_forward(H, W, _p(image), _p(gt), _p(static_hw), C.c_float(lam), _p(partials), _p(dmaps), s), "das3r_photometric_forward")
+    _lib.check(lib.das3r_photometric_finish(H, W, _p(partials), C.c_float(lam), _p(out8), s), "das3r_photometric_finish")
+    d_render, d_static = torch.empty_like(image), torch.empty(H, W, device=dev)
+    _lib.check(lib.das3r_photometric_backward(H, W, _p(image), _p(gt), _p(static_hw), C.c_float(lam), _p(dmaps), _p(st.one), _p(d_render),
+                                              _p(d_static), s), "das3r_photometric_backward")
+    # ---- rasterizer backward (examines the forward's binning self-check first: include/das3r_raster.h)
+    g_means2D, _g_colors, g_opac, g_means3D, _g_cov, g_sh, g_scales, g_rot = _backward_impl(
+        rs, I, d_render, means3D, shs, e, opac, scales, rotations, e, geom, binning, img, cap)
+    # ---- pre-transform backward, pose chain rule
+    g_xyz, g_rotation, g_scaling = torch.empty_like(model._xyz), torch.empty_like(model._rotation), torch.empty_like(model._scaling)
+    g_opacity_raw = torch.empty_like(model._opacity)
+    g_conf = torch.empty_like(conf_flat) if st.mask_is_everything else torch.zeros_like(conf_flat)   # (every position is written when all pixels are Gaussians)
+    _lib.check(lib.das3r_pretransform_backward(P, _p(model._xyz), _p(model._rotation), _p(model._scaling), _p(model._opacity), _p(conf_flat),
+                                               _p(st.mask_index), _p(mats), C.c_void_p(mats.data_ptr() + 48), _p(g_means3D), _p(g_rot), _p(g_scales),
+                                               _p(g_opac), _p(g_xyz), _p(g_rotation), _p(g_scaling), _p(g_opacity_raw), _p(g_conf), _p(st.g_small), s),
+               "das3r_pretransform_backward")
+    _lib.check(lib.das3r_pose_chain_qt(_p(q_row), _p(st.g_small), _p(gq_row), _p(gt_row), s), "das3r_pose_chain_qt")
+    # ---- hand the gradients over
+    model._xyz.grad, model._rotation.grad, model._scaling.grad, model._opacity.grad = g_xyz, g_rotation, g_scaling, g_opacity_raw
+    if deg == 0:
+        model._features_dc.grad = g_sh
+    else:
+        model._features_dc.grad = g_sh[:, :1].contiguous()
+        rest = g_sh[:, 1:].contiguous()
+        if rest.shape[1] == K - 1 and K - 1 < model._features_rest.shape[1]:
+            old = getattr(model._features_rest, "_das3r_compact_grad", None)
+            model._features_rest._das3r_compact_grad = rest if old is None else old + rest
+        else:
+            model._features_rest.grad = rest
+    model._conf_static.grad = g_conf.view(model._conf_static.shape)
+    st.means2D.grad = g_means2D
+    pkg = _Pkg(render=image, viewspace_points=st.means2D, radii=radii)
+    return out8, d_static, pkg
+
+
+def train_step(model, cam, opt, iteration, pipe, background):
+    """das3r_amd.train.train_step(fused=True) without autograd.  -> (loss, psnr_frame, package): 0-dim device tensors."""
+    model.update_learning_rate(iteration)
+    if iteration % 3000 == 0:
+        model.oneupSHdegree()
+    st = _state(model)
+    uid = cam.uid
+    with torch.no_grad():
+        out8, d_static, pkg = forward_backward(model, cam, model.Q[uid], model.T[uid], st.Qg[uid], st.Tg[uid], model._conf_static[uid],
+                                               opt.lambda_dssim, background)
+        model._conf_static.grad[uid] += d_static             # the loss sees conf_static twice: as opacity factor and as the frame's mask
+        model.optimizer.step()
+        model.optimizer.zero_grad(set_to_none=True)
+        model.Q.grad, model.T.grad = st.Qg, st.Tg
+        model.optimizer_cam.step(gate=out8[4], threshold=opt.psnr_threshold)
+        model.optimizer_cam.zero_grad(set_to_none=True)
+        st.Qg[uid].zero_()                                   # dense pose gradients: zero at rest
+        st.Tg[uid].zero_()
+    return out8[0], out8[4], pkg
+
+
+def test_pose_step(model, cam, static_hw, opt, background):
+    """One view of train_test_psnr.py's pass over the held-out views (das3r_amd.train.test_pose_pass): render with the test pose,
+    loss, backward — and every gradient dropped: the Gaussian optimizer is zeroed without a step and optimizer_cam owns no
+    gradient here.  Reproduced for its cost; nothing changes."""
+    st = _state(model)
+    uid = cam.uid
+    if st.tQg is None:   # (the held-out poses were set after the first training step)
+        st.tQg, st.tTg = torch.zeros_like(model.test_Q), torch.zeros_like(model.test_T)
+    with torch.no_grad():
+        out8, _d_static, _pkg = forward_backward(model, cam, model.test_Q[uid], model.test_T[uid], st.tQg[uid], st.tTg[uid], static_hw,
+                                                 opt.lambda_dssim, background)
+        model.optimizer.zero_grad(set_to_none=True)
+        model.optimizer_cam.zero_grad(set_to_none=True)
+    return out8

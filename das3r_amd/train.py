@@ -27,7 +27,14 @@ def make_camera(uid, image, focal, W, H, device, focal_y=None, camera_center=Non
 
 
 def train_step(model: SplatModel, cam, opt: OptimParams, iteration, pipe, background, fused=False):
-    """One iteration of the reference hot loop (train_gui.py:532-589).  Returns (loss, psnr_frame, render package)."""
+    """One iteration of the reference hot loop (train_gui.py:532-589).  Returns (loss, psnr_frame, render package).
+    fused: the opt-in fused kernels of SURVEY.md section 8(f); with fused optimizers on both parameter sets and the default `pipe` the
+    iteration runs as a straight sequence of C-ABI calls without autograd (das3r_amd/fast_step.py; `model.fast_step = False` keeps
+    the autograd form of round 3 — same kernels, the reference's Python around them)."""
+    if fused:
+        from . import fast_step
+        if fast_step.available(model, pipe):
+            return fast_step.train_step(model, cam, opt, iteration, pipe, background)
     model.update_learning_rate(iteration)
     if iteration % 3000 == 0:
         model.oneupSHdegree()
@@ -85,7 +92,7 @@ def train(model, cameras, opt: OptimParams, iterations, pipe=None, background=No
         loss, p, _ = train_step(model, cam, opt, it, pipe, background, fused=fused)
         if not stack and test_cameras and model.enable_test:
             test_pose_pass(model, test_cameras, gt_dynamic_masks, opt, pipe, background, rng, fused=fused)
-        ema = 0.4 * loss + 0.6 * ema          # stays on the device: a float() here would stall the host every iteration
+        ema = torch.lerp(ema, loss, 0.4)      # 0.4 loss + 0.6 ema, one kernel; stays on the device: a float() here would stall the host every iteration
         last_psnr = p
         if log_every and it % log_every == 0:
             print(f"[ITER {it}] loss {float(ema):.5f} psnr_frame {float(last_psnr):.2f}")
@@ -115,8 +122,18 @@ def test_pose_pass(model, test_cams, gt_dynamic_masks, opt: OptimParams, pipe, b
     fused: the same render + loss kernels as the training step (round 3: with the PyTorch glue this pass was more than half of a
     DAVIS-shaped job — five 6.6 M-Gaussian views at ~40 ms each per 45 iterations of 3.7 ms), and no host sync on the gate."""
     stack = list(test_cams)
+    direct = False
+    if fused:
+        from . import fast_step
+        direct = fast_step.available(model, pipe)
     while stack:
         cam = stack.pop(rng.randint(0, len(stack) - 1))
+        if direct:   # (das3r_amd/fast_step.py: the same render + loss + backward as a straight sequence of C-ABI calls)
+            m = gt_dynamic_masks.get(cam.uid) if gt_dynamic_masks else None
+            H, W = cam.image_height, cam.image_width
+            static_hw = (1 - resize_mask_nearest(m, H, W)[0]).contiguous() if m is not None else _ones_hw(model, H, W)
+            fast_step.test_pose_step(model, cam, static_hw, opt, background)
+            continue
         pkg = das3r_render(cam, model, pipe, background, camera_pose=model.get_RT_test(cam.uid), fused=fused)
         m = gt_dynamic_masks.get(cam.uid) if gt_dynamic_masks else None
         if fused:
@@ -139,6 +156,13 @@ def test_pose_pass(model, test_cams, gt_dynamic_masks, opt: OptimParams, pipe, b
             model.optimizer_cam.zero_grad(set_to_none=True)
             if model.test_Q.grad is not None:   # (test_Q / test_T do get gradients; nothing ever consumes them)
                 model.test_Q.grad = model.test_T.grad = None
+
+
+def _ones_hw(model, H, W):
+    t = getattr(model, "_ones_hw", None)
+    if t is None or tuple(t.shape) != (H, W):
+        t = model._ones_hw = torch.ones(H, W, device=model.get_xyz.device)
+    return t
 
 
 @torch.no_grad()

@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define DAS3R_ABI_VERSION 9
+#define DAS3R_ABI_VERSION 10
 
 typedef enum {
     DAS3R_OK = 0,
@@ -170,6 +170,12 @@ int das3r_knn3_mean_dist2(int32_t P, const float *points /* [P,3] */, float *out
  * the chain rule back from dL/d(mats) (the g_small of das3r_pretransform_backward) to dL/d(pose). */
 int das3r_pose_matrices(const float *pose, float *mats, das3r_stream_t stream);
 int das3r_pose_chain(const float *pose, const float *g_mats, float *g_pose, das3r_stream_t stream);
+/* The same two with the pose given as DAS3R stores it — one row of Q (frames, 4) and one of T (frames, 3), scene/gaussian_model.py:
+ * 149-184 — and its gradient written straight into the rows of two dense gradient buffers (no torch.cat, no index backward).
+ * das3r_pose_chain_qt also leaves g_mats[0 .. 28) ZERO: the sums of das3r_pretransform_backward are accumulated into it, so a
+ * caller-owned buffer stays zero at rest (ABI 10). */
+int das3r_pose_matrices_qt(const float *q, const float *t, float *mats, das3r_stream_t stream);
+int das3r_pose_chain_qt(const float *q, float *g_mats, float *g_q, float *g_t, das3r_stream_t stream);
 /* §8f-1: the per-Gaussian pre-transform + activations of /root/reference/gaussian_renderer/__init__.py:83-97,107 in one
  * pass: means3D = R xyz + t, rotations = Lq rot (quadmultiply(pose[:4], .) as a 4x4 matrix), scales = exp(scaling),
  * opacities = sigmoid(opacity_raw) * conf_flat[mask_index[i]] (mask_index NULL = identity).  R [3,3], t [3], Lq [4,4]:
@@ -223,6 +229,10 @@ int das3r_adam_step_gated(int32_t n, const das3r_adam_tensor *tensors, float bet
 int64_t das3r_photometric_blocks(int32_t H, int32_t W);
 int das3r_photometric_forward(int32_t H, int32_t W, const float *render, const float *gt, const float *static_mask, float lambda,
                               float *partials, float *dmaps, das3r_stream_t stream);
+/* Adds the das3r_photometric_blocks(H, W) rows of `partials` on the device: out8 = {loss, mse_r, mse_g, mse_b, psnr_frame, 0, 0, 0}
+ * with psnr_frame = mean_c 20 log10(1 / sqrt(mse_c)) (utils/image_utils.py:17-19; the 26 dB gate of train_gui.py:584) — one launch
+ * instead of a dozen scalar PyTorch kernels per iteration (ABI 10). */
+int das3r_photometric_finish(int32_t H, int32_t W, const float *partials, float lambda, float *out8, das3r_stream_t stream);
 int das3r_photometric_backward(int32_t H, int32_t W, const float *render, const float *gt, const float *static_mask, float lambda,
                                const float *dmaps, const float *grad_loss, float *d_render, float *d_static, das3r_stream_t stream);
 

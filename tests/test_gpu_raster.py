@@ -76,14 +76,15 @@ def test_compact_sh_layouts_and_ragged_waves_vs_oracle(degree):
 
 
 
-@pytest.mark.parametrize("binning_path", ["radix", "local"])
+@pytest.mark.parametrize("binning_path", ["radix", "local", "seg"])
 @pytest.mark.parametrize("name", ["basic_deg3", "ragged_image", "long_lists", "deep", "culled", "depth_ties", "world_camera"])
 def test_binning_bit_exact(name, binning_path, monkeypatch):
     """Per-Gaussian geometry, depth order, per-tile splat lists and tile ranges are integer / exactly-rounded fp32 work:
     they must equal the oracle's bit for bit (binning over upstream's 3-sigma square: DAS3R_RECT=upstream; the default
     opacity-aware clipped rectangle is covered by test_tight_rect_is_exact) — with the global depth sort and with the local
     depth order (lists emitted in index order and sorted by the compositing kernel: in LDS, or, "long_lists", in global
-    memory when a list has more than 1024 entries)."""
+    memory when a list has more than 1024 entries), and with the segmented path of round 4 ("seg": partition by (tile, depth
+    bucket), then segment_sort_kernel — segkey.h, segsort.hip)."""
     monkeypatch.setenv("DAS3R_RECT", "upstream")
     monkeypatch.setenv("DAS3R_BINNING", binning_path)
     from das3r_amd import _lib
@@ -104,7 +105,8 @@ def test_binning_bit_exact(name, binning_path, monkeypatch):
     _lib.profile_enable(False)
     kernels = _lib.profile_report()
     ran = lambda prefix: any(k.startswith(prefix) for k in kernels)
-    assert ran("depth_hist") == (binning_path == "radix"), kernels   # the local order skips the global depth sort
+    assert ran("depth_hist") == (binning_path == "radix"), kernels   # the local order and the segmented path skip the global depth sort
+    assert ran("segment_sort") == (binning_path == "seg"), kernels
     assert np.array_equal(radii.cpu().numpy(), ref_radii)
     P, npix = sc.P, sc.W * sc.H
     L = _lib.layout(P, I, sc.W, sc.H)
@@ -505,6 +507,93 @@ def test_failed_binning_is_reported_before_the_backward_pass(monkeypatch):
     assert torch.allclose(again, good, rtol=1e-4, atol=1e-9)
 
 
+def _at_depths(sc, z_new):
+    """The scene with every splat moved along its ray to depth z_new (camera at the origin looking down +z): same pixel, same
+    footprint in pixels."""
+    from das3r_amd.synth import Scene
+    f = (z_new / sc.means3D[:, 2]).to(torch.float32)
+    return Scene(**{**sc.__dict__, "means3D": (sc.means3D * f[:, None]).contiguous(), "scales": (sc.scales * f[:, None]).contiguous()})
+
+
+def _lists_of(sc, mode, dev):
+    """-> (I, point_list, ranges, kernels that ran) of one forward through the C-ABI."""
+    from das3r_amd import GaussianRasterizationSettings, _lib
+    from das3r_amd.rasterizer import _forward_impl
+    _lib.profile_report()
+    _lib.profile_enable(True)
+    kw = {k: v.to(dev) for k, v in util.raster_inputs(sc, mode).items()}
+    skw = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in util.settings_kwargs(sc, mode).items()}
+    e = torch.empty(0, device=dev)
+    I, color, radii, geom, binning, img = _forward_impl(
+        GaussianRasterizationSettings(**skw), kw["means3D"], kw.get("shs", e), kw.get("colors_precomp", e), kw["opacities"],
+        kw.get("scales", e), kw.get("rotations", e), kw.get("cov3D_precomp", e))
+    torch.cuda.synchronize()
+    _lib.profile_enable(False)
+    kernels = _lib.profile_report()
+    L = _lib.layout(sc.P, I, sc.W, sc.H)
+    pl = _view(binning, L["point_list"], torch.int32, I).cpu().numpy().astype(np.uint32)
+    tiles = ((sc.W + 15) // 16) * ((sc.H + 15) // 16)
+    rg = _view(img, L["ranges"], torch.int32, 2 * tiles).cpu().numpy().reshape(tiles, 2).astype(np.uint32)
+    return I, pl, rg, kernels, color
+
+
+@pytest.mark.parametrize("case", ["one_wall", "three_layers", "thin_slab", "ties_and_spread", "one_tile_wall"])
+def test_segmented_binning_long_and_degenerate_segments(case, monkeypatch):
+    """The segmented path (segkey.h, segsort.hip) where its depth buckets cannot help: every splat at ONE depth (a wall parallel to
+    the image plane: each tile's whole list is one segment, ties broken by the index), three exact layers (segments of a third of
+    a list: a few thousand entries, sorted by rank in LDS or, past the LDS span, by the global-memory network), a slab 1e-5 thick
+    (distinct depths in one histogram bin), exact ties mixed into a spread, and 20 000 equal depths in a single tile (one segment
+    of 20 000).  Lists, ranges and num_rendered bit-identical to the C oracle's in every case."""
+    from das3r_amd.synth import make_scene
+    g = torch.Generator().manual_seed(41)
+    if case == "one_tile_wall":
+        sc = make_scene(P=20000, W=16, H=16, focal=30.0, sh_degree=0, seed=51, s_px=(0.5, 2.0), opacity=0.02)
+        sc = _at_depths(sc, torch.full((sc.P,), 4.0))
+    else:
+        sc = make_scene(P=9000, W=48, H=32, focal=50.0, sh_degree=0, seed=52, s_px=(0.5, 3.0), opacity=0.05)
+        if case == "one_wall":
+            z = torch.full((sc.P,), 4.0)
+        elif case == "three_layers":
+            z = torch.tensor([3.0, 4.0, 5.5])[torch.randint(0, 3, (sc.P,), generator=g)]
+        elif case == "thin_slab":
+            z = 4.0 + 1e-5 * torch.rand(sc.P, generator=g)
+        else:
+            z = torch.where(torch.rand(sc.P, generator=g) < 0.5, torch.tensor(2.5), 1.0 + 9.0 * torch.rand(sc.P, generator=g))
+        sc = _at_depths(sc, z)
+    mode = dict(colors_precomp=False, cov3D_precomp=False, scale_modifier=1.0)
+    monkeypatch.setenv("DAS3R_RECT", "upstream")
+    monkeypatch.setenv("DAS3R_BINNING", "seg")
+    ref_color, _, _, S = util.run_oracle(sc, mode, backward=False)
+    I, pl, rg, kernels, color = _lists_of(sc, mode, _dev())
+    assert any(k.startswith("segment_sort") for k in kernels) and not any(k.startswith("depth_hist") for k in kernels), kernels
+    assert I == S["num_rendered"] and I > 4 * sc.P // 5
+    assert np.array_equal(rg, S["ranges"])
+    assert np.array_equal(pl, S["point_list"]), "per-tile (depth, index) order must match exactly"
+    util.assert_color_close(color.cpu().numpy(), ref_color, case)
+
+
+def test_segmented_binning_is_chosen_for_long_lists_and_backs_off(monkeypatch):
+    """Unforced: the first forward of a shape has no history (global sort), the next ones with long lists take the segmented path;
+    a segment that does not fit in LDS (here: 20 000 equal depths in one tile) is still sorted exactly and sends the following
+    forwards of the shape back to the global sort for a while.  Every forward's list is the oracle's."""
+    from das3r_amd.synth import make_scene
+    monkeypatch.delenv("DAS3R_BINNING", raising=False)
+    monkeypatch.setenv("DAS3R_RECT", "upstream")
+    mode = dict(colors_precomp=False, cov3D_precomp=False, scale_modifier=1.0)
+    # (P differs from every other test's at this image size: the choice of path is remembered per (P, W, H) and thread)
+    spread = make_scene(P=20011, W=16, H=16, focal=30.0, sh_degree=0, seed=53, s_px=(0.5, 2.0), opacity=0.02)
+    wall = _at_depths(spread, torch.full((spread.P,), 4.0))
+    dev = _dev()
+    want = {id(sc): util.run_oracle(sc, mode, backward=False)[3]["point_list"] for sc in (spread, wall)}
+    took = []
+    for sc in (spread, spread, spread, wall, wall, spread):
+        I, pl, _, kernels, _ = _lists_of(sc, mode, dev)
+        assert np.array_equal(pl, want[id(sc)])
+        took.append("seg" if any(k.startswith("segment_sort") for k in kernels) else ("radix" if any(k.startswith("depth_hist") for k in kernels) else "local"))
+    assert took[0] == "radix" and took[1] == "seg" and took[2] == "seg", took      # history, then the segmented path
+    assert took[3] == "seg" and took[4] == "radix" and took[5] == "radix", took   # the wall's segment was too long: back-off
+
+
 @pytest.mark.parametrize("render", ["quad", "rows"])
 @pytest.mark.parametrize("name", ["basic_deg3", "long_lists", "deep", "depth_ties", "ragged_image"])
 def test_depth_orders_agree(name, render, monkeypatch):
@@ -514,15 +603,16 @@ def test_depth_orders_agree(name, render, monkeypatch):
     sc, mode = util.scene_variant(name)
     monkeypatch.setenv("DAS3R_RENDER", render)
     out = {}
-    for kind in ("radix", "local"):
+    for kind in ("radix", "local", "seg"):
         monkeypatch.setenv("DAS3R_BINNING", kind)
         c, r, g, fn = _run_hip(sc, mode)
         out[kind] = (c, r, g, fn.num_rendered)
     ca, ra, ga, na = out["radix"]
-    cb, rb, gb, nb = out["local"]
-    assert na == nb and torch.equal(ca, cb) and torch.equal(ra, rb)
-    for k in ga:
-        util.assert_grad_close(gb[k].cpu().numpy(), ga[k].cpu().numpy(), f"local vs global depth order dL/d{k}", tol=1e-5)
+    for kind in ("local", "seg"):   # (seg: the segmented path of round 4 — same lists, emission slots numbered in index order like local)
+        cb, rb, gb, nb = out[kind]
+        assert na == nb and torch.equal(ca, cb) and torch.equal(ra, rb), kind
+        for k in ga:
+            util.assert_grad_close(gb[k].cpu().numpy(), ga[k].cpu().numpy(), f"{kind} vs global depth order dL/d{k}", tol=1e-5)
 
 
 def test_speculative_capacity_is_redone_when_the_scene_grows(monkeypatch):

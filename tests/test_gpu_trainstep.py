@@ -145,6 +145,43 @@ def test_active_sh_prefix_steps_like_the_full_tensor(degree):
         assert float(far.double().mean()) <= 1e-3, (k, float(far.double().mean()))
 
 
+@pytest.mark.parametrize("degree", [0, 1, 3])
+def test_direct_fused_step_matches_the_autograd_fused_step(degree):
+    """Round 4: the fused iteration as a straight sequence of C-ABI calls (das3r_amd/fast_step.py: no autograd, cached settings, pose
+    rows in and out, loss / PSNR / gate on the device) against round 3's form of it (the same kernels under torch.autograd and the
+    reference's Python; model.fast_step = False): four steps over three cameras — losses, frame PSNR, every parameter, the pose
+    gate, the Adam moments of f_rest — at SH degree 0 (DC tensor alone), 1 (active prefix, compact gradient) and 3 (full tensor)."""
+    from das3r_amd import fast_step
+    from das3r_amd.train import train_step
+    out = []
+    for direct in (True, False):
+        model, cams, _, opt, _dense = _pair(frames=3, W=32, H=24, seed=9, heldout=False, iterations=100, fused=True, generic=True)
+        model.fast_step = direct
+        assert fast_step.available(model, PIPE) == direct
+        model.active_sh_degree = degree
+        model.optimizer.set_active_sh_degree(degree)
+        with torch.no_grad():
+            g = torch.Generator(device="cpu").manual_seed(11)
+            model._features_rest.copy_((torch.randn(model._features_rest.shape, generator=g) * 0.05).to(model._features_rest.device))
+        bg = torch.zeros(3, device="cuda")
+        rec = []
+        for it, u in enumerate([0, 2, 1, 0], start=1):
+            loss, ps, pkg = train_step(model, cams[u], opt, it, PIPE, bg, fused=True)
+            rec.append((float(loss), float(ps), pkg["viewspace_points"].grad.detach().clone(), int(pkg["visibility_filter"].sum())))
+        st = model.optimizer.state[model._features_rest]
+        out.append((rec, {k: getattr(model, a).detach().clone() for k, a in NAMES.items()}, st["exp_avg"].clone(), st["step"],
+                    model.optimizer_cam._gate_state.clone()))
+    (ra, pa, ma, sa, ga), (rb, pb, mb, sb, gb) = out
+    assert sa == sb == 4 and torch.equal(ga, gb)
+    for (la, psa, m2a, va), (lb, psb, m2b, vb) in zip(ra, rb):
+        assert abs(la - lb) <= 1e-6 * abs(lb) and abs(psa - psb) <= 1e-4 and va == vb, (la, lb, psa, psb)
+        assert torch.allclose(m2a, m2b, rtol=1e-4, atol=1e-7 * float(m2b.abs().max()))
+    assert torch.allclose(ma, mb, rtol=1e-4, atol=1e-9)
+    for k in pa:
+        far = (pa[k] - pb[k]).abs() > 1e-5 + 1e-4 * pb[k].abs()   # (an Adam step moves an element by at most its learning rate: sign flips of noise-level gradients)
+        assert float(far.double().mean()) <= 1e-3, (k, float(far.double().mean()))
+
+
 def test_heldout_report_semantics(tmp_path):
     """train_test_psnr.py:241-302: the mask is nearest-resized to the render size and applied to both images, only views WITH a
     mask count, the line appended to test_log.txt has the reference's wording."""

@@ -1,0 +1,106 @@
+"""CPU model of the depth buckets of the segmented binning path (das3r_amd/csrc/segkey.h, round 4): the numpy restatement of
+depth_bin / depth_bucket, operation by operation (fp32 fma, fp32 multiply, truncation), and the two properties the path rests on:
+
+  * MONOTONE: a smaller depth never lands in a later bucket — the one thing correctness needs (the segments are sorted exactly
+    afterwards, segsort.hip; the GPU tests hold the resulting lists to the oracle bit for bit);
+  * BALANCED enough: whatever the depth distribution (uniform, one wall, two walls and a sky, five decades), no bucket holds much
+    more than its share unless the depths themselves are (nearly) equal — what keeps the segments inside LDS.
+"""
+import numpy as np
+import pytest
+
+DBINS, DBIN_SHIFT, DBIN0 = 256, 19, (127 - 8) << 4
+
+
+def depth_bin(bits):
+    raw = (bits >> DBIN_SHIFT).astype(np.int64) - DBIN0
+    return np.clip(raw, 0, DBINS - 1)
+
+
+def bucket_map(bits_all, weights, dbits):
+    """-> function bits -> bucket, built the way scan_emit_kernel builds it from the preprocess kernel's histogram."""
+    hist = np.bincount(depth_bin(bits_all), weights=weights, minlength=DBINS).astype(np.uint64)
+    tot = int(hist.sum())
+    sh = 0
+    while (tot >> sh) >= (1 << 24):
+        sh += 1
+    cs = (hist >> np.uint64(sh)).astype(np.uint64)
+    ex = np.concatenate([[0], np.cumsum(cs)[:-1]]).astype(np.uint64)
+    tot2 = int(cs.sum())
+    cnt, cdf = cs.astype(np.float32), ex.astype(np.float32)
+    scale = np.float32(np.float32(1 << dbits) / np.float32(tot2)) if tot2 else np.float32(0)
+    nb = 1 << dbits
+
+    def f(bits):
+        raw = (bits >> DBIN_SHIFT).astype(np.int64) - DBIN0
+        b = np.clip(raw, 0, DBINS - 1)
+        frac = ((bits & ((1 << DBIN_SHIFT) - 1)).astype(np.float32) * np.float32(1.0 / (1 << DBIN_SHIFT))).astype(np.float32)
+        frac = np.where(raw < 0, np.float32(0), np.where(raw > DBINS - 1, np.float32(1), frac)).astype(np.float32)
+        # fp32 fma: exact in float64 (24-bit x 24-bit product + a 24-bit addend fits 53 bits here), rounded once to fp32
+        pos = (cnt[b].astype(np.float64) * frac.astype(np.float64) + cdf[b].astype(np.float64)).astype(np.float32)
+        v = (pos * scale).astype(np.float32)
+        return np.minimum(v.astype(np.uint32), nb - 1)
+    return f
+
+
+def _bits(z):
+    return np.asarray(z, dtype=np.float32).view(np.uint32)
+
+
+CASES = {
+    "uniform_1_10": lambda g, n: g.uniform(1.0, 10.0, n),
+    "one_wall": lambda g, n: np.full(n, 4.0),
+    "thin_slab": lambda g, n: 4.0 + 1e-5 * g.random(n),
+    "two_walls_and_sky": lambda g, n: np.concatenate([2.0 + 1e-3 * g.random(n // 3), 3.7 + 0.05 * g.random(n // 3), g.uniform(50, 90, n - 2 * (n // 3))]),
+    "five_decades": lambda g, n: 10.0 ** g.uniform(-2.5, 2.5, n),
+    "outside_the_bins": lambda g, n: np.concatenate([g.uniform(0.0011, 0.0035, n // 2), g.uniform(300, 5000, n - n // 2)]),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("dbits", [2, 7])
+def test_buckets_are_monotone_in_the_depth_bits(name, dbits):
+    g = np.random.default_rng(3)
+    z = CASES[name](g, 200_000).astype(np.float32)
+    w = g.integers(1, 5, z.shape[0])
+    bits = _bits(z)
+    f = bucket_map(bits, w, dbits)
+    order = np.sort(bits)
+    b = f(order)
+    assert (np.diff(b.astype(np.int64)) >= 0).all(), "a smaller depth landed in a later bucket"
+    assert b.max() < (1 << dbits)
+    # every representable depth between two neighbours of the set, too (the map is built from the histogram, not from the set)
+    probe = np.sort(_bits(np.nextafter(z[:5000], np.float32(np.inf)))) if name != "one_wall" else order[:10]
+    both = np.sort(np.concatenate([order[:5000], probe]))
+    assert (np.diff(f(both).astype(np.int64)) >= 0).all()
+
+
+CASES["two_rough_walls_and_sky"] = lambda g, n: np.concatenate([2.0 * (1 + 0.03 * g.random(n // 3)), 3.7 + 0.2 * g.random(n // 3), g.uniform(50, 90, n - 2 * (n // 3))])
+
+
+CASES["slab_1_percent"] = lambda g, n: 4.0 * (1 + 0.01 * g.random(n))
+
+
+@pytest.mark.parametrize("name", ["uniform_1_10", "two_rough_walls_and_sky", "five_decades", "slab_1_percent"])
+def test_buckets_are_about_equally_full(name):
+    """128 buckets: the fullest holds at most 8x its share when the depths are spread inside their histogram bins (a bin is 1/16
+    octave = 4.4 % of the depth; inside it the map interpolates linearly in the mantissa bits, so content that fills only the first
+    fifth of a bin — the edge of a wall, a slab 1 % thick — is five times as dense as the map assumes).  What the map cannot split is a
+    spike much NARROWER than a bin next to other content in the same bin ("two_walls_and_sky": a wall 0.05 % thick, a third of the
+    scene, ends in one bucket): its (tile, bucket) segments are then a third of a tile's list — still sorted exactly, by rank in LDS
+    up to 3072 entries and by the global-memory network beyond, which also sends the shape back to the global sort (segsort.hip)."""
+    g = np.random.default_rng(5)
+    z = CASES[name](g, 400_000).astype(np.float32)
+    bits = _bits(z)
+    f = bucket_map(bits, np.ones_like(bits), 7)
+    counts = np.bincount(f(bits), minlength=128)
+    assert counts.max() <= 8 * z.shape[0] / 128, (name, counts.max(), z.shape[0] / 128)
+
+
+def test_counts_beyond_2_to_24_are_shifted_not_rounded():
+    g = np.random.default_rng(7)
+    z = g.uniform(1.0, 10.0, 100_000).astype(np.float32)
+    bits = _bits(z)
+    f = bucket_map(bits, np.full(bits.shape, 1 << 12, dtype=np.int64), 7)   # total 4.1e8 > 2^24
+    b = f(np.sort(bits))
+    assert (np.diff(b.astype(np.int64)) >= 0).all() and b.max() == 127 and b.min() == 0
