@@ -148,6 +148,7 @@ void compute_layout(int P, int64_t I, int W, int H, Layout *L) {
     L->tile_passes = (L->tbits + 7) / 8;
     L->dbits = 0;
     L->kbits = L->tbits;
+    L->kshift = 0;
     L->chunksP = sort_num_chunks(P);
     L->chunksI = sort_num_chunks(I);
     size_t o = 0;
@@ -434,7 +435,7 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     bool seg = !local && seg_bits > 0 && (forced == 2 || (forced == 0 && verdict.radix_left == 0 && verdict.last_I >= 0 &&
                                                            (verdict.last_I >> seg_bits) <= SEG_AVG * L.ntiles));
     auto apply_seg = [&]() {   // (compute_layout starts every layout without buckets)
-        if (seg) { L.dbits = seg_bits; L.kbits = L.tbits + seg_bits; }
+        if (seg) { L.dbits = seg_bits; L.kbits = L.tbits + seg_bits; L.kshift = 16; }
     };
     if (forced == 0 && verdict.radix_left > 0) verdict.radix_left--;
     const uint32_t count_tag = ++mb->seq ? mb->seq : ++mb->seq;

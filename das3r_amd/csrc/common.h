@@ -207,7 +207,8 @@ struct Layout {
     // segmented binning path (segkey.h): the partition key is (tile id << dbits | depth bucket), kbits = tbits + dbits wide, in the
     // SAME number of passes the tile ids alone need (the backward pass lays the buffers out without knowing the path).  dbits = 0
     // everywhere else.  g_dhist: u32[256] depth histogram of the forward
-    int dbits, kbits;
+    int dbits, kbits, kshift;   // kshift: 16 on the segmented path — the key's low bits hold the fraction of the depth map (segkey.h), the
+                                // partition's digits start above them
     size_t g_dhist;
 };
 // depth-bucket bits the tile partition's passes have room for (0: none — the tile ids fill their passes)

@@ -56,6 +56,23 @@ struct Sums {
 constexpr int PIX_CST_ROW = 16 * 16 + 16;   // bytes per block row of constants (+16: the four rows of a wave on different banks)
 constexpr int PIX_ST_ROW = 16 * 8 + 8;      // bytes per block row of state
 
+// The pair's two tests (power <= 0, alpha >= 1/255) and what hangs on them: alpha and G where both pass, 0 elsewhere.
+// DAS3R_BLK_ARITH: by arithmetic, as the forward kernels take them (render_common.h alpha_if_visible: same decisions bit for bit) —
+// v_cmp / v_cndmask issue at half rate on this chip; G of a dropped pair may be anything, inf included (a degenerate conic):
+// min(G, alpha * 1e38) is G wherever alpha >= 1/255 (then G <= 1) and 0 where alpha is 0, NaN and inf included (v_min drops a NaN).
+#ifdef DAS3R_BLK_ARITH
+#define BLK_SELECT(a1, power, G, am_out, Gm_out)                                                                              \
+    am_out = alpha_if_visible(a1, power);                                                                                     \
+    Gm_out = fminf(G, __fmul_rn(am_out, 1e38f));
+#else
+#define BLK_SELECT(a1, power, G, am_out, Gm_out)                                                                              \
+    {                                                                                                                         \
+        const bool active = (!(power > 0.0f)) & (a1 >= (1.0f / 255.0f));                                                      \
+        am_out = active ? a1 : 0.f;                                                                                           \
+        Gm_out = active ? G : 0.f;                                                                                            \
+    }
+#endif
+
 // One image row KY of the block: its four pixel steps K = 4 KY .. 4 KY + 3, interleaved.  pair_alpha's arithmetic, bit for bit
 // (render_common.h), so that every pair takes the decision the forward kernel took.
 // ABL (tools/probes/blk_loop_probe.hip only; results are wrong): 1 = without the two row scans, 2 = without the state hand-off
@@ -80,9 +97,7 @@ __device__ __forceinline__ void block_row(const SplatRegs &sp, PixelRegs &px, Su
         /* where the pair takes part the minimum is min(0.99, o G) as in pair_alpha, elsewhere it fails the 1/255 test         */ \
         const float lastrel = PIX ? pc[U].w : bc<K>(px.lastrel);                                                              \
         const float a1 = fminf(fminf(0.99f, __fmul_rn(sp.o, G)), lastrel - sp.posrel);                                        \
-        const bool active = (!(power > 0.0f)) & (a1 >= (1.0f / 255.0f));                                                      \
-        am[U] = active ? a1 : 0.f;                                                                                            \
-        Gm[U] = active ? G : 0.f;                                                                                             \
+        BLK_SELECT(a1, power, G, am[U], Gm[U])                                                                                \
         rinv[U] = __builtin_amdgcn_rcpf(1.f - am[U]);                                                                         \
         Pinc[U] = rinv[U];                                                                                                    \
     }

@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
         const uint32_t ex = block_exclusive_scan_256(cs, ws, &tot2);
         s_cnt[EMIT ? tid : 0] = (float)cs;
         s_cdf[EMIT ? tid : 0] = (float)ex;
-        dscale = tot2 ? (float)(1u << dbits) / (float)tot2 : 0.f;
+        dscale = tot2 ? (float)(1u << (dbits + SEG_FRAC_BITS)) / (float)tot2 : 0.f;   // (bucket + fraction: segkey.h)
         __syncthreads();
     }
 
@@ -154,10 +154,12 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
                     binned_rect(p, radius, tiles_x, tiles_y, tight_rect != 0, rminx, rminy, rmaxx, rmaxy);
                 }
                 uint32_t l = ex;   // place in the workgroup's run
-                const uint32_t bucket = (EMIT && dbits > 0) ? depth_bucket(dkv[k], s_cnt, s_cdf, dscale, 1u << dbits) : 0u;
+                // segmented path: key = tile id | bucket | 16 bits of fraction (kshift = 16: the partition's digits start above the fraction)
+                const int kshift = (EMIT && dbits > 0) ? SEG_FRAC_BITS : 0;
+                const uint32_t bucket = (EMIT && dbits > 0) ? depth_bucket(dkv[k], s_cnt, s_cdf, dscale, 1u << (dbits + SEG_FRAC_BITS)) : 0u;
                 for (int y = rminy; y < rmaxy; y++)
                     for (int x = rminx; x < rmaxx; x++) {
-                        const uint32_t t = ((uint32_t)(y * tiles_x + x) << dbits) | bucket;
+                        const uint32_t t = ((uint32_t)(y * tiles_x + x) << (dbits + kshift)) | bucket;
                         if (via_lds) {
                             e_key[EMIT ? l : 0] = t;
                             e_gid[EMIT ? l : 0] = g[k];
@@ -166,7 +168,7 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
                             gids[o] = g[k];   // gid_of[emission slot]
                             for (int q = 0, sh = 0, dw = tile_digit_width(tbits); sh < tbits; q++, sh += dw) {
                                 const int bits = (tbits - sh) < dw ? (tbits - sh) : dw;
-                                atomicAdd(&h[EMIT ? q : 0][(t >> sh) & ((1u << bits) - 1u)], 1u);
+                                atomicAdd(&h[EMIT ? q : 0][(t >> (sh + kshift)) & ((1u << bits) - 1u)], 1u);
                             }
                         }
                         o++;
@@ -176,6 +178,7 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
         }
         if (via_lds) {
             __syncthreads();
+            const int kshift2 = (EMIT && dbits > 0) ? SEG_FRAC_BITS : 0;
             for (uint32_t l = tid; l < tot; l += 256u) {   // unit stride: tile ids and splat ids of the run [carry, carry + tot)
                 const uint32_t o = carry + l;
                 if (o < cap) {
@@ -184,7 +187,7 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
                     gids[o] = e_gid[EMIT ? l : 0];
                     for (int q = 0, sh = 0, dw = tile_digit_width(tbits); sh < tbits; q++, sh += dw) {
                         const int bits = (tbits - sh) < dw ? (tbits - sh) : dw;
-                        atomicAdd(&h[EMIT ? q : 0][(t >> sh) & ((1u << bits) - 1u)], 1u);
+                        atomicAdd(&h[EMIT ? q : 0][(t >> (sh + kshift2)) & ((1u << bits) - 1u)], 1u);
                     }
                 }
             }

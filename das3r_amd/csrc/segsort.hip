@@ -6,9 +6,12 @@
 //
 // A workgroup owns the segments that START inside its window of SEG_CH list positions and holds them — the window plus up to
 // SEG_OVER positions of overhang — in LDS.  Segment boundaries come from the partition keys (flags + one block-wide running
-// maximum), then every owned entry counts the keys of its own segment below its own 64-bit word (depth bits << 32 | position:
-// positions follow the index order, the partition passes being stable) with broadcast LDS reads — neighbouring lanes sit in the
-// same segment — and stores its (splat id, emission slot) at that rank, in place: a segment is read and written by its owner only.
+// maximum).  The key's low 16 bits are the FRACTION of the depth map below the bucket (segkey.h): monotone in the depth, so an
+// entry's rank inside its segment is the number of (fraction << 12 | position) words below its own — positions follow the index
+// order, the partition passes being stable — counted with broadcast LDS reads (neighbouring lanes sit in the same segment); only
+// where two entries of a segment share a fraction (about one segment in ten on the benchmark) are their exact depth bits
+// fetched and the tie group re-ranked by (depth bits, position).  The (splat id, emission slot) pairs are stored at their ranks,
+// in place: a segment is read and written by its owner only.
 // A segment that does not end inside the LDS span (a wall parallel to the image plane: thousands of equal depths in one tile) is
 // sorted by the same workgroup with a bitonic network over global memory — slow, exact — and the host is told through the mailbox
 // word the local depth order uses, so that the next forwards of this shape take the global sort for a while (api.hip).
@@ -44,6 +47,12 @@ __device__ __forceinline__ uint32_t block_exclusive_max_256(const uint32_t v, ui
     return ex;
 }
 
+__device__ __forceinline__ void count_below(uint32_t &rank, const uint32_t kj, const uint32_t ki) {
+    // rank += [kj < ki]: the borrow of kj - ki, added with carry — two full-rate instructions (v_cmp + v_cndmask issue at half rate)
+    uint32_t tmp;
+    asm("v_sub_co_u32 %1, vcc, %2, %3\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(rank), "=&v"(tmp) : "v"(kj), "v"(ki) : "vcc");
+}
+
 __global__ void __launch_bounds__(256) segment_sort_kernel(uint32_t cap, const uint32_t *__restrict__ n_ptr, const uint32_t *__restrict__ kk /*partition keys, final order*/,
                                                            uint32_t *__restrict__ pl, uint32_t *__restrict__ sl, const uint32_t *__restrict__ depth_key /*[P] by splat*/,
                                                            uint32_t last_g, uint32_t *__restrict__ dk /*u32[cap] scratch (the dead key buffer)*/,
@@ -51,27 +60,26 @@ __global__ void __launch_bounds__(256) segment_sort_kernel(uint32_t cap, const u
     const uint32_t n = n_ptr ? min(*n_ptr, cap) : cap;
     const uint32_t w0 = blockIdx.x * (uint32_t)SEG_CH;
     if (w0 >= n) return;
-    __shared__ unsigned long long s_key[SEG_CAP];          // first: the partition keys of positions w0 - 1 .. w0 + SEG_CAP (u32[SEG_CAP + 2])
+    __shared__ uint32_t s_a[SEG_CAP + 2];       // the partition keys of positions w0 - 1 .. w0 + SEG_CAP; then the sort words by position; then tie depths by rank
+    __shared__ uint32_t s_sorted[SEG_CAP];      // the sort words at their ranks
     __shared__ uint16_t s_start[SEG_CAP + 1], s_end[SEG_CAP + 1];
     __shared__ uint32_t ws[4];
-    __shared__ uint32_t s_long;                            // start (relative) of the owned segment that leaves the LDS span, or SEG_NONE
-    uint32_t *skk = reinterpret_cast<uint32_t *>(s_key);   // skk[r] = kk[w0 - 1 + r]
+    __shared__ uint32_t s_long;                 // start (relative) of the owned segment that leaves the LDS span, or SEG_NONE
     const int tid = threadIdx.x;
-    static_assert(SEG_CAP + 2 <= 2 * SEG_CAP, "the partition keys borrow the sort words' array");
     for (int r = tid; r < SEG_CAP + 2; r += 256) {
         const long long idx = (long long)w0 - 1 + r;
-        skk[r] = (idx >= 0 && idx < (long long)n) ? kk[idx] : 0u;
+        s_a[r] = (idx >= 0 && idx < (long long)n) ? kk[idx] : 0u;   // s_a[r] = kk[w0 - 1 + r]
     }
     for (int r = tid; r < SEG_CAP + 1; r += 256) s_end[r] = (uint16_t)SEG_NONE;
     if (tid == 0) s_long = SEG_NONE;
     __syncthreads();
-    // position p (0 .. SEG_CAP) starts a segment iff its key differs from the one before it; the position just behind the list
-    // counts as a start (it ends the last segment), nothing beyond it does
+    // position p (0 .. SEG_CAP) starts a segment iff its (tile, bucket) — the key above the 16 fraction bits — differs from the one
+    // before it; the position just behind the list counts as a start (it ends the last segment), nothing beyond it does
     auto flag = [&](const int p) -> bool {
         const uint32_t idx = w0 + (uint32_t)p;
         if (idx > n) return false;
         if (idx == n || idx == 0u) return true;
-        return skk[p] != skk[p + 1];
+        return (s_a[p] >> SEG_FRAC_BITS) != (s_a[p + 1] >> SEG_FRAC_BITS);
     };
     uint32_t last = 0u;   // (last start of this thread's positions) + 1, 0 = none
 #pragma unroll
@@ -91,12 +99,20 @@ __global__ void __launch_bounds__(256) segment_sort_kernel(uint32_t cap, const u
             s_start[p] = running ? (uint16_t)(running - 1u) : (uint16_t)SEG_NONE;
         }
     }
-    __syncthreads();   // (the partition keys are dead from here on: s_key takes the array)
+    // the sort words (fraction << 12 | position), in place of the keys: read, barrier, write
+    uint32_t word[SEG_CAP / 256];
+#pragma unroll
+    for (int u = 0; u < SEG_CAP / 256; u++) {
+        const int p = tid + 256 * u;
+        word[u] = ((s_a[p + 1] & ((1u << SEG_FRAC_BITS) - 1u)) << 12) | (uint32_t)p;
+    }
+    __syncthreads();   // (flags and keys read by everybody)
+#pragma unroll
+    for (int u = 0; u < SEG_CAP / 256; u++) s_a[tid + 256 * u] = word[u];
     // owned in LDS: a true start inside the window whose end is known.  Thread t holds the PAIRS of neighbouring positions
-    // 2 t + 512 u, + 1 (u < SEG_PAIRS): neighbours nearly always share their segment, and then every key of it is read from LDS once
-    // for both of them (r4, first version: one position per lane and 64-bit compares — 0.20 ms on the 5 M-splat DAS3R shape, the
-    // LDS reads and v_cmp_lt_u64 in equal parts).
-    uint32_t g[SEG_PAIRS][2], slot[SEG_PAIRS][2];
+    // 2 t + 512 u, + 1 (u < SEG_PAIRS): neighbours nearly always share their segment, and then every word of it is read from LDS once
+    // for both of them
+    uint32_t g[SEG_PAIRS][2], slot[SEG_PAIRS][2], dest[SEG_PAIRS][2];
     bool own[SEG_PAIRS][2];
 #pragma unroll
     for (int u = 0; u < SEG_PAIRS; u++)
@@ -107,9 +123,8 @@ __global__ void __launch_bounds__(256) segment_sort_kernel(uint32_t cap, const u
             const bool cand = w0 + (uint32_t)p < n && s != SEG_NONE && s < (uint32_t)SEG_CH;
             own[u][e] = cand && s_end[s] != SEG_NONE;
             if (cand && s_end[s] == SEG_NONE && (uint32_t)p == s) s_long = s;   // (one writer at most)
-            g[u][e] = slot[u][e] = 0u;
+            g[u][e] = slot[u][e] = dest[u][e] = 0u;
         }
-    __syncthreads();   // (s_long published; nobody reads the partition keys any more: s_key takes the array)
 #pragma unroll
     for (int u = 0; u < SEG_PAIRS; u++) {
         const int p0 = 2 * tid + 512 * u;
@@ -124,64 +139,100 @@ __global__ void __launch_bounds__(256) segment_sort_kernel(uint32_t cap, const u
             }
             g[u][0] = min(gv.x, last_g); g[u][1] = min(gv.y, last_g);
             slot[u][0] = sv.x; slot[u][1] = sv.y;
-#pragma unroll
-            for (int e = 0; e < 2; e++)
-                if (own[u][e]) s_key[p0 + e] = ((unsigned long long)depth_key[g[u][e]] << 32) | (unsigned long long)(p0 + e);
         }
     }
-    __syncthreads();   // (also: every load of pl / sl above has arrived — the stores below may overwrite them)
-    // rank of a position = keys of its segment below its own word (depth bits << 32 | position).  [key_j < key_i] is the borrow of the
-    // 64-bit subtraction: v_sub_co + v_subb_co + v_addc_co, three full-rate instructions (v_cmp_lt_u64 is not)
-    auto count_below = [](uint32_t &rank, const uint2 kj, const uint2 ki) {
-        uint32_t tmp;
-        asm("v_sub_co_u32 %1, vcc, %2, %4\n\t"
-            "v_subb_co_u32 %1, vcc, %3, %5, vcc\n\t"
-            "v_addc_co_u32 %0, vcc, 0, %0, vcc"
-            : "+v"(rank), "=&v"(tmp)
-            : "v"(kj.x), "v"(kj.y), "v"(ki.x), "v"(ki.y)
-            : "vcc");
-    };
-    const uint2 *keys2 = reinterpret_cast<const uint2 *>(s_key);
+    __syncthreads();   // the sort words are in place, s_long is published, every load of pl / sl has arrived (the stores below overwrite them)
 #pragma unroll
-    for (int u = 0; u < SEG_PAIRS; u++) {   // (unrolled: own / g / slot are registers)
+    for (int u = 0; u < SEG_PAIRS; u++) {   // (unrolled: own / g / slot / dest are registers)
         const int p0 = 2 * tid + 512 * u;
         if (!(own[u][0] || own[u][1])) continue;
         const uint32_t s0 = own[u][0] ? s_start[p0] : s_start[p0 + 1], s1 = own[u][1] ? s_start[p0 + 1] : s0;
         if (s0 == s1) {   // the pair shares its segment (or one of the two is not owned: its rank is computed and dropped)
             const uint32_t t = s_end[s0];
-            const uint2 k0 = keys2[own[u][0] ? p0 : p0 + 1], k1 = keys2[own[u][1] ? p0 + 1 : p0];
+            const uint32_t k0 = s_a[own[u][0] ? p0 : p0 + 1], k1 = s_a[own[u][1] ? p0 + 1 : p0];
             uint32_t r0 = 0, r1 = 0, j = s0;
             for (; j + 4 <= t; j += 4) {
-                const uint2 a = keys2[j], b = keys2[j + 1], c = keys2[j + 2], d = keys2[j + 3];
+                const uint32_t a = s_a[j], b = s_a[j + 1], c = s_a[j + 2], d = s_a[j + 3];
                 count_below(r0, a, k0); count_below(r1, a, k1);
                 count_below(r0, b, k0); count_below(r1, b, k1);
                 count_below(r0, c, k0); count_below(r1, c, k1);
                 count_below(r0, d, k0); count_below(r1, d, k1);
             }
             for (; j < t; j++) {
-                const uint2 a = keys2[j];
+                const uint32_t a = s_a[j];
                 count_below(r0, a, k0); count_below(r1, a, k1);
             }
-            if (own[u][0]) { pl[w0 + s0 + r0] = g[u][0]; sl[w0 + s0 + r0] = slot[u][0]; }
-            if (own[u][1]) { pl[w0 + s0 + r1] = g[u][1]; sl[w0 + s0 + r1] = slot[u][1]; }
+            dest[u][0] = s0 + r0;
+            dest[u][1] = s0 + r1;
         } else {          // a segment boundary between the two
 #pragma unroll
             for (int e = 0; e < 2; e++)
                 if (own[u][e]) {
                     const uint32_t s = e ? s1 : s0, t = s_end[s];
-                    const uint2 k = keys2[p0 + e];
+                    const uint32_t k = s_a[p0 + e];
                     uint32_t r = 0;
-                    for (uint32_t j = s; j < t; j++) count_below(r, keys2[j], k);
-                    pl[w0 + s + r] = g[u][e];
-                    sl[w0 + s + r] = slot[u][e];
+                    for (uint32_t j = s; j < t; j++) count_below(r, s_a[j], k);
+                    dest[u][e] = s + r;
                 }
         }
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+            if (own[u][e]) s_sorted[dest[u][e]] = s_a[p0 + e];
     }
+    // ---- ties: two entries of a segment with the same fraction need their exact depth bits ----
+    bool tied[SEG_PAIRS][2];
+    int any = 0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < SEG_PAIRS; u++)
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            tied[u][e] = false;
+            if (own[u][e]) {
+                const int p = 2 * tid + 512 * u + e;
+                const uint32_t s = s_start[p], t = s_end[s], at = dest[u][e], f = s_sorted[at] >> 12;
+                tied[u][e] = (at > s && (s_sorted[at - 1u] >> 12) == f) || (at + 1u < t && (s_sorted[at + 1u] >> 12) == f);
+                any |= tied[u][e] ? 1 : 0;
+            }
+        }
+    if (__syncthreads_or(any)) {   // (uniform; rare)
+#pragma unroll
+        for (int u = 0; u < SEG_PAIRS; u++)
+#pragma unroll
+            for (int e = 0; e < 2; e++)
+                if (tied[u][e]) s_a[dest[u][e]] = depth_key[g[u][e]];   // (the sort words by position are dead: the array takes the depths, by rank)
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < SEG_PAIRS; u++)
+#pragma unroll
+            for (int e = 0; e < 2; e++)
+                if (tied[u][e]) {
+                    const int p = 2 * tid + 512 * u + e;
+                    const uint32_t s = s_start[p], t = s_end[s], at = dest[u][e], f = s_sorted[at] >> 12, mine = s_a[at];
+                    uint32_t lo = at, hi = at + 1u;
+                    while (lo > s && (s_sorted[lo - 1u] >> 12) == f) lo--;
+                    while (hi < t && (s_sorted[hi] >> 12) == f) hi++;
+                    uint32_t r = 0;   // the group [lo, hi) in (depth bits, position) order
+                    for (uint32_t k = lo; k < hi; k++) {
+                        const uint32_t dkk = s_a[k], pk = s_sorted[k] & 0xFFFu;
+                        r += (dkk < mine || (dkk == mine && pk < (uint32_t)p)) ? 1u : 0u;
+                    }
+                    dest[u][e] = lo + r;
+                }
+    }
+#pragma unroll
+    for (int u = 0; u < SEG_PAIRS; u++)
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+            if (own[u][e]) {
+                pl[w0 + dest[u][e]] = g[u][e];
+                sl[w0 + dest[u][e]] = slot[u][e];
+            }
     // ---- a segment that leaves the LDS span (rare; uniform branch) ----
     const uint32_t sl0 = s_long;
     if (sl0 == SEG_NONE) return;
     const uint32_t S = w0 + sl0;
-    const uint32_t key = kk[S];
+    const uint32_t key = kk[S] >> SEG_FRAC_BITS;
     __shared__ uint32_t s_T;
     if (tid == 0) {
         s_T = n;
@@ -190,7 +241,7 @@ __global__ void __launch_bounds__(256) segment_sort_kernel(uint32_t cap, const u
     __syncthreads();
     for (uint32_t base = w0 + (uint32_t)SEG_CAP; base < n; base += 256u) {   // its end: the first position with another key
         const uint32_t idx = base + tid;
-        if (idx < n && kk[idx] != key) atomicMin(&s_T, idx);
+        if (idx < n && (kk[idx] >> SEG_FRAC_BITS) != key) atomicMin(&s_T, idx);
         __syncthreads();
         if (s_T != n) break;   // (uniform: read behind the barrier)
         __syncthreads();

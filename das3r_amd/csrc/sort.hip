@@ -15,6 +15,7 @@
 // chunk of 64*ipl keys, keeps its 256 digit counters in LDS and ranks keys with wavefront ballots
 // (match-any over the digit bits + popcount prefix) — no block barriers in the ranking loop.
 #include "granule.h"
+#include "segkey.h"
 #include <algorithm>
 #include "splat_math.h"
 
@@ -332,11 +333,12 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
             uint32_t *other = kfinal == keyA ? keyB : keyA;   // the previous pass's keys: dead, scratch for a segment too long for LDS
             rc1 = launch_segment_sort(I, n_ptr, kfinal, (uint32_t *)(binning + L.pub.point_list), (uint32_t *)(binning + L.b_slot),
                                       (const uint32_t *)(geom + L.pub.depth_key), (uint32_t)(P - 1), other, seg_host_flag, seg_flag_value, debug, s);
+            static_assert(SEG_FRAC_BITS == 16, "segsort.hip reads the fraction from the key's low 16 bits");
             if (rc1) return rc1;
         }
         const int rearm = emit_slot ? EMIT_SLOT_WORDS : 0;
         DAS3R_LAUNCH(tile_ranges_kernel, dim3(div_up(std::max<int64_t>(I, rearm), 256)), dim3(256), 0, s, (uint32_t)I, n_ptr, kfinal, ranges,
-                     emit_slot ? emit_slot : (uint32_t *)(geom + L.g_ticket) + 8, host_late, tag, (uint32_t)rearm, (uint32_t)switches().inject_fault, L.dbits);
+                     emit_slot ? emit_slot : (uint32_t *)(geom + L.g_ticket) + 8, host_late, tag, (uint32_t)rearm, (uint32_t)switches().inject_fault, L.dbits + L.kshift);
         KERNEL_CHECK(s, debug, "tile_ranges");
         return DAS3R_OK;
     }

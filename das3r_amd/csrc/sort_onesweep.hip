@@ -350,8 +350,9 @@ int launch_onesweep_partition(int64_t cap, char *geom, char *binning, const Layo
     int shift = 0, rc;
     for (int p = 0; p < L.tile_passes; p++) {
         const int dw = tile_digit_width(L.kbits), bits = (L.kbits - shift) < dw ? (L.kbits - shift) : dw;   // (kbits = tbits unless segmented: common.h)
+        const int at = shift + L.kshift;   // (segmented: the digits sit above the 16 fraction bits of the key)
         uint32_t *v2out = ((L.tile_passes - 1 - p) & 1) ? e_tmp : slot_list;
-        if ((rc = onesweep_pass(kin, vin, kout, vout, cap, n_ptr, shift, bits, ghist + p * 256, status + p * per_pass, ticket + p,
+        if ((rc = onesweep_pass(kin, vin, kout, vout, cap, n_ptr, at, bits, ghist + p * 256, status + p * per_pass, ticket + p,
                                 v2in, v2out, err, debug, s)))
             return rc;
         shift += bits;

@@ -3,13 +3,15 @@ depth_bin / depth_bucket, operation by operation (fp32 fma, fp32 multiply, trunc
 
   * MONOTONE: a smaller depth never lands in a later bucket — the one thing correctness needs (the segments are sorted exactly
     afterwards, segsort.hip; the GPU tests hold the resulting lists to the oracle bit for bit);
+  * the sixteen bits BELOW the bucket (the fraction that rides in the key's low bits and orders a segment without a trip to the depth
+    keys) are part of the same monotone value, and they separate the entries of a segment well: few ties;
   * BALANCED enough: whatever the depth distribution (uniform, one wall, two walls and a sky, five decades), no bucket holds much
     more than its share unless the depths themselves are (nearly) equal — what keeps the segments inside LDS.
 """
 import numpy as np
 import pytest
 
-DBINS, DBIN_SHIFT, DBIN0 = 256, 19, (127 - 8) << 4
+DBINS, DBIN_SHIFT, DBIN0, FRAC = 256, 19, (127 - 8) << 4, 16
 
 
 def depth_bin(bits):
@@ -18,7 +20,7 @@ def depth_bin(bits):
 
 
 def bucket_map(bits_all, weights, dbits):
-    """-> function bits -> bucket, built the way scan_emit_kernel builds it from the preprocess kernel's histogram."""
+    """-> function bits -> (bucket << 16 | fraction), built the way scan_emit_kernel builds it from the preprocess kernel's histogram."""
     hist = np.bincount(depth_bin(bits_all), weights=weights, minlength=DBINS).astype(np.uint64)
     tot = int(hist.sum())
     sh = 0
@@ -28,8 +30,8 @@ def bucket_map(bits_all, weights, dbits):
     ex = np.concatenate([[0], np.cumsum(cs)[:-1]]).astype(np.uint64)
     tot2 = int(cs.sum())
     cnt, cdf = cs.astype(np.float32), ex.astype(np.float32)
-    scale = np.float32(np.float32(1 << dbits) / np.float32(tot2)) if tot2 else np.float32(0)
-    nb = 1 << dbits
+    scale = np.float32(np.float32(1 << (dbits + FRAC)) / np.float32(tot2)) if tot2 else np.float32(0)
+    nb = 1 << (dbits + FRAC)   # bucket and sixteen bits of fraction below it (the key's low bits: segsort.hip)
 
     def f(bits):
         raw = (bits >> DBIN_SHIFT).astype(np.int64) - DBIN0
@@ -67,8 +69,8 @@ def test_buckets_are_monotone_in_the_depth_bits(name, dbits):
     f = bucket_map(bits, w, dbits)
     order = np.sort(bits)
     b = f(order)
-    assert (np.diff(b.astype(np.int64)) >= 0).all(), "a smaller depth landed in a later bucket"
-    assert b.max() < (1 << dbits)
+    assert (np.diff(b.astype(np.int64)) >= 0).all(), "a smaller depth landed in a later bucket, or in an earlier fraction of its bucket"
+    assert b.max() < (1 << (dbits + FRAC))
     # every representable depth between two neighbours of the set, too (the map is built from the histogram, not from the set)
     probe = np.sort(_bits(np.nextafter(z[:5000], np.float32(np.inf)))) if name != "one_wall" else order[:10]
     both = np.sort(np.concatenate([order[:5000], probe]))
@@ -93,7 +95,7 @@ def test_buckets_are_about_equally_full(name):
     z = CASES[name](g, 400_000).astype(np.float32)
     bits = _bits(z)
     f = bucket_map(bits, np.ones_like(bits), 7)
-    counts = np.bincount(f(bits), minlength=128)
+    counts = np.bincount(f(bits) >> FRAC, minlength=128)
     assert counts.max() <= 8 * z.shape[0] / 128, (name, counts.max(), z.shape[0] / 128)
 
 
@@ -103,4 +105,18 @@ def test_counts_beyond_2_to_24_are_shifted_not_rounded():
     bits = _bits(z)
     f = bucket_map(bits, np.full(bits.shape, 1 << 12, dtype=np.int64), 7)   # total 4.1e8 > 2^24
     b = f(np.sort(bits))
-    assert (np.diff(b.astype(np.int64)) >= 0).all() and b.max() == 127 and b.min() == 0
+    assert (np.diff(b.astype(np.int64)) >= 0).all() and (b.max() >> FRAC) == 127 and (b.min() >> FRAC) == 0
+
+
+def test_fractions_rarely_tie_inside_a_segment():
+    """What the fraction bits buy: on a spread depth distribution two entries of the same (tile, bucket) segment share all sixteen
+    fraction bits only rarely — segment_sort_kernel fetches exact depth bits for tie groups only."""
+    g = np.random.default_rng(11)
+    z = g.uniform(1.0, 10.0, 1_000_000).astype(np.float32)
+    bits = _bits(z)
+    v = bucket_map(bits, np.ones_like(bits), 7)(bits)
+    tile = g.integers(0, 416, z.shape[0]).astype(np.uint64)
+    seg = (tile << np.uint64(23)) | v.astype(np.uint64)          # (tile, bucket, fraction): equal values = a tie inside a segment
+    _, counts = np.unique(seg, return_counts=True)
+    tied = int(counts[counts > 1].sum())
+    assert tied <= 0.02 * z.shape[0], tied
