@@ -44,7 +44,7 @@ __device__ __forceinline__ bool block_hit(const float4 xyh, const float cx, cons
 // A row's list: 256 one-byte positions + one pad word.  The four rows of a wave read position t of THEIR lists in the same
 // instruction: at a stride of 256 B those four bytes sit in one bank (r02 PMC: 1.8e7 conflict cycles in 2.8e7 LDS cycles at
 // 1 M splats); 260 B puts them in four neighbouring banks.
-constexpr int ROW_LIST_STRIDE = TILE_PIX + 4;
+constexpr int ROW_LIST_STRIDE = TILE_PIX;   // (round 3 padded the rows by 4 bytes against bank conflicts; round 4 trades that for the eighth workgroup per CU)
 
 // Build the four per-row index lists of this wave for a staged batch of n splats.  lists: this wave's [4][256] bytes.
 // Returns the four lengths (wave-uniform).  Round 3: octagon test per block (render_common.h) instead of the bounding box —
@@ -78,8 +78,13 @@ __device__ __forceinline__ void build_row_lists(const StagedSplat *stage, const 
 // PREFETCH (few tiles, long lists, globally sorted: the DAS3R shape — 416 workgroups for 1024 workgroup slots, so nobody else
 // covers a workgroup's trips to memory): the records of batch i + 1 and the list words of batch i + 2 are in flight while batch i
 // composites; a batch used to start with two trips in a row (list word -> record) behind the barrier.
+// Round 4: the non-prefetching instantiation is compiled for EIGHT workgroups per CU instead of seven (DESIGN.md r3 section 7.5 iii:
+// "320 bytes of LDS and 3 registers away") — 64 VGPRs (waves-per-EU attribute; two spills outside the walk) and exactly 20 480 B of
+// LDS: the done flags of the early exit live in the tail of s_gid instead of __syncthreads_count's 256-byte scratch, the list rows
+// lose their 4 bytes of bank padding.  1 M splats at 1080p: 0.2298 -> 0.2242 ms (same box, A-B-B-B).
+#define FWD_WAVES(PREFETCH) __attribute__((amdgpu_waves_per_eu((PREFETCH) ? 1 : 8, 8)))
 template <bool PREFETCH>
-__global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
+__global__ void __launch_bounds__(256) FWD_WAVES(PREFETCH) render_forward_rows_kernel(const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list,
                                                                   int W, int H, int tiles_x, int ntiles_strip /*render_common.h pack_tiles*/, const float4 *__restrict__ xyh,
                                                                   const float4 *__restrict__ conic_opacity,
                                                                   const float4 *__restrict__ rgbd, const float *__restrict__ bg,
@@ -149,7 +154,16 @@ __global__ void __launch_bounds__(256) render_forward_rows_kernel(const uint2 *_
         if (PREFETCH) {
             stage = stage_all + (i % NBUF) * TILE_PIX;
             if ((i & 15) == 0 && __syncthreads_count(live == 0.f) == TILE_PIX) break;   // (rare on this path: checked every 16 batches)
-        } else if (__syncthreads_count(live == 0.f) == TILE_PIX) break;
+        } else {
+            // the four waves' "all my pixels have stopped" flags live in the last eight words of s_gid, which only a list of more than
+            // LOCAL_MAX - 8 entries sorted in LDS needs (such a tile goes without the early exit: the walk of stopped pixels is idle work, not wrong)
+            const bool flags_free = !sorted_here || (int)(range.y - range.x) <= LOCAL_MAX - 8;   // (uniform)
+            uint32_t *const s_done = s_gid + (LOCAL_MAX - 8) + ((i & 1) << 2);
+            const bool wave_done = __ballot(live != 0.f) == 0ull;
+            if (flags_free && lane == 0) s_done[wave] = wave_done ? 1u : 0u;
+            __syncthreads();
+            if (flags_free && (s_done[0] & s_done[1] & s_done[2] & s_done[3])) break;
+        }
         PHASE_MARK(1)   // waiting for the workgroup's slowest wave
         if (nb > 1 && i > 0 && (i * TILE_PIX) % BUCKET == 0) ckpt_slot(lb.ckpt, range, tile, next_slot++)[cpix] = make_float4(T, C0, C1, C2);
         const uint32_t progress = range.x + i * TILE_PIX + tid;

@@ -18,7 +18,7 @@ Per-kernel shares (they sum to B_fwd + B_bwd):
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (≈6.3 TB/s achievable)
 
 BINNING_KERNELS = ("radix_hist_kernel", "radix_rowscan_kernel", "radix_scatter_kernel", "depth_hist_kernel", "onesweep_pass_kernel",
-                   "scan_emit_kernel", "emit_kernel", "tile_ranges_kernel")
+                   "scan_emit_kernel", "emit_kernel", "tile_ranges_kernel", "segment_sort_kernel")
 
 
 def algorithmic_bytes(P, D, M, I, W, H):

@@ -4,7 +4,7 @@
 W=$1; shift
 cp das3r_amd/libdas3r_hip.so /tmp/libdas3r_hip.default.so
 for v in "$@"; do
-  cp das3r_amd/libdas3r_hip.$v.so das3r_amd/libdas3r_hip.so
+  if [ "$v" = default ]; then cp /tmp/libdas3r_hip.default.so das3r_amd/libdas3r_hip.so; else cp das3r_amd/libdas3r_hip.$v.so das3r_amd/libdas3r_hip.so; fi
   echo "#### variant $v"
   timeout 120 python tools/gpu_perf.py --workloads $W --steps 30 2>&1 | grep "==\|render_\|preprocess\|onesweep\|scan_emit"
 done
