@@ -19,6 +19,7 @@ both to the float64 trainer and to each other — and nothing here is reachable 
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -41,10 +42,16 @@ class _Pkg(dict):
 
 def available(model, pipe):
     """The direct path covers the configuration the farm trains in: fused optimizers on both parameter sets, the default `pipe`."""
+    if os.environ.get("DAS3R_FAST_STEP", "1") == "0":   # (A-B runs of whole jobs: tools/farm_davis_shape.py)
+        return False
     return (getattr(model, "fast_step", True) and getattr(model.optimizer, "is_fused", False) and hasattr(model.optimizer_cam, "_gate_state")
             and model.optimizer.handles_compact_sh(model._features_rest)
             and not getattr(pipe, "compute_cov3D_python", False) and not getattr(pipe, "convert_SHs_python", False)
-            and not getattr(pipe, "debug", False) and model._xyz.device.type == "cuda")
+            and not getattr(pipe, "debug", False) and model._xyz.device.type == "cuda"
+            # the C-ABI takes plain pointers: every parameter must be a dense fp32 tensor (anything else keeps the autograd form, which
+            # goes through .contiguous())
+            and all(t.is_contiguous() and t.dtype == torch.float32 for t in (model._xyz, model._rotation, model._scaling, model._opacity,
+                                                                            model._features_dc, model._features_rest, model._conf_static, model.Q, model.T)))
 
 
 class _State:
@@ -74,6 +81,20 @@ def _state(model):
     if st is None or st.P != model._xyz.shape[0] or st.Qg.shape != model.Q.shape:
         st = model._fast_state = _State(model)
     return st
+
+
+def _dense_f32(obj, name):
+    """obj.<name> as a contiguous fp32 tensor — the C-ABI takes plain pointers (a ground-truth image that came through the on-disk
+    formats is a [3, H, W] VIEW of H x W x 3 memory: round 4's first version of this file read it as if it were dense and trained a
+    whole job towards a scrambled image).  A copy is made once per tensor and kept on the object."""
+    t = getattr(obj, name)
+    if t.is_contiguous() and t.dtype == torch.float32:
+        return t
+    cache = getattr(obj, "_das3r_dense", None)
+    if cache is None or cache[0] != (name, t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version):
+        cache = ((name, t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version), t.detach().contiguous().float())
+        obj._das3r_dense = cache
+    return cache[1]
 
 
 def _settings(st, cam, model, bg):
@@ -127,7 +148,8 @@ def forward_backward(model, cam, q_row, t_row, gq_row, gt_row, static_hw, lambda
     e = st.e
     I, image, radii, geom, binning, img, cap = _forward_full(rs, means3D, shs, e, opac, scales, rotations, e)
     # ---- loss
-    gt = cam.original_image
+    gt = _dense_f32(cam, "original_image")
+    static_hw = static_hw if (static_hw.is_contiguous() and static_hw.dtype == torch.float32) else static_hw.contiguous().float()
     nb = int(lib.das3r_photometric_blocks(H, W))
     partials = torch.empty(nb, 8, device=dev)
     dmaps = torch.empty(4, 3, H, W, device=dev)

@@ -175,7 +175,7 @@ def load_sequence(seq_dir, device="cpu", gt_mask_dir=None, dataset="sintel"):
         name = os.path.basename(im["name"])
         idx = name.split(".")[0].split("_")[-1]
         rgb = np.asarray(Image.open(os.path.join(seq_dir, "images", name)).convert("RGB"), dtype=np.float32) / 255.0
-        out["images"].append(rgb.transpose(2, 0, 1))
+        out["images"].append(np.ascontiguousarray(rgb.transpose(2, 0, 1)))   # (dense [3, H, W]: np.stack keeps the layout of its inputs)
         out["depths"].append(np.load(os.path.join(seq_dir, "depth_maps", f"frame_{idx}.npy")).astype(np.float32))
         out["confs"].append(np.load(os.path.join(seq_dir, "confidence_maps", f"conf_{idx}.npy")).astype(np.float32))
         out["dyna_avg"].append(np.load(os.path.join(seq_dir, "dyna_avg", f"dyna_avg_{idx}.npy")).astype(np.float32))

@@ -158,6 +158,10 @@ def test_direct_fused_step_matches_the_autograd_fused_step(degree):
         model, cams, _, opt, _dense = _pair(frames=3, W=32, H=24, seed=9, heldout=False, iterations=100, fused=True, generic=True)
         model.fast_step = direct
         assert fast_step.available(model, PIPE) == direct
+        if degree == 1:   # ground-truth images as they come out of numpy-stacked H x W x 3 files: [3, H, W] VIEWS, not dense tensors
+            for c in cams:
+                c.original_image = c.original_image.permute(1, 2, 0).contiguous().permute(2, 0, 1)
+                assert not c.original_image.is_contiguous()
         model.active_sh_degree = degree
         model.optimizer.set_active_sh_degree(degree)
         with torch.no_grad():
