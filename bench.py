@@ -2,7 +2,7 @@
 """bench.py — throughput of the rasterizer hot path (forward + backward through the drop-in GaussianRasterizer API) on
 synthetic random-splat scenes, with the roofline of the dominant kernel and the CPU oracle timed beside it.
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload c4|c2|ds|c1|c4d] [--no-extras] [--no-cpu-baseline]
+    python bench.py [--gpus N --steps K --warmup W] [--workload c4|c2|ds|dsc|c1|c4d] [--no-extras] [--no-cpu-baseline]
 
 Default workload: c4 = BASELINE.json configs[3] (1 M splats at 1080p), the configuration north_star's roofline target is
 stated on.  A step = one forward + one backward of one scene (inputs resident in HBM).  With N > 1 every rank renders its OWN
@@ -33,6 +33,8 @@ WORKLOAD_DESC = {
     "c4d": "1M -> 1.3M random splats (clone/split of the top-gradient 5 % every 100 steps), 1920x1080, SH degree 3, "
            "forward+backward (BASELINE.json configs[3] with its densification stress, SURVEY.md §8d)",
     "ds": "5M random splats, 512x208, SH degree 0, forward+backward (shape of real DAS3R Sintel training)",
+    "dsc": "5M splats on a smooth depth relief (1 % noise), 512x208, SH degree 0, forward+backward (the DAS3R shape with the spatially "
+           "coherent depth of a real scene: a tile sees a thin depth band)",
 }
 INIT_STEPS = 30
 ITERS_PER_SCENE = 4000   # BASELINE.json configs[2] / [4]: one sequence = 4000 optimisation iterations
@@ -480,7 +482,7 @@ def extras_main(main_workload):
         ds_step()
     out["train_step_davis"] = {"fused_ms": round(rk.timed(ds_step, 50, 5) / 50 * 1e3, 4), "splats": ds_splats, "frames": 45, "image": [512, 288]}
     del ds_step
-    for w, k in (("c2", 300), ("ds", 50), ("c1", 300), ("c4d", 700), ("c4", 200)):
+    for w, k in (("c2", 300), ("ds", 50), ("dsc", 50), ("c1", 300), ("c4d", 700), ("c4", 200)):
         if w == main_workload:
             continue
         torch.cuda.empty_cache()

@@ -71,7 +71,7 @@ static void load_switches() {
 #endif
     w.rect_upstream = (e = env("DAS3R_RECT")) && e[0] == 'u';
     w.verbose = env("DAS3R_VERBOSE") != nullptr;
-    if ((e = env("DAS3R_BINNING"))) w.binning = e[0] == 'l' ? 1 : (e[0] == 'r' ? -1 : (e[0] == 's' ? 2 : 0));
+    if ((e = env("DAS3R_BINNING"))) w.binning = e[0] == 'l' ? 1 : (e[0] == 'r' ? -1 : (e[0] == 's' ? (strchr(e, '3') ? 3 : 2) : 0));
     w.capacity_exact = (e = env("DAS3R_CAPACITY")) && e[0] == 'e';
     w.fused_emit_off = (e = env("DAS3R_FUSED_EMIT")) && e[0] == '0';
     if ((e = env("DAS3R_RENDER"))) w.render_fwd = e[0] == 'q' ? 1 : (e[0] == 'r' ? 2 : 0);
@@ -149,6 +149,7 @@ void compute_layout(int P, int64_t I, int W, int H, Layout *L) {
     L->dbits = 0;
     L->kbits = L->tbits;
     L->kshift = 0;
+    L->part_passes = L->tile_passes;
     L->chunksP = sort_num_chunks(P);
     L->chunksI = sort_num_chunks(I);
     size_t o = 0;
@@ -193,7 +194,7 @@ void compute_layout(int P, int64_t I, int W, int H, Layout *L) {
     L->b_e2 = take(4 * In);
     L->b_ghist = take(4 * 4 * RADIX_SIZE);
     L->b_ticket = take(256);
-    L->b_status = take(onesweep_status_bytes((int64_t)In, L->tile_passes));
+    L->b_status = take(onesweep_status_bytes((int64_t)In, L->tile_passes + 1));   // (+ 1: the segmented path may take one more pass)
     L->b_ctrl_bytes = o - L->b_ghist;
     L->b_ckpt = take(((size_t)In / BUCKET + (size_t)(L->ntiles > 0 ? L->ntiles : 1) + 2) * 256 * 16);
     L->pub.binning_bytes = o;
@@ -264,7 +265,7 @@ struct Mailbox {
 // Everything the library remembers between calls, per host thread and per device (a thread that renders on two GPUs gets two
 // of these; nothing is shared between threads: any number of them may render concurrently, each on its own stream).
 constexpr uint32_t CHECK_SLOTS = 16, CHECK_WORD0 = 16, MAILBOX_BYTES = 4 * (CHECK_WORD0 + 2 * CHECK_SLOTS);
-struct Verdict { int P, W, H; int64_t last_I, peak_I; int radix_left, backoff; uint32_t gen; };
+struct Verdict { int P, W, H; int64_t last_I, peak_I; int radix_left, backoff; uint32_t gen; int seg_extra; bool last_seg; };
 struct PerDevice {
     Mailbox mb;
     uint32_t pending[CHECK_SLOTS] = {};             // per slot: tag of the forward whose self-check word has not been examined yet
@@ -417,12 +418,17 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     constexpr int64_t LOCAL_AVG = 384;   // mean list length up to which the local order wins (measured: 1 M splats at 1080p, mean 320: -4 %)
     const uint32_t too_long = mb->host[10];   // != 0: a forward of the shape with that generation number met a list too long for LDS
     if (too_long) mb->host[10] = 0;
+    const uint32_t want_bits = mb->host[11];  // != 0: the segmented path of that generation sorted a segment long enough to want more bucket bits
+    if (want_bits) mb->host[11] = 0;
     if (verdict.P != P || verdict.W != W || verdict.H != H) {
         const uint32_t gen = verdict.gen + 1u ? verdict.gen + 1u : 1u;
         verdict = Verdict{P, W, H, -1, 0, 0, 64, gen};
-    } else if (too_long == verdict.gen) {
+    } else if (too_long == verdict.gen && !(verdict.last_seg && verdict.seg_extra == 0 && L.tile_passes < 3 && seg_dbits(L, L.tile_passes + 1) > 0)) {
         verdict.radix_left = verdict.backoff;   // global sort for a while; longer every time it happens again
         if (verdict.backoff < 4096) verdict.backoff *= 2;
+    } else if (too_long == verdict.gen || want_bits == verdict.gen) {
+        verdict.seg_extra = 1;                  // the segmented path with one more partition pass of bucket bits from now on (this shape);
+                                                // a segment that is too long even then sends the shape back to the global sort (above)
     }
     const int forced = switches().binning;   // DAS3R_BINNING=local | radix | seg: force one (diagnostics, tests)
     bool local = use_onesweep() && (forced == 1 || (forced == 0 && verdict.radix_left == 0 && verdict.last_I <= LOCAL_AVG * L.ntiles));
@@ -430,13 +436,25 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     // the tile ids leave free, and every (tile, bucket) segment is sorted inside LDS (segkey.h, segsort.hip).  Needs free key bits
     // and segments that stay short on average; a segment that did not fit in LDS sends the shape back to the global sort for a
     // while, like a list too long for the local order does (the same mailbox word and back-off).
+    // The buckets are global: they split a tile's list well when its depths are spread (random-depth benchmarks) and badly when a tile
+    // sees a thin depth band of a wide scene (every real scene: its Gaussians lie on surfaces).  A forward that had to rank a long
+    // segment says so (mailbox word 11), and the shape takes ONE MORE partition pass from then on: eight more bucket bits — a band
+    // that held 3 % of the scene's instances in 4 of 128 buckets is cut into a thousand (r4, coherent-depth 5 M-splat scene:
+    // segment sort 1.08 ms with two passes, see DESIGN.md with three).
     constexpr int64_t SEG_AVG = 384;         // mean entries per segment up to which it is taken
-    const int seg_bits = use_onesweep() ? seg_dbits(L) : 0;
-    bool seg = !local && seg_bits > 0 && (forced == 2 || (forced == 0 && verdict.radix_left == 0 && verdict.last_I >= 0 &&
-                                                           (verdict.last_I >> seg_bits) <= SEG_AVG * L.ntiles));
+    const int seg_passes = L.tile_passes + ((forced == 3 || (forced == 0 && verdict.seg_extra)) ? 1 : 0);
+    const int seg_bits = (use_onesweep() && seg_passes <= 3) ? seg_dbits(L, seg_passes) : 0;
+    bool seg = !local && seg_bits > 0 && (forced >= 2 || (forced == 0 && verdict.radix_left == 0 && verdict.last_I >= 0 &&
+                                                           (verdict.last_I >> std::min(seg_bits, 20)) <= SEG_AVG * L.ntiles));
     auto apply_seg = [&]() {   // (compute_layout starts every layout without buckets)
-        if (seg) { L.dbits = seg_bits; L.kbits = L.tbits + seg_bits; L.kshift = 16; }
+        if (seg) {
+            L.dbits = seg_bits;
+            L.kbits = L.tbits + seg_bits;
+            L.kshift = std::min(16, 32 - L.kbits);
+            L.part_passes = seg_passes;
+        }
     };
+    verdict.last_seg = seg;
     if (forced == 0 && verdict.radix_left > 0) verdict.radix_left--;
     const uint32_t count_tag = ++mb->seq ? mb->seq : ++mb->seq;
     unsigned long long *arrive = arrive_ring + (size_t)(count_tag % ARRIVE_SLOTS) * ARRIVE_WORDS;

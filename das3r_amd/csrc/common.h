@@ -23,7 +23,7 @@ struct Switches {
     bool sort_classic;     // DAS3R_SORT=classic: histogram + row scan + scatter per digit instead of the one-sweep passes
     bool rect_upstream;    // DAS3R_RECT=upstream: bin over upstream's 3-sigma square (bit-exact list tests)
     bool verbose;          // DAS3R_VERBOSE
-    int binning;           // DAS3R_BINNING=local | radix | seg: 1 | -1 | 2 (0: chosen per scene)
+    int binning;           // DAS3R_BINNING=local | radix | seg | seg3: 1 | -1 | 2 | 3 (0: chosen per scene; seg3 = seg with one more partition pass of bucket bits)
     bool capacity_exact;   // DAS3R_CAPACITY=exact: never lay the binning buffer out speculatively
     bool fused_emit_off;   // DAS3R_FUSED_EMIT=0
     bool no_sh_stage;      // DAS3R_NO_SH_STAGE
@@ -207,12 +207,13 @@ struct Layout {
     // segmented binning path (segkey.h): the partition key is (tile id << dbits | depth bucket), kbits = tbits + dbits wide, in the
     // SAME number of passes the tile ids alone need (the backward pass lays the buffers out without knowing the path).  dbits = 0
     // everywhere else.  g_dhist: u32[256] depth histogram of the forward
-    int dbits, kbits, kshift;   // kshift: 16 on the segmented path — the key's low bits hold the fraction of the depth map (segkey.h), the
+    int dbits, kbits, kshift;   // kshift: the key's low bits hold the fraction of the depth map (segkey.h: min(16, 32 - kbits) bits), the
                                 // partition's digits start above them
+    int part_passes;            // passes of the instance partition: tile_passes, or one more when the segmented path wants more bucket bits
     size_t g_dhist;
 };
-// depth-bucket bits the tile partition's passes have room for (0: none — the tile ids fill their passes)
-static inline int seg_dbits(const Layout &L) { return 8 * L.tile_passes - L.tbits; }
+// depth-bucket bits `passes` partition passes (at most three) have room for beside the tile ids (<= 0: none)
+static inline int seg_dbits(const Layout &L, int passes) { return 8 * (passes < 3 ? passes : 3) - L.tbits; }
 
 // Local depth order (short tile lists): the binning skips the global depth sort, the tile lists arrive in index order and
 // the forward compositing kernel sorts each one by (depth bits, index) itself (render_common.h: local_sort_tile) — in LDS up
@@ -294,7 +295,7 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
                    uint32_t *emit_slot = nullptr /*fused emission: {err, pad, ghist} ring slot, re-armed by the last kernel*/,
                    uint32_t *seg_host_flag = nullptr, uint32_t seg_flag_value = 0 /*segmented path (L.dbits > 0): mailbox word for a segment too long for LDS*/);
 // segsort.hip: exact (depth bits, index) order inside every (tile, depth bucket) segment of the partitioned list, in place
-int launch_segment_sort(int64_t cap, const uint32_t *n_ptr, const uint32_t *keys_final, uint32_t *point_list, uint32_t *slot_list,
+int launch_segment_sort(int64_t cap, const uint32_t *n_ptr, const uint32_t *keys_final, int fbits, uint32_t *point_list, uint32_t *slot_list,
                         const uint32_t *depth_key, uint32_t last_g, uint32_t *scratch_keys, uint32_t *host_flag, uint32_t flag_value, bool debug,
                         hipStream_t s);
 // lb.point_list != null: the tile lists are in index order and the kernel sorts them by depth first

@@ -51,7 +51,8 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
     uint32_t *__restrict__ gids, uint32_t cap, uint32_t *__restrict__ ghist /*[passes][256]*/, int tbits /*bits of the partition key*/, int tight_rect,
     const uint32_t *__restrict__ rect32 /*packed binned rectangles by splat (common.h g_rect) or null*/,
     // segmented path (segkey.h; index order only): partition key = tile id << dbits | depth bucket of the splat
-    int dbits, const uint32_t *__restrict__ depth_keys /*[P] by splat*/, const uint32_t *__restrict__ dhist /*[256] depth histogram of this forward*/
+    int dbits, int fbits /*fraction bits below the bucket in the key: Layout.kshift*/, const uint32_t *__restrict__ depth_keys /*[P] by splat*/,
+    const uint32_t *__restrict__ dhist /*[256] depth histogram of this forward*/
 #ifdef DAS3R_EXPERIMENTS
     , unsigned long long *__restrict__ wg_trace_ptr /*common.h SCAN_STAMP*/
 #endif
@@ -91,7 +92,7 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
         const uint32_t ex = block_exclusive_scan_256(cs, ws, &tot2);
         s_cnt[EMIT ? tid : 0] = (float)cs;
         s_cdf[EMIT ? tid : 0] = (float)ex;
-        dscale = tot2 ? (float)(1u << (dbits + SEG_FRAC_BITS)) / (float)tot2 : 0.f;   // (bucket + fraction: segkey.h)
+        dscale = tot2 ? (float)(1u << (dbits + fbits)) / (float)tot2 : 0.f;   // (bucket + fraction: segkey.h)
         __syncthreads();
     }
 
@@ -155,8 +156,8 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
                 }
                 uint32_t l = ex;   // place in the workgroup's run
                 // segmented path: key = tile id | bucket | 16 bits of fraction (kshift = 16: the partition's digits start above the fraction)
-                const int kshift = (EMIT && dbits > 0) ? SEG_FRAC_BITS : 0;
-                const uint32_t bucket = (EMIT && dbits > 0) ? depth_bucket(dkv[k], s_cnt, s_cdf, dscale, 1u << (dbits + SEG_FRAC_BITS)) : 0u;
+                const int kshift = (EMIT && dbits > 0) ? fbits : 0;
+                const uint32_t bucket = (EMIT && dbits > 0) ? depth_bucket(dkv[k], s_cnt, s_cdf, dscale, 1u << (dbits + fbits)) : 0u;
                 for (int y = rminy; y < rmaxy; y++)
                     for (int x = rminx; x < rmaxx; x++) {
                         const uint32_t t = ((uint32_t)(y * tiles_x + x) << (dbits + kshift)) | bucket;
@@ -178,7 +179,7 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(
         }
         if (via_lds) {
             __syncthreads();
-            const int kshift2 = (EMIT && dbits > 0) ? SEG_FRAC_BITS : 0;
+            const int kshift2 = (EMIT && dbits > 0) ? fbits : 0;
             for (uint32_t l = tid; l < tot; l += 256u) {   // unit stride: tile ids and splat ids of the run [carry, carry + tot)
                 const uint32_t o = carry + l;
                 if (o < cap) {
@@ -263,7 +264,7 @@ int launch_scan(int P, char *geom, const Layout &L, uint32_t *host_out, uint32_t
 #define GO(IT)                                                                                                               \
     DAS3R_LAUNCH((scan_emit_kernel<false, IT>), dim3(nblocks), dim3(256), 0, s, SCAN_COMMON, 0, 0,                            \
                  (const float4 *)(geom + L.pub.xy),                                                                           \
-                 (const int32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (uint32_t *)nullptr, 0, 0, RECT32, 0,              \
+                 (const int32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (uint32_t *)nullptr, 0, 0, RECT32, 0, 0,           \
                  (const uint32_t *)nullptr, (const uint32_t *)nullptr SCAN_TRACE_ARG)
     switch (scan_items(P)) { case 1: GO(1); break; case 2: GO(2); break; case 4: GO(4); break; case 8: GO(8); break; default: GO(16); }
 #undef GO
@@ -278,7 +279,7 @@ int launch_scan_emit(int P, int64_t cap, const int32_t *radii, char *geom, char 
 #define GO(IT)                                                                                                               \
     DAS3R_LAUNCH((scan_emit_kernel<true, IT>), dim3(nblocks), dim3(256), 0, s, SCAN_COMMON, L.tiles_x, L.tiles_y,              \
                  (const float4 *)(geom + L.pub.xy), radii, (uint32_t *)(binning + L.b_keyA), (uint32_t *)(binning + L.b_gid_of), \
-                 (uint32_t)cap, (uint32_t *)(binning + L.b_ghist), L.kbits, use_tight_rect() ? 1 : 0, RECT32, index_order ? L.dbits : 0,      \
+                 (uint32_t)cap, (uint32_t *)(binning + L.b_ghist), L.kbits, use_tight_rect() ? 1 : 0, RECT32, index_order ? L.dbits : 0, L.kshift, \
                  (const uint32_t *)(geom + L.pub.depth_key), (const uint32_t *)(geom + L.g_dhist) SCAN_TRACE_ARG)
     switch (scan_items(P)) { case 1: GO(1); break; case 2: GO(2); break; case 4: GO(4); break; case 8: GO(8); break; default: GO(16); }
 #undef GO

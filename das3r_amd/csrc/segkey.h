@@ -29,12 +29,11 @@ __device__ __forceinline__ uint32_t depth_bin(const uint32_t bits) {
     return (uint32_t)(raw < 0 ? 0 : (raw > DBINS - 1 ? DBINS - 1 : raw));
 }
 // cnt / cdf: the workgroup's LDS copies of the (shifted) bin counts and their exclusive running sums, as floats (exact integers
-// below 2^24); scale = nb / total (0 when nothing is visible).  nb = 2^(dbits + SEG_FRAC_BITS): the result is the bucket AND the
-// next SEG_FRAC_BITS bits of the same monotone map below it — the partition passes sort on the bucket bits only, the fraction
+// below 2^24); scale = nb / total (0 when nothing is visible).  nb = 2^(dbits + fbits), fbits = min(16, 32 - key bits): the result is the
+// bucket AND the next fbits bits of the same monotone map below it — the partition passes sort on the bucket bits only, the fraction
 // rides along in the key's low bits for free and orders a segment without a trip to the depth keys wherever it has no ties
 // (segsort.hip; the first version gathered the depth of every instance: 4 bytes out of a 64-byte line each, 0.20 - 0.28 ms of a
 // 2.1 ms step on the 5 M-splat DAS3R shape).
-constexpr int SEG_FRAC_BITS = 16;
 __device__ __forceinline__ uint32_t depth_bucket(const uint32_t bits, const float *cnt, const float *cdf, const float scale, const uint32_t nb) {
     const int raw = (int)(bits >> DBIN_SHIFT) - DBIN0;
     const uint32_t bin = (uint32_t)(raw < 0 ? 0 : (raw > DBINS - 1 ? DBINS - 1 : raw));

@@ -56,7 +56,11 @@ __device__ __forceinline__ void count_below(uint32_t &rank, const uint32_t kj, c
     asm("v_sub_co_u32 %1, vcc, %2, %3\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(rank), "=&v"(tmp) : "v"(kj), "v"(ki) : "vcc");
 }
 
+constexpr uint32_t SEG_WANT_MORE = 384;   // ranking is quadratic in a segment's length: a workgroup whose owned segments average more than this
+                                          // (weighted by their length: sum len^2 > SEG_CH * this) asks the host for more bucket bits
+                                          // (mailbox word host_flag + 1) — one long segment among short ones does not
 __global__ void __launch_bounds__(SEG_T) segment_sort_kernel(uint32_t cap, const uint32_t *__restrict__ n_ptr, const uint32_t *__restrict__ kk /*partition keys, final order*/,
+                                                             int fbits /*fraction bits below (tile, bucket) in a key*/,
                                                            uint32_t *__restrict__ pl, uint32_t *__restrict__ sl, const uint32_t *__restrict__ depth_key /*[P] by splat*/,
                                                            uint32_t last_g, uint32_t *__restrict__ dk /*u32[cap] scratch (the dead key buffer)*/,
                                                            uint32_t *__restrict__ host_flag, uint32_t flag_value) {
@@ -69,9 +73,9 @@ __global__ void __launch_bounds__(SEG_T) segment_sort_kernel(uint32_t cap, const
     __shared__ uint32_t ws[SEG_T / 64];
     __shared__ uint32_t s_long;                 // start (relative) of the owned segment that leaves the LDS span, or SEG_NONE
     __shared__ uint16_t s_defer[SEG_CAP / 2];   // deferred second entries of straddling pairs: position, then rank (the owner keeps its list slot)
-    __shared__ uint32_t s_ndefer;
+    __shared__ uint32_t s_ndefer, s_work;
     const int tid = threadIdx.x;
-    if (tid == 0) s_ndefer = 0u;
+    if (tid == 0) s_ndefer = s_work = 0u;
     for (int r = tid; r < SEG_CAP + 2; r += SEG_T) {
         const long long idx = (long long)w0 - 1 + r;
         s_a[r] = (idx >= 0 && idx < (long long)n) ? kk[idx] : 0u;   // s_a[r] = kk[w0 - 1 + r]
@@ -102,7 +106,7 @@ __global__ void __launch_bounds__(SEG_T) segment_sort_kernel(uint32_t cap, const
         const uint32_t idx = w0 + (uint32_t)p;
         if (idx > n) return false;
         if (idx == n || idx == 0u) return true;
-        return (s_a[p] >> SEG_FRAC_BITS) != (s_a[p + 1] >> SEG_FRAC_BITS);
+        return (s_a[p] >> fbits) != (s_a[p + 1] >> fbits);
     };
     uint32_t last = 0u;   // (last start of this thread's positions) + 1, 0 = none
 #pragma unroll
@@ -127,7 +131,7 @@ __global__ void __launch_bounds__(SEG_T) segment_sort_kernel(uint32_t cap, const
 #pragma unroll
     for (int u = 0; u < SEG_CAP / SEG_T; u++) {
         const int p = tid + SEG_T * u;
-        word[u] = ((s_a[p + 1] & ((1u << SEG_FRAC_BITS) - 1u)) << 12) | (uint32_t)p;
+        word[u] = ((s_a[p + 1] & ((1u << fbits) - 1u)) << 12) | (uint32_t)p;
     }
     __syncthreads();   // (flags and keys read by everybody)
 #pragma unroll
@@ -146,9 +150,15 @@ __global__ void __launch_bounds__(SEG_T) segment_sort_kernel(uint32_t cap, const
             const bool cand = w0 + (uint32_t)p < n && s != SEG_NONE && s < (uint32_t)SEG_CH;
             own[u][e] = cand && s_end[s] != SEG_NONE;
             if (cand && s_end[s] == SEG_NONE && (uint32_t)p == s) s_long = s;   // (one writer at most)
+            if (cand && (uint32_t)p == s && s_end[s] != SEG_NONE) {
+                const uint32_t len = (uint32_t)s_end[s] - s;
+                if (len > 64u) atomicAdd(&s_work, len * len);
+            }
             dest[u][e] = 0u;
         }
     __syncthreads();   // the sort words are in place, s_long is published, every load of pl / sl has arrived (the stores below overwrite them)
+    if (tid == 0 && s_work > (uint32_t)SEG_CH * SEG_WANT_MORE)   // (still sorted here, exactly — but by rank, and that is quadratic)
+        __hip_atomic_store(host_flag + 1, flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // A pair that straddles a segment boundary (one pair in ~50, i.e. most waves hold one) would send its whole wave through a second,
     // nearly empty pass over a segment per straddler: its second entry is DEFERRED instead — noted in LDS, and ranked afterwards by
     // a compacted pass, one deferred entry per lane (r4: 0.22 -> see DESIGN.md on the 5 M-splat DAS3R shape).
@@ -264,7 +274,7 @@ __global__ void __launch_bounds__(SEG_T) segment_sort_kernel(uint32_t cap, const
     const uint32_t sl0 = s_long;
     if (sl0 == SEG_NONE) return;
     const uint32_t S = w0 + sl0;
-    const uint32_t key = kk[S] >> SEG_FRAC_BITS;
+    const uint32_t key = kk[S] >> fbits;
     __shared__ uint32_t s_T;
     if (tid == 0) {
         s_T = n;
@@ -273,7 +283,7 @@ __global__ void __launch_bounds__(SEG_T) segment_sort_kernel(uint32_t cap, const
     __syncthreads();
     for (uint32_t base = w0 + (uint32_t)SEG_CAP; base < n; base += (uint32_t)SEG_T) {   // its end: the first position with another key
         const uint32_t idx = base + tid;
-        if (idx < n && (kk[idx] >> SEG_FRAC_BITS) != key) atomicMin(&s_T, idx);
+        if (idx < n && (kk[idx] >> fbits) != key) atomicMin(&s_T, idx);
         __syncthreads();
         if (s_T != n) break;   // (uniform: read behind the barrier)
         __syncthreads();
@@ -304,11 +314,11 @@ __global__ void __launch_bounds__(SEG_T) segment_sort_kernel(uint32_t cap, const
         }
 }
 
-int launch_segment_sort(int64_t cap, const uint32_t *n_ptr, const uint32_t *keys_final, uint32_t *point_list, uint32_t *slot_list,
+int launch_segment_sort(int64_t cap, const uint32_t *n_ptr, const uint32_t *keys_final, int fbits, uint32_t *point_list, uint32_t *slot_list,
                         const uint32_t *depth_key, uint32_t last_g, uint32_t *scratch_keys, uint32_t *host_flag, uint32_t flag_value, bool debug,
                         hipStream_t s) {
     if (cap <= 0) return DAS3R_OK;
-    DAS3R_LAUNCH(segment_sort_kernel, dim3(div_up(cap, SEG_CH)), dim3(SEG_T), 0, s, (uint32_t)cap, n_ptr, keys_final, point_list, slot_list, depth_key, last_g,
+    DAS3R_LAUNCH(segment_sort_kernel, dim3(div_up(cap, SEG_CH)), dim3(SEG_T), 0, s, (uint32_t)cap, n_ptr, keys_final, fbits, point_list, slot_list, depth_key, last_g,
                  scratch_keys, host_flag, flag_value);
     KERNEL_CHECK(s, debug, "segment_sort");
     return DAS3R_OK;

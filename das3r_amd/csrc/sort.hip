@@ -331,9 +331,8 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
         if (dead_keys) *dead_keys = kfinal;   // the tile keys are dead once tile_ranges_kernel has run
         if (L.dbits > 0) {   // segmented path: exact depth order inside every (tile, bucket) segment, in place (segsort.hip)
             uint32_t *other = kfinal == keyA ? keyB : keyA;   // the previous pass's keys: dead, scratch for a segment too long for LDS
-            rc1 = launch_segment_sort(I, n_ptr, kfinal, (uint32_t *)(binning + L.pub.point_list), (uint32_t *)(binning + L.b_slot),
+            rc1 = launch_segment_sort(I, n_ptr, kfinal, L.kshift, (uint32_t *)(binning + L.pub.point_list), (uint32_t *)(binning + L.b_slot),
                                       (const uint32_t *)(geom + L.pub.depth_key), (uint32_t)(P - 1), other, seg_host_flag, seg_flag_value, debug, s);
-            static_assert(SEG_FRAC_BITS == 16, "segsort.hip reads the fraction from the key's low 16 bits");
             if (rc1) return rc1;
         }
         const int rearm = emit_slot ? EMIT_SLOT_WORDS : 0;

@@ -343,15 +343,19 @@ int launch_onesweep_partition(int64_t cap, char *geom, char *binning, const Layo
     uint32_t *ghist = ghist_override ? ghist_override : (uint32_t *)(binning + L.b_ghist), *ticket = (uint32_t *)(binning + L.b_ticket);
     u64 *status = (u64 *)(binning + L.b_status);
     const size_t per_pass = onesweep_status_bytes(cap, 1) / sizeof(u64);
-    // payloads: the splat id (read from gid_of by the first pass, then ping-pong B -> A ...) and the emission slot e (the input index
-    // in the first pass, then ping-pong so that the LAST pass writes slot_list)
-    uint32_t *kin = keyA, *kout = keyB, *vout = valB;
+    // payloads: the splat id (read from gid_of by the first pass, then ping-pong so that the LAST pass writes the buffer the layout calls
+    // point_list, whatever the number of passes: the backward pass lays the buffers out from tile_passes alone) and the emission slot e
+    // (the input index in the first pass, then ping-pong so that the last pass writes slot_list)
+    uint32_t *const pl_final = (uint32_t *)(binning + L.pub.point_list), *const pl_other = pl_final == valA ? valB : valA;
+    const int passes = L.part_passes;
+    uint32_t *kin = keyA, *kout = keyB;
     const uint32_t *vin = gid_of, *v2in = nullptr;
     int shift = 0, rc;
-    for (int p = 0; p < L.tile_passes; p++) {
+    for (int p = 0; p < passes; p++) {
         const int dw = tile_digit_width(L.kbits), bits = (L.kbits - shift) < dw ? (L.kbits - shift) : dw;   // (kbits = tbits unless segmented: common.h)
-        const int at = shift + L.kshift;   // (segmented: the digits sit above the 16 fraction bits of the key)
-        uint32_t *v2out = ((L.tile_passes - 1 - p) & 1) ? e_tmp : slot_list;
+        const int at = shift + L.kshift;   // (segmented: the digits sit above the fraction bits of the key)
+        uint32_t *vout = ((passes - 1 - p) & 1) ? pl_other : pl_final;
+        uint32_t *v2out = ((passes - 1 - p) & 1) ? e_tmp : slot_list;
         if ((rc = onesweep_pass(kin, vin, kout, vout, cap, n_ptr, at, bits, ghist + p * 256, status + p * per_pass, ticket + p,
                                 v2in, v2out, err, debug, s)))
             return rc;
@@ -359,7 +363,6 @@ int launch_onesweep_partition(int64_t cap, char *geom, char *binning, const Layo
         uint32_t *t = kin; kin = kout; kout = t;
         vin = vout;
         v2in = v2out;
-        vout = (vout == valB) ? valA : valB;
     }
     *keys_final = kin;
     return DAS3R_OK;

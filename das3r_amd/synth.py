@@ -16,6 +16,10 @@ WORKLOADS = {
     "c2": dict(P=100_000, W=1920, H=1080, focal=1200.0, sh_degree=3, seed=2),
     "c4": dict(P=1_000_000, W=1920, H=1080, focal=1200.0, sh_degree=3, seed=4),
     "ds": dict(P=5_000_000, W=512, H=208, focal=600.0, sh_degree=0, seed=5, s_px=(0.3, 1.5), opacity=0.02),
+    # ds with SPATIALLY COHERENT depth — what a real DAS3R scene looks like to a tile: every pixel of every frame is a Gaussian on
+    # the scene's surfaces, so a 16x16 tile sees a thin depth band (here a smooth relief z(u, v) with 1 % of noise), not the whole
+    # depth range as the random-depth `ds` does.  Same shape and count; the worst case for depth buckets that are global (round 4)
+    "dsc": dict(P=5_000_000, W=512, H=208, focal=600.0, sh_degree=0, seed=5, s_px=(0.3, 1.5), opacity=0.02, coherent=0.01),
     # c4 with the splats crowded towards the top of the frame (density ~ 1 / sqrt(height)): what an image with a busy band does to a
     # tile order that hands every XCD one contiguous band (tools/gpu_perf.py --workloads c4s; not a bench line)
     "c4s": dict(P=1_000_000, W=1920, H=1080, focal=1200.0, sh_degree=3, seed=4, y_skew=2.0),
@@ -59,7 +63,7 @@ def _logu(g, n, lo, hi):
     return torch.exp(torch.rand(n, generator=g) * (math.log(hi) - math.log(lo)) + math.log(lo))
 
 
-def make_scene(P, W, H, focal, sh_degree, seed, s_px=(0.5, 4.0), opacity=None, max_sh_degree=3, bg=(0.0, 0.0, 0.0), y_skew=1.0):
+def make_scene(P, W, H, focal, sh_degree, seed, s_px=(0.5, 4.0), opacity=None, max_sh_degree=3, bg=(0.0, 0.0, 0.0), y_skew=1.0, coherent=None):
     """Camera at the origin looking down +z (DAS3R convention: viewmatrix = I, campos = 0,
     projmatrix = I @ P^T — /root/reference/gaussian_renderer/__init__.py:57-61)."""
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -68,8 +72,12 @@ def make_scene(P, W, H, focal, sh_degree, seed, s_px=(0.5, 4.0), opacity=None, m
     view = torch.eye(4)
     proj = view @ projection_matrix(0.01, 100.0, fovx, fovy).transpose(0, 1)
     z = torch.rand(P, generator=g) * 9.0 + 1.0
-    x = z * tanfovx * (torch.rand(P, generator=g) * 2.2 - 1.1)
-    y = z * tanfovy * (torch.rand(P, generator=g) ** y_skew * 2.2 - 1.1)   # (y_skew > 1: crowded towards the top)
+    u, v = torch.rand(P, generator=g) * 2.2 - 1.1, torch.rand(P, generator=g) ** y_skew * 2.2 - 1.1   # (y_skew > 1: crowded towards the top)
+    if coherent is not None:   # depth = a smooth relief over the image + relative noise `coherent`
+        z = (4.0 + 2.0 * torch.sin(3.0 * u) * torch.cos(2.0 * v) + 1.5 * torch.cos(5.0 * u + 1.0)) * (1.0 + coherent * torch.randn(P, generator=g))
+        z = z.clamp_min(0.5)
+    x = z * tanfovx * u
+    y = z * tanfovy * v
     means3D = torch.stack([x, y, z], 1).contiguous()
     spx = _logu(g, P, *s_px)
     aniso = torch.stack([_logu(g, P, 0.5, 2.0) for _ in range(3)], 1)

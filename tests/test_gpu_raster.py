@@ -76,7 +76,7 @@ def test_compact_sh_layouts_and_ragged_waves_vs_oracle(degree):
 
 
 
-@pytest.mark.parametrize("binning_path", ["radix", "local", "seg"])
+@pytest.mark.parametrize("binning_path", ["radix", "local", "seg", "seg3"])
 @pytest.mark.parametrize("name", ["basic_deg3", "ragged_image", "long_lists", "deep", "culled", "depth_ties", "world_camera"])
 def test_binning_bit_exact(name, binning_path, monkeypatch):
     """Per-Gaussian geometry, depth order, per-tile splat lists and tile ranges are integer / exactly-rounded fp32 work:
@@ -84,13 +84,15 @@ def test_binning_bit_exact(name, binning_path, monkeypatch):
     opacity-aware clipped rectangle is covered by test_tight_rect_is_exact) — with the global depth sort and with the local
     depth order (lists emitted in index order and sorted by the compositing kernel: in LDS, or, "long_lists", in global
     memory when a list has more than 1024 entries), and with the segmented path of round 4 ("seg": partition by (tile, depth
-    bucket), then segment_sort_kernel — segkey.h, segsort.hip)."""
+    bucket), then segment_sort_kernel — segkey.h, segsort.hip; "seg3": the same with one more partition pass of bucket bits, what a
+    shape takes after a forward had to rank a long segment)."""
     monkeypatch.setenv("DAS3R_RECT", "upstream")
     monkeypatch.setenv("DAS3R_BINNING", binning_path)
     from das3r_amd import _lib
     _lib.profile_report()   # drain
     _lib.profile_enable(True)
     sc, mode = util.scene_variant(name)
+    L0_passes = 1 if ((sc.W + 15) // 16) * ((sc.H + 15) // 16) <= 256 else 2   # partition passes the tile ids alone need
     _, ref_radii, _, S = util.run_oracle(sc, mode, backward=False)
     from das3r_amd import GaussianRasterizationSettings
     from das3r_amd.rasterizer import _forward_impl
@@ -106,7 +108,8 @@ def test_binning_bit_exact(name, binning_path, monkeypatch):
     kernels = _lib.profile_report()
     ran = lambda prefix: any(k.startswith(prefix) for k in kernels)
     assert ran("depth_hist") == (binning_path == "radix"), kernels   # the local order and the segmented path skip the global depth sort
-    assert ran("segment_sort") == (binning_path == "seg"), kernels
+    assert ran("segment_sort") == binning_path.startswith("seg"), kernels
+    assert kernels["onesweep_pass_kernel"][0] == {"radix": 4 + L0_passes, "local": L0_passes, "seg": L0_passes, "seg3": L0_passes + 1}[binning_path], kernels
     assert np.array_equal(radii.cpu().numpy(), ref_radii)
     P, npix = sc.P, sc.W * sc.H
     L = _lib.layout(P, I, sc.W, sc.H)
@@ -537,8 +540,9 @@ def _lists_of(sc, mode, dev):
     return I, pl, rg, kernels, color
 
 
+@pytest.mark.parametrize("passes", ["seg", "seg3"])
 @pytest.mark.parametrize("case", ["one_wall", "three_layers", "thin_slab", "ties_and_spread", "one_tile_wall"])
-def test_segmented_binning_long_and_degenerate_segments(case, monkeypatch):
+def test_segmented_binning_long_and_degenerate_segments(case, passes, monkeypatch):
     """The segmented path (segkey.h, segsort.hip) where its depth buckets cannot help: every splat at ONE depth (a wall parallel to
     the image plane: each tile's whole list is one segment, ties broken by the index), three exact layers (segments of a third of
     a list: a few thousand entries, sorted by rank in LDS or, past the LDS span, by the global-memory network), a slab 1e-5 thick
@@ -562,7 +566,7 @@ def test_segmented_binning_long_and_degenerate_segments(case, monkeypatch):
         sc = _at_depths(sc, z)
     mode = dict(colors_precomp=False, cov3D_precomp=False, scale_modifier=1.0)
     monkeypatch.setenv("DAS3R_RECT", "upstream")
-    monkeypatch.setenv("DAS3R_BINNING", "seg")
+    monkeypatch.setenv("DAS3R_BINNING", passes)
     ref_color, _, _, S = util.run_oracle(sc, mode, backward=False)
     I, pl, rg, kernels, color = _lists_of(sc, mode, _dev())
     assert any(k.startswith("segment_sort") for k in kernels) and not any(k.startswith("depth_hist") for k in kernels), kernels
@@ -574,8 +578,9 @@ def test_segmented_binning_long_and_degenerate_segments(case, monkeypatch):
 
 def test_segmented_binning_is_chosen_for_long_lists_and_backs_off(monkeypatch):
     """Unforced: the first forward of a shape has no history (global sort), the next ones with long lists take the segmented path;
-    a segment that does not fit in LDS (here: 20 000 equal depths in one tile) is still sorted exactly and sends the following
-    forwards of the shape back to the global sort for a while.  Every forward's list is the oracle's."""
+    a segment that does not fit in LDS (here: 20 000 equal depths in one tile) is still sorted exactly and makes the shape take one
+    more partition pass of bucket bits; when that does not help either (equal depths share every bucket) the following forwards go
+    back to the global sort for a while.  Every forward's list is the oracle's."""
     from das3r_amd.synth import make_scene
     monkeypatch.delenv("DAS3R_BINNING", raising=False)
     monkeypatch.setenv("DAS3R_RECT", "upstream")
@@ -589,9 +594,10 @@ def test_segmented_binning_is_chosen_for_long_lists_and_backs_off(monkeypatch):
     for sc in (spread, spread, spread, wall, wall, spread):
         I, pl, _, kernels, _ = _lists_of(sc, mode, dev)
         assert np.array_equal(pl, want[id(sc)])
-        took.append("seg" if any(k.startswith("segment_sort") for k in kernels) else ("radix" if any(k.startswith("depth_hist") for k in kernels) else "local"))
-    assert took[0] == "radix" and took[1] == "seg" and took[2] == "seg", took      # history, then the segmented path
-    assert took[3] == "seg" and took[4] == "radix" and took[5] == "radix", took   # the wall's segment was too long: back-off
+        took.append(("seg%d" % kernels["onesweep_pass_kernel"][0]) if any(k.startswith("segment_sort") for k in kernels)
+                    else ("radix" if any(k.startswith("depth_hist") for k in kernels) else "local"))
+    assert took[:3] == ["radix", "seg1", "seg1"], took    # history, then the segmented path (one tile: one partition pass)
+    assert took[3:] == ["seg1", "seg2", "radix"], took    # the wall: too long -> one more pass of bucket bits -> still one segment -> global sort
 
 
 @pytest.mark.parametrize("render", ["quad", "rows"])
