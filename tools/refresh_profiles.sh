@@ -5,14 +5,14 @@
 #   <rn>_pmc_<w>.json / .txt     PMC passes (tools/pmc_collect.sh)
 #   <rn>_train_step_*.json       DAS3R-shaped optimisation step, unfused / fused
 # Everything lands in gpurun_out/profiles/ (copied into profiles/ by hand after a look).  Every child is time-bounded.
-R=$PWD; RN=${1:-r03}; OUT=$R/gpurun_out/profiles; mkdir -p $OUT
+R=$PWD; RN=${1:-r04}; OUT=$R/gpurun_out/profiles; mkdir -p $OUT
 export PYTHONPATH=$R
 timeout 300 python bench.py --full-line 2>$OUT/${RN}_bench_c4.stderr | tail -1 > $OUT/${RN}_bench_c4.json
-for w in c2 ds; do
+for w in c2 ds dsc; do
   timeout 200 python bench.py --workload $w --no-extras 2>/dev/null | tail -1 > $OUT/${RN}_bench_$w.json
 done
 cd /tmp; export TMPDIR=/tmp
-for w in c4 c2 ds; do
+for w in c4 c2 ds dsc; do
   rm -rf /tmp/kt_$w
   timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt_$w -o kt --output-format csv -- python $R/bench.py --workload $w --no-cpu-baseline --no-pmc > /dev/null 2>&1
   f=$(find /tmp/kt_$w -name '*kernel_stats.csv' | head -1)
