@@ -435,14 +435,14 @@ def cpu_baseline_of(sc_cpu, name, budget_s=30.0):
             "fwd_only": {"value": round(sc_cpu.P / medf / 1e6, 4), "unit": "Msplats/s", "ms_per_step": round(medf * 1e3, 2)}}
 
 
-def train_step_timer(dev, fused, frames=20, W=512, H=208):
+def train_step_timer(dev, fused, frames=20, W=512, H=208, depth="noise"):
     """-> (step callable, splats): the DAS3R-shaped optimisation step (render + masked L1/SSIM loss + backward + both Adam steps,
     train_gui.py:542-589) on a synthetic sequence with one Gaussian per pixel of every frame."""
     import torch
     from types import SimpleNamespace
     from das3r_amd.model import OptimParams
     from das3r_amd.train import build_from_sequence, synthetic_sequence, train_step
-    seq = synthetic_sequence(frames=frames, W=W, H=H, focal=600.0, n_splats=20000, seed=0, device=str(dev))
+    seq = synthetic_sequence(frames=frames, W=W, H=H, focal=600.0, n_splats=20000, seed=0, device=str(dev), depth=depth)
     model, cams = build_from_sequence(seq)
     opt = OptimParams(iterations=ITERS_PER_SCENE)
     model.training_setup(opt, fused=fused)
@@ -474,6 +474,14 @@ def extras_main(main_workload):
     out["train_step_fused_ms"] = round(rk.timed(fs_step, 100, 10) / 100 * 1e3, 4)
     out["train_step_splats"] = fs_splats
     del fs_step
+    torch.cuda.empty_cache()
+    # the same step on depth maps with the spatial coherence of a real predictor's (a smooth relief + 1 % noise instead of independent
+    # noise per pixel: a tile then sees a thin depth band, DESIGN.md section 4 ledger (ao)) — what a real sequence costs
+    co_step, _ = train_step_timer(dev, fused=True, depth="smooth")
+    for _ in range(INIT_STEPS):
+        co_step()
+    out["train_step_fused_smooth_depth_ms"] = round(rk.timed(co_step, 100, 10) / 100 * 1e3, 4)
+    del co_step
     torch.cuda.empty_cache()
     # the same step at the DAVIS size of the reference's held-out runs: 45 training frames of 512x288 = 6.6 M Gaussians
     # (scripts/testing_psnr_davis.sh:35-59; the whole 4000-iteration job at that size: profiles/r03_farm_davis_shape.json)
@@ -589,6 +597,8 @@ def main():
                      "image": [512, 208], "iters": 100}
             if "train_step_davis" in extras:
                 train["davis_shape"] = extras.pop("train_step_davis")
+            if "train_step_fused_smooth_depth_ms" in extras:
+                train["fused_smooth_depth"] = extras.pop("train_step_fused_smooth_depth_ms")
             if "train_step_unfused_ms" in extras:
                 train["unfused"] = extras.pop("train_step_unfused_ms")
     if train is None:

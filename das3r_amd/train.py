@@ -228,9 +228,12 @@ def latex_rows(results):
     return head, row
 
 
-def synthetic_sequence(frames=6, W=128, H=80, focal=110.0, n_splats=6000, seed=0, device="cuda"):
+def synthetic_sequence(frames=6, W=128, H=80, focal=110.0, n_splats=6000, seed=0, device="cuda", depth="noise"):
     """A static random splat cloud seen from `frames` slightly different poses -> per-frame images, depth proxies,
-    confidences, dynamic maps, intrinsics and poses in the layout SplatModel.create_from_frames expects."""
+    confidences, dynamic maps, intrinsics and poses in the layout SplatModel.create_from_frames expects.
+    depth: "noise" — 5 .. 5.5, independent per pixel (rounds 1-3: every tile sees the whole depth slab); "smooth" (round 4) — a
+    smooth relief with 1 % of noise, i.e. the spatially coherent depth a predictor's depth maps have: a tile sees a thin band of the
+    scene's depth range (ledger (ao))."""
     from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
     from .synth import make_scene
     dev = torch.device(device)
@@ -253,7 +256,12 @@ def synthetic_sequence(frames=6, W=128, H=80, focal=110.0, n_splats=6000, seed=0
         images.append(img.clamp(0, 1))
         poses7.append(torch.cat([torch.tensor([1.0, 0, 0, 0]), t]))
         c2w.append(torch.linalg.inv(view))
-        depths.append(torch.full((H, W), 5.0) + 0.5 * torch.rand(H, W, generator=g))
+        if depth == "smooth":
+            vv, uu = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, W), indexing="ij")
+            relief = 4.0 + 2.0 * torch.sin(3.0 * uu + 0.3 * f) * torch.cos(2.0 * vv) + 1.5 * torch.cos(5.0 * uu + 1.0)
+            depths.append(relief * (1.0 + 0.01 * torch.randn(H, W, generator=g)))
+        else:
+            depths.append(torch.full((H, W), 5.0) + 0.5 * torch.rand(H, W, generator=g))
     images = torch.stack(images)
     K = torch.tensor([[focal, 0, W / 2], [0, focal, H / 2], [0, 0, 1.0]]).repeat(frames, 1, 1).to(dev)
     return dict(images=images, depths=torch.stack(depths).to(dev), confs=torch.full((frames, H, W), 2.0, device=dev),

@@ -139,3 +139,23 @@ def test_farm_job_on_a_sequence_directory(tmp_path):
     assert poses.shape == (F - 1, 4, 4) and np.allclose(poses[:, 3], [0, 0, 0, 1])   # the optimised TRAINING poses (train_gui.py:467-480)
     log = (out / "test_log.txt").read_text()
     assert log.startswith("[ITER 12] Evaluating test: L1 ") and " PSNR " in log
+
+
+def test_farm_job_direct_and_autograd_iterations_agree_on_a_sequence_directory(tmp_path, monkeypatch):
+    """Round 4: the whole job — a sequence that came through the on-disk formats, 60 fused iterations with the held-out passes, the
+    report — with the direct iteration (das3r_amd/fast_step.py) and with the autograd form of the same kernels (DAS3R_FAST_STEP=0):
+    same held-out PSNR and L1.  (The first direct iteration read the ground-truth image by plain pointer; from disk it was a
+    [3, H, W] view of H x W x 3 memory, and a whole job trained towards a scrambled target with every unit test green.)"""
+    from das3r_amd import io_formats as io
+    from das3r_amd.farm import run_sequence_job
+    from das3r_amd.train import synthetic_sequence
+    seq = synthetic_sequence(frames=12, W=64, H=48, focal=70.0, n_splats=2500, seed=8)
+    d = tmp_path / "data" / "scene_b"
+    io.write_sequence_dir(seq, str(d))
+    recs = []
+    for fast in ("1", "0"):
+        monkeypatch.setenv("DAS3R_FAST_STEP", fast)
+        recs.append(run_sequence_job(0, 60, torch.device("cuda:0"), seq_dir=str(d), out_dir=str(tmp_path / ("out" + fast)), fused=True))
+    a, b = recs
+    assert a["ok"] == b["ok"] == 1
+    assert abs(a["psnr"] - b["psnr"]) <= 1e-3 and abs(a["l1"] - b["l1"]) <= 1e-5 * abs(b["l1"]) + 1e-7, (a, b)

@@ -296,22 +296,31 @@ def test_tight_rect_is_exact(name, monkeypatch):
         util.assert_grad_close(g_t[k].cpu().numpy(), g_up[k].cpu().numpy(), f"tight vs upstream rect dL/d{k}", tol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["basic_deg3", "long_lists", "deep", "culled"])
-def test_forward_kernels_agree_bit_for_bit(name, monkeypatch):
-    """The two forward compositing kernels (sub-list per 8x8 quadrant / per 4x4 block, render_rows.hip) visit every pixel's
-    splats in the same order with the same arithmetic: image, radii, final_T and n_contrib must be identical, and so must the
-    gradients computed from their saved state (up to the order of the per-wave LDS adds)."""
+@pytest.mark.parametrize("binning", ["radix", "seg"])
+@pytest.mark.parametrize("name", ["basic_deg3", "long_lists", "deep", "culled", "ragged_image", "depth_ties"])
+def test_forward_kernels_agree_bit_for_bit(name, binning, monkeypatch):
+    """The two forward compositing kernels (sub-list per 8x8 quadrant / per 4x4 block, render_rows.hip) visit every pixel's splats in
+    the same order with the same arithmetic: image, radii, final_T and n_contrib must be identical, and so must the gradients computed
+    from their saved state (up to the order of the per-wave LDS adds) — on lists from the global sort and from the segmented path."""
     sc, mode = util.scene_variant(name)
+    monkeypatch.setenv("DAS3R_BINNING", binning)
     out = {}
     for kind in ("quad", "rows"):
         monkeypatch.setenv("DAS3R_RENDER", kind)
+        from das3r_amd import _lib
+        _lib.profile_report()
+        _lib.profile_enable(True)
         c, r, g, fn = _run_hip(sc, mode)
+        _lib.profile_enable(False)
+        ran = _lib.profile_report()
+        assert any(k.startswith({"quad": "render_forward_kernel", "rows": "render_forward_rows"}[kind]) for k in ran), (kind, list(ran))
         out[kind] = (c, r, g, fn.num_rendered)
     cq, rq, gq, nq = out["quad"]
-    cr, rr, gr, nr = out["rows"]
-    assert nq == nr and torch.equal(cq, cr) and torch.equal(rq, rr)
-    for k in gq:   # the backward kernel consumes the forward's final_T / n_contrib: any difference there shows up here
-        util.assert_grad_close(gr[k].cpu().numpy(), gq[k].cpu().numpy(), f"rows vs quad forward dL/d{k}", tol=1e-5)
+    for kind in ("rows",):
+        cr, rr, gr, nr = out[kind]
+        assert nq == nr and torch.equal(cq, cr) and torch.equal(rq, rr), kind
+        for k in gq:   # the backward kernel consumes the forward's final_T / n_contrib: any difference there shows up here
+            util.assert_grad_close(gr[k].cpu().numpy(), gq[k].cpu().numpy(), f"{kind} vs quad forward dL/d{k}", tol=1e-5)
 
 
 def test_scratch_alignment_does_not_matter(monkeypatch):

@@ -32,14 +32,18 @@ def main():
             pl = binning[L["point_list"]:L["point_list"] + 4 * I].view(torch.int32).clone()
             tiles = ((sc.W + 15) // 16) * ((sc.H + 15) // 16)
             rg = img[L["ranges"]:L["ranges"] + 8 * tiles].view(torch.int32).clone()
+            npix = sc.W * sc.H
+            ft = img[L["final_T"]:L["final_T"] + 4 * npix].view(torch.float32).clone()
+            nc = img[L["n_contrib"]:L["n_contrib"] + 4 * npix].view(torch.int32).clone()
             if kind in out:
                 kind = kind + "2"
-            out[kind] = (I, pl, rg, color.clone(), radii.clone())
-        I0, pl0, rg0, c0, r0 = out["radix"]
+            out[kind] = (I, pl, rg, color.clone(), radii.clone(), ft, nc)
+        I0, pl0, rg0, c0, r0, ft0, nc0 = out["radix"]
         for k in ("seg", "seg2"):
-            I1, pl1, rg1, c1, r1 = out[k]
+            I1, pl1, rg1, c1, r1, ft1, nc1 = out[k]
             bad = int((pl0 != pl1).sum()) if I0 == I1 else -1
-            print(f"{w} {k}: I {I0} {I1}  list mismatches {bad}  ranges equal {bool(torch.equal(rg0, rg1))}  image equal {bool(torch.equal(c0, c1))}  radii equal {bool(torch.equal(r0, r1))}")
+            print(f"{w} {k}: I {I0} {I1}  list mismatches {bad}  ranges equal {bool(torch.equal(rg0, rg1))}  image equal {bool(torch.equal(c0, c1))}  radii equal {bool(torch.equal(r0, r1))}"
+                  f"  final_T equal {bool(torch.equal(ft0, ft1))}  n_contrib equal {bool(torch.equal(nc0, nc1))}")
             if bad > 0:
                 idx = torch.nonzero(pl0 != pl1).reshape(-1)
                 print("   first mismatches at", idx[:8].tolist(), "last", idx[-3:].tolist())

@@ -26,11 +26,12 @@ def main():
     ap.add_argument("--fused-loss", action="store_true")
     ap.add_argument("--fused-pre", action="store_true")
     ap.add_argument("--breakdown", action="store_true")
+    ap.add_argument("--depth", default="noise", choices=("noise", "smooth"), help="depth maps of the synthetic sequence (das3r_amd.train.synthetic_sequence)")
     args = ap.parse_args()
     from types import SimpleNamespace
     from das3r_amd.model import OptimParams
     from das3r_amd.train import build_from_sequence, synthetic_sequence, train_step
-    seq = synthetic_sequence(frames=args.frames, W=args.W, H=args.H, focal=600.0, n_splats=20000, seed=0)
+    seq = synthetic_sequence(frames=args.frames, W=args.W, H=args.H, focal=600.0, n_splats=20000, seed=0, depth=args.depth)
     model, cams = build_from_sequence(seq)
     opt = OptimParams(iterations=4000)
     model.training_setup(opt, fused=args.fused_adam) if args.fused_adam else model.training_setup(opt)
