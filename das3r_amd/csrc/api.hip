@@ -497,12 +497,13 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     // the binning buffer is laid out for that forward's count + 25 % and the whole forward is enqueued before the host looks
     // at the mailbox (the kernels clamp to the capacity).  Should the scene have grown past it, the binning and the
     // compositing are redone with the exact size.  DAS3R_CAPACITY=exact switches the speculation off.
-    if (local && verdict.last_I >= 0 && a->capacity_hint != -1 && !switches().capacity_exact) {
+    if ((local || seg) && verdict.last_I >= 0 && a->capacity_hint != -1 && !switches().capacity_exact) {   // (round 4: the segmented path too)
         // headroom: 25 % over the last count, 5 % over the (slowly forgotten) largest one — a camera that moves between views
         // of different density overflows rarely
         cap = std::max(verdict.last_I + verdict.last_I / 4, verdict.peak_I + verdict.peak_I / 20) + 4096;
         if (cap > (int64_t)0x7FFFFF00) cap = (int64_t)0x7FFFFF00;
         compute_layout(P, cap, W, H, &L);
+        apply_seg();
         saved->binning = alloc_binning(user, L.pub.binning_bytes);
         if (!saved->binning) { set_error("scratch allocation failed (binning %zu B)", L.pub.binning_bytes); return DAS3R_ERR_ALLOC; }
         // The count is not needed before the end of this call: the preprocess kernel skips its count reduction and the scan
@@ -513,7 +514,7 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         bool &emit_ring_dirty = T->emit_ring_dirty;
         uint32_t &emit_last_tag = T->emit_last_tag;
         constexpr size_t EMIT_SLOT_BYTES = sizeof(uint32_t) * EMIT_SLOT_WORDS + sizeof(unsigned long long) * EMIT_STATUS_GRANULES;
-        const bool fused_emit = grid_is_resident(div_up(P, 256)) && !switches().fused_emit_off;
+        const bool fused_emit = local && grid_is_resident(div_up(P, 256)) && !switches().fused_emit_off;
         uint32_t *emit_slot = nullptr;
         if (fused_emit) {
             if (!emit_ring) {
@@ -535,9 +536,14 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
             if ((rc = bin_and_render(cap, true, true, nullptr, 0, emit_slot))) return rc;
             emit_ring_dirty = false;
         } else {
+            uint32_t *dhist = nullptr;
+            if (seg) {   // the depth histogram of this forward (segkey.h): zeroed here, filled by the preprocess kernel, read by the emission
+                dhist = (uint32_t *)(saved->geom + L.g_dhist);
+                HIP_TRY(hipMemsetAsync(dhist, 0, 4 * 256, s));
+            }
             if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, saved->binning + L.b_ghist, L.b_ctrl_bytes, L, nullptr, mb->dev,
-                                        count_tag, s))) return rc;
-            if ((rc = bin_and_render(cap, true, true, mb->dev, count_tag))) return rc;
+                                        count_tag, s, nullptr, dhist))) return rc;
+            if ((rc = bin_and_render(cap, local, true, mb->dev, count_tag))) return rc;
         }
         if ((rc = mailbox_wait(mb, 2, count_tag, s))) return rc;
         I = (int64_t)mb->host[0];
@@ -549,9 +555,10 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
             compute_layout(P, cap, W, H, &L);
             saved->binning = alloc_binning(user, L.pub.binning_bytes);
             if (!saved->binning) { set_error("scratch allocation failed (binning %zu B)", L.pub.binning_bytes); return DAS3R_ERR_ALLOC; }
+            apply_seg();
             HIP_TRY(hipMemsetAsync(saved->geom + L.g_ghist, 0, L.g_ctrl_bytes, s));          // tickets and look-back words of the scan
             HIP_TRY(hipMemsetAsync(saved->img + L.pub.ranges, 0, 8 * (size_t)L.ntiles, s));
-            if ((rc = bin_and_render(cap, true, false))) return rc;
+            if ((rc = bin_and_render(cap, local, false))) return rc;
         }
     } else {
         uint32_t *dhist = nullptr;
