@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(256) FWD_WAVES(PREFETCH) render_forward_rows_k
 // rows forces one of the two forward kernels (A-B runs, tests).
 bool use_row_private(int64_t instances, int ntiles) {
     const int forced = switches().render_fwd;
-    if (forced) return forced == 2;
+    if (forced == 1 || forced == 2) return forced == 2;   // (3: render_lanes.hip where it applies, else by length)
     return instances >= (int64_t)128 * ntiles;
 }
 

@@ -20,6 +20,9 @@ def _view(buf, off, dtype, count):
     return buf[off:off + count * item].view(dtype)
 
 
+LANES_COLOR_TOL = 2e-6   # render_lanes.hip: the same colour terms in four partial sums per pixel (colours in [0, 1])
+
+
 def _run_hip(sc, mode, backward=True):
     from das3r_amd import GaussianRasterizationSettings, GaussianRasterizer
     dev = _dev()
@@ -299,27 +302,47 @@ def test_tight_rect_is_exact(name, monkeypatch):
 @pytest.mark.parametrize("binning", ["radix", "seg"])
 @pytest.mark.parametrize("name", ["basic_deg3", "long_lists", "deep", "culled", "ragged_image", "depth_ties"])
 def test_forward_kernels_agree_bit_for_bit(name, binning, monkeypatch):
-    """The two forward compositing kernels (sub-list per 8x8 quadrant / per 4x4 block, render_rows.hip) visit every pixel's splats in
-    the same order with the same arithmetic: image, radii, final_T and n_contrib must be identical, and so must the gradients computed
-    from their saved state (up to the order of the per-wave LDS adds) — on lists from the global sort and from the segmented path."""
+    """The forward compositing kernels — sub-list per 8x8 quadrant, per 4x4 block (render_rows.hip), four lanes per pixel
+    (render_lanes.hip) — visit every pixel's splats in the same order with the same arithmetic for alpha and T: radii, final_T and
+    n_contrib must be identical; so must the image of the first two, while the four-lanes kernel adds a pixel's colour terms in four
+    partial sums (LANES_COLOR_TOL); and the gradients computed from their saved state agree (up to the order of the per-wave LDS adds)
+    — on lists from the global sort and from the segmented path."""
+    from das3r_amd import GaussianRasterizationSettings, _lib, rasterizer
     sc, mode = util.scene_variant(name)
     monkeypatch.setenv("DAS3R_BINNING", binning)
-    out = {}
-    for kind in ("quad", "rows"):
+    dev = _dev()
+    out, state = {}, {}
+    for kind in ("quad", "rows", "lanes"):
         monkeypatch.setenv("DAS3R_RENDER", kind)
-        from das3r_amd import _lib
         _lib.profile_report()
         _lib.profile_enable(True)
         c, r, g, fn = _run_hip(sc, mode)
         _lib.profile_enable(False)
         ran = _lib.profile_report()
-        assert any(k.startswith({"quad": "render_forward_kernel", "rows": "render_forward_rows"}[kind]) for k in ran), (kind, list(ran))
+        assert any(k.startswith({"quad": "render_forward_kernel", "rows": "render_forward_rows", "lanes": "render_forward_lanes"}[kind]) for k in ran), (kind, list(ran))
         out[kind] = (c, r, g, fn.num_rendered)
+        # the saved per-pixel state itself
+        kw = {k: v.to(dev) for k, v in util.raster_inputs(sc, mode).items()}
+        skw = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in util.settings_kwargs(sc, mode).items()}
+        rs = GaussianRasterizationSettings(**skw)
+        e = torch.empty(0, device=dev)
+        I, _, _, _, _, img, _ = rasterizer._forward_full(rs, kw["means3D"], kw.get("shs", e), kw.get("colors_precomp", e), kw["opacities"],
+                                                         kw.get("scales", e), kw.get("rotations", e), kw.get("cov3D_precomp", e), exact=True)
+        torch.cuda.synchronize()
+        L = _lib.layout(sc.P, I, sc.W, sc.H)
+        npix = sc.W * sc.H
+        state[kind] = (img[L["final_T"]:L["final_T"] + 4 * npix].clone(), img[L["n_contrib"]:L["n_contrib"] + 4 * npix].clone())
     cq, rq, gq, nq = out["quad"]
-    for kind in ("rows",):
+    for kind in ("rows", "lanes"):
         cr, rr, gr, nr = out[kind]
-        assert nq == nr and torch.equal(cq, cr) and torch.equal(rq, rr), kind
-        for k in gq:   # the backward kernel consumes the forward's final_T / n_contrib: any difference there shows up here
+        assert nq == nr and torch.equal(rq, rr), kind
+        assert torch.equal(state["quad"][0], state[kind][0]), f"{kind}: final_T"
+        assert torch.equal(state["quad"][1], state[kind][1]), f"{kind}: n_contrib"
+        if kind == "lanes":
+            assert (cq - cr).abs().max().item() <= LANES_COLOR_TOL, (kind, (cq - cr).abs().max().item())
+        else:
+            assert torch.equal(cq, cr), kind
+        for k in gq:   # the backward kernel consumes the forward's final_T / n_contrib / checkpoints: any difference there shows up here
             util.assert_grad_close(gr[k].cpu().numpy(), gq[k].cpu().numpy(), f"{kind} vs quad forward dL/d{k}", tol=1e-5)
 
 

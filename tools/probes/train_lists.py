@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Tile lists of the DAS3R-shaped training scene (tools/train_bench.py's model) per depth kind: list lengths, the pixels' Σalpha
+and stops, entries per 4x4 block of a tile (the compositing kernels' row shares).   python tools/probes/train_lists.py smooth"""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from types import SimpleNamespace
+from das3r_amd import _lib
+from das3r_amd.rasterizer import _forward_full
+from das3r_amd.render import rasterizer_inputs
+from das3r_amd.train import build_from_sequence, synthetic_sequence
+from das3r_amd.model import OptimParams
+
+for depth in sys.argv[1].split(","):
+    seq = synthetic_sequence(frames=20, W=512, H=208, focal=600.0, n_splats=20000, seed=0, depth=depth)
+    model, cams = build_from_sequence(seq)
+    model.training_setup(OptimParams(iterations=4000), fused=True)
+    pipe = SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
+    bg = torch.zeros(3, device="cuda")
+    cam = cams[3]
+    pose = model.get_RT(cam.uid) if hasattr(model, "get_RT") else None
+    with torch.no_grad():
+        rs, kw = rasterizer_inputs(cam, model, pipe, bg, camera_pose=pose, fused=True)
+        e = torch.empty(0, device="cuda")
+        _lib.pair_counters(True)
+        I, color, radii, geom, binning, img, cap = _forward_full(rs, kw["means3D"], kw["shs"], e, kw["opacities"], kw["scales"], kw["rotations"], e, exact=True)
+        torch.cuda.synchronize()
+        pc = _lib.pair_counters(False)
+    W, H = 512, 208
+    P = kw["means3D"].shape[0]
+    L = _lib.layout(P, I, W, H)
+    tx, ty = (W + 15) // 16, (H + 15) // 16
+    nt = tx * ty
+    rg = img[L["ranges"]:L["ranges"] + 8 * nt].view(torch.int32).reshape(nt, 2).long()
+    ln = (rg[:, 1] - rg[:, 0]).cpu().numpy()
+    nc = img[L["n_contrib"]:L["n_contrib"] + 4 * W * H].view(torch.int32).cpu().numpy()
+    fT = img[L["final_T"]:L["final_T"] + 4 * W * H].view(torch.float32).cpu().numpy()
+    print(f"== {depth}: P {P} I {I} tiles {nt} list mean {ln.mean():.0f} pcts 10/50/90/99/max {np.percentile(ln, [10, 50, 90, 99, 100])}")
+    print(f"   radii>0 {(radii > 0).sum().item()}  n_contrib mean {nc.mean():.0f} max {nc.max()}  final_T mean {fT.mean():.4f} min {fT.min():.5f}  stopped pixels (T<1e-4-ish) {(fT < 2e-4).mean():.4f}")
+    print(f"   pair counters {pc}")
+    # entries per 4x4 block (the kernels' bounding-box test), per 256-entry batch of a tile's list: share of the busiest block
+    pl = binning[L["point_list"]:L["point_list"] + 4 * I].view(torch.int32).long()
+    xyh = _lib.splat_field(geom, L, "xy", P)[pl]
+    tile_of = torch.repeat_interleave(torch.arange(nt, device="cuda"), rg[:, 1] - rg[:, 0])
+    pos = torch.arange(I, device="cuda") - rg[tile_of, 0]
+    bx, by = (tile_of % tx).float() * 16, (tile_of // tx).float() * 16
+    hits = []
+    for r in range(16):
+        cx, cy = bx + (r % 4) * 4 + 1.5, by + (r // 4) * 4 + 1.5
+        hits.append(((xyh[:, 0] - cx).abs() <= xyh[:, 2] + 1.5) & ((xyh[:, 1] - cy).abs() <= xyh[:, 3] + 1.5))
+    hits = torch.stack(hits, 1).long()                                   # [I, 16]
+    print(f"   blocks hit per entry: mean {hits.sum(1).float().mean():.2f}")
+    batch = tile_of * 64 + pos // 256                                     # (lists < 16384)
+    per = torch.zeros(nt * 64, 16, dtype=torch.long, device="cuda").index_add_(0, batch, hits)
+    used = per.sum(1) > 0
+    per = per[used].float()
+    # a wave holds blocks {0,1,4,5}, {2,3,6,7}, {8,9,12,13}, {10,11,14,15}: it iterates for its longest row, the workgroup for its slowest wave
+    wv = torch.tensor([[0, 1, 4, 5], [2, 3, 6, 7], [8, 9, 12, 13], [10, 11, 14, 15]], device="cuda")
+    wmax = per[:, wv].max(2).values                                       # [batches, 4]
+    print(f"   per 256-entry batch: mean row share {per.mean():.1f}  mean of the wave's longest row {wmax.mean():.1f}  mean of the workgroup's longest row {wmax.max(1).values.mean():.1f}")
+    tot = torch.zeros(nt, 4, device="cuda").index_add_(0, torch.arange(nt * 64, device="cuda")[used] // 64, wmax)
+    lock = tot.max(1).values.cpu().numpy()                                # per tile: Σ over batches of the workgroup's slowest wave ≈ its iterations (barrier per batch)
+    print(f"   per tile Σ_batches max-wave iterations: mean {lock.mean():.0f} max {lock.max():.0f};   Σ_batches mean-row: {per.mean(1).sum().item() / nt:.0f}")
