@@ -24,8 +24,14 @@
 namespace das3r {
 
 constexpr int LN_THREADS = 1024;   // sixteen waves: one per 4x4 block of the tile
-constexpr int LN_BATCH = 512;      // entries staged per batch (two staging areas: one barrier per batch)
-constexpr int LN_LIST = LN_BATCH + 8;
+#ifndef LN_BATCH_N
+#define LN_BATCH_N 512
+#endif
+constexpr int LN_BATCH = LN_BATCH_N;      // entries staged per batch (two staging areas: one barrier per batch)
+#ifndef LN_UNROLL
+#define LN_UNROLL 2   // (1, 2 or 4)
+#endif
+constexpr int LN_LIST = LN_BATCH + 4 * LN_UNROLL + 4;
 
 template <int CTRL>
 __device__ __forceinline__ float quad_perm(const float v) {
@@ -41,6 +47,17 @@ __device__ __forceinline__ void quad_factors(const float v, const float m0, cons
         "v_max_f32_dpp %2, %3, %6 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1"
         : "=&v"(f0), "=&v"(f1), "=&v"(f2)
         : "v"(v), "v"(m0), "v"(m1), "v"(m2));
+}
+// min / max of numbers known not to be signalling NaNs (fminf / fmaxf canonicalise operands whose origin the compiler cannot see)
+__device__ __forceinline__ float min_raw(const float a, const float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float max_raw(const float a, const float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 __device__ __forceinline__ float quad_sum(const float v) {
     const float a = v + quad_perm<0xB1>(v);   // [1,0,3,2]
@@ -88,41 +105,28 @@ __global__ void __launch_bounds__(LN_THREADS) __attribute__((amdgpu_waves_per_eu
     int steps = 0;
     for (int i = tid; i < 16 * LN_LIST; i += LN_THREADS) (&lists[0][0])[i] = 0;   // (a stale list word must name a staged entry)
 
-    // the records of batch i + 1 and the list words of batch i + 2 are in flight while batch i composites (threads 0 .. LN_BATCH - 1)
-    float4 pf0 = make_float4(0.f, 0.f, 0.f, 0.f), pf1 = pf0, pf2 = pf0;
+    // Staging (threads 0 .. LN_BATCH - 1: waves 0 .. 7): batch i + 1 goes into the other area DURING batch i — its records are fetched behind
+    // the barrier of batch i (nobody reads that area any more: everybody has finished batch i - 1), arrive while the wave builds its list
+    // and are written in front of its walk, so that the walk does not carry them in registers; the list words of batch i + 2 are in
+    // flight meanwhile.
     uint32_t g_ahead = 0u;
-    const bool loader = tid < LN_BATCH;   // (waves 0 .. 7: uniform per wave)
+    const bool loader = tid < LN_BATCH;   // (uniform per wave)
     if (loader) {
+        StagedSplat rec = null_splat();
         if ((uint32_t)tid < n) {
             const uint32_t g = min(point_list[range.x + tid], lb.last_g);
-            pf0 = xyh[(size_t)g * SPLAT_REC];
-            pf1 = conic_opacity[(size_t)g * SPLAT_REC];
-            pf2 = rgbd[(size_t)g * SPLAT_REC];
+            rec.xyh = xyh[(size_t)g * SPLAT_REC];
+            rec.co = conic_opacity[(size_t)g * SPLAT_REC];
+            rec.rgbd = rgbd[(size_t)g * SPLAT_REC];
         }
         if ((uint32_t)(LN_BATCH + tid) < n) g_ahead = point_list[range.x + LN_BATCH + tid];
+        stage_all[tid] = rec;
     }
     for (int i = 0; i < rounds; i++) {
         StagedSplat *const stage = stage_all + (i & 1) * LN_BATCH;
         const uint32_t first = (uint32_t)i * LN_BATCH;
         const bool wave_done = __ballot(live != 0.f) == 0ull;
         if (lane == 0) s_done[i & 1][wave] = wave_done ? 1u : 0u;
-        if (loader) {
-            const uint32_t progress = range.x + first + tid;
-            if (progress < range.y) {
-                stage[tid].xyh = pf0;
-                stage[tid].co = pf1;
-                stage[tid].rgbd = pf2;
-            } else {
-                stage[tid] = null_splat();
-            }
-            if (progress + LN_BATCH < range.y) {
-                const uint32_t g = min(g_ahead, lb.last_g);
-                pf0 = xyh[(size_t)g * SPLAT_REC];
-                pf1 = conic_opacity[(size_t)g * SPLAT_REC];
-                pf2 = rgbd[(size_t)g * SPLAT_REC];
-            }
-            if (progress + 2 * LN_BATCH < range.y) g_ahead = point_list[progress + 2 * LN_BATCH];
-        }
         lds_barrier();   // (the loads just issued stay in flight: render_common.h)
         {   // every pixel of the tile has stopped?  (flags of this batch: rewritten two batches on, behind the next barrier)
             const uint32_t d = s_done[i & 1][lane & 15];
@@ -133,62 +137,89 @@ __global__ void __launch_bounds__(LN_THREADS) __attribute__((amdgpu_waves_per_eu
             if (k == 0) ckpt_slot(lb.ckpt, range, tile, next_slot)[cpix] = make_float4(T, q0, q1, q2);
             next_slot++;
         }
-        if (wave_done) continue;   // (uniform; the wave still stages and meets the barriers)
+        StagedSplat rec = null_splat();
+        const uint32_t progress = range.x + first + LN_BATCH + tid;   // my entry of batch i + 1
+        if (loader && i + 1 < rounds) {
+            if (progress < range.y) {
+                const uint32_t g = min(g_ahead, lb.last_g);
+                rec.xyh = xyh[(size_t)g * SPLAT_REC];
+                rec.co = conic_opacity[(size_t)g * SPLAT_REC];
+                rec.rgbd = rgbd[(size_t)g * SPLAT_REC];
+            }
+            if (progress + LN_BATCH < range.y) g_ahead = point_list[progress + LN_BATCH];
+        }
         // ---- this block's list of the batch ------------------------------------------------------------------------------------
         uint16_t *const mine = lists[wave];
         int len = 0;
-        const int nstaged = (int)min(n - first, (uint32_t)LN_BATCH);
+        if (!wave_done) {
+            const int nstaged = (int)min(n - first, (uint32_t)LN_BATCH);
 #pragma unroll
-        for (int c = 0; c < LN_BATCH / 64; c++) {
-            const int s = c * 64 + lane;
-            const float4 p = stage[s].xyh;   // (entries past the list hold extents no block can meet)
-            const bool hit = s < nstaged && fabsf(p.x - bcx) <= p.z + 1.5f && fabsf(p.y - bcy) <= p.w + 1.5f;
-            const uint64_t m = __ballot(hit);
-            const int at = len + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (hit) mine[at] = (uint16_t)s;
-            len += __popcll(m);
+            for (int c = 0; c < LN_BATCH / 64; c++) {
+                const int s = c * 64 + lane;
+                const float4 p = stage[s].xyh;   // (entries past the list hold extents no block can meet)
+                const bool hit = s < nstaged && fabsf(p.x - bcx) <= p.z + 1.5f && fabsf(p.y - bcy) <= p.w + 1.5f;
+                const uint64_t m = __ballot(hit);
+                const int at = len + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (hit) mine[at] = (uint16_t)s;
+                len += __popcll(m);
+            }
         }
+        if (loader && i + 1 < rounds) stage_all[((i + 1) & 1) * LN_BATCH + tid] = rec;
+        if (wave_done) continue;   // (uniform; the wave has staged its share and meets the barriers)
         // ---- the walk: four entries per step, one per lane of a quad -----------------------------------------------------------
         float lastf = -1.0f;
         const float lenf = (float)len - kf;   // (my position of step t exists where lenf - t >= 1)
-        for (int t = 0; t < len; t += 4) {
-            if ((t & 63) == 0 && __ballot(live != 0.f) == 0ull) break;
-            steps++;
-            const int j = (int)mine[t + k];
+        // alpha of staged entry j for my pixel (0 where it is invisible or the list has no such position), its colour
+        auto entry_alpha = [&](const int j, const float rem, float4 &c) -> float {
             const float4 p = stage[j].xyh;
             const float4 co = stage[j].co;
-            const float4 c = lds_read4(&stage[j].rgbd);
+            c = lds_read4(&stage[j].rgbd);
             const float dx = p.x - pxf, dy = p.y - pyf;
             const float q = __fmaf_rn(__fmul_rn(co.x, dx), dx, __fmul_rn(__fmul_rn(co.z, dy), dy));
             const float power = __fmaf_rn(-0.5f, q, -__fmul_rn(__fmul_rn(co.y, dx), dy));   // (pair_alpha's arithmetic)
-            const float a1 = fminf(fminf(0.99f, __fmul_rn(co.w, __expf(power))), lenf - (float)t);
-            const float a = alpha_if_visible(a1, power) * live;   // (a1 is not positive where the list has no position)
+            const float a1 = fminf(fminf(0.99f, __fmul_rn(co.w, __expf(power))), rem);
+            return alpha_if_visible(a1, power);   // (a1 is not positive where the list has no position)
+        };
+        // the quad's four entries into the pixel, in list order
+        auto blend_step = [&](const float av, const float4 c, const float jf) {
+            const float a = av * live;
             const float om = 1.0f - a;
             // T in front of my entry: the pixel's T times the factors of the lanes in front of me, in list order
             float f0, f1, f2;
             quad_factors(om, mk0, mk1, mk2, f0, f1, f2);
             const float x = __fmul_rn(__fmul_rn(__fmul_rn(T, f0), f1), f2);
             const float tn = __fmul_rn(x, om);   // the reference's test_T of my entry
-            const float jf = (float)j;
-            if (__builtin_expect(__ballot(tn < 0.0001f) == 0ull, 1)) {
-                const float wT = a * x;
-                C0 = __fmaf_rn(c.x, wT, C0);
-                C1 = __fmaf_rn(c.y, wT, C1);
-                C2 = __fmaf_rn(c.z, wT, C2);
-                lastf = fmaxf(lastf, fminf(jf, __fmaf_rn(a, 1e30f, -1.0f)));
-                T = quad_perm<0xFF>(tn);
-            } else {
-                // a pixel of this wave stops inside the step: test_T falls along the quad, the entries in front of the first failure
-                // are taken as they are (their T does not involve the failing entry), the failing one and those behind it are not
-                const float s = tn < 0.0001f ? 0.f : 1.f;
-                const float w = a * s, wT = w * x;
-                C0 = __fmaf_rn(c.x, wT, C0);
-                C1 = __fmaf_rn(c.y, wT, C1);
-                C2 = __fmaf_rn(c.z, wT, C2);
-                lastf = fmaxf(lastf, fminf(jf, __fmaf_rn(w, 1e30f, -1.0f)));
-                T = quad_min(s != 0.f ? tn : T);   // T behind the last entry taken (the pixel's T where none is)
-                live *= quad_min(s);
+            // A pixel of this wave stops inside the step (rare: once in a pixel's life): test_T falls along the quad, the entries in front
+            // of the first failure are taken as they are (their T does not involve the failing entry), the failing one and those behind
+            // it are not.  Only the three values below differ; the common path overwrites nothing it has to keep.
+            float s = 1.0f, t_next = quad_perm<0xFF>(tn), l_next = live;
+            if (__builtin_expect(__ballot(tn < 0.0001f) != 0ull, 0)) {
+                s = tn < 0.0001f ? 0.f : 1.f;
+                t_next = quad_min(s != 0.f ? tn : T);   // T behind the last entry taken (the pixel's T where none is)
+                l_next = live * quad_min(s);
             }
+            const float w = a * s, wT = w * x;
+            C0 = __fmaf_rn(c.x, wT, C0);
+            C1 = __fmaf_rn(c.y, wT, C1);
+            C2 = __fmaf_rn(c.z, wT, C2);
+            lastf = max_raw(lastf, min_raw(jf, __fmaf_rn(w, 1e30f, -1.0f)));
+            T = t_next;
+            live = l_next;
+        };
+        // LN_UNROLL steps per trip: the entries' fetches and exponents are independent of the pixel's state and overlap; the blends follow in order
+        for (int t = 0; t < len; t += 4 * LN_UNROLL) {
+            if ((t & 63) == 0 && __ballot(live != 0.f) == 0ull) break;
+            steps += min(LN_UNROLL, (len - t + 3) >> 2);
+            int j[LN_UNROLL];
+            float4 c[LN_UNROLL];
+            float av[LN_UNROLL];
+            const float rem = lenf - (float)t;
+#pragma unroll
+            for (int u = 0; u < LN_UNROLL; u++) j[u] = (int)mine[t + 4 * u + k];
+#pragma unroll
+            for (int u = 0; u < LN_UNROLL; u++) av[u] = entry_alpha(j[u], rem - (float)(4 * u), c[u]);
+#pragma unroll
+            for (int u = 0; u < LN_UNROLL; u++) blend_step(av[u], c[u], (float)j[u]);
         }
         if (lastf >= 0.0f) last_contributor = first + (uint32_t)lastf + 1u;
     }

@@ -4,7 +4,7 @@
 # The default library is rebuilt at the end.
 set -e
 cd "$(dirname "$0")/../das3r_amd/csrc"
-SRC="api.hip render_rows.hip render_fwd.hip render_bwd_blk.hip render_bwd.hip preprocess.hip preprocess_bwd.hip sort_onesweep.hip scan_emit.hip segsort.hip"
+SRC="api.hip render_rows.hip render_fwd.hip render_bwd_blk.hip render_bwd.hip preprocess.hip preprocess_bwd.hip sort_onesweep.hip scan_emit.hip segsort.hip render_lanes.hip"
 while [ $# -ge 2 ]; do
   touch $SRC
   make -s -j8 XFLAGS="$2" 2>&1 | grep -i " error" -A6 || true

@@ -27,6 +27,13 @@ for depth in sys.argv[1].split(","):
         I, color, radii, geom, binning, img, cap = _forward_full(rs, kw["means3D"], kw["shs"], e, kw["opacities"], kw["scales"], kw["rotations"], e, exact=True)
         torch.cuda.synchronize()
         pc = _lib.pair_counters(False)
+    from das3r_amd import GaussianRasterizer
+    leaves = {k: (v.detach().clone().requires_grad_(True) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in kw.items()}
+    _lib.pair_counters(True)
+    img2, _ = GaussianRasterizer(raster_settings=rs)(**leaves)
+    img2.backward(torch.randn_like(img2))
+    torch.cuda.synchronize()
+    print(f"   forward + backward pair counters {_lib.pair_counters(False)}")
     W, H = 512, 208
     P = kw["means3D"].shape[0]
     L = _lib.layout(P, I, W, H)
@@ -62,3 +69,11 @@ for depth in sys.argv[1].split(","):
     tot = torch.zeros(nt, 4, device="cuda").index_add_(0, torch.arange(nt * 64, device="cuda")[used] // 64, wmax)
     lock = tot.max(1).values.cpu().numpy()                                # per tile: Σ over batches of the workgroup's slowest wave ≈ its iterations (barrier per batch)
     print(f"   per tile Σ_batches max-wave iterations: mean {lock.mean():.0f} max {lock.max():.0f};   Σ_batches mean-row: {per.mean(1).sum().item() / nt:.0f}")
+    for B in (256, 512, 1024):
+        nbt = 16384 // B * 2
+        batch = tile_of * nbt + pos // B
+        per = torch.zeros(nt * nbt, 16, dtype=torch.long, device="cuda").index_add_(0, batch, hits)
+        steps = (per + 3) // 4                                            # four-lanes kernel: steps of a block per batch
+        tmax = steps.max(1).values.reshape(nt, nbt).sum(1).float()        # a barrier per batch: the workgroup's slowest block
+        tmean = steps.float().mean(1).reshape(nt, nbt).sum(1)
+        print(f"   four lanes per pixel, batches of {B}: steps per tile, slowest block per batch: mean {tmax.mean():.0f} max {tmax.max():.0f};  mean block: mean {tmean.mean():.0f} max {tmean.max():.0f}")
