@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "adam_math.h"
 
 namespace das3r {
 
@@ -67,11 +68,9 @@ __global__ void __launch_bounds__(256) adam_kernel(const AdamTable T, float beta
             const int col = (int)(e % active_len);
             const long long off = (row_len == active_len) ? e : (e / active_len) * row_len + col;
             const float gr = g[(grad_row_len == row_len) ? off : (e / active_len) * grad_row_len + col];   // (a compact gradient: its own row stride)
-            float mm = m[off], vv = v[off];
-            mm = mm + (gr - mm) * (1.0f - beta1);
-            vv = vv * beta2 + (1.0f - beta2) * gr * gr;
-            const float denom = sqrtf(vv) / bc2_sqrt + eps;
-            p[off] = p[off] - (col < head_len ? step_size : step_size_tail) * (mm / denom);
+            float pp = p[off], mm = m[off], vv = v[off];
+            adam_update(pp, mm, vv, gr, beta1, beta2, eps, col < head_len ? step_size : step_size_tail, bc2_sqrt);
+            p[off] = pp;
             m[off] = mm;
             v[off] = vv;
         }

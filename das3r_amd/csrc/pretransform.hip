@@ -10,6 +10,7 @@
 // HBM-bound: 44 B in + 44 B out per splat forward, 88 B in + 44 B out backward.  Opt-in (das3r_render(fused=True)); the
 // default path of an unmodified DAS3R checkout is untouched.
 #include "common.h"
+#include "adam_math.h"
 
 namespace das3r {
 
@@ -44,12 +45,35 @@ __global__ void __launch_bounds__(256) pretransform_forward_kernel(int P, const 
     }
 }
 
+// a b as a rounded fp32 number, whatever consumes it: a gradient is the same number in every MODE below — written to memory (MODE 0) or
+// handed to the Adam step in a register (MODE 1), where the compiler would otherwise contract the product into the step's first subtraction
+// (__fmul_rn is a plain multiplication to this compiler, contraction included)
+__device__ __forceinline__ float rounded_product(const float a, const float b) {
+    float r = a * b;
+    asm volatile("" : "+v"(r));
+    return r;
+}
+
+// The four per-Gaussian parameter tensors the pre-transform reads, as Adam sees them (MODE 1 below): parameter, first and second
+// moment, step_size = lr / (1 - beta1^t) and sqrt(1 - beta2^t) of the group it belongs to.
+struct GeometryAdam {
+    float *p[4], *m[4], *v[4];   // xyz [P,3], rotation [P,4], scaling [P,3], opacity [P,1]
+    float step_size[4], bc2_sqrt[4];
+    float beta1, beta2, eps;
+};
+
+// MODE 0: the backward as a producer of gradients (g_xyz, g_rotation, g_scaling, g_opacity_raw, g_conf_flat, the 28 pose sums).
+// MODE 1 (round 4): the same gradients never leave the registers — the Adam step of the four tensors is taken on the spot (adam_math.h:
+//   the arithmetic of adam_kernel): the gradients are not written (44 B per Gaussian) and not read back by the optimizer (44 B), the
+//   parameters are read once for both; g_conf_flat and the pose sums leave as before (the confidence map and the camera have their own steps).
+// MODE 2: the pose sums alone (the held-out-pose pass drops every other gradient: das3r_amd/fast_step.py test_pose_step).
+template <int MODE>
 __global__ void __launch_bounds__(256) pretransform_backward_kernel(
-    int P, const float *__restrict__ xyz, const float *__restrict__ rot, const float *__restrict__ scaling,
-    const float *__restrict__ opacity_raw, const float *__restrict__ conf_flat, const int64_t *__restrict__ mask_index,
-    const float *__restrict__ Rm, const float *__restrict__ Lq, const float *__restrict__ g_means3D, const float *__restrict__ g_rot,
-    const float *__restrict__ g_scales, const float *__restrict__ g_opac, float *__restrict__ g_xyz, float *__restrict__ g_rotation,
-    float *__restrict__ g_scaling, float *__restrict__ g_opacity_raw, float *__restrict__ g_conf_flat, float *__restrict__ g_small) {
+    int P, const float *xyz, const float *rot, const float *scaling, const float *opacity_raw /*(MODE 1: A.p[0 .. 3], written below — no __restrict__)*/,
+    const float *__restrict__ conf_flat, const int64_t *__restrict__ mask_index, const float *__restrict__ Rm, const float *__restrict__ Lq,
+    const float *__restrict__ g_means3D, const float *__restrict__ g_rot, const float *__restrict__ g_scales, const float *__restrict__ g_opac,
+    float *__restrict__ g_xyz, float *__restrict__ g_rotation, float *__restrict__ g_scaling, float *__restrict__ g_opacity_raw,
+    float *__restrict__ g_conf_flat, float *__restrict__ g_small, const GeometryAdam A) {
     __shared__ float red[4][28];
     float R[9], L[16];
 #pragma unroll
@@ -62,30 +86,73 @@ __global__ void __launch_bounds__(256) pretransform_backward_kernel(
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x) {
         const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
         const float gx = g_means3D[3 * (size_t)i], gy = g_means3D[3 * (size_t)i + 1], gz = g_means3D[3 * (size_t)i + 2];
-        g_xyz[3 * (size_t)i] = R[0] * gx + R[3] * gy + R[6] * gz;       // R^T g
-        g_xyz[3 * (size_t)i + 1] = R[1] * gx + R[4] * gy + R[7] * gz;
-        g_xyz[3 * (size_t)i + 2] = R[2] * gx + R[5] * gy + R[8] * gz;
+        const float rx[3] = {R[0] * gx + R[3] * gy + R[6] * gz, R[1] * gx + R[4] * gy + R[7] * gz, R[2] * gx + R[5] * gy + R[8] * gz};   // R^T g
         acc[0] += gx * x; acc[1] += gx * y; acc[2] += gx * z;
         acc[3] += gy * x; acc[4] += gy * y; acc[5] += gy * z;
         acc[6] += gz * x; acc[7] += gz * y; acc[8] += gz * z;
         acc[9] += gx; acc[10] += gy; acc[11] += gz;
         const float4 q = reinterpret_cast<const float4 *>(rot)[i];
         const float4 gq = reinterpret_cast<const float4 *>(g_rot)[i];
-        reinterpret_cast<float4 *>(g_rotation)[i] =
-            make_float4(L[0] * gq.x + L[4] * gq.y + L[8] * gq.z + L[12] * gq.w, L[1] * gq.x + L[5] * gq.y + L[9] * gq.z + L[13] * gq.w,
-                        L[2] * gq.x + L[6] * gq.y + L[10] * gq.z + L[14] * gq.w, L[3] * gq.x + L[7] * gq.y + L[11] * gq.z + L[15] * gq.w);
+        const float4 rq = make_float4(L[0] * gq.x + L[4] * gq.y + L[8] * gq.z + L[12] * gq.w, L[1] * gq.x + L[5] * gq.y + L[9] * gq.z + L[13] * gq.w,
+                                      L[2] * gq.x + L[6] * gq.y + L[10] * gq.z + L[14] * gq.w, L[3] * gq.x + L[7] * gq.y + L[11] * gq.z + L[15] * gq.w);
         const float gv[4] = {gq.x, gq.y, gq.z, gq.w}, qv[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
         for (int a = 0; a < 4; a++)
 #pragma unroll
             for (int b = 0; b < 4; b++) acc[12 + 4 * a + b] += gv[a] * qv[b];
+        if constexpr (MODE == 2) continue;
+        float sc[3], rs[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) g_scaling[3 * (size_t)i + k] = g_scales[3 * (size_t)i + k] * expf(scaling[3 * (size_t)i + k]);
-        const float s = 1.0f / (1.0f + expf(-opacity_raw[i]));
+        for (int k = 0; k < 3; k++) {
+            sc[k] = scaling[3 * (size_t)i + k];
+            rs[k] = rounded_product(g_scales[3 * (size_t)i + k], expf(sc[k]));
+        }
+        const float o = opacity_raw[i];
+        const float s = 1.0f / (1.0f + expf(-o));
         const int64_t ci = mask_index ? mask_index[i] : (int64_t)i;
         const float c = conf_flat[ci], go = g_opac[i];
-        g_opacity_raw[i] = go * c * s * (1.0f - s);
+        const float ro = rounded_product(go * c * s, 1.0f - s);
         g_conf_flat[ci] = go * s;   // mask positions are unique: plain store into the pre-zeroed buffer
+        if constexpr (MODE == 0) {
+            g_xyz[3 * (size_t)i] = rx[0];
+            g_xyz[3 * (size_t)i + 1] = rx[1];
+            g_xyz[3 * (size_t)i + 2] = rx[2];
+            reinterpret_cast<float4 *>(g_rotation)[i] = rq;
+#pragma unroll
+            for (int k = 0; k < 3; k++) g_scaling[3 * (size_t)i + k] = rs[k];
+            g_opacity_raw[i] = ro;
+        } else {
+            float pv[3] = {x, y, z};
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                float m = A.m[0][3 * (size_t)i + k], v = A.v[0][3 * (size_t)i + k];
+                adam_update(pv[k], m, v, rx[k], A.beta1, A.beta2, A.eps, A.step_size[0], A.bc2_sqrt[0]);
+                A.p[0][3 * (size_t)i + k] = pv[k];
+                A.m[0][3 * (size_t)i + k] = m;
+                A.v[0][3 * (size_t)i + k] = v;
+            }
+            float4 qm = reinterpret_cast<const float4 *>(A.m[1])[i], qvv = reinterpret_cast<const float4 *>(A.v[1])[i], qp = q;
+            adam_update(qp.x, qm.x, qvv.x, rq.x, A.beta1, A.beta2, A.eps, A.step_size[1], A.bc2_sqrt[1]);
+            adam_update(qp.y, qm.y, qvv.y, rq.y, A.beta1, A.beta2, A.eps, A.step_size[1], A.bc2_sqrt[1]);
+            adam_update(qp.z, qm.z, qvv.z, rq.z, A.beta1, A.beta2, A.eps, A.step_size[1], A.bc2_sqrt[1]);
+            adam_update(qp.w, qm.w, qvv.w, rq.w, A.beta1, A.beta2, A.eps, A.step_size[1], A.bc2_sqrt[1]);
+            reinterpret_cast<float4 *>(A.p[1])[i] = qp;
+            reinterpret_cast<float4 *>(A.m[1])[i] = qm;
+            reinterpret_cast<float4 *>(A.v[1])[i] = qvv;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                float m = A.m[2][3 * (size_t)i + k], v = A.v[2][3 * (size_t)i + k];
+                adam_update(sc[k], m, v, rs[k], A.beta1, A.beta2, A.eps, A.step_size[2], A.bc2_sqrt[2]);
+                A.p[2][3 * (size_t)i + k] = sc[k];
+                A.m[2][3 * (size_t)i + k] = m;
+                A.v[2][3 * (size_t)i + k] = v;
+            }
+            float op = o, m = A.m[3][i], v = A.v[3][i];
+            adam_update(op, m, v, ro, A.beta1, A.beta2, A.eps, A.step_size[3], A.bc2_sqrt[3]);
+            A.p[3][i] = op;
+            A.m[3][i] = m;
+            A.v[3][i] = v;
+        }
     }
     // 28 sums over all splats: wave reduction on the DPP network, 4 waves through LDS, one atomic per workgroup
     const int lane = __lane_id(), wave = threadIdx.x >> 6;
@@ -211,8 +278,55 @@ extern "C" int das3r_pretransform_backward(int32_t P, const float *xyz, const fl
     if (P == 0) return DAS3R_OK;
     hipStream_t s = (hipStream_t)stream;
     const int blocks = div_up(P, 256) < 1024 ? div_up(P, 256) : 1024;
-    DAS3R_LAUNCH(pretransform_backward_kernel, dim3(blocks), dim3(256), 0, s, P, xyz, rot, scaling, opacity_raw, conf_flat, mask_index, R,
-                 Lq, g_means3D, g_rot, g_scales, g_opac, g_xyz, g_rotation, g_scaling, g_opacity_raw, g_conf_flat, g_small);
+    DAS3R_LAUNCH((pretransform_backward_kernel<0>), dim3(blocks), dim3(256), 0, s, P, xyz, rot, scaling, opacity_raw, conf_flat, mask_index, R,
+                 Lq, g_means3D, g_rot, g_scales, g_opac, g_xyz, g_rotation, g_scaling, g_opacity_raw, g_conf_flat, g_small, GeometryAdam{});
     KERNEL_CHECK(s, false, "pretransform_backward");
+    return DAS3R_OK;
+}
+
+// The backward of the pre-transform with the Adam step of the four tensors it differentiates taken in the same pass (ABI 11; see
+// pretransform_backward_kernel MODE 1).  xyz / rot / scaling / opacity_raw ARE slots[0 .. 3].param and are updated in place.
+extern "C" int das3r_pretransform_backward_adam(int32_t P, const float *conf_flat, const int64_t *mask_index, const float *R, const float *Lq,
+                                                const float *g_means3D, const float *g_rot, const float *g_scales, const float *g_opac,
+                                                float *g_conf_flat, float *g_small, const das3r_adam_slot *slots, float beta1, float beta2, float eps,
+                                                das3r_stream_t stream) {
+    if (P < 0 || !slots || (P > 0 && (!conf_flat || !R || !Lq || !g_means3D || !g_rot || !g_scales || !g_opac || !g_conf_flat || !g_small))) {
+        set_error("das3r_pretransform_backward_adam: invalid argument");
+        return DAS3R_ERR_INVALID_ARG;
+    }
+    GeometryAdam A;
+    for (int k = 0; k < 4; k++) {
+        if (P > 0 && (!slots[k].param || !slots[k].exp_avg || !slots[k].exp_avg_sq || !(slots[k].bc2_sqrt > 0.f))) {
+            set_error("das3r_pretransform_backward_adam: bad slot %d", k);
+            return DAS3R_ERR_INVALID_ARG;
+        }
+        A.p[k] = slots[k].param; A.m[k] = slots[k].exp_avg; A.v[k] = slots[k].exp_avg_sq;
+        A.step_size[k] = slots[k].step_size; A.bc2_sqrt[k] = slots[k].bc2_sqrt;
+    }
+    A.beta1 = beta1; A.beta2 = beta2; A.eps = eps;
+    if (P == 0) return DAS3R_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = div_up(P, 256) < 2048 ? div_up(P, 256) : 2048;
+    DAS3R_LAUNCH((pretransform_backward_kernel<1>), dim3(blocks), dim3(256), 0, s, P, (const float *)A.p[0], (const float *)A.p[1], (const float *)A.p[2],
+                 (const float *)A.p[3], conf_flat, mask_index, R, Lq, g_means3D, g_rot, g_scales, g_opac, (float *)nullptr, (float *)nullptr,
+                 (float *)nullptr, (float *)nullptr, g_conf_flat, g_small, A);
+    KERNEL_CHECK(s, false, "pretransform_backward_adam");
+    return DAS3R_OK;
+}
+
+// The 28 pose sums alone (MODE 2): what a pass that only differentiates the camera needs.
+extern "C" int das3r_pretransform_pose_sums(int32_t P, const float *xyz, const float *rot, const float *R, const float *Lq, const float *g_means3D,
+                                            const float *g_rot, float *g_small, das3r_stream_t stream) {
+    if (P < 0 || (P > 0 && (!xyz || !rot || !R || !Lq || !g_means3D || !g_rot || !g_small))) {
+        set_error("das3r_pretransform_pose_sums: invalid argument");
+        return DAS3R_ERR_INVALID_ARG;
+    }
+    if (P == 0) return DAS3R_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = div_up(P, 256) < 1024 ? div_up(P, 256) : 1024;
+    DAS3R_LAUNCH((pretransform_backward_kernel<2>), dim3(blocks), dim3(256), 0, s, P, xyz, rot, (const float *)nullptr, (const float *)nullptr,
+                 (const float *)nullptr, (const int64_t *)nullptr, R, Lq, g_means3D, g_rot, (const float *)nullptr, (const float *)nullptr,
+                 (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, g_small, GeometryAdam{});
+    KERNEL_CHECK(s, false, "pretransform_pose_sums");
     return DAS3R_OK;
 }

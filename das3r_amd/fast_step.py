@@ -9,8 +9,10 @@ whole conf_static tensor for one frame's mask gradient, a dozen scalar kernels f
     pose row of Q, row of T  -> das3r_pose_matrices_qt -> das3r_pretransform_forward
     cached settings (identity view, projection, zero campos: built once per camera)
     das3r_raster_forward -> das3r_photometric_forward -> das3r_photometric_finish  {loss, mse, psnr_frame} on the device
-    das3r_photometric_backward -> das3r_raster_backward -> das3r_pretransform_backward -> das3r_pose_chain_qt
-    FusedAdam.step (one launch), FusedAdam.step(gate = psnr_frame) for the poses
+    das3r_photometric_backward -> das3r_raster_backward -> das3r_pretransform_backward_adam -> das3r_pose_chain_qt
+        (ABI 11: the chain rule through the pre-transform AND the Adam step of xyz / rotation / scaling / opacity in one pass — those
+         four gradients never reach memory; model.fuse_geometry_adam = False keeps das3r_pretransform_backward + gradients)
+    FusedAdam.step (one launch: f_dc, f_rest, conf_static), FusedAdam.step(gate = psnr_frame) for the poses
 
 Gradients land where FusedAdam expects them (`p.grad`, or the compact SH gradient of fused._ShPrefix's contract); the pose gradient
 is written into row `uid` of two dense, otherwise zero buffers (torch's index backward produces exactly that dense gradient, and
@@ -116,10 +118,14 @@ def _settings(st, cam, model, bg):
     return rs
 
 
-def forward_backward(model, cam, q_row, t_row, gq_row, gt_row, static_hw, lambda_dssim, bg):
+def forward_backward(model, cam, q_row, t_row, gq_row, gt_row, static_hw, lambda_dssim, bg, geometry="grads"):
     """Render `cam` with the pose (q_row, t_row: views of one row of Q / T), masked photometric loss against cam.original_image
     under `static_hw` [H, W], and the complete backward.  Gradients: model parameters' .grad (f_rest: compact or none, as in
     das3r_amd.render), the pose gradient into gq_row / gt_row, d loss / d static_hw returned.
+    geometry: what becomes of the gradients of xyz / rotation / scaling / opacity, which exist in camera space when the rasterizer's backward
+    returns — "grads": chain rule through the pre-transform, left on the parameters' .grad; "adam": the same chain rule with the Adam
+    step of the four tensors taken in that very pass (das3r_pretransform_backward_adam: they never reach memory; model.optimizer.step()
+    then finds the four without gradient and passes them by); "pose": the camera's sums alone, every per-Gaussian gradient dropped.
     -> (out8 = {loss, mse x 3, psnr_frame, ...} device tensor, d_static [H, W], package)"""
     lib = _lib.load()
     st = _state(model)
@@ -164,27 +170,43 @@ def forward_backward(model, cam, q_row, t_row, gq_row, gt_row, static_hw, lambda
     g_means2D, _g_colors, g_opac, g_means3D, _g_cov, g_sh, g_scales, g_rot = _backward_impl(
         rs, I, d_render, means3D, shs, e, opac, scales, rotations, e, geom, binning, img, cap)
     # ---- pre-transform backward, pose chain rule
-    g_xyz, g_rotation, g_scaling = torch.empty_like(model._xyz), torch.empty_like(model._rotation), torch.empty_like(model._scaling)
-    g_opacity_raw = torch.empty_like(model._opacity)
-    g_conf = torch.empty_like(conf_flat) if st.mask_is_everything else torch.zeros_like(conf_flat)   # (every position is written when all pixels are Gaussians)
-    _lib.check(lib.das3r_pretransform_backward(P, _p(model._xyz), _p(model._rotation), _p(model._scaling), _p(model._opacity), _p(conf_flat),
-                                               _p(st.mask_index), _p(mats), C.c_void_p(mats.data_ptr() + 48), _p(g_means3D), _p(g_rot), _p(g_scales),
-                                               _p(g_opac), _p(g_xyz), _p(g_rotation), _p(g_scaling), _p(g_opacity_raw), _p(g_conf), _p(st.g_small), s),
-               "das3r_pretransform_backward")
+    conf_grad = None
+    if geometry == "pose":
+        _lib.check(lib.das3r_pretransform_pose_sums(P, _p(model._xyz), _p(model._rotation), _p(mats), C.c_void_p(mats.data_ptr() + 48), _p(g_means3D),
+                                                    _p(g_rot), _p(st.g_small), s), "das3r_pretransform_pose_sums")
+    else:
+        g_conf = torch.empty_like(conf_flat) if st.mask_is_everything else torch.zeros_like(conf_flat)   # (every position is written when all pixels are Gaussians)
+        if geometry == "adam":
+            opt = model.optimizer
+            slots, keep = opt.adam_slots([model._xyz, model._rotation, model._scaling, model._opacity])
+            _lib.check(lib.das3r_pretransform_backward_adam(P, _p(conf_flat), _p(st.mask_index), _p(mats), C.c_void_p(mats.data_ptr() + 48), _p(g_means3D),
+                                                            _p(g_rot), _p(g_scales), _p(g_opac), _p(g_conf), _p(st.g_small), slots,
+                                                            C.c_float(opt.betas[0]), C.c_float(opt.betas[1]), C.c_float(opt.eps), s),
+                       "das3r_pretransform_backward_adam")
+            del keep
+        else:
+            g_xyz, g_rotation, g_scaling = torch.empty_like(model._xyz), torch.empty_like(model._rotation), torch.empty_like(model._scaling)
+            g_opacity_raw = torch.empty_like(model._opacity)
+            _lib.check(lib.das3r_pretransform_backward(P, _p(model._xyz), _p(model._rotation), _p(model._scaling), _p(model._opacity), _p(conf_flat),
+                                                       _p(st.mask_index), _p(mats), C.c_void_p(mats.data_ptr() + 48), _p(g_means3D), _p(g_rot), _p(g_scales),
+                                                       _p(g_opac), _p(g_xyz), _p(g_rotation), _p(g_scaling), _p(g_opacity_raw), _p(g_conf), _p(st.g_small), s),
+                       "das3r_pretransform_backward")
+            model._xyz.grad, model._rotation.grad, model._scaling.grad, model._opacity.grad = g_xyz, g_rotation, g_scaling, g_opacity_raw
+        conf_grad = g_conf
     _lib.check(lib.das3r_pose_chain_qt(_p(q_row), _p(st.g_small), _p(gq_row), _p(gt_row), s), "das3r_pose_chain_qt")
     # ---- hand the gradients over
-    model._xyz.grad, model._rotation.grad, model._scaling.grad, model._opacity.grad = g_xyz, g_rotation, g_scaling, g_opacity_raw
-    if deg == 0:
-        model._features_dc.grad = g_sh
-    else:
-        model._features_dc.grad = g_sh[:, :1].contiguous()
-        rest = g_sh[:, 1:].contiguous()
-        if rest.shape[1] == K - 1 and K - 1 < model._features_rest.shape[1]:
-            old = getattr(model._features_rest, "_das3r_compact_grad", None)
-            model._features_rest._das3r_compact_grad = rest if old is None else old + rest
+    if geometry != "pose":
+        if deg == 0:
+            model._features_dc.grad = g_sh
         else:
-            model._features_rest.grad = rest
-    model._conf_static.grad = g_conf.view(model._conf_static.shape)
+            model._features_dc.grad = g_sh[:, :1].contiguous()
+            rest = g_sh[:, 1:].contiguous()
+            if rest.shape[1] == K - 1 and K - 1 < model._features_rest.shape[1]:
+                old = getattr(model._features_rest, "_das3r_compact_grad", None)
+                model._features_rest._das3r_compact_grad = rest if old is None else old + rest
+            else:
+                model._features_rest.grad = rest
+        model._conf_static.grad = conf_grad.view(model._conf_static.shape)
     st.means2D.grad = g_means2D
     pkg = _Pkg(render=image, viewspace_points=st.means2D, radii=radii)
     return out8, d_static, pkg
@@ -199,7 +221,7 @@ def train_step(model, cam, opt, iteration, pipe, background):
     uid = cam.uid
     with torch.no_grad():
         out8, d_static, pkg = forward_backward(model, cam, model.Q[uid], model.T[uid], st.Qg[uid], st.Tg[uid], model._conf_static[uid],
-                                               opt.lambda_dssim, background)
+                                               opt.lambda_dssim, background, geometry="adam" if getattr(model, "fuse_geometry_adam", True) else "grads")
         model._conf_static.grad[uid] += d_static             # the loss sees conf_static twice: as opacity factor and as the frame's mask
         model.optimizer.step()
         model.optimizer.zero_grad(set_to_none=True)
@@ -221,7 +243,7 @@ def test_pose_step(model, cam, static_hw, opt, background):
         st.tQg, st.tTg = torch.zeros_like(model.test_Q), torch.zeros_like(model.test_T)
     with torch.no_grad():
         out8, _d_static, _pkg = forward_backward(model, cam, model.test_Q[uid], model.test_T[uid], st.tQg[uid], st.tTg[uid], static_hw,
-                                                 opt.lambda_dssim, background)
+                                                 opt.lambda_dssim, background, geometry="pose")
         model.optimizer.zero_grad(set_to_none=True)
         model.optimizer_cam.zero_grad(set_to_none=True)
     return out8

@@ -159,6 +159,31 @@ class FusedAdam:
                 elif p.grad is not None:
                     p.grad.zero_()
 
+    def adam_slots(self, params):
+        """Counts one step of `params` (fp32 device tensors of this optimizer) and returns (_lib.AdamSlot array, keep-alive list) for a
+        kernel that takes their Adam step itself (das3r_pretransform_backward_adam: das3r_amd/fast_step.py).  The parameters must not
+        carry a gradient: step() then passes them by, as torch.optim.Adam passes a parameter without gradient."""
+        b1, b2 = self.betas
+        slots = (_lib.AdamSlot * len(params))()
+        keep = []
+        for k, p in enumerate(params):
+            group = next((g for g in self.param_groups if any(q is p for q in g["params"])), None)
+            if group is None:
+                raise RuntimeError("FusedAdam.adam_slots: a tensor that is not a parameter of this optimizer")
+            if p.grad is not None:
+                raise RuntimeError("FusedAdam.adam_slots: the parameter already carries a gradient (its step would be taken twice)")
+            if p.device.type != "cuda" or p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError("FusedAdam: dense fp32 tensors on a HIP device only (no CPU path)")
+            st = self.state.get(p)
+            if st is None:
+                st = self.state[p] = dict(step=0, exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p))
+            st["step"] += 1
+            t = st["step"]
+            slots[k].param, slots[k].exp_avg, slots[k].exp_avg_sq = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            slots[k].step_size, slots[k].bc2_sqrt = group["lr"] / (1.0 - b1 ** t), math.sqrt(1.0 - b2 ** t)
+            keep += [p, st["exp_avg"], st["exp_avg_sq"]]
+        return slots, keep
+
     @torch.no_grad()
     def step(self, gate=None, threshold=0.0):
         """gate: optional 0-dim device tensor — the step is taken iff gate > threshold, decided on the device (no host sync);

@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define DAS3R_ABI_VERSION 10
+#define DAS3R_ABI_VERSION 11
 
 typedef enum {
     DAS3R_OK = 0,
@@ -218,6 +218,26 @@ int das3r_adam_step(int32_t n, const das3r_adam_tensor *tensors, float beta1, fl
  * tensors[i].step_size / step_size_tail hold the plain learning rates here; bc2_sqrt is ignored. */
 int das3r_adam_step_gated(int32_t n, const das3r_adam_tensor *tensors, float beta1, float beta2, float eps, const float *gate,
                           float threshold, int32_t *state, das3r_stream_t stream);
+
+/* ABI 11: the backward of the pre-transform with the Adam step of the four tensors it differentiates — xyz, rotation, scaling, raw
+ * opacity: the reference's groups "xyz", "rotation", "scaling", "opacity" (/root/reference/scene/gaussian_model.py:236-261) — taken in the
+ * same pass: their gradients are neither written nor read back, the parameters are read once for both.  slots[0 .. 3] (a HOST array)
+ * name the four tensors in that order (they are the xyz / rot / scaling / opacity_raw of das3r_pretransform_backward, updated in
+ * place) with their moments and step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t) as in das3r_adam_tensor.  g_conf_flat and
+ * g_small leave as from das3r_pretransform_backward (zero on entry): the confidence map and the camera pose have their own steps.
+ * Same arithmetic as das3r_pretransform_backward followed by das3r_adam_step on the four tensors. */
+typedef struct {
+    float *param, *exp_avg, *exp_avg_sq;
+    float step_size, bc2_sqrt;
+} das3r_adam_slot;
+int das3r_pretransform_backward_adam(int32_t P, const float *conf_flat, const int64_t *mask_index, const float *R, const float *Lq,
+                                     const float *g_means3D, const float *g_rot, const float *g_scales, const float *g_opac,
+                                     float *g_conf_flat, float *g_small, const das3r_adam_slot *slots, float beta1, float beta2, float eps,
+                                     das3r_stream_t stream);
+/* ABI 11: g_small of das3r_pretransform_backward alone — for a pass that differentiates nothing but the camera pose (the held-out
+ * pose alignment of /root/reference/train_test_psnr.py). */
+int das3r_pretransform_pose_sums(int32_t P, const float *xyz, const float *rot, const float *R, const float *Lq, const float *g_means3D,
+                                 const float *g_rot, float *g_small, das3r_stream_t stream);
 
 /* ---- fused photometric loss (opt-in) ------------------------------------------------------------------
  * DAS3R's per-iteration loss (/root/reference/train_gui.py:560-571, utils/loss_utils.py:39-66): with image = render * static,

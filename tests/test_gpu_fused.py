@@ -78,6 +78,63 @@ def test_pretransform_rejects_cpu_tensors():
                      torch.tensor([1.0, 0, 0, 0, 0, 0, 0]))
 
 
+@pytest.mark.parametrize("with_mask", [True, False])
+def test_pretransform_backward_with_the_adam_step_inside_matches_the_two_kernels(with_mask):
+    """ABI 11: das3r_pretransform_backward_adam (the chain rule through the pre-transform and the Adam step of xyz / rotation / scaling /
+    opacity in one pass: the four gradients never reach memory) against das3r_pretransform_backward followed by FusedAdam.step() on the
+    same four tensors — parameters and both moments over three steps with changing learning rates, the confidence gradient, the 28 pose
+    sums; and das3r_pretransform_pose_sums against those sums."""
+    import ctypes as C
+
+    from das3r_amd import _lib
+    from das3r_amd.fused import FusedAdam
+    lib = _lib.load()
+    P = 1000 if with_mask else 7 * 9 * 3
+    a, mask = _inputs(P, frames=3, hw=(7, 9) if not with_mask else (20, 30), seed=3)
+    idx = torch.nonzero(mask).reshape(-1).contiguous() if with_mask else None
+    names, lrs = ("xyz", "rot", "scaling", "opacity_raw"), (1.6e-4, 1e-3, 5e-3, 0.05)
+    conf = a["conf"].detach().reshape(-1).contiguous()
+    pa = [a[k].detach().clone() for k in names]           # two-kernel form
+    pb = [a[k].detach().clone() for k in names]           # one-pass form
+    oa = FusedAdam([dict(params=[t], lr=lr) for t, lr in zip(pa, lrs)], lr=0.0, eps=1e-15)
+    ob = FusedAdam([dict(params=[t], lr=lr) for t, lr in zip(pb, lrs)], lr=0.0, eps=1e-15)
+    mats = torch.empty(28, device="cuda")
+    _lib.check(lib.das3r_pose_matrices(C.c_void_p(a["pose"].detach().data_ptr()), C.c_void_p(mats.data_ptr()), None), "das3r_pose_matrices")
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    R, Lq = C.c_void_p(mats.data_ptr()), C.c_void_p(mats.data_ptr() + 48)
+    g = torch.Generator().manual_seed(8)
+    for step in range(3):
+        gm, gr, gs, go = (torch.randn(P, c, generator=g).cuda() * (10.0 ** (step - 1)) for c in (3, 4, 3, 1))
+        if step == 2:
+            oa.param_groups[0]["lr"] = ob.param_groups[0]["lr"] = 3e-5
+        ga = [torch.empty_like(t) for t in pa]
+        gconf_a, gconf_b = torch.zeros_like(conf), torch.zeros_like(conf)
+        small_a, small_b, small_c = (torch.zeros(28, device="cuda") for _ in range(3))
+        _lib.check(lib.das3r_pretransform_backward(P, *(ptr(t) for t in pa), ptr(conf), ptr(idx), R, Lq, ptr(gm), ptr(gr), ptr(gs), ptr(go),
+                                                   *(ptr(t) for t in ga), ptr(gconf_a), ptr(small_a), None), "das3r_pretransform_backward")
+        for t, gt in zip(pa, ga):
+            t.grad = gt
+        oa.step()
+        oa.zero_grad(set_to_none=True)
+        _lib.check(lib.das3r_pretransform_pose_sums(P, ptr(pb[0]), ptr(pb[1]), R, Lq, ptr(gm), ptr(gr), ptr(small_c), None), "das3r_pretransform_pose_sums")
+        slots, keep = ob.adam_slots(pb)
+        _lib.check(lib.das3r_pretransform_backward_adam(P, ptr(conf), ptr(idx), R, Lq, ptr(gm), ptr(gr), ptr(gs), ptr(go), ptr(gconf_b), ptr(small_b), slots,
+                                                        C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15), None), "das3r_pretransform_backward_adam")
+        ob.step()   # (nothing carries a gradient: passes all four by)
+        torch.cuda.synchronize()
+        assert torch.equal(gconf_a, gconf_b)
+        for sm in (small_b, small_c):
+            assert float((sm - small_a).abs().max()) <= 1e-5 * float(small_a.abs().max())   # (float atomics: order)
+        for k, ta, tb in zip(names, pa, pb):
+            assert torch.equal(ta, tb), (step, k, float((ta - tb).abs().max()))
+            for key in ("exp_avg", "exp_avg_sq"):
+                assert torch.equal(oa.state[ta][key], ob.state[tb][key]), (step, k, key)
+            assert oa.state[ta]["step"] == ob.state[tb]["step"] == step + 1
+    with pytest.raises(RuntimeError):   # a parameter that already carries a gradient would step twice
+        pb[0].grad = torch.zeros_like(pb[0])
+        ob.adam_slots(pb)
+
+
 def _adam_params(seed=0, P=777, K=15):
     g = torch.Generator().manual_seed(seed)
     shapes = dict(xyz=(P, 3), f_dc=(P, 1, 3), f_rest=(P, K, 3), opacity=(P, 1), scaling=(P, 3), rotation=(P, 4), conf=(3, 7, 9))

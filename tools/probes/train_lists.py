@@ -77,3 +77,21 @@ for depth in sys.argv[1].split(","):
         tmax = steps.max(1).values.reshape(nt, nbt).sum(1).float()        # a barrier per batch: the workgroup's slowest block
         tmean = steps.float().mean(1).reshape(nt, nbt).sum(1)
         print(f"   four lanes per pixel, batches of {B}: steps per tile, slowest block per batch: mean {tmax.mean():.0f} max {tmax.max():.0f};  mean block: mean {tmean.mean():.0f} max {tmean.max():.0f}")
+    # run-ahead model: NB staging areas of B entries, a block starts batch i once it is staged; batch i is staged by the time every block has
+    # finished batch i - NB + 1 (loaders write one batch ahead of their own walk); cost = steps (+ a fixed cull per batch)
+    for B, NBs in ((512, (2,)), (256, (2, 3, 4, 6))):
+        nbt = 16384 // B * 2
+        batch = tile_of * nbt + pos // B
+        per = torch.zeros(nt * nbt, 16, dtype=torch.long, device="cuda").index_add_(0, batch, hits)
+        st = ((per + 3) // 4).reshape(nt, nbt, 16).float().cpu().numpy() + 3.0 * (B / 512)   # (cull: ~130 instructions per 512 entries = 3 steps)
+        for NB in NBs:
+            fin = np.zeros((nt, nbt + 1, 16))
+            for i in range(nbt):
+                if NB == 2:
+                    start = np.broadcast_to(fin[:, i, :].max(1, keepdims=True), (nt, 16))          # a barrier per batch
+                else:
+                    ready = fin[:, max(i - NB + 2, 0), :].max(1, keepdims=True) if i - NB + 2 > 0 else 0.0
+                    start = np.maximum(fin[:, i, :], ready)
+                fin[:, i + 1, :] = start + st[:, i, :]
+            mk = fin[:, nbt, :].max(1)
+            print(f"   model B={B} NB={NB}: tile makespan mean {mk.mean():.0f} max {mk.max():.0f} steps")
