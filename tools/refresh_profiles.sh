@@ -3,7 +3,7 @@
 #   <rn>_bench_<w>.json          bench line of workload w (c4 = the default line with every extra; c2 / ds on their own)
 #   <rn>_<w>_kernel_stats.csv    rocprofv3 --kernel-trace --stats of the same bench command (extras run in a profiler-free child)
 #   <rn>_pmc_<w>.json / .txt     PMC passes (tools/pmc_collect.sh)
-#   <rn>_train_step_*.json       DAS3R-shaped optimisation step, unfused / fused
+#   <rn>_train_step_*.json       DAS3R-shaped optimisation step, unfused / fused / fused on spatially coherent depth maps
 # Everything lands in gpurun_out/profiles/ (copied into profiles/ by hand after a look).  Every child is time-bounded.
 R=$PWD; RN=${1:-r04}; OUT=$R/gpurun_out/profiles; mkdir -p $OUT
 export PYTHONPATH=$R
@@ -25,5 +25,6 @@ for w in c4 c2 ds; do
 done
 timeout 200 python tools/train_bench.py --breakdown 2>/dev/null | tail -1 > $OUT/${RN}_train_step_unfused.json
 timeout 200 python tools/train_bench.py --fused-adam --fused-loss --fused-pre --breakdown 2>/dev/null | tail -1 > $OUT/${RN}_train_step_fused.json
+timeout 200 python tools/train_bench.py --fused-adam --fused-loss --fused-pre --breakdown --depth smooth 2>/dev/null | tail -1 > $OUT/${RN}_train_step_fused_smooth_depth.json
 timeout 300 python tools/knn_bench.py 2>/dev/null > $OUT/${RN}_knn.json
 ls -la $OUT
