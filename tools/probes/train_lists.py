@@ -95,3 +95,12 @@ for depth in sys.argv[1].split(","):
                 fin[:, i + 1, :] = start + st[:, i, :]
             mk = fin[:, nbt, :].max(1)
             print(f"   model B={B} NB={NB}: tile makespan mean {mk.mean():.0f} max {mk.max():.0f} steps")
+    # backward: a block walks the entries in front of the TILE's last contributor; how many lie in front of its OWN last contributor?
+    ncp = torch.from_numpy(nc.astype(np.int64)).cuda().reshape(H, W)
+    pad = torch.zeros(ty * 16, tx * 16, dtype=torch.long, device="cuda")
+    pad[:H, :W] = ncp
+    blk = pad.reshape(ty, 4, 4, tx, 4, 4).permute(0, 3, 1, 4, 2, 5).reshape(nt, 16, 16).max(2).values    # [tile, block]: last contributor (1-based list position)
+    tmax = blk.max(1).values
+    walked_tile = (hits * (pos < tmax[tile_of]).unsqueeze(1)).sum().item()
+    walked_blk = (hits * (pos.unsqueeze(1) < blk[tile_of])).sum().item()
+    print(f"   backward (entry, block) pairs in front of the tile's last contributor {walked_tile}, in front of the block's own {walked_blk} ({walked_blk / max(walked_tile, 1):.2f})")
