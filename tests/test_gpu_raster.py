@@ -288,6 +288,9 @@ def test_tight_rect_is_exact(name, monkeypatch):
     pixel of the tile: the image must be bit-identical to binning over upstream's square, gradients equal up to the order of
     LDS adds, and the instance count can only shrink."""
     sc, mode = util.scene_variant(name)
+    # (bit-identity of the IMAGE across two different lists needs a forward kernel that adds a pixel's colour terms one by one: the
+    #  four-lanes kernel groups them by fours, and a dropped entry shifts the groups — same terms, last-bit differences)
+    monkeypatch.setenv("DAS3R_RENDER", "rows")
     monkeypatch.setenv("DAS3R_RECT", "upstream")
     c_up, r_up, g_up, fn_up = _run_hip(sc, mode)
     n_up = fn_up.num_rendered
@@ -765,6 +768,7 @@ def test_local_order_at_every_list_length(P, monkeypatch):
     rs = GaussianRasterizationSettings(**scd.settings_kwargs())
     e = torch.empty(0, device=dev)
     out = {}
+    monkeypatch.setenv("DAS3R_RENDER", "rows")     # (one forward kernel for both: the four-lanes kernel, which a single long globally sorted list would get, adds colours in another order)
     for kind in ("radix", "local"):
         monkeypatch.setenv("DAS3R_BINNING", kind)
         I, color, radii, geom, binning, img = _forward_impl(rs, scd.means3D, scd.shs, e, scd.opacities, scd.scales, scd.rotations, e)
