@@ -34,7 +34,7 @@ namespace das3r {
 // broadcasts), 1 constants from LDS, 2 constants and state from LDS.
 // ABL: timing experiments only (DAS3R_ABLATE with DAS3R_RENDER_BWD=blk128p1; results are wrong): 1 no batches at all (what the rounds
 // cost without them), 2 batches without the record add, 4 nothing written out, 8 bounding-box block test only, 16 no quadrant ellipse test
-template <int MB, int PIX, int ABL = 0, int OCC = 5>
+template <int MB, int PIX, int ABL = 0, int OCC = 5, bool LAST = false>
 __global__ void __launch_bounds__(256, OCC) render_backward_blk_kernel(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int tiles_x, int ntiles_strip /*render_common.h pack_tiles*/,
     const float4 *__restrict__ xyh, const float4 *__restrict__ conic_opacity, const float4 *__restrict__ rgbd,
@@ -179,6 +179,20 @@ __global__ void __launch_bounds__(256, OCC) render_backward_blk_kernel(
                 px.lastrel = (float)(rel < 0 ? 0ll : (rel > MB ? (long long)MB : rel));
                 if constexpr (PIX > 0) *reinterpret_cast<float *>(cst_row + s * 16 + 12) = px.lastrel;
             }
+            // LAST (long lists: the bucket-parallel launches): the last contributor of each of the wave's four BLOCKS, relative to the round — an
+            // entry behind it gets nothing from that block (every pixel's clamp makes its pairs inert) and need not be listed for it.  On the
+            // random-depth benchmarks a tile's blocks stop within a few entries of each other (and the short lists of the 1080p benchmarks
+            // pay 2 % for the test: not compiled in there); on a real sequence's depth maps (a tile's list is spatially sorted) 19 % of the listed
+            // (entry, block) pairs of the DAS3R training shape lie behind their block's last contributor (tools/probes/train_lists.py):
+            // backward 0.478 -> 0.412 ms.
+            float blk_last[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (LAST) {
+                int v = (int)px.lastrel;
+#pragma unroll
+                for (int o = 8; o >= 1; o >>= 1) v = max(v, __shfl_xor(v, o, 64));   // (max over the 16 lanes of the row)
+#pragma unroll
+                for (int r = 0; r < 4; r++) blk_last[r] = (float)__builtin_amdgcn_readlane(v, 16 * r);
+            }
             __syncthreads();
             PHASE_MARK(9)   // staging the round
 
@@ -195,9 +209,10 @@ __global__ void __launch_bounds__(256, OCC) render_backward_blk_kernel(
                 const bool qhit = (j < n) && ((ABL & 16) ? rect_hit_tight_tau(p, co, splat_tau(co.w), (float)qx0, (float)qy0) : true);
                 float hd1, hd2;
                 diagonal_extents(p, co, hd1, hd2);
+                const float posrel_j = (float)(MB - 1 - j);   // (SplatRegs::posrel of the walk: the entry takes part for a pixel iff posrel < lastrel)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const bool hit = qhit && block_hit_oct(p.x, p.y, p.z, p.w, (ABL & 8) ? 1e30f : hd1, (ABL & 8) ? 1e30f : hd2,
+                    const bool hit = qhit && (!LAST || posrel_j < blk_last[r]) && block_hit_oct(p.x, p.y, p.z, p.w, (ABL & 8) ? 1e30f : hd1, (ABL & 8) ? 1e30f : hd2,
                                                            (float)(qx0 + ((r & 1) << 2)) + 1.5f, (float)(qy0 + ((r >> 1) << 2)) + 1.5f);
                     const uint64_t m = __ballot(hit);
                     const int at = len[r] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -331,7 +346,11 @@ int launch_render_backward_blk(const das3r_raster_args *a, const float *dL_dpix,
         (const float4 *)(geom + L.pub.rgbd), a->bg, (const float *)(img + L.pub.final_T),                                 \
         (const uint32_t *)(img + L.pub.n_contrib), dL_dpix, (const uint32_t *)(binning + L.b_slot), partial,              \
         (uint32_t)(a->P - 1), (uint32_t)L.capacity, (const float4 *)(binning + L.b_ckpt), PAIRS_ARG
-#define GO(MBV, PIX, OCC) DAS3R_LAUNCH((render_backward_blk_kernel<MBV, PIX, 0, OCC>), dim3(xcd_grid(L), slices > 1 ? slices : 1), dim3(TILE_PIX), 0, s, ARGS)
+#define GO(MBV, PIX, OCC)                                                                                                                             \
+    do {                                                                                                                                              \
+        if (slices > 1) DAS3R_LAUNCH((render_backward_blk_kernel<MBV, PIX, 0, OCC, true>), dim3(xcd_grid(L), slices), dim3(TILE_PIX), 0, s, ARGS);   \
+        else DAS3R_LAUNCH((render_backward_blk_kernel<MBV, PIX, 0, OCC, false>), dim3(xcd_grid(L), 1), dim3(TILE_PIX), 0, s, ARGS);                   \
+    } while (0)
     // DAS3R_RENDER_BWD=blk<entries per round>[p<PIX>][o<workgroups per CU>]: blk128 (registers), blk128p1 (constants in LDS), blk160p1o4 ...
     // default (no DAS3R_RENDER_BWD): constants in LDS for 128-entry rounds (1 M splats at 1080p: 0.381 vs 0.407 ms), registers for 192
     // (DAS3R shape: 0.497 vs 0.534 ms)
