@@ -50,6 +50,9 @@ def main():
             torch.cuda.synchronize()
             print(f"{w} jitter: {args.steps} steps in {time.perf_counter() - t0:.1f} s, counts {sorted(v[0] for v in refs.values())}, "
                   f"exactly sized (first / redone) {redone}, mismatches {mismatches}")
+            record["workloads"][w] = dict(jitter=True, steps=args.steps, seconds=round(time.perf_counter() - t0, 1), scale_modifiers=mods,
+                                          num_rendered_values=sorted(v[0] for v in refs.values()), exactly_sized_or_redone=int(redone),
+                                          image_mismatches=mismatches)
             continue
         it = 0
         while (time.perf_counter() - t0 < args.seconds) if args.seconds > 0 else (it < args.steps):
