@@ -72,6 +72,73 @@ __device__ __forceinline__ uint32_t quad_max(const uint32_t v) {
     return max(a, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x4E, 0xf, 0xf, true));
 }
 
+// Per-pixel state of a quad's lanes and the lane's constants.  T and live are the same in the four lanes of a quad; C: this lane's entries.
+struct QuadLane {
+    float T, live, C0, C1, C2;
+    float pxf, pyf, kf, mk0, mk1, mk2;   // pixel centre; lane of the quad; max(1 - alpha_j, mk[j]): the factor of the quad's lane j in front of MY entry — 1 - alpha_j for j < k, 1 for j >= k
+    int k;
+};
+
+// The walk of one block's list `mine[0 .. len)` (staged indices) of a staged batch: four entries per step, one per lane of a quad.
+// -> staged index of this lane's last contributing entry as a float, -1 = none.
+__device__ __forceinline__ float lanes_walk(const StagedSplat *__restrict__ stage, const uint16_t *__restrict__ mine, const int len, QuadLane &q, int &steps) {
+    float lastf = -1.0f;
+    const float lenf = (float)len - q.kf;   // (my position of step t exists where lenf - t >= 1)
+    // alpha of staged entry j for my pixel (0 where it is invisible or the list has no such position), its colour
+    auto entry_alpha = [&](const int j, const float rem, float4 &c) -> float {
+        const float4 p = stage[j].xyh;
+        const float4 co = stage[j].co;
+        c = lds_read4(&stage[j].rgbd);
+        const float dx = p.x - q.pxf, dy = p.y - q.pyf;
+        const float qq = __fmaf_rn(__fmul_rn(co.x, dx), dx, __fmul_rn(__fmul_rn(co.z, dy), dy));
+        const float power = __fmaf_rn(-0.5f, qq, -__fmul_rn(__fmul_rn(co.y, dx), dy));   // (pair_alpha's arithmetic)
+        const float a1 = fminf(fminf(0.99f, __fmul_rn(co.w, __expf(power))), rem);
+        return alpha_if_visible(a1, power);   // (a1 is not positive where the list has no position)
+    };
+    // the quad's four entries into the pixel, in list order
+    auto blend_step = [&](const float av, const float4 c, const float jf) {
+        const float a = av * q.live;
+        const float om = 1.0f - a;
+        // T in front of my entry: the pixel's T times the factors of the lanes in front of me, in list order
+        float f0, f1, f2;
+        quad_factors(om, q.mk0, q.mk1, q.mk2, f0, f1, f2);
+        const float x = __fmul_rn(__fmul_rn(__fmul_rn(q.T, f0), f1), f2);
+        const float tn = __fmul_rn(x, om);   // the reference's test_T of my entry
+        // A pixel of this wave stops inside the step (rare: once in a pixel's life): test_T falls along the quad, the entries in front
+        // of the first failure are taken as they are (their T does not involve the failing entry), the failing one and those behind
+        // it are not.  Only the three values below differ; the common path overwrites nothing it has to keep.
+        float s = 1.0f, t_next = quad_perm<0xFF>(tn), l_next = q.live;
+        if (__builtin_expect(__ballot(tn < 0.0001f) != 0ull, 0)) {
+            s = tn < 0.0001f ? 0.f : 1.f;
+            t_next = quad_min(s != 0.f ? tn : q.T);   // T behind the last entry taken (the pixel's T where none is)
+            l_next = q.live * quad_min(s);
+        }
+        const float w = a * s, wT = w * x;
+        q.C0 = __fmaf_rn(c.x, wT, q.C0);
+        q.C1 = __fmaf_rn(c.y, wT, q.C1);
+        q.C2 = __fmaf_rn(c.z, wT, q.C2);
+        lastf = max_raw(lastf, min_raw(jf, __fmaf_rn(w, 1e30f, -1.0f)));
+        q.T = t_next;
+        q.live = l_next;
+    };
+    // LN_UNROLL steps per trip: the entries' fetches and exponents are independent of the pixel's state and overlap; the blends follow in order
+    for (int t = 0; t < len; t += 4 * LN_UNROLL) {
+        if ((t & 63) == 0 && __ballot(q.live != 0.f) == 0ull) break;
+        steps += min(LN_UNROLL, (len - t + 3) >> 2);
+        int j[LN_UNROLL];
+        float4 c[LN_UNROLL];
+        float av[LN_UNROLL];
+        const float rem = lenf - (float)t;
+#pragma unroll
+        for (int u = 0; u < LN_UNROLL; u++) j[u] = (int)mine[t + 4 * u + q.k];
+#pragma unroll
+        for (int u = 0; u < LN_UNROLL; u++) av[u] = entry_alpha(j[u], rem - (float)(4 * u), c[u]);
+#pragma unroll
+        for (int u = 0; u < LN_UNROLL; u++) blend_step(av[u], c[u], (float)j[u]);
+    }
+    return lastf;
+}
+
 __global__ void __launch_bounds__(LN_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) render_forward_lanes_kernel(const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H,
                                                                           int tiles_x, int ntiles_strip /*render_common.h pack_tiles*/,
                                                                           const float4 *__restrict__ xyh, const float4 *__restrict__ conic_opacity,
@@ -88,16 +155,14 @@ __global__ void __launch_bounds__(LN_THREADS) __attribute__((amdgpu_waves_per_eu
     const int bx = tile % tiles_x, by = tile / tiles_x;
     const int px = bx * TILE_X + ((wave & 3) << 2) + (pix & 3), py = by * TILE_Y + ((wave >> 2) << 2) + (pix >> 2);
     const bool inside = px < W && py < H;
-    const float pxf = (float)px, pyf = (float)py;
     const float bcx = (float)(bx * TILE_X + ((wave & 3) << 2)) + 1.5f, bcy = (float)(by * TILE_Y + ((wave >> 2) << 2)) + 1.5f;
     const uint2 range = safe_range(ranges[tile], lb.cap);
     const uint32_t n = range.y - range.x;
     const int rounds = (int)((n + LN_BATCH - 1) / LN_BATCH);
-    // max(1 - alpha_j, mk[j]): the factor of the quad's lane j in front of MY entry — 1 - alpha_j for j < k, 1 for j >= k
-    const float mk0 = k > 0 ? 0.f : 1.f, mk1 = k > 1 ? 0.f : 1.f, mk2 = k > 2 ? 0.f : 1.f;
-    const float kf = (float)k;
-
-    float T = 1.0f, live = inside ? 1.f : 0.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;   // (T and live: the same in the four lanes of a quad; C: this lane's entries)
+    QuadLane q;
+    q.T = 1.0f; q.live = inside ? 1.f : 0.f; q.C0 = q.C1 = q.C2 = 0.f;
+    q.pxf = (float)px; q.pyf = (float)py; q.k = k; q.kf = (float)k;
+    q.mk0 = k > 0 ? 0.f : 1.f; q.mk1 = k > 1 ? 0.f : 1.f; q.mk2 = k > 2 ? 0.f : 1.f;
     uint32_t last_contributor = 0;                                              // (this lane's entries; the quad's maximum is the pixel's)
     const int nb = ckpt_buckets(range);
     const int cpix = ((py - by * TILE_Y) << 4) + (px - bx * TILE_X);
@@ -125,7 +190,7 @@ __global__ void __launch_bounds__(LN_THREADS) __attribute__((amdgpu_waves_per_eu
     for (int i = 0; i < rounds; i++) {
         StagedSplat *const stage = stage_all + (i & 1) * LN_BATCH;
         const uint32_t first = (uint32_t)i * LN_BATCH;
-        const bool wave_done = __ballot(live != 0.f) == 0ull;
+        const bool wave_done = __ballot(q.live != 0.f) == 0ull;
         if (lane == 0) s_done[i & 1][wave] = wave_done ? 1u : 0u;
         lds_barrier();   // (the loads just issued stay in flight: render_common.h)
         {   // every pixel of the tile has stopped?  (flags of this batch: rewritten two batches on, behind the next barrier)
@@ -133,8 +198,8 @@ __global__ void __launch_bounds__(LN_THREADS) __attribute__((amdgpu_waves_per_eu
             if (__ballot(d != 0u) == ~0ull) break;
         }
         if (nb > 1 && i > 0 && first % BUCKET == 0) {   // the state in front of list position `first`
-            const float q0 = quad_sum(C0), q1 = quad_sum(C1), q2 = quad_sum(C2);
-            if (k == 0) ckpt_slot(lb.ckpt, range, tile, next_slot)[cpix] = make_float4(T, q0, q1, q2);
+            const float q0 = quad_sum(q.C0), q1 = quad_sum(q.C1), q2 = quad_sum(q.C2);
+            if (k == 0) ckpt_slot(lb.ckpt, range, tile, next_slot)[cpix] = make_float4(q.T, q0, q1, q2);
             next_slot++;
         }
         StagedSplat rec = null_splat();
@@ -167,73 +232,20 @@ __global__ void __launch_bounds__(LN_THREADS) __attribute__((amdgpu_waves_per_eu
         if (loader && i + 1 < rounds) stage_all[((i + 1) & 1) * LN_BATCH + tid] = rec;
         if (wave_done) continue;   // (uniform; the wave has staged its share and meets the barriers)
         // ---- the walk: four entries per step, one per lane of a quad -----------------------------------------------------------
-        float lastf = -1.0f;
-        const float lenf = (float)len - kf;   // (my position of step t exists where lenf - t >= 1)
-        // alpha of staged entry j for my pixel (0 where it is invisible or the list has no such position), its colour
-        auto entry_alpha = [&](const int j, const float rem, float4 &c) -> float {
-            const float4 p = stage[j].xyh;
-            const float4 co = stage[j].co;
-            c = lds_read4(&stage[j].rgbd);
-            const float dx = p.x - pxf, dy = p.y - pyf;
-            const float q = __fmaf_rn(__fmul_rn(co.x, dx), dx, __fmul_rn(__fmul_rn(co.z, dy), dy));
-            const float power = __fmaf_rn(-0.5f, q, -__fmul_rn(__fmul_rn(co.y, dx), dy));   // (pair_alpha's arithmetic)
-            const float a1 = fminf(fminf(0.99f, __fmul_rn(co.w, __expf(power))), rem);
-            return alpha_if_visible(a1, power);   // (a1 is not positive where the list has no position)
-        };
-        // the quad's four entries into the pixel, in list order
-        auto blend_step = [&](const float av, const float4 c, const float jf) {
-            const float a = av * live;
-            const float om = 1.0f - a;
-            // T in front of my entry: the pixel's T times the factors of the lanes in front of me, in list order
-            float f0, f1, f2;
-            quad_factors(om, mk0, mk1, mk2, f0, f1, f2);
-            const float x = __fmul_rn(__fmul_rn(__fmul_rn(T, f0), f1), f2);
-            const float tn = __fmul_rn(x, om);   // the reference's test_T of my entry
-            // A pixel of this wave stops inside the step (rare: once in a pixel's life): test_T falls along the quad, the entries in front
-            // of the first failure are taken as they are (their T does not involve the failing entry), the failing one and those behind
-            // it are not.  Only the three values below differ; the common path overwrites nothing it has to keep.
-            float s = 1.0f, t_next = quad_perm<0xFF>(tn), l_next = live;
-            if (__builtin_expect(__ballot(tn < 0.0001f) != 0ull, 0)) {
-                s = tn < 0.0001f ? 0.f : 1.f;
-                t_next = quad_min(s != 0.f ? tn : T);   // T behind the last entry taken (the pixel's T where none is)
-                l_next = live * quad_min(s);
-            }
-            const float w = a * s, wT = w * x;
-            C0 = __fmaf_rn(c.x, wT, C0);
-            C1 = __fmaf_rn(c.y, wT, C1);
-            C2 = __fmaf_rn(c.z, wT, C2);
-            lastf = max_raw(lastf, min_raw(jf, __fmaf_rn(w, 1e30f, -1.0f)));
-            T = t_next;
-            live = l_next;
-        };
-        // LN_UNROLL steps per trip: the entries' fetches and exponents are independent of the pixel's state and overlap; the blends follow in order
-        for (int t = 0; t < len; t += 4 * LN_UNROLL) {
-            if ((t & 63) == 0 && __ballot(live != 0.f) == 0ull) break;
-            steps += min(LN_UNROLL, (len - t + 3) >> 2);
-            int j[LN_UNROLL];
-            float4 c[LN_UNROLL];
-            float av[LN_UNROLL];
-            const float rem = lenf - (float)t;
-#pragma unroll
-            for (int u = 0; u < LN_UNROLL; u++) j[u] = (int)mine[t + 4 * u + k];
-#pragma unroll
-            for (int u = 0; u < LN_UNROLL; u++) av[u] = entry_alpha(j[u], rem - (float)(4 * u), c[u]);
-#pragma unroll
-            for (int u = 0; u < LN_UNROLL; u++) blend_step(av[u], c[u], (float)j[u]);
-        }
+        const float lastf = lanes_walk(stage, mine, len, q, steps);
         if (lastf >= 0.0f) last_contributor = first + (uint32_t)lastf + 1u;
     }
-    const float q0 = quad_sum(C0), q1 = quad_sum(C1), q2 = quad_sum(C2);
+    const float q0 = quad_sum(q.C0), q1 = quad_sum(q.C1), q2 = quad_sum(q.C2);
     const uint32_t last = quad_max(last_contributor);
     if (k == 0)
-        for (; nb > 1 && next_slot < nb; next_slot++) ckpt_slot(lb.ckpt, range, tile, next_slot)[cpix] = make_float4(T, q0, q1, q2);   // (final values)
+        for (; nb > 1 && next_slot < nb; next_slot++) ckpt_slot(lb.ckpt, range, tile, next_slot)[cpix] = make_float4(q.T, q0, q1, q2);   // (final values)
     if (inside && k == 0) {
         const size_t at = (size_t)py * W + px, plane = (size_t)H * W;
-        final_T[at] = T;
+        final_T[at] = q.T;
         n_contrib[at] = last;
-        out_color[at] = q0 + T * bg[0];
-        out_color[plane + at] = q1 + T * bg[1];
-        out_color[2 * plane + at] = q2 + T * bg[2];
+        out_color[at] = q0 + q.T * bg[0];
+        out_color[plane + at] = q1 + q.T * bg[1];
+        out_color[2 * plane + at] = q2 + q.T * bg[2];
     }
     if (pairs != nullptr && lane == 0 && steps > 0) {
         atomicAdd(pairs, (unsigned long long)steps * 64ull);
@@ -251,10 +263,12 @@ bool use_quad_lanes(const Layout &L, const LocalBin &lb) {
 
 int launch_render_forward_lanes(const das3r_raster_args *a, float *out_color, char *geom, char *binning, char *img, const Layout &L, const LocalBin &lb,
                                 hipStream_t s) {
-    DAS3R_LAUNCH(render_forward_lanes_kernel, dim3(xcd_grid(L)), dim3(LN_THREADS), 0, s, (const uint2 *)(img + L.pub.ranges),
-                 (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height, L.tiles_x, pack_tiles(L),
-                 (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity), (const float4 *)(geom + L.pub.rgbd), a->bg,
-                 (float *)(img + L.pub.final_T), (uint32_t *)(img + L.pub.n_contrib), out_color, lb, pair_counters());
+#define ARGS                                                                                                                                   \
+    (const uint2 *)(img + L.pub.ranges), (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height, L.tiles_x, pack_tiles(L), \
+        (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity), (const float4 *)(geom + L.pub.rgbd), a->bg,                \
+        (float *)(img + L.pub.final_T), (uint32_t *)(img + L.pub.n_contrib), out_color, lb, pair_counters()
+    DAS3R_LAUNCH(render_forward_lanes_kernel, dim3(xcd_grid(L)), dim3(LN_THREADS), 0, s, ARGS);
+#undef ARGS
     KERNEL_CHECK(s, a->debug, "render_forward_lanes");
     return DAS3R_OK;
 }
