@@ -26,5 +26,13 @@ done
 timeout 200 python tools/train_bench.py --breakdown 2>/dev/null | tail -1 > $OUT/${RN}_train_step_unfused.json
 timeout 200 python tools/train_bench.py --fused-adam --fused-loss --fused-pre --breakdown 2>/dev/null | tail -1 > $OUT/${RN}_train_step_fused.json
 timeout 200 python tools/train_bench.py --fused-adam --fused-loss --fused-pre --breakdown --depth smooth 2>/dev/null | tail -1 > $OUT/${RN}_train_step_fused_smooth_depth.json
+cd /tmp
+for d in noise smooth; do   # the same train step under rocprofv3
+  rm -rf /tmp/kt_ts_$d
+  timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/kt_ts_$d -o kt --output-format csv -- python $R/tools/train_bench.py --fused-adam --fused-loss --fused-pre --depth $d --iters 200 > /dev/null 2>&1
+  f=$(find /tmp/kt_ts_$d -name '*kernel_stats.csv' | head -1)
+  [ -n "$f" ] && cp $f $OUT/${RN}_train_step_${d}_depth_kernel_stats.csv
+done
+cd $R
 timeout 300 python tools/knn_bench.py 2>/dev/null > $OUT/${RN}_knn.json
 ls -la $OUT
