@@ -154,10 +154,11 @@ def test_direct_fused_step_matches_the_autograd_fused_step(degree):
     from das3r_amd import fast_step
     from das3r_amd.train import train_step
     out = []
-    for direct in (True, False):
+    for direct in (True, False, "grads"):   # ("grads": the direct form with the pre-transform's backward and Adam as two kernels — model.fuse_geometry_adam = False)
         model, cams, _, opt, _dense = _pair(frames=3, W=32, H=24, seed=9, heldout=False, iterations=100, fused=True, generic=True)
-        model.fast_step = direct
-        assert fast_step.available(model, PIPE) == direct
+        model.fast_step = bool(direct)
+        model.fuse_geometry_adam = direct is True
+        assert fast_step.available(model, PIPE) == bool(direct)
         if degree == 1:   # ground-truth images as they come out of numpy-stacked H x W x 3 files: [3, H, W] VIEWS, not dense tensors
             for c in cams:
                 c.original_image = c.original_image.permute(1, 2, 0).contiguous().permute(2, 0, 1)
@@ -175,15 +176,17 @@ def test_direct_fused_step_matches_the_autograd_fused_step(degree):
         st = model.optimizer.state[model._features_rest]
         out.append((rec, {k: getattr(model, a).detach().clone() for k, a in NAMES.items()}, st["exp_avg"].clone(), st["step"],
                     model.optimizer_cam._gate_state.clone()))
-    (ra, pa, ma, sa, ga), (rb, pb, mb, sb, gb) = out
-    assert sa == sb == 4 and torch.equal(ga, gb)
-    for (la, psa, m2a, va), (lb, psb, m2b, vb) in zip(ra, rb):
-        assert abs(la - lb) <= 1e-6 * abs(lb) and abs(psa - psb) <= 1e-4 and va == vb, (la, lb, psa, psb)
-        assert torch.allclose(m2a, m2b, rtol=1e-4, atol=1e-7 * float(m2b.abs().max()))
-    assert torch.allclose(ma, mb, rtol=1e-4, atol=1e-9)
-    for k in pa:
-        far = (pa[k] - pb[k]).abs() > 1e-5 + 1e-4 * pb[k].abs()   # (an Adam step moves an element by at most its learning rate: sign flips of noise-level gradients)
-        assert float(far.double().mean()) <= 1e-3, (k, float(far.double().mean()))
+    ref = out[1]   # the autograd form
+    for form in (out[0], out[2]):   # (the two direct forms run the same kernels; their pose sums meet in float atomics, so they are held to the autograd form like each other)
+        (ra, pa, ma, sa, ga), (rb, pb, mb, sb, gb) = form, ref
+        assert sa == sb == 4 and torch.equal(ga, gb)
+        for (la, psa, m2a, va), (lb, psb, m2b, vb) in zip(ra, rb):
+            assert abs(la - lb) <= 1e-6 * abs(lb) and abs(psa - psb) <= 1e-4 and va == vb, (la, lb, psa, psb)
+            assert torch.allclose(m2a, m2b, rtol=1e-4, atol=1e-7 * float(m2b.abs().max()))
+        assert torch.allclose(ma, mb, rtol=1e-4, atol=1e-9)
+        for k in pa:
+            far = (pa[k] - pb[k]).abs() > 1e-5 + 1e-4 * pb[k].abs()   # (an Adam step moves an element by at most its learning rate: sign flips of noise-level gradients)
+            assert float(far.double().mean()) <= 1e-3, (k, float(far.double().mean()))
 
 
 def test_heldout_report_semantics(tmp_path):
