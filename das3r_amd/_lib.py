@@ -196,8 +196,9 @@ def profile_enable(on):
     L.das3r_profile_enable(int(bool(on)))
 
 
-def profile_report():
-    """-> {kernel name: (launches, total_ms)}; clears the records.  Template arguments are stripped from names."""
+def profile_report(raw=False):
+    """-> {kernel name: (launches, total_ms)}; clears the records.  Template arguments are stripped from names unless `raw` (the
+    names are the launch sites' own text, e.g. "render_backward_blk_kernel<MBV, PIX, 0, OCC, true>": the instantiation's LAST flag)."""
     L = load()
     L.das3r_profile_report.restype = C.c_int
     L.das3r_profile_report.argtypes = [C.c_char_p, C.c_size_t]
@@ -206,7 +207,9 @@ def profile_report():
     out = {}
     for line in buf.value.decode().splitlines():
         name, n, ms = line.rsplit(" ", 2)
-        name = name.strip("() ").split("<")[0]
+        name = name.strip("() ")
+        if not raw:
+            name = name.split("<")[0]
         c, t = out.get(name, (0, 0.0))
         out[name] = (c + int(n), t + float(ms))
     return out

@@ -11,6 +11,7 @@ the reference's own farm for the predictor stage (/root/reference/dynamic_predic
 import argparse
 import json
 import os
+import sys
 import threading
 import time
 
@@ -68,21 +69,28 @@ class Rendezvous:
     """File-based guard around the one collective of the farm: a rank that dies with a HIP fault must not
     leave the others blocked in all_reduce / all_gather until the RCCL timeout.
 
-    Every rank keeps a heartbeat file fresh from a daemon thread (it stops with the process) and, when its sequences are done,
-    publishes its records as records_<rank>.json (written atomically).  Rank 0 DECIDES how the table is assembled and writes the
-    decision down; the others wait for it:
-      "collective"  every rank has published: all of them are alive and about to enter the gather — the collective cannot hang;
-      "files"       a rank's heartbeat went stale (dead) or it never published within the deadline (hung): nobody enters a
-                    collective; the table is assembled from the record files, and a sequence nobody reported is looked up in
-                    its own <out>/<sequence>/test_log.txt (train.scrape_test_logs — what the reference's scripts scrape,
-                    scripts/get_testing_psnr_davis.py:8-17) before it is marked failed.
-    A rank that cannot get a decision (rank 0 died) falls back to "files" on its own after the same deadline.  Single node: the
-    directory is on the node's file system (the farm is one node by definition)."""
+    Every rank keeps a heartbeat file fresh from a daemon thread (it stops with the process); the file carries the time of the rank's
+    last PROGRESS tick (`tick()`: called by the job loop at every sequence boundary and every few hundred iterations), so that a rank
+    whose process lives but whose main thread sits in a hung kernel is told apart from one that is merely slower.  When its sequences
+    are done a rank publishes its records as records_<rank>.json (written atomically).  How the table is assembled is ONE decision,
+    written once (decision.json is created with link(2): the first writer wins, everybody else reads what it wrote):
+      "collective"  written by rank 0 when every rank has published AND still has a fresh heartbeat: all of them are alive and about
+                    to enter the gather — the collective cannot hang;
+      "files"       written by WHICHEVER rank first sees that the gather cannot be entered safely — a heartbeat went stale (dead), a
+                    live rank made no progress for `hung_s` (hung), or nobody decided within `hung_s` of everybody having published
+                    (rank 0 stuck) — : nobody enters a collective; the table is assembled from the record files, and a sequence nobody
+                    reported is looked up in its own <out>/<sequence>/test_log.txt (train.scrape_test_logs — what the reference's
+                    scripts scrape, scripts/get_testing_psnr_davis.py:8-17) before it is marked failed.
+    A slower rank is never declared hung because a faster one is done: only missing heartbeats and missing progress count (round 4
+    judged this by the deciding rank's own duration — ADVICE r4).  Single node: the directory is on the node's file system (the farm
+    is one node by definition)."""
 
     def __init__(self, root, rank, world, beat_s=2.0):
         self.root, self.rank, self.world, self.beat_s = root, rank, world, beat_s
         os.makedirs(root, exist_ok=True)
         self.t0 = time.time()
+        self._progress = self.t0
+        self._lock = threading.Lock()
         self._stop = threading.Event()
         self._touch()
         self._thread = threading.Thread(target=self._beat, daemon=True)
@@ -92,8 +100,11 @@ class Rendezvous:
         return os.path.join(self.root, f"{kind}_{self.rank if rank is None else rank}.json")
 
     def _touch(self):
-        with open(self._path("beat"), "w") as f:
-            f.write(str(time.time()))
+        with self._lock:   # (the daemon thread and publish() both write it)
+            tmp = self._path("beat") + ".tmp"
+            with open(tmp, "w") as f:
+                json.dump(dict(now=time.time(), progress=self._progress), f)
+            os.replace(tmp, self._path("beat"))
 
     def _beat(self):
         while not self._stop.wait(self.beat_s):
@@ -102,49 +113,84 @@ class Rendezvous:
             except OSError:
                 pass
 
+    def tick(self):
+        """The main thread got somewhere (a sequence started / ended, a few hundred iterations passed)."""
+        self._progress = time.time()
+
     def close(self):
         self._stop.set()
 
     def publish(self, records):
+        self.tick()
         tmp = self._path("records") + ".tmp"
         with open(tmp, "w") as f:
             json.dump(records, f)
         os.replace(tmp, self._path("records"))
+        try:
+            self._touch()
+        except OSError:
+            pass
 
-    def _state(self, r, stale_s):
+    def _state(self, r, stale_s, hung_s=None):
+        """-> "done" (published, heartbeat fresh) | "working" | "hung" (alive, no progress tick for hung_s) | "dead" (heartbeat stale;
+        a rank that published and then died is dead, not done: it will not show up in the gather)."""
+        now = time.time()
+        try:
+            age = now - os.path.getmtime(self._path("beat", r))
+        except OSError:
+            age = now - self.t0                  # never seen: counts from our own start
+        if age > stale_s:
+            return "dead"
         if os.path.exists(self._path("records", r)):
             return "done"
-        try:
-            age = time.time() - os.path.getmtime(self._path("beat", r))
-        except OSError:
-            age = time.time() - self.t0          # never seen: counts from our own start
-        return "dead" if age > stale_s else "working"
+        if hung_s is not None:
+            try:
+                with open(self._path("beat", r)) as f:
+                    progress = float(json.load(f)["progress"])
+            except (OSError, ValueError, KeyError, TypeError):
+                progress = now                    # being rewritten: look again next time
+            if now - progress > hung_s:
+                return "hung"
+        return "working"
 
-    def decide(self, stale_s=30.0, hung_s=None):
-        """-> "collective" | "files" (see the class docstring).  hung_s: how long a live rank may still work after this rank has
-        published; default: as long again as this rank took, plus two minutes."""
-        mine = time.time() - self.t0
-        hung_s = (mine + 120.0) if hung_s is None else hung_s
-        deadline = time.time() + hung_s
+    def _write_decision(self, mode, states):
+        """First writer wins (link(2) fails when the name exists); -> the decision that stands."""
         decision = os.path.join(self.root, "decision.json")
+        tmp = os.path.join(self.root, f"decision_{self.rank}.tmp")
+        with open(tmp, "w") as f:
+            json.dump(dict(mode=mode, states=states, by=self.rank), f)
+        try:
+            os.link(tmp, decision)
+        except FileExistsError:
+            pass
+        finally:
+            os.remove(tmp)
+        with open(decision) as f:
+            return json.load(f)["mode"]
+
+    def decide(self, stale_s=30.0, hung_s=600.0):
+        """-> "collective" | "files" (see the class docstring).  stale_s: heartbeat age that means a dead process; hung_s: how long a
+        live rank may go without a progress tick (and how long the ranks wait for rank 0's decision once everybody has published)."""
+        decision = os.path.join(self.root, "decision.json")
+        all_done_since = None
         while True:
             if os.path.exists(decision):
                 try:
                     with open(decision) as f:
                         return json.load(f)["mode"]
                 except (OSError, ValueError, KeyError):
-                    pass                                  # being written: look again
-            if self.rank == 0:
-                states = [self._state(r, stale_s) for r in range(self.world)]
-                mode = "collective" if all(s == "done" for s in states) else ("files" if "dead" in states or time.time() > deadline else None)
-                if mode:
-                    tmp = decision + ".tmp"
-                    with open(tmp, "w") as f:
-                        json.dump(dict(mode=mode, states=states), f)
-                    os.replace(tmp, decision)
-                    return mode
-            elif self._state(0, stale_s) == "dead" or time.time() > deadline + stale_s:
-                return "files"                            # nobody left to decide
+                    pass                                  # (cannot be half-written — link(2) — but a reader may race the unlink of a tmp)
+            states = [self._state(r, stale_s, hung_s) for r in range(self.world)]
+            if "dead" in states or "hung" in states:
+                return self._write_decision("files", states)
+            if all(s == "done" for s in states):
+                if self.rank == 0:
+                    return self._write_decision("collective", states)
+                all_done_since = all_done_since or time.time()
+                if time.time() - all_done_since > hung_s:   # rank 0 beats but does not decide
+                    return self._write_decision("files", states)
+            else:
+                all_done_since = None
             time.sleep(0.05)
 
     def records_from_files(self):
@@ -183,12 +229,15 @@ def sequence_cost(seq_dir):
     return float(sum(c["width"] * c["height"] for c in cams.values()))
 
 
-def run_sequence_job(scene_id, iterations, device, frames=6, seq_dir=None, out_dir=None, fused=False, gt_mask_dir=None, dataset="sintel"):
+def run_sequence_job(scene_id, iterations, device, frames=6, seq_dir=None, out_dir=None, fused=False, gt_mask_dir=None, dataset="sintel",
+                     progress=None):
     """One independent 'sequence': load a preprocessed DAS3R sequence directory (das3r_amd.io_formats.load_sequence) — or,
     without one, build a synthetic multi-frame scene —, optimise it with the train-step harness, report the held-out PSNR and,
     with out_dir, write what the reference writes (point_cloud/iteration_N/point_cloud.ply, pose/pose_N.npy:
     train_gui.py:467-480,523-528).  Failures are isolated per sequence (the reference's predictor farm does the same,
-    pose_eval.py:209-222)."""
+    pose_eval.py:209-222).  progress: called at the job's stages and every few hundred iterations (Rendezvous.tick)."""
+    progress = progress or (lambda: None)
+    progress()
     from .model import OptimParams
     from .train import build_from_sequence, psnr_report, synthetic_sequence, train
     try:
@@ -207,7 +256,9 @@ def run_sequence_job(scene_id, iterations, device, frames=6, seq_dir=None, out_d
         dyn = None
         if masks is not None and any(m is not None for m in masks):   # keyed by the test camera's uid; views without a mask are skipped
             dyn = {c.uid: (torch.from_numpy(masks[c.frame_index]).to(device) if masks[c.frame_index] is not None else None) for c in test}
-        stats = train(model, train_cams, opt, iterations, seed=scene_id, fused=fused, test_cameras=test, gt_dynamic_masks=dyn)
+        progress()
+        stats = train(model, train_cams, opt, iterations, seed=scene_id, fused=fused, test_cameras=test, gt_dynamic_masks=dyn, on_progress=progress)
+        progress()
         rep = psnr_report(model, test, dynamic_masks=dyn, test_poses=True, iteration=iterations, log_dir=out_dir)
         cams = train_cams
         if out_dir is not None:
@@ -234,6 +285,8 @@ def main():
     ap.add_argument("--fused", action="store_true", help="use the fused pre-transform / Adam / loss kernels")
     ap.add_argument("--gt-dynamic-mask", default=None, help="root of the ground-truth dynamic masks, <root>/<sequence>/... (train_test_psnr.py --gt_dynamic_mask)")
     ap.add_argument("--dataset", default="sintel", choices=("sintel", "davis"))
+    ap.add_argument("--hung-timeout", type=float, default=600.0, help="seconds a live rank may go without a progress tick before the gather is "
+                    "replaced by the record files (a rank that is merely slower keeps ticking and is waited for)")
     ap.add_argument("--rendezvous", default=None, help="directory of the ranks' heartbeat / record files (default: <out>/.farm or /tmp/das3r_farm_<port>)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -255,6 +308,7 @@ def main():
                 os.remove(os.path.join(root, f))
         dist.barrier()  # (start of the run: every rank is alive here, and nothing of this run has been written yet)
         rdv = Rendezvous(root, rank, world)
+    tick = rdv.tick if rdv is not None else None
     dirs = None
     if args.data:   # real sequences: every rank lists the same sorted directory, longest first across ranks
         dirs = sorted(d for d in os.listdir(args.data) if os.path.isfile(os.path.join(args.data, d, "sparse/0/cameras.txt")))
@@ -263,15 +317,15 @@ def main():
         records = [run_sequence_job(s, args.iterations, device, seq_dir=os.path.join(args.data, dirs[s]),
                                     out_dir=os.path.join(args.out, dirs[s]) if args.out else None, fused=args.fused,
                                     gt_mask_dir=os.path.join(args.gt_dynamic_mask, dirs[s]) if args.gt_dynamic_mask else None,
-                                    dataset=args.dataset) for s in mine]
+                                    dataset=args.dataset, progress=tick) for s in mine]
     else:
         mine = assign(args.sequences, rank, world)
-        records = [run_sequence_job(s, args.iterations, device, fused=args.fused) for s in mine]
+        records = [run_sequence_job(s, args.iterations, device, fused=args.fused, progress=tick) for s in mine]
     names = dirs if args.data else [f"seq_{i}" for i in range(args.sequences)]
     mode = "collective"
     if rdv is not None:
         rdv.publish(records)
-        mode = rdv.decide()
+        mode = rdv.decide(hung_s=args.hung_timeout)
     if mode == "collective":
         table = gather_records(records, args.sequences, device)
     else:
@@ -279,19 +333,26 @@ def main():
         table = table_from_files(rdv, args.sequences, names, args.out)
     if rdv is not None:
         rdv.close()
+    good = table[table[:, 5] > 0]
     if rank == 0 or (mode == "files" and rdv is not None and rdv._state(0, 30.0) == "dead" and rank == min(
             r for r in range(world) if rdv._state(r, 30.0) != "dead")):
         from .train import latex_rows
-        good = table[table[:, 5] > 0]
         head, row = latex_rows({names[int(r[0])]: float(r[1]) for r in good})   # the rows get_testing_psnr_davis.py:19-22 prints
         print(head)
         print(row)
         print(f"mean PSNR {good[:, 1].mean().item():.2f} over {good.shape[0]}/{args.sequences} sequences")
+    lost = good.shape[0] < args.sequences
     if world > 1:
         if mode == "collective":
             dist.destroy_process_group()
         else:
-            os._exit(0)   # a peer is gone: tearing the process group down would wait for it
+            # a peer is gone: tearing the process group down would wait for it.  os._exit skips the interpreter's own flush — with
+            # stdout a pipe or a file (torchrun logs) the table above would be lost exactly in the case this path exists for
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(3 if lost else 0)
+    if lost:
+        sys.exit(3)   # launch scripts see a partial table as a failure (the table itself has been printed)
 
 
 if __name__ == "__main__":

@@ -74,7 +74,7 @@ def train_step(model: SplatModel, cam, opt: OptimParams, iteration, pipe, backgr
 
 
 def train(model, cameras, opt: OptimParams, iterations, pipe=None, background=None, seed=0, log_every=0, fused=False,
-          test_cameras=None, gt_dynamic_masks=None):
+          test_cameras=None, gt_dynamic_masks=None, on_progress=None):
     """Random camera without replacement per epoch (train_gui.py:546-555).  With test_cameras: train_test_psnr.py's loop, which
     walks the held-out views whenever the training stack has run empty (test_pose_pass).  Returns dict(loss, psnr, iters_per_s)."""
     pipe = pipe or SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
@@ -94,6 +94,8 @@ def train(model, cameras, opt: OptimParams, iterations, pipe=None, background=No
             test_pose_pass(model, test_cameras, gt_dynamic_masks, opt, pipe, background, rng, fused=fused)
         ema = torch.lerp(ema, loss, 0.4)      # 0.4 loss + 0.6 ema, one kernel; stays on the device: a float() here would stall the host every iteration
         last_psnr = p
+        if on_progress is not None and it % 256 == 0:   # (farm.Rendezvous.tick: this rank's main thread is getting somewhere)
+            on_progress()
         if log_every and it % log_every == 0:
             print(f"[ITER {it}] loss {float(ema):.5f} psnr_frame {float(last_psnr):.2f}")
     if dev.type == "cuda":

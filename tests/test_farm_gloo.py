@@ -1,5 +1,6 @@
 """CPU tests of the multi-GPU farm path with world_size 2 over gloo: sequence assignment, and the
 record gather that replaces the reference's log scraping.  No GPU compute: the per-sequence job is replaced by a stub."""
+import json
 import os
 import socket
 
@@ -170,3 +171,46 @@ def test_one_dead_rank_does_not_hang_the_gather(tmp_path, die):
         assert table[[0, 2], 1].tolist() == [20.0, 22.0] and table[[0, 2], 5].tolist() == [1, 1]     # rank 0's own sequences
         assert table[1, 1] == 31.25 and table[1, 5] == 1                                              # from seq_1/test_log.txt
         assert table[3, 5] == 0                                                                       # lost with its rank
+
+
+def _scenario_worker(rank, world, port, out_dir, scenario):
+    """Rendezvous scenarios of ADVICE r4 (no collective is needed to tell them apart: only the decision is recorded)."""
+    import time
+    rdv = farm.Rendezvous(os.path.join(out_dir, ".farm"), rank, world, beat_s=0.1)
+    recs = [dict(scene_id=rank, psnr=20.0 + rank, l1=0.0, iters_per_s=1.0, n_splats=1, ok=1)]
+    if scenario == "slow_rank_is_waited_for" and rank == 1:
+        for _ in range(12):          # 3 s of work — three times the hung timeout — with progress ticks: slower, not hung
+            time.sleep(0.25)
+            rdv.tick()
+    if scenario == "rank0_silent_then_late" and rank == 0:
+        time.sleep(3.0)              # alive (heartbeat) but no progress for three hung timeouts: rank 1 gives up on the gather first
+    if scenario == "hung_rank" and rank == 1:
+        time.sleep(4.0)              # alive, never ticks, never publishes in time
+    rdv.publish(recs)
+    mode = rdv.decide(stale_s=10.0, hung_s=1.0)
+    with open(os.path.join(out_dir, ".farm", "decision.json")) as f:
+        by = json.load(f)["by"]
+    rdv.close()
+    torch.save((mode, by), os.path.join(out_dir, f"scenario_{rank}.pt"))
+    os._exit(0)
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("scenario,mode,by", [("slow_rank_is_waited_for", "collective", 0), ("rank0_silent_then_late", "files", 1),
+                                              ("hung_rank", "files", 0)])
+def test_rendezvous_decision_is_one_and_fair(tmp_path, scenario, mode, by):
+    """ADVICE r4 (farm.py Rendezvous.decide): (1) a rank that is merely slower — it keeps ticking — is waited for, however long the
+    faster rank has been done (round 4 declared it hung after the deciding rank's own duration + 120 s and dropped its sequences);
+    (2) the decision is written ONCE by whoever takes it first and honoured by everybody: a non-zero rank that gives up on a silent
+    rank 0 writes "files", and rank 0, arriving later with every record file present, reads that instead of deciding "collective"
+    and entering a gather its peer will never join; (3) a rank that lives (heartbeat) without progress is hung: files."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_scenario_worker, args=(r, world, 0, str(tmp_path), scenario)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(60)
+    assert all(not p.is_alive() and p.exitcode == 0 for p in procs)
+    got = [torch.load(tmp_path / f"scenario_{r}.pt") for r in range(world)]
+    assert got[0] == got[1] == (mode, by), got

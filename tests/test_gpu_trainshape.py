@@ -58,14 +58,10 @@ def _oracle_as_renderer(means3D, means2D, opac, shs=None, scales=None, rotations
     return _COracleRaster.apply(means3D, means2D, opac, shs, scales, rotations, settings), None, None
 
 
-@pytest.mark.parametrize("degree", [0, 1])
-def test_sintel_shaped_step_vs_float64_host_and_c_oracle(degree, monkeypatch):
-    import oracle.dense_trainer as dt
-    from das3r_amd.fused import masked_photometric_loss
+def _sintel_model(degree, depth="noise"):
     from das3r_amd.model import OptimParams
-    from das3r_amd.render import das3r_render
     from das3r_amd.train import build_from_sequence, synthetic_sequence
-    seq = synthetic_sequence(frames=22, W=512, H=208, focal=600.0, n_splats=20000, seed=2)
+    seq = synthetic_sequence(frames=22, W=512, H=208, focal=600.0, n_splats=20000, seed=2, depth=depth)
     model, cams, test = build_from_sequence(seq, heldout=True)
     P = model.get_xyz.shape[0]
     assert len(cams) == 20 and len(test) == 2 and P == 20 * 512 * 208
@@ -79,6 +75,62 @@ def test_sintel_shaped_step_vs_float64_host_and_c_oracle(degree, monkeypatch):
         model._conf_static.mul_(0.6 + 0.4 * torch.rand(model._conf_static.shape, generator=gen).cuda())
     model.active_sh_degree = degree
     model.optimizer.set_active_sh_degree(degree)
+    return model, cams, opt, P
+
+
+def _host_step(model, cams, uid, degree, monkeypatch):
+    """float64 host restatement of the iteration with the C oracle as its renderer -> (host trainer after backward, loss, frame PSNR,
+    means2D leaf)"""
+    import oracle.dense_trainer as dt
+    monkeypatch.setattr(dt, "rasterize_dense", _oracle_as_renderer)
+    cpu = lambda t: t.detach().cpu()
+    params = dict(xyz=cpu(model._xyz), f_dc=cpu(model._features_dc), f_rest=cpu(model._features_rest), opacity=cpu(model._opacity),
+                  scaling=cpu(model._scaling), rotation=cpu(model._rotation), conf_static=cpu(model._conf_static), Q=cpu(model.Q),
+                  T=cpu(model.T), mask=cpu(model.aggregated_mask))
+    cameras = [dict(gt=cpu(c.original_image), fovx=c.FoVx, fovy=c.FoVy, proj_T=cpu(c.projection_matrix)) for c in cams]
+    host = dt.DenseTrainer(params, cameras, iterations=4000)
+    host.active_deg = degree
+    d_loss, d_psnr, d_m2d = host.loss_of(uid, torch.zeros(3, dtype=torch.float64))
+    d_loss.backward()
+    return host, d_loss, d_psnr, d_m2d
+
+
+FLIP_ELEMENTS = 2e-6   # fraction of a gradient tensor's elements that may miss the max-norm bound because of a threshold flip ...
+FLIP_REL = 5e-2        # ... each of them still within this much of the tensor's largest element
+
+
+def _compare_grads(pairs, what):
+    """Max-norm 2e-3 of the largest element and the element-wise bound of the module docstring.  The max-norm bound may be missed by
+    single elements (at most FLIP_ELEMENTS of the tensor, >= 3, each within FLIP_REL): one (pixel, Gaussian) pair whose alpha sits on
+    1/255 or whose T sits on 1e-4 decides differently on the two sides, and at this shape — Gaussians of one or two pixels — that
+    pair can be half of a Gaussian's gradient; when the Gaussian is one of the tensor's largest, the flip shows in the max norm.
+    Measured with tools/probes/smooth_step_diag.py on the smooth-depth sequence with IDENTICAL fp32 inputs on both sides: one Gaussian
+    of 2 129 920 off by 5 % (1.6e-3 .. 2.1e-3 of the maximum), everything else within the element-wise bound; with the float64 host's
+    inputs (rounded to fp32 on one side, computed in fp32 on the other) a handful more, up to 5.6e-3 — on the first-forward path and
+    the steady-state path alike (their gradients are bit-identical to each other)."""
+    report = {}
+    for k, g, r in pairs:
+        assert g is not None and r is not None, k
+        g, r = g.detach().double().cpu().reshape(-1), r.reshape(-1)
+        scale = float(r.abs().max())
+        assert scale > 0 and bool(torch.isfinite(g).all()), k
+        d = (g - r).abs()
+        rel = float(d.max()) / scale
+        flips = int((d > 2e-3 * scale).sum())
+        bad = float((d > 1e-2 * r.abs() + 1e-4 * scale).double().mean())
+        report[k] = (rel, bad)
+        assert flips <= max(3, int(FLIP_ELEMENTS * d.numel())) and rel <= FLIP_REL, (what, k, rel, flips)
+        assert bad <= 1e-3, (what, k, bad)
+    return report
+
+
+@pytest.mark.parametrize("degree", [0, 1])
+def test_sintel_shaped_step_vs_float64_host_and_c_oracle(degree, monkeypatch):
+    """The FIRST iteration of a model (autograd form of the fused path): the library has not seen the shape, so the binning is the
+    global depth sort and the forward the rows kernel; the steady state is the test below."""
+    from das3r_amd.fused import masked_photometric_loss
+    from das3r_amd.render import das3r_render
+    model, cams, opt, P = _sintel_model(degree)
     uid = 7
     bg = torch.zeros(3, device="cuda")
 
@@ -90,16 +142,7 @@ def test_sintel_shaped_step_vs_float64_host_and_c_oracle(degree, monkeypatch):
     torch.cuda.synchronize()
 
     # ---- float64 host restatement with the C oracle as its renderer
-    monkeypatch.setattr(dt, "rasterize_dense", _oracle_as_renderer)
-    cpu = lambda t: t.detach().cpu()
-    params = dict(xyz=cpu(model._xyz), f_dc=cpu(model._features_dc), f_rest=cpu(model._features_rest), opacity=cpu(model._opacity),
-                  scaling=cpu(model._scaling), rotation=cpu(model._rotation), conf_static=cpu(model._conf_static), Q=cpu(model.Q),
-                  T=cpu(model.T), mask=cpu(model.aggregated_mask))
-    cameras = [dict(gt=cpu(c.original_image), fovx=c.FoVx, fovy=c.FoVy, proj_T=cpu(c.projection_matrix)) for c in cams]
-    host = dt.DenseTrainer(params, cameras, iterations=4000)
-    host.active_deg = degree
-    d_loss, d_psnr, d_m2d = host.loss_of(uid, torch.zeros(3, dtype=torch.float64))
-    d_loss.backward()
+    host, d_loss, d_psnr, d_m2d = _host_step(model, cams, uid, degree, monkeypatch)
 
     assert abs(float(loss) - float(d_loss)) <= 2e-5 * abs(float(d_loss)) + 1e-7, (float(loss), float(d_loss))
     assert abs(psnr_frame - float(d_psnr)) < 2e-3, (psnr_frame, float(d_psnr))
@@ -114,16 +157,70 @@ def test_sintel_shaped_step_vs_float64_host_and_c_oracle(degree, monkeypatch):
         assert model._features_rest.grad is None and compact is not None and tuple(compact.shape) == (P, K1, 3)
         assert float(host.p["f_rest"].grad[:, K1:].abs().max()) == 0.0
         pairs.append(("f_rest", compact, host.p["f_rest"].grad[:, :K1]))
-    report = {}
-    for k, g, r in pairs:
-        assert g is not None and r is not None, k
-        g, r = g.detach().double().cpu().reshape(-1), r.reshape(-1)
-        scale = float(r.abs().max())
-        assert scale > 0 and bool(torch.isfinite(g).all()), k
-        rel = float((g - r).abs().max()) / scale
-        bad = float(((g - r).abs() > 1e-2 * r.abs() + 1e-4 * scale).double().mean())
-        report[k] = (rel, bad)
-        assert rel <= 2e-3, (k, rel)
-        assert bad <= 1e-3, (k, bad)
+    report = _compare_grads(pairs, f"degree {degree}")
     print("degree", degree, "P", P, "loss", float(loss), "max-norm / outlier fraction per gradient:",
+          {k: (f"{a:.1e}", f"{b:.1e}") for k, (a, b) in report.items()})
+
+
+@pytest.mark.parametrize("depth,degree", [("noise", 0), ("smooth", 0), ("smooth", 1)])
+def test_sintel_shaped_steady_state_direct_step_vs_float64_host_and_c_oracle(depth, degree, monkeypatch):
+    """the iteration the train-step time is QUOTED on — the direct form (das3r_amd/fast_step.py: a straight sequence
+    of C-ABI calls, no autograd) in its steady state, on both kinds of depth maps (depth="smooth": the spatially coherent maps of a depth
+    predictor, bench.py's train_step_smooth_ms).  Two warm-up passes over the same view teach the library the shape (they drop every
+    per-Gaussian gradient: geometry="pose", nothing changes), then the THIRD forward + backward is held to the float64 host
+    restatement with oracle/raster_oracle.c as its renderer: loss, frame PSNR, every parameter gradient, the pose gradient, the mask
+    gradient — and the kernels that ran are the ones the train-step profiles show: segmented binning without a global depth sort,
+    render_forward_lanes_kernel, the bucket-parallel render_backward_blk_kernel with the block-level last contributor.
+    Reference: /root/reference/train_gui.py:532-589 around gaussian_renderer/__init__.py:83-140."""
+    from das3r_amd import _lib, fast_step
+    model, cams, opt, P = _sintel_model(degree, depth)
+    assert fast_step.available(model, PIPE)
+    uid = 7
+    cam = cams[uid]
+    bg = torch.zeros(3, device="cuda")
+    st = fast_step._state(model)
+    Qg, Tg = torch.zeros_like(model.Q), torch.zeros_like(model.T)
+
+    def run(geometry):
+        with torch.no_grad():
+            out = fast_step.forward_backward(model, cam, model.Q[uid], model.T[uid], Qg[uid], Tg[uid], model._conf_static[uid],
+                                             opt.lambda_dssim, bg, geometry=geometry)
+        torch.cuda.synchronize()
+        return out
+
+    run("pose")
+    run("pose")
+    Qg.zero_()
+    Tg.zero_()
+    _lib.profile_report()
+    _lib.profile_enable(True)
+    try:
+        out8, d_static, pkg = run("grads")
+    finally:
+        _lib.profile_enable(False)
+    kernels = _lib.profile_report(raw=True)
+    n = lambda prefix, sub="": sum(c for k, (c, _) in kernels.items() if k.startswith(prefix) and sub in k)
+    assert n("segment_sort_kernel") == 1 and n("depth_hist_kernel") == 0, kernels
+    assert n("render_forward_lanes_kernel") == 1 and n("render_forward_rows_kernel") == 0, kernels
+    assert n("render_backward_blk_kernel", "true>") == 1 and n("render_backward_") == 1, kernels
+    loss, psnr_frame = float(out8[0]), float(out8[4])
+
+    host, d_loss, d_psnr, d_m2d = _host_step(model, cams, uid, degree, monkeypatch)
+    d_loss, d_psnr = d_loss.detach(), d_psnr.detach()
+    assert abs(loss - float(d_loss)) <= 2e-5 * abs(float(d_loss)) + 1e-7, (loss, float(d_loss))
+    assert abs(psnr_frame - float(d_psnr)) < 2e-3, (psnr_frame, float(d_psnr))
+    conf_grad = model._conf_static.grad.clone()
+    conf_grad[uid] += d_static          # the loss sees conf_static twice: as opacity factor and as the frame's mask (train_step adds it)
+    pairs = [(k, getattr(model, a).grad, host.p[k].grad) for k, a in NAMES.items() if k not in ("conf_static", "Q", "T")]
+    pairs += [("conf_static", conf_grad, host.p["conf_static"].grad), ("Q", Qg, host.p["Q"].grad), ("T", Tg, host.p["T"].grad),
+              ("means2D", pkg["viewspace_points"].grad, d_m2d.grad)]
+    K1 = (degree + 1) ** 2 - 1
+    compact = getattr(model._features_rest, "_das3r_compact_grad", None)
+    if degree == 0:
+        assert model._features_rest.grad is None and compact is None
+    else:
+        assert compact is not None and tuple(compact.shape) == (P, K1, 3)
+        pairs.append(("f_rest", compact, host.p["f_rest"].grad[:, :K1]))
+    report = _compare_grads(pairs, f"{depth} depth, degree {degree}")
+    print("steady state,", depth, "depth, degree", degree, "loss", loss, "kernels", sorted(kernels),
           {k: (f"{a:.1e}", f"{b:.1e}") for k, (a, b) in report.items()})
