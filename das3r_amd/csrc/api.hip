@@ -492,6 +492,13 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         }
         return launch_render_forward(a, in->colors_precomp, out->out_color, saved->geom, saved->binning, saved->img, L, lb, s);
     };
+    // prefiltered: the caller's promise that no point fails the near-plane cull (upstream traps when one does: auxiliary.h in_frustum);
+    // the preprocess kernel leaves this call's tag in mailbox word 12 when one did
+    auto prefiltered_ok = [&]() -> int {
+        if (!a->prefiltered || mb->host[12] != count_tag) return DAS3R_OK;
+        set_error("Point is filtered although prefiltered is set. This shouldn't happen!");
+        return DAS3R_ERR_INVALID_ARG;
+    };
     int64_t I, cap;
     // Local order + a previous forward of the same shape: nothing else could be enqueued while the count is on its way, so
     // the binning buffer is laid out for that forward's count + 25 % and the whole forward is enqueued before the host looks
@@ -546,6 +553,7 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
             if ((rc = bin_and_render(cap, local, true, mb->dev, count_tag))) return rc;
         }
         if ((rc = mailbox_wait(mb, 2, count_tag, s))) return rc;
+        if ((rc = prefiltered_ok())) return rc;
         I = (int64_t)mb->host[0];
         if (I > (int64_t)0x7FFFFF00) { set_error("num_rendered %lld exceeds 2^31", (long long)I); return DAS3R_ERR_OVERFLOW; }
         verdict.last_I = I;
@@ -569,6 +577,7 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, nullptr, 0, L, arrive, mb->dev, count_tag, s, nullptr, dhist))) return rc;
         if (!local && !seg && (rc = launch_depth_sort(P, saved->geom, L, 0, nullptr, 0, a->debug != 0, s))) return rc;
         if ((rc = mailbox_wait(mb, 2, count_tag, s))) return rc;    // usually there already: preprocess finished long ago
+        if ((rc = prefiltered_ok())) return rc;
         I = cap = (int64_t)mb->host[0];
         if (cap > (int64_t)0x7FFFFF00) { set_error("num_rendered %lld exceeds 2^31", (long long)cap); return DAS3R_ERR_OVERFLOW; }
         verdict.last_I = I;

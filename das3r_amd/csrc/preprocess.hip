@@ -22,7 +22,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     const float *__restrict__ projmatrix, const float *__restrict__ campos, int W, int H, float tanfovx, float tanfovy,
     int tiles_x, int tiles_y, int32_t *__restrict__ radii, uint32_t *__restrict__ depth_key, float4 *__restrict__ xyh,
     float4 *__restrict__ conic_opacity, float4 *__restrict__ rgbd, uint8_t *__restrict__ clamped,
-    uint32_t *__restrict__ tiles_touched, uint32_t *__restrict__ rect32, int tight_rect, uint32_t *__restrict__ zero_a, uint32_t zero_a_words, uint32_t *__restrict__ zero_b,
+    uint32_t *__restrict__ tiles_touched, uint32_t *__restrict__ rect32, int tight_rect /*bit 0: opacity-aware clipped rectangle; bit 1: prefiltered*/, uint32_t *__restrict__ zero_a, uint32_t zero_a_words, uint32_t *__restrict__ zero_b,
     uint32_t zero_b_words, uint32_t *__restrict__ zero_c, uint32_t zero_c_words, unsigned long long *__restrict__ arrive,
     uint32_t *__restrict__ host_out, uint32_t tag, const EmitArgs em,
     uint32_t *__restrict__ dhist /*segmented binning path: 256-bin depth histogram of this forward, zeroed by the caller (segkey.h); else null*/,
@@ -155,12 +155,18 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
                 }
                 xy_out = make_float4(px, py, hx, hy);
                 // instances are binned over the clipped rectangle (radii keeps upstream's value)
-                binned_rect(xy_out, r, tiles_x, tiles_y, tight_rect != 0, bx0, by0, bx1, by1);
+                binned_rect(xy_out, r, tiles_x, tiles_y, (tight_rect & 1) != 0, bx0, by0, bx1, by1);
                 tiles_out = (uint32_t)((bx1 - bx0) * (by1 - by0));
                 co_out = make_float4(conA, conB, conC, op);
                 rgbd_out = make_float4(col.x, col.y, col.z, p_view.z);
             }
         }
+    } else if ((tight_rect & 2) && live) {
+        // prefiltered = true is the caller's promise that no point is culled here; upstream:auxiliary.h in_frustum prints "Point is
+        // filtered although prefiltered is set" and traps.  Here the forward fails with that message: the tag of this call in word 12
+        // of the host mailbox, examined by das3r_raster_forward once the count has arrived (api.hip)
+        __hip_atomic_store(host_out + 12, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
     }
     if (live) {
     radii[idx] = radius_out;
@@ -355,7 +361,7 @@ int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int
         in->cov3D_precomp, in->colors_precomp, a->viewmatrix, a->projmatrix, a->campos, a->image_width, a->image_height,  \
         a->tanfovx, a->tanfovy, L.tiles_x, L.tiles_y, radii, (uint32_t *)(geom + L.g_keyA), (float4 *)(geom + L.pub.xy),  \
         (float4 *)(geom + L.pub.conic_opacity), (float4 *)(geom + L.pub.rgbd), (uint8_t *)(geom + L.pub.clamped),         \
-        (uint32_t *)(geom + L.pub.tiles_touched), (uint32_t *)(geom + L.g_rect), use_tight_rect() ? 1 : 0, (uint32_t *)(geom + L.g_ghist), (uint32_t)(L.g_ctrl_bytes / 4),                 \
+        (uint32_t *)(geom + L.pub.tiles_touched), (uint32_t *)(geom + L.g_rect), (use_tight_rect() ? 1 : 0) | (a->prefiltered ? 2 : 0), (uint32_t *)(geom + L.g_ghist), (uint32_t)(L.g_ctrl_bytes / 4),                 \
         (uint32_t *)(img + L.pub.ranges), (uint32_t)(2 * L.ntiles), (uint32_t *)binning_ctrl, (uint32_t)(binning_ctrl_bytes / 4), arrive, host_out, tag, em, dhist, dhist_mask
     const bool stage = has_sh && a->M == 16 && a->sh_degree >= 2 && ((uintptr_t)in->shs & 15) == 0 && !switches().no_sh_stage;
     if (has_sh && !has_cov && stage) DAS3R_LAUNCH((preprocess_kernel<true, false, true>), grid, block, 0, s, ARGS);

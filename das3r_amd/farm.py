@@ -230,24 +230,26 @@ def sequence_cost(seq_dir):
 
 
 def run_sequence_job(scene_id, iterations, device, frames=6, seq_dir=None, out_dir=None, fused=False, gt_mask_dir=None, dataset="sintel",
-                     progress=None):
+                     progress=None, seq=None):
     """One independent 'sequence': load a preprocessed DAS3R sequence directory (das3r_amd.io_formats.load_sequence) — or,
     without one, build a synthetic multi-frame scene —, optimise it with the train-step harness, report the held-out PSNR and,
     with out_dir, write what the reference writes (point_cloud/iteration_N/point_cloud.ply, pose/pose_N.npy:
     train_gui.py:467-480,523-528).  Failures are isolated per sequence (the reference's predictor farm does the same,
-    pose_eval.py:209-222).  progress: called at the job's stages and every few hundred iterations (Rendezvous.tick)."""
+    pose_eval.py:209-222).  seq: a sequence dict built by the caller (train.consistent_sequence: the self-consistent synthetic stand-in).
+    progress: called at the job's stages and every few hundred iterations (Rendezvous.tick)."""
     progress = progress or (lambda: None)
     progress()
     from .model import OptimParams
     from .train import build_from_sequence, psnr_report, synthetic_sequence, train
     try:
-        masks = None
-        if seq_dir is not None:
+        if seq is not None:
+            pass
+        elif seq_dir is not None:
             from .io_formats import load_sequence
             seq = load_sequence(seq_dir, device=device, gt_mask_dir=gt_mask_dir, dataset=dataset)
-            masks = seq.get("gt_dynamic_masks")   # ground-truth masks only: the report skips views without one
         else:
             seq = synthetic_sequence(frames=frames, seed=scene_id, device=device)
+        masks = seq.get("gt_dynamic_masks")   # ground-truth masks only: the report skips views without one
         # Gaussians, training poses and conf_static from the TRAINING frames only; the held-out frames ((idx + 5) % 10 == 0) give
         # their poses and their images as ground truth (scene/__init__.py:88-93, dataset_readers.py:342-347)
         model, train_cams, test = build_from_sequence(seq, heldout=True)
@@ -275,6 +277,59 @@ def run_sequence_job(scene_id, iterations, device, frames=6, seq_dir=None, out_d
         return dict(scene_id=scene_id, psnr=float("nan"), l1=float("nan"), iters_per_s=0.0, n_splats=0, ok=0)
 
 
+def run_jobs(items, job, jobs_per_gpu=1, device=None):
+    """[job(item) for item in items] with `jobs_per_gpu` of them in flight on this rank's GPU.
+
+    One optimisation job leaves the GPU half idle whichever way one looks at it: its compositing kernels are bound by VALU issue at
+    < 8 % of the HBM bandwidth, its per-Gaussian / binning / Adam / loss kernels by HBM or latency at < 18 % VALU issue, strictly one
+    after the other on one stream (profiles/r04_train_step_fused.json).  Independent sequences have nothing to wait for in each other:
+    K host threads per rank, each with its OWN HIP stream (torch's current stream is per thread), its own model and its own library
+    state (api.hip: thread_local per-device state, host mailbox, allocator callbacks) pull sequences from the rank's list, and the
+    hardware interleaves one job's compositing with another's streaming kernels.  ctypes and torch release the GIL inside their calls;
+    what the threads share of the interpreter is the glue between calls.  Results come back in the order of `items`; an exception of a
+    job is raised here (run_sequence_job itself never raises: failures are per-sequence records)."""
+    items = list(items)
+    K = max(1, min(int(jobs_per_gpu), len(items)))
+    if K == 1:
+        return [job(it) for it in items]
+    import queue
+    todo = queue.Queue()
+    for k, it in enumerate(items):
+        todo.put((k, it))
+    out, errors = [None] * len(items), []
+    use_gpu = device is not None and torch.device(device).type == "cuda"
+
+    def worker():
+        try:
+            if use_gpu:
+                torch.cuda.set_device(device)
+                stream = torch.cuda.Stream(device=device)
+                ctx = torch.cuda.stream(stream)
+            else:
+                import contextlib
+                stream, ctx = None, contextlib.nullcontext()
+            with ctx:
+                while True:
+                    try:
+                        k, it = todo.get_nowait()
+                    except queue.Empty:
+                        break
+                    out[k] = job(it)
+                if stream is not None:
+                    stream.synchronize()
+        except BaseException as ex:  # noqa: BLE001 - re-raised by the caller's thread
+            errors.append(ex)
+
+    threads = [threading.Thread(target=worker, name=f"das3r-job-{i}") for i in range(K)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sequences", type=int, default=8)
@@ -285,6 +340,8 @@ def main():
     ap.add_argument("--fused", action="store_true", help="use the fused pre-transform / Adam / loss kernels")
     ap.add_argument("--gt-dynamic-mask", default=None, help="root of the ground-truth dynamic masks, <root>/<sequence>/... (train_test_psnr.py --gt_dynamic_mask)")
     ap.add_argument("--dataset", default="sintel", choices=("sintel", "davis"))
+    ap.add_argument("--jobs-per-gpu", type=int, default=1, help="sequences in flight per GPU: K host threads per rank, each with its own stream "
+                    "and model (one job's VALU-bound compositing overlaps another's HBM / latency-bound kernels); 2 is the measured optimum")
     ap.add_argument("--hung-timeout", type=float, default=600.0, help="seconds a live rank may go without a progress tick before the gather is "
                     "replaced by the record files (a rank that is merely slower keeps ticking and is waited for)")
     ap.add_argument("--rendezvous", default=None, help="directory of the ranks' heartbeat / record files (default: <out>/.farm or /tmp/das3r_farm_<port>)")
@@ -314,13 +371,14 @@ def main():
         dirs = sorted(d for d in os.listdir(args.data) if os.path.isfile(os.path.join(args.data, d, "sparse/0/cameras.txt")))
         args.sequences = len(dirs)
         mine = assign(len(dirs), rank, world, costs=[sequence_cost(os.path.join(args.data, d)) for d in dirs])
-        records = [run_sequence_job(s, args.iterations, device, seq_dir=os.path.join(args.data, dirs[s]),
-                                    out_dir=os.path.join(args.out, dirs[s]) if args.out else None, fused=args.fused,
-                                    gt_mask_dir=os.path.join(args.gt_dynamic_mask, dirs[s]) if args.gt_dynamic_mask else None,
-                                    dataset=args.dataset, progress=tick) for s in mine]
+        job = lambda s: run_sequence_job(s, args.iterations, device, seq_dir=os.path.join(args.data, dirs[s]),
+                                         out_dir=os.path.join(args.out, dirs[s]) if args.out else None, fused=args.fused,
+                                         gt_mask_dir=os.path.join(args.gt_dynamic_mask, dirs[s]) if args.gt_dynamic_mask else None,
+                                         dataset=args.dataset, progress=tick)
     else:
         mine = assign(args.sequences, rank, world)
-        records = [run_sequence_job(s, args.iterations, device, fused=args.fused, progress=tick) for s in mine]
+        job = lambda s: run_sequence_job(s, args.iterations, device, fused=args.fused, progress=tick)
+    records = run_jobs(mine, job, args.jobs_per_gpu, device)
     names = dirs if args.data else [f"seq_{i}" for i in range(args.sequences)]
     mode = "collective"
     if rdv is not None:

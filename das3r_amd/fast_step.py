@@ -26,7 +26,7 @@ import os
 import torch
 
 from . import _lib
-from .rasterizer import GaussianRasterizationSettings, _backward_impl, _forward_full, _stream
+from .rasterizer import GaussianRasterizationSettings, _backward_impl, _forward_full, _on_device, _stream
 
 _p = lambda t: C.c_void_p(t.data_ptr())
 
@@ -101,20 +101,26 @@ def _dense_f32(obj, name):
 
 def _settings(st, cam, model, bg):
     """GaussianRasterizationSettings of render() for this camera (gaussian_renderer/__init__.py:53-78): identity view matrix,
-    projmatrix = I @ P^T, campos = 0.  Built once per (camera, SH degree, background tensor)."""
-    key = (id(cam), model.active_sh_degree, bg.data_ptr())
-    rs = st.settings.get(key)
-    if rs is None:
-        dev = st.dev
-        ident = torch.eye(4, device=dev)
-        proj = ident @ cam.projection_matrix.to(dev)
-        rs = GaussianRasterizationSettings(
-            image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=math.tan(float(cam.FoVx) * 0.5),
-            tanfovy=math.tan(float(cam.FoVy) * 0.5), bg=bg, scale_modifier=1.0, viewmatrix=ident.contiguous(), projmatrix=proj.contiguous(),
-            sh_degree=model.active_sh_degree, campos=torch.zeros(3, device=dev), prefiltered=False, debug=False)
-        if len(st.settings) > 4096:
-            st.settings.clear()
-        st.settings[key] = rs
+    projmatrix = I @ P^T, campos = 0.  Built once per (image size, FoV, projection-matrix tensor, SH degree, background tensor) —
+    keyed on the VALUES the settings are made of plus the identity of the two tensors they are built from, both of which the entry
+    keeps alive (so neither id can be handed to another object while the entry exists); never on the camera object's own id
+    (CPython hands the id of a freed camera to the next one: a camera made per iteration with another size or FoV was served the
+    stale settings).  Rebuilt when the projection matrix was written since."""
+    pm = cam.projection_matrix
+    key = (int(cam.image_height), int(cam.image_width), float(cam.FoVx), float(cam.FoVy), model.active_sh_degree, id(bg), id(pm))
+    hit = st.settings.get(key)
+    if hit is not None and hit[1] is pm and hit[2] == pm._version and hit[0].bg is bg:
+        return hit[0]
+    dev = st.dev
+    ident = torch.eye(4, device=dev)
+    proj = ident @ pm.to(dev)
+    rs = GaussianRasterizationSettings(
+        image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=math.tan(float(cam.FoVx) * 0.5),
+        tanfovy=math.tan(float(cam.FoVy) * 0.5), bg=bg, scale_modifier=1.0, viewmatrix=ident.contiguous(), projmatrix=proj.contiguous(),
+        sh_degree=model.active_sh_degree, campos=torch.zeros(3, device=dev), prefiltered=False, debug=False)
+    if len(st.settings) > 4096:
+        st.settings.clear()
+    st.settings[key] = (rs, pm, pm._version)
     return rs
 
 
@@ -127,8 +133,13 @@ def forward_backward(model, cam, q_row, t_row, gq_row, gt_row, static_hw, lambda
     step of the four tensors taken in that very pass (das3r_pretransform_backward_adam: they never reach memory; model.optimizer.step()
     then finds the four without gradient and passes them by); "pose": the camera's sums alone, every per-Gaussian gradient dropped.
     -> (out8 = {loss, mse x 3, psnr_frame, ...} device tensor, d_static [H, W], package)"""
-    lib = _lib.load()
     st = _state(model)
+    with _on_device(st.dev):   # (the library's per-device state and the raw stream belong to the model's GPU, current or not)
+        return _forward_backward(st, model, cam, q_row, t_row, gq_row, gt_row, static_hw, lambda_dssim, bg, geometry)
+
+
+def _forward_backward(st, model, cam, q_row, t_row, gq_row, gt_row, static_hw, lambda_dssim, bg, geometry):
+    lib = _lib.load()
     dev, P = st.dev, st.P
     H, W = int(cam.image_height), int(cam.image_width)
     s = _stream(dev)
@@ -219,7 +230,7 @@ def train_step(model, cam, opt, iteration, pipe, background):
         model.oneupSHdegree()
     st = _state(model)
     uid = cam.uid
-    with torch.no_grad():
+    with torch.no_grad(), _on_device(st.dev):   # (FusedAdam's launches too)
         out8, d_static, pkg = forward_backward(model, cam, model.Q[uid], model.T[uid], st.Qg[uid], st.Tg[uid], model._conf_static[uid],
                                                opt.lambda_dssim, background, geometry="adam" if getattr(model, "fuse_geometry_adam", True) else "grads")
         model._conf_static.grad[uid] += d_static             # the loss sees conf_static twice: as opacity factor and as the frame's mask
@@ -241,7 +252,7 @@ def test_pose_step(model, cam, static_hw, opt, background):
     uid = cam.uid
     if st.tQg is None:   # (the held-out poses were set after the first training step)
         st.tQg, st.tTg = torch.zeros_like(model.test_Q), torch.zeros_like(model.test_T)
-    with torch.no_grad():
+    with torch.no_grad(), _on_device(st.dev):
         out8, _d_static, _pkg = forward_backward(model, cam, model.test_Q[uid], model.test_T[uid], st.tQg[uid], st.tTg[uid], static_hw,
                                                  opt.lambda_dssim, background, geometry="pose")
         model.optimizer.zero_grad(set_to_none=True)

@@ -83,7 +83,7 @@ def train(model, cameras, opt: OptimParams, iterations, pipe=None, background=No
     rng = random.Random(seed)
     stack, ema, last_psnr = [], torch.zeros((), device=dev), torch.zeros((), device=dev)
     if dev.type == "cuda":
-        torch.cuda.synchronize()
+        torch.cuda.current_stream(dev).synchronize()   # (this job's stream only: other jobs may share the GPU — farm.run_jobs)
     t0 = time.perf_counter()
     for it in range(1, iterations + 1):
         if not stack:
@@ -99,7 +99,7 @@ def train(model, cameras, opt: OptimParams, iterations, pipe=None, background=No
         if log_every and it % log_every == 0:
             print(f"[ITER {it}] loss {float(ema):.5f} psnr_frame {float(last_psnr):.2f}")
     if dev.type == "cuda":
-        torch.cuda.synchronize()
+        torch.cuda.current_stream(dev).synchronize()
     return dict(loss=float(ema), psnr=float(last_psnr), iters_per_s=iterations / (time.perf_counter() - t0))
 
 
@@ -235,7 +235,11 @@ def synthetic_sequence(frames=6, W=128, H=80, focal=110.0, n_splats=6000, seed=0
     confidences, dynamic maps, intrinsics and poses in the layout SplatModel.create_from_frames expects.
     depth: "noise" — 5 .. 5.5, independent per pixel (rounds 1-3: every tile sees the whole depth slab); "smooth" (round 4) — a
     smooth relief with 1 % of noise, i.e. the spatially coherent depth a predictor's depth maps have: a tile sees a thin band of the
-    scene's depth range (ledger (ao))."""
+    scene's depth range (ledger (ao)).  Both kinds of maps are UNRELATED to the cloud that made the images: such a
+    sequence times a job, its held-out PSNR (17 - 18 dB) says nothing.  depth="rendered" (round 5) is the self-consistent one:
+    consistent_sequence below."""
+    if depth == "rendered":
+        return consistent_sequence(frames=frames, W=W, H=H, focal=focal, n_splats=n_splats, seed=seed, device=device)
     from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
     from .synth import make_scene
     dev = torch.device(device)
@@ -269,6 +273,80 @@ def synthetic_sequence(frames=6, W=128, H=80, focal=110.0, n_splats=6000, seed=0
     return dict(images=images, depths=torch.stack(depths).to(dev), confs=torch.full((frames, H, W), 2.0, device=dev),
                 dyna_avg=torch.zeros(frames, H, W, device=dev), K=K, cam2world=torch.stack(c2w).to(dev),
                 w2c_pose7=torch.stack(poses7).to(dev), focal=focal, W=W, H=H)
+
+
+def consistent_sequence(frames=22, W=512, H=208, focal=600.0, n_splats=20000, seed=0, device="cuda", moving=True, depth_noise=0.0,
+                        pose_noise=0.0):
+    """A SELF-CONSISTENT synthetic sequence: images, depth maps and poses all come from ONE scene, so that the
+    optimisation DAS3R runs on it has something to converge to and its held-out PSNR means something (a stand-in for BASELINE
+    configs[2] / [4], whose datasets are not in the container; protocol /root/reference/train_test_psnr.py:241-302, split
+    scene/dataset_readers.py:342-347).
+
+      * the scene: `n_splats` opaque-ish Gaussians (opacity 0.9, 2 - 6 pixels) ON a smooth relief z(u, v) (das3r_amd.synth
+        make_scene(coherent=...): the surface of a real scene), coloured at random — a textured surface;
+      * per frame: the image rendered by the rasterizer from that frame's pose, and the DEPTH MAP RENDERED FROM THE SAME CLOUD: one
+        more render with colors_precomp = (z_camera, 1, 0) gives sum(w z) and sum(w) = 1 - T_final per pixel, depth = their ratio
+        (the expected depth of the blend; where less than 5 % of a pixel is covered, the scene's mean depth) — what a perfect depth
+        predictor would hand DAS3R.  depth_noise / pose_noise: relative depth error / pose translation error (the predictor's) on top;
+      * a MOVING OBJECT (`moving`): a disc that crosses the frame, painted over the images in its own colour, nearer than the surface
+        in the depth maps, with dyna_avg = 1 inside it (DAS3R's dynamic map: conf_static = 1 - dyna_avg keeps those pixels'
+        Gaussians transparent and masks them in the loss) and returned per frame as `gt_dynamic_masks` (bool numpy arrays: the report
+        then measures the static region only, as train_test_psnr.py does with --gt_dynamic_mask).
+    -> the dict synthetic_sequence returns, plus gt_dynamic_masks."""
+    from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    from .synth import make_scene
+    dev = torch.device(device)
+    sc = make_scene(P=n_splats, W=W, H=H, focal=focal, sh_degree=0, seed=100 + seed, s_px=(2.0, 6.0), opacity=0.9, coherent=0.002).to(dev)
+    g = torch.Generator().manual_seed(seed)
+    fovx, fovy = focal2fov(focal, W), focal2fov(focal, H)
+    zero3 = torch.zeros(3, device=dev)
+    vv, uu = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    disc_rgb = torch.tensor([0.9, 0.2, 0.1]).view(3, 1, 1)
+    radius = 0.11 * H + 4.0
+    images, poses7, c2w, depths, dyna, masks = [], [], [], [], [], []
+    mean_z = float(sc.means3D[:, 2].mean())
+    for f in range(frames):
+        t = torch.tensor([0.05 * (f - frames / 2), 0.02 * math.sin(f), 0.0]) + 0.005 * torch.randn(3, generator=g)
+        view = torch.eye(4)
+        view[:3, 3] = t                                    # world -> camera (pure translation)
+        view_t = view.t().contiguous().to(dev)
+        proj = (view_t @ projection_matrix(0.01, 100.0, fovx, fovy).t().to(dev)).contiguous()
+        rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=math.tan(fovx / 2), tanfovy=math.tan(fovy / 2),
+                                           bg=zero3, scale_modifier=1.0, viewmatrix=view_t, projmatrix=proj,
+                                           sh_degree=0, campos=(-t).to(dev), prefiltered=False, debug=False)
+        m2 = torch.zeros_like(sc.means3D)
+        with torch.no_grad():
+            img, _ = GaussianRasterizer(rs)(means3D=sc.means3D, means2D=m2, opacities=sc.opacities, shs=sc.shs, scales=sc.scales,
+                                            rotations=sc.rotations)
+            zc = sc.means3D[:, 2] + float(t[2])            # camera-space depth of every Gaussian in this frame
+            zcol = torch.stack([zc, torch.ones_like(zc), torch.zeros_like(zc)], 1).contiguous()
+            zimg, _ = GaussianRasterizer(rs)(means3D=sc.means3D, means2D=m2, opacities=sc.opacities, colors_precomp=zcol, scales=sc.scales,
+                                             rotations=sc.rotations)
+        cover = zimg[1]
+        d = torch.where(cover > 0.05, zimg[0] / cover.clamp_min(1e-6), torch.full_like(cover, mean_z)).cpu()
+        img = img.clamp(0, 1).cpu()
+        mask = torch.zeros(H, W, dtype=torch.bool)
+        if moving:   # the disc crosses the frame from left to right, bobbing
+            cx = W * (0.12 + 0.76 * f / max(frames - 1, 1))
+            cy = H * (0.5 + 0.22 * math.sin(0.7 * f))
+            mask = (uu - cx) ** 2 + (vv - cy) ** 2 <= radius * radius
+            img = torch.where(mask[None], disc_rgb.expand(3, H, W), img)
+            d = torch.where(mask, 0.6 * d, d)
+        if depth_noise:
+            d = d * (1.0 + depth_noise * torch.randn(H, W, generator=g))
+        tp = t + pose_noise * torch.randn(3, generator=g) if pose_noise else t
+        vp = torch.eye(4)
+        vp[:3, 3] = tp
+        images.append(img)
+        depths.append(d)
+        dyna.append(mask.float())
+        masks.append(mask.numpy())
+        poses7.append(torch.cat([torch.tensor([1.0, 0, 0, 0]), tp]))
+        c2w.append(torch.linalg.inv(vp))
+    K = torch.tensor([[focal, 0, W / 2], [0, focal, H / 2], [0, 0, 1.0]]).repeat(frames, 1, 1).to(dev)
+    return dict(images=torch.stack(images).to(dev), depths=torch.stack(depths).to(dev), confs=torch.full((frames, H, W), 2.0, device=dev),
+                dyna_avg=torch.stack(dyna).to(dev), K=K, cam2world=torch.stack(c2w).to(dev), w2c_pose7=torch.stack(poses7).to(dev),
+                focal=focal, W=W, H=H, gt_dynamic_masks=masks)
 
 
 def split_sequence(seq):

@@ -81,7 +81,8 @@ typedef struct {
     const float *viewmatrix; /* [4,4]  device, row-vector layout */
     const float *projmatrix; /* [4,4]  device, row-vector layout */
     const float *campos;     /* [3]    device */
-    int32_t prefiltered;
+    int32_t prefiltered;     /* !=0: the caller's promise that no Gaussian fails the near-plane cull (upstream:auxiliary.h in_frustum traps
+                              * when one does); das3r_raster_forward then fails with upstream's message instead of rendering */
     int32_t debug;           /* !=0: synchronise + check after every kernel */
     int64_t capacity_hint;   /* 0: the library lays the binning buffer out as it sees fit — exactly for num_rendered (which reaches
                               * the host from the first kernel of the forward), or, for a shape it has seen before, with headroom

@@ -48,3 +48,33 @@ def test_direct_iteration_is_only_taken_with_fused_optimizers_and_the_default_pi
     monkeypatch.setenv("DAS3R_FAST_STEP", "0")
     fused.fast_step = True
     assert not fast_step.available(fused, pipe)                  # switched off in the environment
+
+
+def test_fast_step_settings_are_keyed_on_values_not_on_the_camera_id():
+    """ADVICE r4 (fast_step.py _settings): the cache was keyed on id(cam) without keeping the camera alive — CPython hands a freed
+    object's id to the next allocation, so a camera made later with another size / FoV got the stale settings.  Now: values + the two
+    tensors the settings are built from (kept alive by the entry)."""
+    from types import SimpleNamespace
+
+    from das3r_amd import fast_step
+    st = SimpleNamespace(dev=torch.device("cpu"), settings={})
+    model = SimpleNamespace(active_sh_degree=0)
+    bg = torch.zeros(3)
+    mk = lambda W, H, f: SimpleNamespace(image_height=H, image_width=W, FoVx=f, FoVy=f, projection_matrix=torch.eye(4) * f)
+    a, b = mk(64, 32, 0.5), mk(64, 32, 0.5)
+    ra, rb = fast_step._settings(st, a, model, bg), fast_step._settings(st, b, model, bg)
+    assert fast_step._settings(st, a, model, bg) is ra and fast_step._settings(st, b, model, bg) is rb and ra is not rb
+    for _ in range(64):   # cameras made per iteration: whatever id they get, the settings are theirs
+        del a
+        a = mk(128, 48, 0.7)
+        rs = fast_step._settings(st, a, model, bg)
+        assert (rs.image_width, rs.image_height) == (128, 48) and abs(rs.tanfovx - __import__("math").tan(0.35)) < 1e-12
+        del a
+        a = mk(64, 32, 0.5)
+        rs = fast_step._settings(st, a, model, bg)
+        assert (rs.image_width, rs.image_height) == (64, 32)
+    a.projection_matrix.mul_(2.0)   # written in place: rebuilt
+    r2 = fast_step._settings(st, a, model, bg)
+    assert r2 is not rs and torch.equal(r2.projmatrix, a.projection_matrix)
+    model.active_sh_degree = 1
+    assert fast_step._settings(st, a, model, bg).sh_degree == 1

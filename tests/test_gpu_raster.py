@@ -196,6 +196,39 @@ def test_mark_visible():
     assert got.dtype == bool and np.array_equal(got, ref)
 
 
+def test_prefiltered_is_honoured():
+    """GaussianRasterizationSettings.prefiltered: the caller's promise that no Gaussian fails the near-plane cull.
+    Kept, the image is the one of prefiltered=False bit for bit (twice: exactly sized and speculative layout); broken, upstream prints
+    "Point is filtered although prefiltered is set. This shouldn't happen!" and traps (upstream:auxiliary.h in_frustum) — here the
+    forward raises with that message, and the next forward of the thread works."""
+    from das3r_amd import GaussianRasterizationSettings, GaussianRasterizer
+    dev = _dev()
+
+    def render(sc, prefiltered):
+        scd = sc.to(dev)
+        kw = scd.settings_kwargs()
+        kw["prefiltered"] = prefiltered
+        with torch.no_grad():
+            return GaussianRasterizer(GaussianRasterizationSettings(**kw))(
+                means3D=scd.means3D, means2D=torch.zeros_like(scd.means3D), opacities=scd.opacities, shs=scd.shs, scales=scd.scales,
+                rotations=scd.rotations)
+
+    sc, _ = util.scene_variant("basic_deg3")            # every splat in front of the near plane
+    assert float(sc.means3D[:, 2].min()) > 0.5
+    ref, ref_radii = render(sc, False)
+    for _ in range(2):
+        c, r = render(sc, True)
+        assert torch.equal(c, ref) and torch.equal(r, ref_radii)
+    bad, _ = util.scene_variant("culled")               # 200 splats behind / at the near plane
+    for _ in range(2):
+        with pytest.raises(RuntimeError, match="Point is filtered although prefiltered is set"):
+            render(bad, True)
+    c, _ = render(bad, False)
+    assert bool(torch.isfinite(c).all())
+    c, r = render(sc, True)
+    assert torch.equal(c, ref) and torch.equal(r, ref_radii)
+
+
 def test_reduction_modes_agree(monkeypatch):
     """The DPP wave reduction of the backward kernel against its ds_bpermute reference reduction."""
     sc, mode = util.scene_variant("long_lists")
