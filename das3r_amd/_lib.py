@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdas3r_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
@@ -53,7 +53,8 @@ EXPORTS = ("das3r_raster_forward", "das3r_raster_backward", "das3r_raster_check"
            "das3r_profile_enable", "das3r_profile_report", "das3r_pretransform_forward", "das3r_pretransform_backward", "das3r_pose_matrices", "das3r_pose_chain",
            "das3r_adam_step", "das3r_adam_step_gated", "das3r_photometric_blocks", "das3r_photometric_forward", "das3r_photometric_backward",
            "das3r_has_experiments", "das3r_pair_counters", "das3r_debug_poison_lds", "das3r_debug_inject_fault",
-           "das3r_pose_matrices_qt", "das3r_pose_chain_qt", "das3r_photometric_finish", "das3r_pretransform_backward_adam", "das3r_pretransform_pose_sums")
+           "das3r_pose_matrices_qt", "das3r_pose_chain_qt", "das3r_photometric_finish", "das3r_pretransform_backward_adam", "das3r_pretransform_pose_sums",
+           "das3r_raster_count_live_pairs")
 
 class AdamSlot(C.Structure):
     """include/das3r_raster.h das3r_adam_slot (ABI 11)."""

@@ -714,6 +714,29 @@ extern "C" int das3r_pair_counters(int enable, uint64_t out[4]) {
     return DAS3R_OK;
 }
 
+// Live pairs of a forward (pair_count.hip): out[0] = (pixel, splat) pairs that were blended, out[1] = (pixel, list position) pairs in
+// front of the pixels' last contributors (what a walk without any culling would evaluate).  Synchronises the stream; measurement only.
+extern "C" int das3r_raster_count_live_pairs(const das3r_raster_args *a, const das3r_raster_saved *saved, uint64_t out[2], das3r_stream_t stream) {
+    if (!a || !saved || !out) { set_error("das3r_raster_count_live_pairs: null argument"); return DAS3R_ERR_INVALID_ARG; }
+    out[0] = out[1] = 0;
+    if (a->P == 0 || saved->num_rendered <= 0) return DAS3R_OK;
+    if (!saved->geom || !saved->binning || !saved->img) { set_error("das3r_raster_count_live_pairs: saved buffers missing"); return DAS3R_ERR_INVALID_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    Layout L;
+    compute_layout(a->P, saved->capacity > 0 ? saved->capacity : saved->num_rendered, a->image_width, a->image_height, &L);
+    unsigned long long *dev = nullptr;
+    HIP_TRY(hipMalloc((void **)&dev, 2 * sizeof(unsigned long long)));
+    int rc = DAS3R_OK;
+    if (hipMemsetAsync(dev, 0, 2 * sizeof(unsigned long long), s) != hipSuccess) rc = DAS3R_ERR_HIP;
+    if (!rc) rc = launch_count_live_pairs(a, saved->geom, saved->binning, saved->img, L, dev, s);
+    if (!rc && (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(out, dev, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)) {
+        set_error("das3r_raster_count_live_pairs: device error");
+        rc = DAS3R_ERR_HIP;
+    }
+    (void)hipFree(dev);
+    return rc;
+}
+
 #ifdef DAS3R_EXPERIMENTS
 static unsigned long long *g_trace = nullptr;
 namespace das3r { unsigned long long *wg_trace() { return g_trace; } }

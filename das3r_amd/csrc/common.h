@@ -308,6 +308,8 @@ int launch_render_forward(const das3r_raster_args *a, const float *colors_precom
 // *quad_rows (out): false = partial[I][9], one row per instance; true = the stream kernel's rows[I][4][12] + existence bytes
 int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
                            float *partial, hipStream_t s, bool *quad_rows, int64_t num_rendered);
+// pair_count.hip (measurement aid): out[0] += live pairs, out[1] += (pixel, list position) pairs below the pixel's n_contrib
+int launch_count_live_pairs(const das3r_raster_args *a, char *geom, char *binning, char *img, const Layout &L, unsigned long long *out, hipStream_t s);
 int launch_preprocess_backward(const das3r_raster_args *a, const das3r_raster_in *in, char *geom, char *binning, const Layout &L,
                                const das3r_raster_grads *g, const float *partial, hipStream_t s, bool quad_rows);
 

@@ -230,12 +230,13 @@ def sequence_cost(seq_dir):
 
 
 def run_sequence_job(scene_id, iterations, device, frames=6, seq_dir=None, out_dir=None, fused=False, gt_mask_dir=None, dataset="sintel",
-                     progress=None, seq=None):
+                     progress=None, seq=None, keep=None):
     """One independent 'sequence': load a preprocessed DAS3R sequence directory (das3r_amd.io_formats.load_sequence) — or,
     without one, build a synthetic multi-frame scene —, optimise it with the train-step harness, report the held-out PSNR and,
     with out_dir, write what the reference writes (point_cloud/iteration_N/point_cloud.ply, pose/pose_N.npy:
     train_gui.py:467-480,523-528).  Failures are isolated per sequence (the reference's predictor farm does the same,
     pose_eval.py:209-222).  seq: a sequence dict built by the caller (train.consistent_sequence: the self-consistent synthetic stand-in).
+    keep: a dict that receives {scene_id: (model, training cameras, held-out cameras)} (tests compare parameters).
     progress: called at the job's stages and every few hundred iterations (Rendezvous.tick)."""
     progress = progress or (lambda: None)
     progress()
@@ -263,6 +264,8 @@ def run_sequence_job(scene_id, iterations, device, frames=6, seq_dir=None, out_d
         progress()
         rep = psnr_report(model, test, dynamic_masks=dyn, test_poses=True, iteration=iterations, log_dir=out_dir)
         cams = train_cams
+        if keep is not None:
+            keep[scene_id] = (model, train_cams, test)
         if out_dir is not None:
             from .io_formats import save_model_ply, save_poses_npy
             save_model_ply(os.path.join(out_dir, "point_cloud", f"iteration_{iterations}", "point_cloud.ply"), model)

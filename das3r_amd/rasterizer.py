@@ -276,6 +276,25 @@ def _backward_impl(rs, num_rendered, grad_out_color, means3D, sh, colors_precomp
     return g_means2D, g_colors, g_opac, g_means3D, g_cov, g_sh, g_scales, g_rot
 
 
+def count_live_pairs(rs, P, M, num_rendered, geom, binning, img, capacity):
+    """Measurement aid (include/das3r_raster.h das3r_raster_count_live_pairs): -> (live pairs, (pixel, list position) pairs below the
+    pixels' last contributors) of the forward that produced these buffers (`_forward_full`'s results)."""
+    lib = _lib.load()
+    device = geom.device
+    keep = []
+    a = _fill_args(rs, P, M, device, keep)
+    saved = _lib.RasterSaved()
+    saved.geom, saved.binning, saved.img = _ptr(geom), _ptr(binning), _ptr(img)
+    saved.num_rendered, saved.capacity = int(num_rendered), int(capacity)
+    out = (C.c_uint64 * 2)()
+    lib.das3r_raster_count_live_pairs.restype = C.c_int
+    lib.das3r_raster_count_live_pairs.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
+    with _on_device(device):
+        rc = lib.das3r_raster_count_live_pairs(C.byref(a), C.byref(saved), out, _stream(device))
+    _lib.check(rc, "das3r_raster_count_live_pairs")
+    return int(out[0]), int(out[1])
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                                      raster_settings)

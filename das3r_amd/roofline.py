@@ -37,7 +37,8 @@ def algorithmic_bytes(P, D, M, I, W, H):
     return per_kernel, b_fwd, b_bwd
 
 
-ALIASES = {"render_forward_rows_kernel": "render_forward_kernel",     # two implementations of each compositing stage
+ALIASES = {"render_forward_rows_kernel": "render_forward_kernel",     # several implementations of each compositing stage
+           "render_forward_lanes_kernel": "render_forward_kernel",
            "render_backward_mfma_kernel": "render_backward_kernel",    # (render_rows.hip, render_bwd_mfma.hip,
            "render_backward_scan_kernel": "render_backward_kernel",    #  render_bwd_scan.hip, render_bwd_blk.hip)
            "render_backward_blk_kernel": "render_backward_kernel"}
@@ -51,3 +52,25 @@ def group_kernel_times(report):
         c, t = out.get(key, (0, 0.0))
         out[key] = (c + n, t + ms)
     return out
+
+
+# ---- the VALU roofline of the compositing kernels -------------------------------------------------------------
+# The compositing kernels are bound by vector-ALU issue, not by HBM: what bounds them from below is the walk of
+# the LIVE (pixel, splat) pairs — the pairs upstream blends (position < n_contrib, power <= 0, alpha >= 1/255), counted by
+# das3r_raster_count_live_pairs — at the instruction count of the kernels' own pair loops, 64 pairs per wave instruction, every
+# instruction at the full rate of 2 cycles per wave64 instruction per SIMD (MI355X_MICROARCH.md: SIMD-32 lanes; half-rate DPP / compare
+# and quarter-rate transcendental instructions make the real walk slower than this bound):
+#     t_valu = live_pairs / 64 * WALK_VALU_PER_64_PAIRS * 2 cycles / (1024 SIMDs * 2.4 GHz)
+# Instruction counts of the shipped pair loops (llvm-objdump of the walk bodies): forward 34 VALU + 1 v_exp per 64
+# pairs (render_rows.hip), backward 48 VALU + 2 transcendentals (render_blk.h block_row).
+WALK_VALU_PER_64_PAIRS = {"render_forward_kernel": 35, "render_backward_kernel": 50}
+SIMDS, CLOCK_HZ, CYCLES_PER_VALU = 1024, 2.4e9, 2.0
+
+
+def valu_roofline(kernel, live_pairs, ms):
+    """-> dict(ideal_valu_insts, ideal_ms, frac): the walk of the live pairs alone against the kernel's measured time."""
+    n = WALK_VALU_PER_64_PAIRS[kernel]
+    insts = live_pairs / 64.0 * n
+    ideal_ms = insts * CYCLES_PER_VALU / (SIMDS * CLOCK_HZ) * 1e3
+    return {"ideal_valu_insts": int(insts), "ideal_ms": round(ideal_ms, 5), "frac": round(ideal_ms / ms, 4) if ms > 0 else None,
+            "def": f"live_pairs / 64 x {n} wave instructions x 2 cycles / (1024 SIMDs x 2.4 GHz) / measured ms"}

@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define DAS3R_ABI_VERSION 11
+#define DAS3R_ABI_VERSION 12
 
 typedef enum {
     DAS3R_OK = 0,
@@ -304,6 +304,11 @@ void das3r_debug_inject_fault(uint32_t bits);
  * same for the backward kernel, [2] / [3] their wave iterations (64 pairs each).  Costs one atomic per wave while enabled, nothing
  * otherwise.  Single-threaded use; synchronises the device. */
 int das3r_pair_counters(int enable, uint64_t out[4]);
+
+/* ABI 12.  Measurement aid (bench.py): the LIVE (pixel, splat) pairs of the forward that produced `saved` — list position below the pixel's
+ * last contributor, power <= 0, alpha >= 1/255 (what upstream:forward.cu renderCUDA blends) — into out[0], and the (pixel, list
+ * position) pairs below the pixels' last contributors into out[1].  A plain walk over the saved buffers; synchronises the stream. */
+int das3r_raster_count_live_pairs(const das3r_raster_args *args, const das3r_raster_saved *saved, uint64_t out[2], das3r_stream_t stream);
 
 /* The library reads its diagnostic / experiment switches (environment variables DAS3R_*) once, at the first
  * call; a process that changes them afterwards (tests, A-B tools) calls this to have them read again. */

@@ -214,3 +214,32 @@ def test_rendezvous_decision_is_one_and_fair(tmp_path, scenario, mode, by):
     assert all(not p.is_alive() and p.exitcode == 0 for p in procs)
     got = [torch.load(tmp_path / f"scenario_{r}.pt") for r in range(world)]
     assert got[0] == got[1] == (mode, by), got
+
+
+def test_run_jobs_on_the_host():
+    """farm.run_jobs without a GPU: K worker threads pull the rank's sequences; results in the order of the items, never more than K
+    in flight, a job's exception re-raised in the caller."""
+    import threading
+    import time
+    lock, state = threading.Lock(), dict(now=0, peak=0)
+
+    def job(i):
+        with lock:
+            state["now"] += 1
+            state["peak"] = max(state["peak"], state["now"])
+        time.sleep(0.02)
+        with lock:
+            state["now"] -= 1
+        return i * i
+
+    assert farm.run_jobs(range(9), job, 3) == [i * i for i in range(9)]
+    assert 2 <= state["peak"] <= 3
+    assert farm.run_jobs([4, 5], job, 1) == [16, 25] and farm.run_jobs([], job, 2) == []
+
+    def bad(i):
+        if i == 1:
+            raise KeyError("sequence 1")
+        return i
+
+    with pytest.raises(KeyError):
+        farm.run_jobs(range(3), bad, 2)

@@ -159,3 +159,132 @@ def test_farm_job_direct_and_autograd_iterations_agree_on_a_sequence_directory(t
     a, b = recs
     assert a["ok"] == b["ok"] == 1
     assert abs(a["psnr"] - b["psnr"]) <= 1e-3 and abs(a["l1"] - b["l1"]) <= 1e-5 * abs(b["l1"]) + 1e-7, (a, b)
+
+
+def test_consistent_sequence_is_self_consistent():
+    """train.consistent_sequence (round 5): the depth map of a frame is the expected depth of the SAME cloud that rendered its image,
+    so unprojecting every pixel at its depth with the frame's pose and re-projecting it into ANOTHER frame lands on that frame's
+    surface: the depth the other frame's map holds at the landing pixel equals the point's depth there (static pixels, away from
+    depth edges) — the property the round-1-4 stand-ins lacked (their depth maps were unrelated to the images)."""
+    from das3r_amd.model import depth_to_points
+    from das3r_amd.train import consistent_sequence
+    seq = consistent_sequence(frames=6, W=256, H=104, focal=300.0, n_splats=12000, seed=3)
+    F, H, W = seq["depths"].shape
+    assert seq["dyna_avg"].sum() > 0 and len(seq["gt_dynamic_masks"]) == F and seq["gt_dynamic_masks"][2].any()
+    pts = depth_to_points(seq["K"], seq["cam2world"], seq["depths"])           # [F, H, W, 3] world points
+    a, b = 1, 4
+    w2c = torch.linalg.inv(seq["cam2world"][b])
+    p = pts[a].reshape(-1, 3) @ w2c[:3, :3].T + w2c[:3, 3]
+    f = seq["focal"]
+    u, v = (f * p[:, 0] / p[:, 2] + W / 2).round().long(), (f * p[:, 1] / p[:, 2] + H / 2).round().long()
+    static = ~torch.from_numpy(seq["gt_dynamic_masks"][a]).reshape(-1).to(p.device)
+    ok = static & (u >= 0) & (u < W) & (v >= 0) & (v < H)
+    db = seq["depths"][b][v[ok], u[ok]]
+    sb = ~torch.from_numpy(seq["gt_dynamic_masks"][b]).to(p.device)[v[ok], u[ok]]
+    rel = ((db - p[ok, 2]).abs() / p[ok, 2])[sb]
+    assert rel.numel() > 0.5 * H * W
+    assert float(rel.median()) < 5e-3 and float((rel < 0.03).float().mean()) > 0.9, (float(rel.median()), float((rel < 0.03).float().mean()))
+    # ... and the colours agree: frame a's pixel colour is what frame b shows at the landing pixel (a textured static surface)
+    ca = seq["images"][a].reshape(3, -1)[:, ok][:, sb]
+    cb = seq["images"][b][:, v[ok], u[ok]][:, sb]
+    assert float((ca - cb).abs().mean()) < 0.05
+
+
+def test_two_jobs_in_flight_reproduce_their_solo_results():
+    """VERDICT r4 item 3 (farm.run_jobs, `--jobs-per-gpu 2`): two independent sequences optimised at the same time on one GPU — two
+    host threads, each with its own stream, model and library state — end where they end alone: held-out PSNR equal to 1e-3 dB, L1
+    alike, every parameter tensor within the tolerances of the lock-step test (an Adam step moves an element by at most its learning
+    rate; the 28 pose sums of a step meet in float atomics, whose order varies from run to run — solo runs differ from each other by
+    as much).  Replaces the serial loop of /root/reference/scripts/testing_psnr_davis.sh:35-59."""
+    from das3r_amd.farm import run_jobs, run_sequence_job
+    from das3r_amd.train import consistent_sequence
+    dev = torch.device("cuda:0")
+    seqs = [consistent_sequence(frames=12, W=128, H=80, focal=150.0, n_splats=3000, seed=20 + s) for s in range(2)]
+    iters = 150
+    solo_keep, duo_keep = {}, {}
+    solo = [run_sequence_job(s, iters, dev, fused=True, seq=seqs[s], keep=solo_keep) for s in range(2)]
+    duo = run_jobs(range(2), lambda s: run_sequence_job(s, iters, dev, fused=True, seq=seqs[s], keep=duo_keep), 2, dev)
+    torch.cuda.synchronize()
+    names = ("_xyz", "_features_dc", "_opacity", "_scaling", "_rotation", "_conf_static", "Q", "T")
+    for s in range(2):
+        a, b = solo[s], duo[s]
+        assert a["ok"] == b["ok"] == 1 and a["scene_id"] == b["scene_id"] == s and a["n_splats"] == b["n_splats"]
+        assert abs(a["psnr"] - b["psnr"]) <= 1e-3 and abs(a["l1"] - b["l1"]) <= 1e-5 * abs(a["l1"]) + 1e-7, (a, b)
+        ma, mb = solo_keep[s][0], duo_keep[s][0]
+        for n in names:
+            pa, pb = getattr(ma, n).detach(), getattr(mb, n).detach()
+            far = (pa - pb).abs() > 1e-5 + 1e-4 * pa.abs()
+            assert float(far.double().mean()) <= 1e-3, (s, n, float(far.double().mean()))
+    assert abs(solo[0]["psnr"] - solo[1]["psnr"]) > 1e-2, "the two sequences are meant to be different jobs"
+
+
+def test_run_jobs_keeps_order_and_raises():
+    from das3r_amd.farm import run_jobs
+    dev = torch.device("cuda:0")
+    seen = []
+
+    def job(i):
+        x = torch.full((1024,), float(i), device=dev)
+        seen.append(torch.cuda.current_stream().cuda_stream)
+        return int(x.sum().item()) // 1024
+
+    assert run_jobs(range(7), job, 3, dev) == list(range(7))
+    assert len(set(seen)) >= 2 and torch.cuda.default_stream().cuda_stream not in seen, "every worker thread has a stream of its own"
+
+    def bad(i):
+        if i == 2:
+            raise ValueError("job 2")
+        return i
+
+    with pytest.raises(ValueError, match="job 2"):
+        run_jobs(range(4), bad, 2, dev)
+
+
+SINTEL_SHAPE = dict(frames=22, W=512, H=208, focal=600.0, n_splats=20000)
+PSNR_BAR_SINTEL = 43.0     # dB, held-out static region after 4000 iterations; measured 44.05 +- 0.1 over seeds 0-2, threads and processes
+PSNR_START_SINTEL = 36.0   # dB, the same report after 20 iterations stays BELOW this: the optimisation is what gets a job over the bar
+
+
+def test_consistent_sintel_shaped_job_reaches_the_psnr_bar(monkeypatch):
+    """VERDICT r4 item 4 — an ABSOLUTE bar for a whole job, the stand-in for BASELINE configs[2] (Sintel market_2, train 4000 iterations,
+    published 29.03 dB on the real sequence): a Sintel-shaped self-consistent synthetic sequence (22 frames of 512 x 208, two held out,
+    2.13 M Gaussians; images, depth maps and poses from ONE scene, a moving object under dyna_avg / ground-truth masks:
+    train.consistent_sequence) through the job the farm runs — 4000 fused iterations with the held-out pose passes, the report of
+    /root/reference/train_test_psnr.py:241-302 over the split of scene/dataset_readers.py:342-347 — must END above PSNR_BAR_SINTEL on
+    the held-out static region, having STARTED below PSNR_START_SINTEL, with the direct iteration (fast_step.py) and the autograd form
+    of the same kernels within 0.1 dB of each other.  Round 4's scrambled-ground-truth defect (a [3, H, W] view read as dense) cost
+    0.6 - 2.2 dB with every unit test green: on the inconsistent stand-ins of rounds 1-4 (held-out PSNR 17 - 18 dB whatever one did)
+    no test could have a bar; this one fails on it."""
+    from das3r_amd.farm import run_sequence_job
+    from das3r_amd.train import consistent_sequence
+    dev = torch.device("cuda:0")
+    seq = consistent_sequence(seed=0, **SINTEL_SHAPE)
+    start = run_sequence_job(0, 20, dev, fused=True, seq=seq)
+    direct = run_sequence_job(0, 4000, dev, fused=True, seq=seq)
+    monkeypatch.setenv("DAS3R_FAST_STEP", "0")
+    autograd = run_sequence_job(0, 4000, dev, fused=True, seq=seq)
+    print("held-out static-region PSNR: after 20 iterations", start["psnr"], "direct", direct["psnr"], "autograd form", autograd["psnr"],
+          "iterations/s", direct["iters_per_s"], autograd["iters_per_s"])
+    assert start["ok"] == direct["ok"] == autograd["ok"] == 1 and direct["n_splats"] == 20 * 512 * 208
+    assert start["psnr"] < PSNR_START_SINTEL, start
+    assert direct["psnr"] >= PSNR_BAR_SINTEL and autograd["psnr"] >= PSNR_BAR_SINTEL, (direct, autograd)
+    assert abs(direct["psnr"] - autograd["psnr"]) <= 0.1, (direct["psnr"], autograd["psnr"])
+
+
+def test_consistent_job_three_forms_agree(monkeypatch):
+    """The same bar at a size the reference's own plain-PyTorch iteration finishes in seconds (12 frames of 256 x 104, 1000 iterations):
+    unfused (torch ops + torch.optim.Adam around the HIP rasterizer: what unmodified DAS3R runs on the drop-in), the autograd form of
+    the fused kernels and the direct iteration end within 0.1 dB of each other and above the bar measured for this size."""
+    from das3r_amd.farm import run_sequence_job
+    from das3r_amd.train import consistent_sequence
+    dev = torch.device("cuda:0")
+    seq = consistent_sequence(frames=12, W=256, H=104, focal=300.0, n_splats=8000, seed=4)
+    direct = run_sequence_job(0, 1000, dev, fused=True, seq=seq)
+    unfused = run_sequence_job(0, 1000, dev, fused=False, seq=seq)
+    monkeypatch.setenv("DAS3R_FAST_STEP", "0")
+    autograd = run_sequence_job(0, 1000, dev, fused=True, seq=seq)
+    print("three forms:", direct["psnr"], autograd["psnr"], unfused["psnr"])
+    assert direct["ok"] == autograd["ok"] == unfused["ok"] == 1
+    for r in (direct, autograd, unfused):
+        assert r["psnr"] >= 38.0, (direct, autograd, unfused)
+    assert max(r["psnr"] for r in (direct, autograd, unfused)) - min(r["psnr"] for r in (direct, autograd, unfused)) <= 0.1
