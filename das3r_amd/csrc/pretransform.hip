@@ -9,6 +9,8 @@
 // (28 sums over all splats: DPP wave reduction -> LDS -> one global atomic per workgroup and component).
 // HBM-bound: 44 B in + 44 B out per splat forward, 88 B in + 44 B out backward.  Opt-in (das3r_render(fused=True)); the
 // default path of an unmodified DAS3R checkout is untouched.
+#include <vector>
+
 #include "common.h"
 #include "adam_math.h"
 
@@ -62,6 +64,8 @@ struct GeometryAdam {
     float beta1, beta2, eps;
 };
 
+constexpr int POSE_MAX_BLOCKS = 2048;   // largest grid of the backward kernels below (rows of the fixed-order pose-sum scratch)
+
 // MODE 0: the backward as a producer of gradients (g_xyz, g_rotation, g_scaling, g_opacity_raw, g_conf_flat, the 28 pose sums).
 // MODE 1 (round 4): the same gradients never leave the registers — the Adam step of the four tensors is taken on the spot (adam_math.h:
 //   the arithmetic of adam_kernel): the gradients are not written (44 B per Gaussian) and not read back by the optimizer (44 B), the
@@ -73,7 +77,8 @@ __global__ void __launch_bounds__(256) pretransform_backward_kernel(
     const float *__restrict__ conf_flat, const int64_t *__restrict__ mask_index, const float *__restrict__ Rm, const float *__restrict__ Lq,
     const float *__restrict__ g_means3D, const float *__restrict__ g_rot, const float *__restrict__ g_scales, const float *__restrict__ g_opac,
     float *__restrict__ g_xyz, float *__restrict__ g_rotation, float *__restrict__ g_scaling, float *__restrict__ g_opacity_raw,
-    float *__restrict__ g_conf_flat, float *__restrict__ g_small, const GeometryAdam A) {
+    float *__restrict__ g_conf_flat, float *__restrict__ g_small, const GeometryAdam A,
+    float *__restrict__ det_partials /*[POSE_MAX_BLOCKS][28] + one arrival word behind them; null: one float atomic per workgroup and sum*/) {
     __shared__ float red[4][28];
     float R[9], L[16];
 #pragma unroll
@@ -162,10 +167,43 @@ __global__ void __launch_bounds__(256) pretransform_backward_kernel(
         if (lane == 63) red[wave][i] = r;
     }
     __syncthreads();
-    if (threadIdx.x < 28) {
-        const float r = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        if (r != 0.f) unsafeAtomicAdd(&g_small[threadIdx.x], r);
+    if (det_partials == nullptr) {
+        if (threadIdx.x < 28) {
+            const float r = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+            if (r != 0.f) unsafeAtomicAdd(&g_small[threadIdx.x], r);
+        }
+        return;
     }
+    // Round 5: the 28 sums in a FIXED order — the workgroups' float atomics met in whatever order the hardware served them, which made
+    // two identical jobs end 0.1 - 0.2 dB apart after 4000 iterations (the only run-to-run difference of the direct iteration).  Every
+    // workgroup stores its 28 partial sums; the last one to arrive (one integer atomic per workgroup) adds the rows in index order:
+    // thread t takes rows t, t + 256, ..., the 256 threads meet in the same fixed tree (DPP, then LDS).  Bit-identical from run to run, and 28 x gridDim.x float
+    // atomics on 28 addresses fewer.
+    __shared__ uint32_t s_last;
+    if (threadIdx.x < 28)
+        __hip_atomic_store(det_partials + (size_t)blockIdx.x * 28 + threadIdx.x,
+                           red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    __syncthreads();
+    uint32_t *const arrived = reinterpret_cast<uint32_t *>(det_partials + (size_t)POSE_MAX_BLOCKS * 28);   // (a fixed place: the grid differs from launch to launch)
+    if (threadIdx.x == 0) s_last = (__hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;   // (uniform)
+    float part[28];
+#pragma unroll
+    for (int i = 0; i < 28; i++) part[i] = 0.f;
+    for (uint32_t b = threadIdx.x; b < gridDim.x; b += 256u)
+#pragma unroll
+        for (int i = 0; i < 28; i++) part[i] += __hip_atomic_load(det_partials + (size_t)b * 28 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int i = 0; i < 28; i++) {   // the same fixed tree as above: DPP within the wave, the four waves through LDS
+        const float r = wave_sum_to_lane63(part[i]);
+        if (lane == 63) red[wave][i] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < 28)   // (g_small accumulates: zero at rest, das3r_pose_chain_qt re-arms it)
+        g_small[threadIdx.x] += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (threadIdx.x == 0) __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
 }
 
 // pose (qw,qx,qy,qz,tx,ty,tz) -> mats[28] = R (9, row-major; rotation of the NORMALISED quaternion, like get_camera_from_tensor),
@@ -209,6 +247,23 @@ __global__ void pose_chain_kernel(const float *__restrict__ pose, float *__restr
     for (int a = 0; a < 3; a++) g_t[a] = g[9 + a];
     if (rearm)
         for (int a = 0; a < 28; a++) g[a] = 0.f;
+}
+
+// Scratch of the fixed-order pose sums: [MAX_BLOCKS][28] floats + the arrival word, one per (host thread, device, stream) — launches on
+// one stream are ordered, launches of different threads / streams each get their own.  Zeroed once (the kernel re-arms the word).
+static float *pose_sum_scratch(hipStream_t s) {
+    struct Slot { int dev; hipStream_t stream; float *buf; };
+    static thread_local std::vector<Slot> slots;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    for (auto &e : slots)
+        if (e.dev == dev && e.stream == s) return e.buf;
+    float *buf = nullptr;
+    const size_t bytes = ((size_t)POSE_MAX_BLOCKS * 28 + 4) * sizeof(float);
+    if (hipMalloc((void **)&buf, bytes) != hipSuccess) return nullptr;
+    if (hipMemsetAsync(buf, 0, bytes, s) != hipSuccess) { (void)hipFree(buf); return nullptr; }
+    slots.push_back({dev, s, buf});
+    return buf;
 }
 
 }  // namespace das3r
@@ -279,7 +334,7 @@ extern "C" int das3r_pretransform_backward(int32_t P, const float *xyz, const fl
     hipStream_t s = (hipStream_t)stream;
     const int blocks = div_up(P, 256) < 1024 ? div_up(P, 256) : 1024;
     DAS3R_LAUNCH((pretransform_backward_kernel<0>), dim3(blocks), dim3(256), 0, s, P, xyz, rot, scaling, opacity_raw, conf_flat, mask_index, R,
-                 Lq, g_means3D, g_rot, g_scales, g_opac, g_xyz, g_rotation, g_scaling, g_opacity_raw, g_conf_flat, g_small, GeometryAdam{});
+                 Lq, g_means3D, g_rot, g_scales, g_opac, g_xyz, g_rotation, g_scaling, g_opacity_raw, g_conf_flat, g_small, GeometryAdam{}, pose_sum_scratch(s));
     KERNEL_CHECK(s, false, "pretransform_backward");
     return DAS3R_OK;
 }
@@ -309,7 +364,7 @@ extern "C" int das3r_pretransform_backward_adam(int32_t P, const float *conf_fla
     const int blocks = div_up(P, 256) < 2048 ? div_up(P, 256) : 2048;
     DAS3R_LAUNCH((pretransform_backward_kernel<1>), dim3(blocks), dim3(256), 0, s, P, (const float *)A.p[0], (const float *)A.p[1], (const float *)A.p[2],
                  (const float *)A.p[3], conf_flat, mask_index, R, Lq, g_means3D, g_rot, g_scales, g_opac, (float *)nullptr, (float *)nullptr,
-                 (float *)nullptr, (float *)nullptr, g_conf_flat, g_small, A);
+                 (float *)nullptr, (float *)nullptr, g_conf_flat, g_small, A, pose_sum_scratch(s));
     KERNEL_CHECK(s, false, "pretransform_backward_adam");
     return DAS3R_OK;
 }
@@ -326,7 +381,7 @@ extern "C" int das3r_pretransform_pose_sums(int32_t P, const float *xyz, const f
     const int blocks = div_up(P, 256) < 1024 ? div_up(P, 256) : 1024;
     DAS3R_LAUNCH((pretransform_backward_kernel<2>), dim3(blocks), dim3(256), 0, s, P, xyz, rot, (const float *)nullptr, (const float *)nullptr,
                  (const float *)nullptr, (const int64_t *)nullptr, R, Lq, g_means3D, g_rot, (const float *)nullptr, (const float *)nullptr,
-                 (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, g_small, GeometryAdam{});
+                 (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, g_small, GeometryAdam{}, pose_sum_scratch(s));
     KERNEL_CHECK(s, false, "pretransform_pose_sums");
     return DAS3R_OK;
 }
