@@ -407,7 +407,11 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     constexpr uint32_t ARRIVE_SLOTS = 16, ARRIVE_WORDS = 8 + 64 * 8;   // per call: top word + 64 sub-counters, one 64-byte line each
     if (!arrive_ring) {
         HIP_TRY(hipMalloc((void **)&arrive_ring, ARRIVE_SLOTS * ARRIVE_WORDS * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(arrive_ring, 0, ARRIVE_SLOTS * ARRIVE_WORDS * sizeof(unsigned long long)));
+        // on the CALLER'S stream, in front of the kernel that counts in it: hipMemset runs on the null stream, which a non-blocking stream
+        // does not wait for — with a second job keeping the GPU busy (round 5: farm.run_jobs) the fill could land AFTER the first preprocess
+        // kernel of this thread had started counting, the last arriver never saw its total, and the forward ended with "the device never
+        // delivered the result of this forward to the host mailbox" (one first-forward in a few dozen two-job runs)
+        HIP_TRY(hipMemsetAsync(arrive_ring, 0, ARRIVE_SLOTS * ARRIVE_WORDS * sizeof(unsigned long long), s));
     }
     // Depth order: scenes with short tile lists (the 100 k-splat 1080p benchmark averages 32 entries per tile) skip the global
     // depth sort — five of the eleven binning launches, each latency-bound at that size; the instances are emitted in index
@@ -701,6 +705,7 @@ extern "C" int das3r_pair_counters(int enable, uint64_t out[4]) {
         if (!g_pairs) HIP_TRY(hipMalloc((void **)&g_pairs, (4 + PHASE_WORDS * PHASE_COPIES) * sizeof(unsigned long long)));
         g_pairs_dev = dev;
         HIP_TRY(hipMemset(g_pairs, 0, (4 + PHASE_WORDS * PHASE_COPIES) * sizeof(unsigned long long)));
+        HIP_TRY(hipDeviceSynchronize());   // (the fill is on the null stream; the kernels that count may be on any)
         return DAS3R_OK;
     }
     if (g_pairs) {
@@ -747,6 +752,7 @@ extern "C" int das3r_debug_wg_trace(int enable, uint64_t *out) {
     if (enable) {
         if (!g_trace) HIP_TRY(hipMalloc((void **)&g_trace, words * 8));
         HIP_TRY(hipMemset(g_trace, 0, words * 8));
+        HIP_TRY(hipDeviceSynchronize());
         return DAS3R_OK;
     }
     if (g_trace) {

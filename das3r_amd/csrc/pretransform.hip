@@ -183,18 +183,42 @@ __global__ void __launch_bounds__(256) pretransform_backward_kernel(
     if (threadIdx.x < 28)
         __hip_atomic_store(det_partials + (size_t)blockIdx.x * 28 + threadIdx.x,
                            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();
+    // (no __threadfence here: an agent-scope release fence writes the XCD's whole L2 back — this kernel has just written > 100 MB of
+    //  parameters and moments, and 2048 workgroups doing that took the kernel from 0.15 to 0.60 ms.  The 28 words are agent-scope atomic
+    //  stores — written through to where the other XCDs see them — and are complete when the store counter says so; the barrier then
+    //  orders them in front of thread 0's arrival, itself a relaxed agent-scope atomic)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     uint32_t *const arrived = reinterpret_cast<uint32_t *>(det_partials + (size_t)POSE_MAX_BLOCKS * 28);   // (a fixed place: the grid differs from launch to launch)
-    if (threadIdx.x == 0) s_last = (__hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) ? 1u : 0u;
+    if (threadIdx.x == 0) s_last = (__hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) ? 1u : 0u;
     __syncthreads();
     if (!s_last) return;   // (uniform)
+    // (every wave of the last workgroup acquires at agent scope — the other workgroups' rows came through other XCDs' L2s — and then reads
+    //  its rows with plain 16-byte loads, all in flight at once: read one atomic word at a time the 224 loads of a thread were 0.45 ms)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     float part[28];
 #pragma unroll
     for (int i = 0; i < 28; i++) part[i] = 0.f;
-    for (uint32_t b = threadIdx.x; b < gridDim.x; b += 256u)
+    const float4 *const rows4 = reinterpret_cast<const float4 *>(det_partials);   // a row = 28 floats = 7 float4
+    for (uint32_t b0 = threadIdx.x; b0 < gridDim.x; b0 += 1024u) {
+        float4 v[4][7];
 #pragma unroll
-        for (int i = 0; i < 28; i++) part[i] += __hip_atomic_load(det_partials + (size_t)b * 28 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int u = 0; u < 4; u++) {
+            const uint32_t b = b0 + 256u * u;
+            const uint32_t bc = b < gridDim.x ? b : gridDim.x - 1u;   // (clamped, not guarded: the loads stay in one block, all in flight)
+#pragma unroll
+            for (int q = 0; q < 7; q++) v[u][q] = rows4[(size_t)bc * 7 + q];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool have = (b0 + 256u * u) < gridDim.x;   // (a select, not a factor: a row may hold an inf)
+#pragma unroll
+            for (int q = 0; q < 7; q++) {
+                part[4 * q] += have ? v[u][q].x : 0.f; part[4 * q + 1] += have ? v[u][q].y : 0.f;
+                part[4 * q + 2] += have ? v[u][q].z : 0.f; part[4 * q + 3] += have ? v[u][q].w : 0.f;
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 28; i++) {   // the same fixed tree as above: DPP within the wave, the four waves through LDS
         const float r = wave_sum_to_lane63(part[i]);

@@ -276,7 +276,8 @@ def run_sequence_job(scene_id, iterations, device, frames=6, seq_dir=None, out_d
         return dict(scene_id=scene_id, psnr=rep["psnr"], l1=rep["l1"], iters_per_s=stats["iters_per_s"],
                     n_splats=model.get_xyz.shape[0], ok=int(rep["views"] > 0 and math.isfinite(rep["psnr"])))
     except Exception as ex:  # noqa: BLE001 - keep the farm alive, report the failure in the table
-        print(f"[farm] sequence {scene_id} failed: {ex!r}")
+        import traceback
+        print(f"[farm] sequence {scene_id} failed: {ex!r}\n{traceback.format_exc()}", file=sys.stderr, flush=True)
         return dict(scene_id=scene_id, psnr=float("nan"), l1=float("nan"), iters_per_s=0.0, n_splats=0, ok=0)
 
 
@@ -343,8 +344,10 @@ def main():
     ap.add_argument("--fused", action="store_true", help="use the fused pre-transform / Adam / loss kernels")
     ap.add_argument("--gt-dynamic-mask", default=None, help="root of the ground-truth dynamic masks, <root>/<sequence>/... (train_test_psnr.py --gt_dynamic_mask)")
     ap.add_argument("--dataset", default="sintel", choices=("sintel", "davis"))
-    ap.add_argument("--jobs-per-gpu", type=int, default=1, help="sequences in flight per GPU: K host threads per rank, each with its own stream "
-                    "and model (one job's VALU-bound compositing overlaps another's HBM / latency-bound kernels); 2 is the measured optimum")
+    ap.add_argument("--jobs-per-gpu", type=int, default=None, help="sequences in flight per GPU: K host threads per rank, each with its own stream "
+                    "and model (one job's VALU-bound compositing overlaps another's HBM / latency-bound kernels).  Default: 2 on a GPU — the "
+                    "measured optimum (profiles/r05_jobs_per_gpu.json: 1.50 x the rate of 1 at the Sintel shape, 1.35 x at the DAVIS shape; "
+                    "3 is no better) — and 1 on the host")
     ap.add_argument("--hung-timeout", type=float, default=600.0, help="seconds a live rank may go without a progress tick before the gather is "
                     "replaced by the record files (a rank that is merely slower keeps ticking and is waited for)")
     ap.add_argument("--rendezvous", default=None, help="directory of the ranks' heartbeat / record files (default: <out>/.farm or /tmp/das3r_farm_<port>)")
@@ -381,7 +384,7 @@ def main():
     else:
         mine = assign(args.sequences, rank, world)
         job = lambda s: run_sequence_job(s, args.iterations, device, fused=args.fused, progress=tick)
-    records = run_jobs(mine, job, args.jobs_per_gpu, device)
+    records = run_jobs(mine, job, args.jobs_per_gpu if args.jobs_per_gpu else (2 if use_gpu else 1), device)
     names = dirs if args.data else [f"seq_{i}" for i in range(args.sequences)]
     mode = "collective"
     if rdv is not None:

@@ -294,3 +294,27 @@ def test_consistent_job_three_forms_agree(monkeypatch):
     for r in (direct, autograd, unfused):
         assert r["psnr"] >= 36.0, (direct, autograd, unfused)   # measured 36.49 - 36.54 for the three forms
     assert max(r["psnr"] for r in (direct, autograd, unfused)) - min(r["psnr"] for r in (direct, autograd, unfused)) <= 0.1
+
+
+def test_many_short_jobs_in_flight_all_finish():
+    """Three worker threads, 24 short jobs of different shapes: every job starts with forwards of a shape its thread has not seen (the
+    exactly sized path, whose count comes through the preprocess kernel's arrival words) while the other threads keep the GPU busy.
+    Round 5 found the arrival words' one-time fill on the null stream — which a worker's non-blocking stream does not wait for — landing
+    after the first preprocess kernel had started counting in them: "the device never delivered the result of this forward to the host
+    mailbox", once in a few dozen two-job runs.  Every job must finish (ok = 1) and a job's result must not depend on its neighbours."""
+    from das3r_amd import _lib
+    from das3r_amd.farm import run_jobs, run_sequence_job
+    from das3r_amd.train import consistent_sequence
+    dev = torch.device("cuda:0")
+    shapes = [(6, 96, 64), (7, 128, 80), (6, 160, 96), (8, 112, 64)]
+    seqs = [consistent_sequence(frames=f, W=w, H=h, focal=1.2 * w, n_splats=2500, seed=40 + i) for i, (f, w, h) in enumerate(shapes)]
+    before = _lib.stats()
+    solo = [run_sequence_job(i, 15, dev, fused=True, seq=seqs[i]) for i in range(len(seqs))]
+    jobs = [i % len(seqs) for i in range(24)]
+    recs = run_jobs(jobs, lambda i: run_sequence_job(i, 15, dev, fused=True, seq=seqs[i]), 3, dev)
+    torch.cuda.synchronize()
+    assert all(r["ok"] == 1 for r in recs), [r for r in recs if r["ok"] != 1]
+    for i, r in zip(jobs, recs):
+        assert r["psnr"] == solo[i]["psnr"] and r["l1"] == solo[i]["l1"], (i, r, solo[i])
+    after = _lib.stats()
+    assert after["failed_checks"] == before["failed_checks"]
