@@ -5,9 +5,9 @@
 #   <rn>_pmc_<w>.json / .txt     PMC passes (tools/pmc_collect.sh)
 #   <rn>_train_step_*.json       DAS3R-shaped optimisation step, unfused / fused / fused on spatially coherent depth maps
 # Everything lands in gpurun_out/profiles/ (copied into profiles/ by hand after a look).  Every child is time-bounded.
-R=$PWD; RN=${1:-r04}; OUT=$R/gpurun_out/profiles; mkdir -p $OUT
+R=$PWD; RN=${1:-r05}; OUT=$R/gpurun_out/profiles; mkdir -p $OUT
 export PYTHONPATH=$R
-timeout 300 python bench.py --full-line 2>$OUT/${RN}_bench_c4.stderr | tail -1 > $OUT/${RN}_bench_c4.json
+timeout 600 python bench.py --full-line 2>$OUT/${RN}_bench_c4.stderr | tail -1 > $OUT/${RN}_bench_c4.json
 for w in c2 ds dsc; do
   timeout 200 python bench.py --workload $w --no-extras 2>/dev/null | tail -1 > $OUT/${RN}_bench_$w.json
 done
