@@ -324,11 +324,27 @@ def run_jobs(items, job, jobs_per_gpu=1, device=None):
         except BaseException as ex:  # noqa: BLE001 - re-raised by the caller's thread
             errors.append(ex)
 
+    # The library's chained kernels (look-back scans / partition passes) skip their arrival tickets when a whole grid is resident at
+    # once — true of a GPU that runs ONE job's kernels.  With several jobs in flight the grids share the CUs: arrival tickets always
+    # (DAS3R_TICKETS=always: a workgroup then only ever waits for workgroups that have started).  The grids of the DAS3R shapes are above
+    # the ticket-free bound anyway; this makes it a rule instead of a coincidence.
+    restore = None
+    if use_gpu and "DAS3R_TICKETS" not in os.environ:
+        from . import _lib
+        os.environ["DAS3R_TICKETS"] = "always"
+        _lib.reload_switches()
+        restore = _lib
     threads = [threading.Thread(target=worker, name=f"das3r-job-{i}") for i in range(K)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
+    try:
+        for t in threads:
+            t.start()
+    finally:
+        for t in threads:
+            if t.ident is not None:
+                t.join()
+        if restore is not None:
+            del os.environ["DAS3R_TICKETS"]
+            restore.reload_switches()
     if errors:
         raise errors[0]
     return out
