@@ -14,7 +14,10 @@ WORLD_SIZE == N.  Prints ONE JSON line on rank 0.
 Extra keys beside the contract's: `roofline`, `cpu_baseline`, `kernels` (per-kernel time and algorithmic GB/s), `extras`
 (N = 1 only, skipped with --no-extras: the other BASELINE shapes c2 / ds / c1, c4 with the densification stress, and
 train-step ms of the DAS3R-shaped optimisation step, fused and unfused), `train_step_ms` + `scenes_per_hour` (every N: the
-farm's unit of work is a 4000-iteration optimisation of one sequence, scripts/testing_psnr_davis.sh:35-59).
+farm's unit of work is a 4000-iteration optimisation of one sequence, scripts/testing_psnr_davis.sh:35-59), `jobs_in_flight`
+(N = 1: WHOLE jobs with K sequences in flight on the GPU — wall time, scenes per hour, held-out PSNR, peak HBM; Sintel shape with
+K = 1, 2 by default, both shapes with K = 1, 2, 3 under DAS3R_BENCH_JOBS=full, nothing under DAS3R_BENCH_JOBS=0; when present,
+`scenes_per_hour` is the measured figure), and per compositing kernel `live_pairs_per_instance` / `padded_work` / `valu_roofline`.
 """
 import argparse
 import json
@@ -531,9 +534,12 @@ def extras_main(main_workload):
     # jobs — model initialisation (distCUDA2), 4000 fused iterations with the held-out pose passes, held-out report — on the
     # self-consistent synthetic sequences (train.consistent_sequence: images, depth maps and poses from one scene + a moving object),
     # whose held-out static-region PSNR is printed beside the rate (the stand-in for configs[2] / [4]: DAS3R_BENCH_JOBS=0 skips it)
-    if os.environ.get("DAS3R_BENCH_JOBS", "1") != "0":
+    # Default: the Sintel shape with K = 1 and 2 (+ 25 s: the line must stay a matter of a minute); DAS3R_BENCH_JOBS=full: both shapes,
+    # K = 1, 2, 3 (+ 2.5 min — what tools/refresh_profiles.sh records in profiles/rNN_bench_c4.json)
+    mode = os.environ.get("DAS3R_BENCH_JOBS", "1")
+    if mode != "0":
         try:
-            out["jobs_in_flight"] = jobs_in_flight(dev)
+            out["jobs_in_flight"] = jobs_in_flight(dev) if mode == "full" else jobs_in_flight(dev, shapes=("sintel",), ks=(1, 2))
         except Exception as ex:  # noqa: BLE001
             out["jobs_in_flight"] = {"error": repr(ex)}
     print("EXTRAS " + json.dumps(out), flush=True)
@@ -562,7 +568,8 @@ def jobs_in_flight(dev, shapes=("sintel", "davis"), ks=(1, 2, 3), iterations=ITE
             torch.cuda.synchronize()
             wall = time.perf_counter() - t0
             rows[str(K)] = {"wall_s": round(wall, 2), "scenes_per_hour": round(K * 3600.0 / wall, 1), "ok": int(all(r["ok"] for r in recs)),
-                            "heldout_psnr": [round(r["psnr"], 2) for r in recs], "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+                            "heldout_psnr": [round(r["psnr"], 2) if r["ok"] else None for r in recs],   # (never a NaN in the JSON line)
+                            "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
         res[name] = rows
         del seqs
     return res
@@ -669,6 +676,8 @@ def main():
     sph_def = f"N x 3600 s / ({ITERS_PER_SCENE} it x train_step_ms.fused): derived from one step (no whole jobs were run)"
     jobs = extras.pop("jobs_in_flight", None) if extras else None
     if jobs and "sintel" in jobs:
+        jobs["sintel"] = {k: v for k, v in jobs["sintel"].items() if v.get("ok")} or None   # (a job that failed finished early: not a rate)
+    if jobs and jobs.get("sintel") and "1" in jobs["sintel"]:
         # measured from whole jobs (initialisation, 4000 iterations with the held-out passes, report), the best number of sequences in
         # flight per GPU; the figure derived from one step stays beside it
         best = max(jobs["sintel"], key=lambda k: jobs["sintel"][k]["scenes_per_hour"])

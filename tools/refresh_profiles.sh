@@ -7,7 +7,7 @@
 # Everything lands in gpurun_out/profiles/ (copied into profiles/ by hand after a look).  Every child is time-bounded.
 R=$PWD; RN=${1:-r05}; OUT=$R/gpurun_out/profiles; mkdir -p $OUT
 export PYTHONPATH=$R
-timeout 600 python bench.py --full-line 2>$OUT/${RN}_bench_c4.stderr | tail -1 > $OUT/${RN}_bench_c4.json
+DAS3R_BENCH_JOBS=full timeout 600 python bench.py --full-line 2>$OUT/${RN}_bench_c4.stderr | tail -1 > $OUT/${RN}_bench_c4.json
 for w in c2 ds dsc; do
   timeout 200 python bench.py --workload $w --no-extras 2>/dev/null | tail -1 > $OUT/${RN}_bench_$w.json
 done
