@@ -77,10 +77,16 @@ def _steady_state(name):
     on.  -> (scene, raw kernel table of the third pass, its outputs)"""
     from das3r_amd import _lib
     from das3r_amd.rasterizer import _backward_impl, _forward_full
+    from das3r_amd.synth import make_scene
     sc, scd, dev, Settings, _ = _setup(name)
     rs = Settings(**scd.settings_kwargs())
     e = torch.empty(0, device=dev)
     ins = (scd.means3D, scd.shs, e, scd.opacities, scd.scales, scd.rotations, e)
+    # what the library has learnt about a shape (P, W, H) — instance counts, "this shape wants one more partition pass" — outlives a test,
+    # and `ds` / `dsc` ARE one shape: a forward of another shape first, so that the three passes below start from nothing whatever ran before
+    tiny = make_scene(P=64, W=48, H=32, focal=40.0, sh_degree=0, seed=1).to(dev)
+    _forward_full(Settings(**tiny.settings_kwargs()), tiny.means3D, tiny.shs, e, tiny.opacities, tiny.scales, tiny.rotations, e)
+    torch.cuda.synchronize()
 
     def step():
         I, color, radii, geom, binning, img, cap = _forward_full(rs, *ins)

@@ -318,3 +318,45 @@ def test_many_short_jobs_in_flight_all_finish():
         assert r["psnr"] == solo[i]["psnr"] and r["l1"] == solo[i]["l1"], (i, r, solo[i])
     after = _lib.stats()
     assert after["failed_checks"] == before["failed_checks"]
+
+
+def test_farm_cli_on_sequence_directories_with_two_jobs_in_flight(tmp_path):
+    """The product as a user runs it for BASELINE configs[4]'s protocol (scripts/testing_psnr_davis.sh:35-59 + get_testing_psnr_davis.py:8-22):
+    `python -m das3r_amd.farm --data <dir of preprocessed sequences> --out <dir> --gt-dynamic-mask <dir> --fused` — three self-consistent
+    sequences written in the reference's on-disk formats (COLMAP text, TUM trajectory, per-frame npy maps, PNG images, Sintel-style
+    ground-truth masks), two of them in flight at a time on one GPU (the default), the held-out static-region report, the LaTeX rows, and
+    per sequence what the reference writes (test_log.txt, point_cloud.ply, pose npy).  The table equals what each sequence gives alone."""
+    import os
+    import subprocess
+    import sys
+    import numpy as np
+    from PIL import Image
+    from das3r_amd import io_formats as io
+    from das3r_amd.farm import run_sequence_job
+    from das3r_amd.train import consistent_sequence
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data, out, masks = tmp_path / "data", tmp_path / "out", tmp_path / "gt"
+    names = ["alley_1", "market_2", "temple_3"]
+    for i, n in enumerate(names):
+        seq = consistent_sequence(frames=12, W=128, H=80, focal=150.0, n_splats=3000, seed=60 + i)
+        io.write_sequence_dir(seq, str(data / n))
+        os.makedirs(masks / n)
+        for f, m in enumerate(seq["gt_dynamic_masks"]):   # Sintel convention: frame_%04d.png, one-based, 0 / 255
+            Image.fromarray((m * 255).astype(np.uint8)).save(masks / n / f"frame_{f + 1:04d}.png")
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    p = subprocess.run([sys.executable, "-m", "das3r_amd.farm", "--data", str(data), "--out", str(out), "--gt-dynamic-mask", str(masks),
+                        "--iterations", "120", "--fused"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert lines[-3] == "Scene & alley-1 & market-2 & temple-3& average" and lines[-2].startswith("PSNR & ")
+    table = [float(v) for v in lines[-2].replace("PSNR &", "").split("&")]
+    assert lines[-1].endswith("over 3/3 sequences")
+    dev = torch.device("cuda:0")
+    for i, n in enumerate(names):
+        log = (out / n / "test_log.txt").read_text().strip().split("\\n")[-1]
+        assert log.startswith("[ITER 120] Evaluating test: L1 ")
+        assert (out / n / "point_cloud" / "iteration_120" / "point_cloud.ply").stat().st_size > 0 and (out / n / "pose" / "pose_120.npy").exists()
+        solo = run_sequence_job(i, 120, dev, seq_dir=str(data / n), fused=True, gt_mask_dir=str(masks / n), dataset="sintel")
+        assert solo["ok"] == 1 and abs(table[i] - solo["psnr"]) < 0.006, (n, table[i], solo["psnr"])   # (the table prints two decimals)
+        assert abs(float(log.split()[-1]) - solo["psnr"]) < 1e-9
+    assert abs(table[3] - sum(table[:3]) / 3) < 0.011
