@@ -189,6 +189,45 @@ def test_direct_fused_step_matches_the_autograd_fused_step(degree):
             assert float(far.double().mean()) <= 1e-3, (k, float(far.double().mean()))
 
 
+def test_direct_and_autograd_forms_stay_locked_through_a_degree_bump_and_gate_flips():
+    """the lock-step of the two forms of the fused iteration over MORE than four steps, across the events of a schedule — the SH
+    degree going up inside the run (iteration 3000: train_gui.py:542-545; the direct form switches from the DC tensor to the active prefix
+    with its compact gradient) and the camera optimizer's PSNR gate (train_gui.py:584) OPENING AND CLOSING from step to step: the gate
+    threshold is put at the median frame PSNR of a dry run, so that about half of the 24 steps move the poses.  After every step: loss
+    and frame PSNR of the two forms agree, the gate took the same decision (FusedAdam's device-side step counter), and at the end every
+    parameter — poses included — agrees within the tolerances of the four-step test."""
+    from das3r_amd import fast_step
+    from das3r_amd.train import train_step
+    iters = list(range(2989, 3013))   # 24 steps around the degree bump at 3000
+    bg = torch.zeros(3, device="cuda")
+
+    def run(direct, threshold):
+        model, cams, _, opt, _dense = _pair(frames=4, W=32, H=24, seed=13, heldout=False, iterations=4000, fused=True, generic=True)
+        opt.psnr_threshold = threshold
+        model.fast_step = direct
+        assert fast_step.available(model, PIPE) == direct
+        with torch.no_grad():
+            g = torch.Generator(device="cpu").manual_seed(3)
+            model._features_rest.copy_((torch.randn(model._features_rest.shape, generator=g) * 0.05).to(model._features_rest.device))
+        rec = []
+        for k, it in enumerate(iters):
+            loss, ps, _ = train_step(model, cams[k % len(cams)], opt, it, PIPE, bg, fused=True)
+            rec.append((float(loss), float(ps), int(model.optimizer_cam._gate_state[0]), model.active_sh_degree))
+        return rec, {k: getattr(model, a).detach().clone() for k, a in NAMES.items()}
+
+    dry, _ = run(True, 1e9)
+    threshold = sorted(r[1] for r in dry)[len(dry) // 2]
+    (ra, pa), (rb, pb) = run(True, threshold), run(False, threshold)
+    opened = [r[1] > threshold for r in ra]
+    assert 6 <= sum(opened) <= len(iters) - 6, "the gate is meant to open on some steps and stay shut on others"
+    assert ra[10][3] == 0 and ra[11][3] == 1 and rb[11][3] == 1, "the SH degree goes up at iteration 3000, inside the run"
+    for k, ((la, psa, ga, da), (lb, psb, gb, db)) in enumerate(zip(ra, rb)):
+        assert abs(la - lb) <= 2e-5 * abs(lb) and abs(psa - psb) <= 2e-3 and ga == gb and da == db, (k, iters[k], la, lb, psa, psb, ga, gb)
+    for k in pa:
+        far = (pa[k] - pb[k]).abs() > 1e-5 + 1e-4 * pb[k].abs()
+        assert float(far.double().mean()) <= 2e-3, (k, float(far.double().mean()))
+
+
 def test_heldout_report_semantics(tmp_path):
     """train_test_psnr.py:241-302: the mask is nearest-resized to the render size and applied to both images, only views WITH a
     mask count, the line appended to test_log.txt has the reference's wording."""
