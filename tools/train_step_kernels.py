@@ -1,5 +1,8 @@
-import sys, json, time
-sys.path.insert(0, '/root/repo')
+"""The DAS3R-shaped fused train step (noise and smooth depth maps): ms per step under bench.py's timing protocol and the per-kernel
+table of the library's own profiler (HIP events around every launch).   python tools/train_step_kernels.py"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 dev = torch.device('cuda:0'); torch.cuda.set_device(0)
 rk = bench.Ranks(bench.parse_args(['--gpus', '1']))
