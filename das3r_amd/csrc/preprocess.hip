@@ -26,8 +26,19 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     uint32_t zero_b_words, uint32_t *__restrict__ zero_c, uint32_t zero_c_words, unsigned long long *__restrict__ arrive,
     uint32_t *__restrict__ host_out, uint32_t tag, const EmitArgs em,
     uint32_t *__restrict__ dhist /*segmented binning path: 256-bin depth histogram of this forward, zeroed by the caller (segkey.h); else null*/,
-    uint32_t dhist_mask /*workgroups with (index & mask) == 0 contribute: a sample is all the bucket map needs*/) {
+    uint32_t dhist_mask /*a pseudo-random 1 / (mask + 1) of the workgroups contribute (`sampled` below): a sample is all the bucket map needs*/) {
     const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
+    // Which workgroups sample the depth histogram: a full-avalanche hash of the index (round 5).  "Every (mask + 1)-th workgroup" is a
+    // biased sample of a DAS3R model — its Gaussians are the pixels of its frames in row-major order, 256 of them are half an image row, and
+    // every 16th workgroup of the Sintel shape is the LEFT half of every 8th row: the histogram never saw the depths of the right half of the
+    // scene, whose instances then piled up in the end buckets — segments of thousands, the segmented path backing off to the global sort on
+    // every self-consistent sequence (tools/probes/job_binning_trace.py).
+    bool sampled = false;   // (uniform)
+    if (dhist != nullptr) {
+        uint32_t h = blockIdx.x * 0x9E3779B1u;
+        h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+        sampled = (h & dhist_mask) == 0u;
+    }
     // Every per-Gaussian input is requested FIRST, ahead of the SH staging loads and their barrier: one trip to memory per
     // workgroup instead of two back to back (the kernel spent 77 % of its wave cycles parked on s_waitcnt at 1 M splats).
     const bool live = gidx < P;   // lanes past the end stay alive (workgroup-wide reduction below): they redo the last splat and store nothing
@@ -196,7 +207,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
             const int f = i * 256 + t;
             if ((size_t)f < lim) dst[f] = rec[f + (f >> 2)];
         }
-        if (em.status != nullptr || (dhist != nullptr && (blockIdx.x & dhist_mask) == 0u)) __syncthreads();   // (the fused emission / the depth histogram reuse the area once more)
+        if (em.status != nullptr || sampled) __syncthreads();   // (the fused emission / the depth histogram reuse the area once more)
     }
     // Segmented binning path: this workgroup's share of the forward's depth histogram (weights = tiles_touched: instances, not
     // splats), counted in LDS — integer ds_add is cheap, unlike the float one — and handed on with one atomic per NON-EMPTY bin:
@@ -204,7 +215,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     // histogram steers how evenly the buckets fill, nothing else (any histogram gives a monotone map), and a few hundred
     // workgroups' worth of splats is sample enough — with all 19 531 workgroups of the 5 M-splat benchmark (random depths: ~100
     // non-empty bins each) the 2 M global atomics on 256 addresses cost this kernel 0.16 ms (0.246 -> 0.407).
-    if (dhist != nullptr && (blockIdx.x & dhist_mask) == 0u) {   // (uniform)
+    if (sampled) {   // (uniform)
         uint32_t *lh = reinterpret_cast<uint32_t *>(sh_lds);
         lh[threadIdx.x] = 0u;
         __syncthreads();
@@ -353,7 +364,7 @@ int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int
     if (P == 0) return DAS3R_OK;
     const EmitArgs em = emit ? *emit : EmitArgs{nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0, nullptr, nullptr};
     dim3 grid(div_up(P, 256)), block(256);
-    uint32_t dhist_mask = 0u;   // sample the depth histogram from <= 512 workgroups spread evenly over the grid
+    uint32_t dhist_mask = 0u;   // sample the depth histogram from <= 512 workgroups spread pseudo-randomly over the grid
     while ((grid.x >> __builtin_popcount(dhist_mask)) > 512u) dhist_mask = (dhist_mask << 1) | 1u;
     const bool has_sh = in->shs != nullptr, has_cov = in->cov3D_precomp != nullptr;
 #define ARGS                                                                                                              \

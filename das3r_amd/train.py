@@ -286,7 +286,7 @@ def consistent_sequence(frames=22, W=512, H=208, focal=600.0, n_splats=20000, se
         make_scene(coherent=...): the surface of a real scene), coloured at random — a textured surface;
       * per frame: the image rendered by the rasterizer from that frame's pose, and the DEPTH MAP RENDERED FROM THE SAME CLOUD: one
         more render with colors_precomp = (z_camera, 1, 0) gives sum(w z) and sum(w) = 1 - T_final per pixel, depth = their ratio
-        (the expected depth of the blend; where less than 5 % of a pixel is covered, the scene's mean depth) — what a perfect depth
+        (the expected depth of the blend; where less than 5 % of a pixel is covered, the relief itself) — what a perfect depth
         predictor would hand DAS3R.  depth_noise / pose_noise: relative depth error / pose translation error (the predictor's) on top;
       * a MOVING OBJECT (`moving`): a disc that crosses the frame, painted over the images in its own colour, nearer than the surface
         in the depth maps, with dyna_avg = 1 inside it (DAS3R's dynamic map: conf_static = 1 - dyna_avg keeps those pixels'
@@ -304,7 +304,8 @@ def consistent_sequence(frames=22, W=512, H=208, focal=600.0, n_splats=20000, se
     disc_rgb = torch.tensor([0.9, 0.2, 0.1]).view(3, 1, 1)
     radius = 0.11 * H + 4.0
     images, poses7, c2w, depths, dyna, masks = [], [], [], [], [], []
-    mean_z = float(sc.means3D[:, 2].mean())
+    ur, vr = (uu + 0.5 - W / 2) / (W / 2), (vv + 0.5 - H / 2) / (H / 2)      # the relief of das3r_amd.synth.make_scene(coherent=...) at the pixel centres
+    relief = 4.0 + 2.0 * torch.sin(3.0 * ur) * torch.cos(2.0 * vr) + 1.5 * torch.cos(5.0 * ur + 1.0)
     for f in range(frames):
         t = torch.tensor([0.05 * (f - frames / 2), 0.02 * math.sin(f), 0.0]) + 0.005 * torch.randn(3, generator=g)
         view = torch.eye(4)
@@ -323,7 +324,9 @@ def consistent_sequence(frames=22, W=512, H=208, focal=600.0, n_splats=20000, se
             zimg, _ = GaussianRasterizer(rs)(means3D=sc.means3D, means2D=m2, opacities=sc.opacities, colors_precomp=zcol, scales=sc.scales,
                                              rotations=sc.rotations)
         cover = zimg[1]
-        d = torch.where(cover > 0.05, zimg[0] / cover.clamp_min(1e-6), torch.full_like(cover, mean_z)).cpu()
+        # (where less than 5 % of a pixel is covered: the relief itself, not a constant — a constant would put thousands of Gaussians at
+        #  EXACTLY one depth, a wall of ties no depth predictor produces and the worst case of the segmented binning)
+        d = torch.where(cover > 0.05, zimg[0] / cover.clamp_min(1e-6), relief.to(dev) - float(t[2])).cpu()
         img = img.clamp(0, 1).cpu()
         mask = torch.zeros(H, W, dtype=torch.bool)
         if moving:   # the disc crosses the frame from left to right, bobbing
