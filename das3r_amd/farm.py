@@ -362,7 +362,7 @@ def main():
     ap.add_argument("--dataset", default="sintel", choices=("sintel", "davis"))
     ap.add_argument("--jobs-per-gpu", type=int, default=None, help="sequences in flight per GPU: K host threads per rank, each with its own stream "
                     "and model (one job's VALU-bound compositing overlaps another's HBM / latency-bound kernels).  Default: 2 on a GPU — the "
-                    "measured optimum (profiles/r05_jobs_per_gpu.json: 1.50 x the rate of 1 at the Sintel shape, 1.35 x at the DAVIS shape; "
+                    "measured optimum (profiles/r05_jobs_per_gpu.json: 1.47 x the rate of 1 at the Sintel shape, 1.34 x at the DAVIS shape; "
                     "3 is no better) — and 1 on the host")
     ap.add_argument("--hung-timeout", type=float, default=600.0, help="seconds a live rank may go without a progress tick before the gather is "
                     "replaced by the record files (a rank that is merely slower keeps ticking and is waited for)")
