@@ -361,7 +361,7 @@ def main():
     ap.add_argument("--gt-dynamic-mask", default=None, help="root of the ground-truth dynamic masks, <root>/<sequence>/... (train_test_psnr.py --gt_dynamic_mask)")
     ap.add_argument("--dataset", default="sintel", choices=("sintel", "davis"))
     ap.add_argument("--jobs-per-gpu", type=int, default=None, help="sequences in flight per GPU: K host threads per rank, each with its own stream "
-                    "and model (one job's VALU-bound compositing overlaps another's HBM / latency-bound kernels).  Default: 2 on a GPU — the "
+                    "and model (one job's VALU-bound compositing overlaps another's HBM / latency-bound kernels).  Default: 2 on a GPU with --fused — the "
                     "measured optimum (profiles/r05_jobs_per_gpu.json: 1.47 x the rate of 1 at the Sintel shape, 1.34 x at the DAVIS shape; "
                     "3 is no better) — and 1 on the host")
     ap.add_argument("--hung-timeout", type=float, default=600.0, help="seconds a live rank may go without a progress tick before the gather is "
@@ -400,7 +400,9 @@ def main():
     else:
         mine = assign(args.sequences, rank, world)
         job = lambda s: run_sequence_job(s, args.iterations, device, fused=args.fused, progress=tick)
-    records = run_jobs(mine, job, args.jobs_per_gpu if args.jobs_per_gpu else (2 if use_gpu else 1), device)
+    # (default: two in flight with the fused kernels — the measured configuration; the reference's PyTorch glue runs its backward passes in
+    #  autograd's one device thread, where two jobs would queue behind each other: one at a time unless asked for)
+    records = run_jobs(mine, job, args.jobs_per_gpu if args.jobs_per_gpu else (2 if (use_gpu and args.fused) else 1), device)
     names = dirs if args.data else [f"seq_{i}" for i in range(args.sequences)]
     mode = "collective"
     if rdv is not None:
