@@ -120,3 +120,43 @@ def test_fractions_rarely_tie_inside_a_segment():
     _, counts = np.unique(seg, return_counts=True)
     tied = int(counts[counts > 1].sum())
     assert tied <= 0.02 * z.shape[0], tied
+
+
+def test_depth_histogram_sample_covers_a_das3r_model():
+    """preprocess.hip picks the workgroups that sample the segmented path's depth histogram with a full-avalanche hash of their index
+    (round 5).  Round 4's rule — `(index & mask) == 0`, every 16th workgroup at the Sintel shape — is a biased sample of a DAS3R model:
+    its Gaussians are the pixels of its frames in row-major order, a workgroup of 256 is half a 512-pixel row, and every 16th workgroup is
+    the LEFT half of every 8th row: the histogram never saw the right half of the scene (docs/ledger.md (ba)).  numpy restatement of
+    the hash and of launch_preprocess's mask: at the Sintel and DAVIS shapes every (tile row, image half) gets its share of the sample,
+    and the old rule provably does not."""
+    import numpy as np
+
+    def mask_of(nblocks):
+        m = 0
+        while (nblocks >> bin(m).count("1")) > 512:
+            m = (m << 1) | 1
+        return m
+
+    def hashed(b, m):
+        h = (b * 0x9E3779B1) & 0xFFFFFFFF
+        h ^= h >> 15
+        h = (h * 0x85EBCA6B) & 0xFFFFFFFF
+        h ^= h >> 13
+        h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+        h ^= h >> 16
+        return (h & m) == 0
+
+    for frames, W, H in ((20, 512, 208), (45, 512, 288)):
+        P = frames * W * H
+        nblocks = (P + 255) // 256
+        m = mask_of(nblocks)
+        b = np.arange(nblocks, dtype=np.uint64)
+        pix = (b * 256) % (W * H)                      # first pixel of the workgroup inside its frame
+        group = (pix // W // 16) * 2 + (pix % W) // 256   # (tile row, left / right half of the image)
+        ngroups = ((H + 15) // 16) * 2
+        new = np.bincount(group[hashed(b, m)].astype(np.int64), minlength=ngroups)
+        old = np.bincount(group[(b & np.uint64(m)) == 0].astype(np.int64), minlength=ngroups)
+        expect = hashed(b, m).sum() / ngroups
+        assert 256 <= hashed(b, m).sum() <= 700
+        assert new.min() >= 0.3 * expect, (frames, W, H, new.tolist())      # every part of the image is in the sample
+        assert (old == 0).sum() >= ngroups // 2, old.tolist()                # the old rule: half of the groups never sampled
