@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdas3r_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
@@ -52,7 +52,7 @@ EXPORTS = ("das3r_raster_forward", "das3r_raster_backward", "das3r_raster_check"
            "das3r_knn3_mean_dist2", "das3r_raster_get_layout", "das3r_abi_version", "das3r_last_error", "das3r_reload_switches", "das3r_get_stats",
            "das3r_profile_enable", "das3r_profile_report", "das3r_pretransform_forward", "das3r_pretransform_backward", "das3r_pose_matrices", "das3r_pose_chain",
            "das3r_adam_step", "das3r_adam_step_gated", "das3r_photometric_blocks", "das3r_photometric_forward", "das3r_photometric_backward",
-           "das3r_has_experiments", "das3r_pair_counters", "das3r_debug_poison_lds", "das3r_debug_inject_fault",
+           "das3r_has_experiments", "das3r_pair_counters", "das3r_debug_poison_lds", "das3r_debug_inject_fault", "das3r_debug_mutate",
            "das3r_pose_matrices_qt", "das3r_pose_chain_qt", "das3r_photometric_finish", "das3r_pretransform_backward_adam", "das3r_pretransform_pose_sums",
            "das3r_raster_count_live_pairs")
 
@@ -155,6 +155,14 @@ def inject_fault(bits):
     L.das3r_debug_inject_fault.restype = None
     L.das3r_debug_inject_fault.argtypes = [C.c_uint32]
     L.das3r_debug_inject_fault(int(bits))
+
+
+def mutate(what):
+    """Test aid: 1 = the block-walk backward evaluates exp(power) (1 + 1e-4), 0 = off (include/das3r_raster.h das3r_debug_mutate)."""
+    L = load()
+    L.das3r_debug_mutate.restype = None
+    L.das3r_debug_mutate.argtypes = [C.c_uint32]
+    L.das3r_debug_mutate(int(what))
 
 
 def poison_lds(pattern=0x7FC00000):

@@ -50,6 +50,7 @@ void profile_end(hipStream_t s) {
 static Switches g_sw;
 static bool g_sw_loaded = false;
 static int g_inject_fault = 0;
+static int g_mutate = 0;
 static void load_switches() {
     Switches w;
     memset(&w, 0, sizeof(w));
@@ -103,6 +104,7 @@ static void load_switches() {
     if ((e = env("DAS3R_TILE_CHUNK"))) { const int v = atoi(e); w.tile_chunk = (v >= 0 && v <= 64 && (v & (v - 1)) == 0) ? v : -1; }
     if ((e = env("DAS3R_TILE_STRIP"))) w.tile_strip = std::max(0, std::min(63, atoi(e)));   // (7-bit field of render_common.h pack_tiles, kept below its sign bit)
     w.inject_fault = g_inject_fault;   // (not an environment variable: das3r_debug_inject_fault)
+    w.mutate = g_mutate;               // (likewise: das3r_debug_mutate)
     g_sw = w;
     __atomic_store_n(&g_sw_loaded, true, __ATOMIC_RELEASE);
 }
@@ -114,12 +116,38 @@ const Switches &switches() {
 // Ticket-free chained kernels wait for lower-numbered workgroups, which is only safe while the whole grid is resident at once.
 // The bound is taken from the device the call runs on (compute partitions have fewer CUs) and stays below what it holds
 // (>= 3 workgroups per CU of the heaviest of these kernels).  DAS3R_TICKETS=always switches the short cut off.
+// Round 6: "the whole grid is resident" presumes that the grid has the device to itself.  The library knows when it does
+// not: every host thread that renders on a device registers there (per_device(), below; un-registered when the thread ends), and
+// once a second thread has, every chained kernel of that device takes its tickets — whatever farm.run_jobs or the environment say
+// (a DAS3R_TICKETS bound set by hand still wins: it is an experiment switch, and says so once on stderr).  Two PROCESSES on one GPU
+// are not seen from here: tools/jobs_per_gpu.py's process mode sets DAS3R_TICKETS=always for its children.
+constexpr int MAX_DEVICES = 64;
+static int g_threads_on_device[MAX_DEVICES] = {};
+struct ThreadRegistrar {
+    bool on[MAX_DEVICES] = {};
+    void add(int dev) {
+        if (!on[dev]) { on[dev] = true; __atomic_fetch_add(&g_threads_on_device[dev], 1, __ATOMIC_RELAXED); }
+    }
+    ~ThreadRegistrar() {
+        for (int d = 0; d < MAX_DEVICES; d++)
+            if (on[d]) __atomic_fetch_sub(&g_threads_on_device[d], 1, __ATOMIC_RELAXED);
+    }
+};
+static thread_local ThreadRegistrar g_registrar;
 bool grid_is_resident(int nblocks) {
     const int forced = switches().tickets;
-    if (forced >= 0) return nblocks <= forced;
-    static thread_local int cached_dev = -1, cached_limit = 0;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return false;
+    const bool shared = __atomic_load_n(&g_threads_on_device[dev], __ATOMIC_RELAXED) > 1;
+    if (forced >= 0) {
+        static bool warned = false;
+        if (shared && forced > 0 && !__atomic_exchange_n(&warned, true, __ATOMIC_RELAXED))
+            fprintf(stderr, "[das3r] DAS3R_TICKETS is set to a bound while several host threads render on device %d: ticket-free chained "
+                            "kernels are only safe when a grid has the device to itself\n", dev);
+        return nblocks <= forced;
+    }
+    if (shared) return false;
+    static thread_local int cached_dev = -1, cached_limit = 0;
     if (dev != cached_dev) {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
@@ -242,6 +270,10 @@ extern "C" void das3r_debug_inject_fault(uint32_t bits) {
     g_inject_fault = (int)bits;
     load_switches();
 }
+extern "C" void das3r_debug_mutate(uint32_t what) {
+    g_mutate = (int)what;
+    load_switches();
+}
 extern "C" const char *das3r_last_error(void) { return g_err; }
 
 extern "C" int das3r_raster_get_layout(int32_t P, int64_t num_rendered, int32_t W, int32_t H, das3r_raster_layout *out) {
@@ -275,13 +307,13 @@ struct PerDevice {
     bool emit_ring_dirty = false;
     uint32_t emit_last_tag = 0;
 };
-constexpr int MAX_DEVICES = 64;
 static int per_device(PerDevice **out) {
     static thread_local PerDevice state[MAX_DEVICES];
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= MAX_DEVICES) { set_error("device ordinal %d not supported", dev); return DAS3R_ERR_INVALID_ARG; }
     PerDevice &T = state[dev];
+    g_registrar.add(dev);   // (grid_is_resident: a second rendering thread on the device switches the ticket-free short cut off)
     if (!T.mb.host) {
         uint32_t *h = nullptr;
         HIP_TRY(hipHostMalloc((void **)&h, MAILBOX_BYTES, hipHostMallocMapped));

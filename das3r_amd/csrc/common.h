@@ -43,6 +43,7 @@ struct Switches {
     int bwd_pad_lds, fwd_pad_lds;   // DAS3R_BWD_PAD_LDS / DAS3R_FWD_PAD_LDS: extra dynamic LDS (occupancy experiments)
     int bwd_buckets;       // DAS3R_BWD_BUCKETS=0 | <slices>: bucket-parallel backward off / forced with that many slices (-1: by list length)
     int inject_fault;
+    int mutate;            // das3r_debug_mutate (tests): 1 = the block-walk backward evaluates exp(power) (1 + 1e-4) — a biased kernel the parity tests must catch
     bool fwd_no_prefetch;   // DAS3R_FWD_PREFETCH=0: the rows forward kernel without its software prefetch (A-B runs)
     int tile_strip;   // DAS3R_TILE_STRIP: rows per strip of the compositing kernels' tile order (0 = row-major)      // DAS3R_INJECT_FAULT: bits OR-ed into the binning self-check word of every forward (fault-injection tests)
 };

@@ -76,8 +76,9 @@ constexpr int PIX_ST_ROW = 16 * 8 + 8;      // bytes per block row of state
 // One image row KY of the block: its four pixel steps K = 4 KY .. 4 KY + 3, interleaved.  pair_alpha's arithmetic, bit for bit
 // (render_common.h), so that every pair takes the decision the forward kernel took.
 // ABL (tools/probes/blk_loop_probe.hip only; results are wrong): 1 = without the two row scans, 2 = without the state hand-off
+// MUT: exp(power) (1 + 1e-4) — das3r_debug_mutate(1), the biased kernel of tests/test_gpu_fullsize.py's mutation test
 // cst / st: LDS byte addresses of the lane's block row of constants / state (PIX > 0 / PIX == 2)
-template <int KY, int PIX = 0, int ABL = 0>
+template <int KY, int PIX = 0, int ABL = 0, bool MUT = false>
 __device__ __forceinline__ void block_row(const SplatRegs &sp, PixelRegs &px, Sums &acc, const char *cst = nullptr, char *st = nullptr) {
     const float dy = PIX ? sp.y - (px.pyf + (float)KY) : sp.y - bc<4 * KY>(px.pyf);
     const float cyy = __fmul_rn(__fmul_rn(sp.C, dy), dy);
@@ -92,7 +93,7 @@ __device__ __forceinline__ void block_row(const SplatRegs &sp, PixelRegs &px, Su
         const float dx = PIX ? sp.x - (px.pxf + (float)U) : sp.x - bc<K>(px.pxf);                                             \
         const float q = __fmaf_rn(__fmul_rn(sp.A, dx), dx, cyy);                                                              \
         const float power = __fmaf_rn(-0.5f, q, -__fmul_rn(__fmul_rn(sp.B, dx), dy));                                         \
-        const float G = __expf(power);                                                                                        \
+        const float G = MUT ? __expf(power) * 1.0001f : __expf(power);   /* MUT: das3r_debug_mutate (the mutation the parity tests must catch) */ \
         /* position < n_contrib  <=>  lastrel - posrel >= 1, else <= 0 (small integers): a third operand of the alpha clamp —  */ \
         /* where the pair takes part the minimum is min(0.99, o G) as in pair_alpha, elsewhere it fails the 1/255 test         */ \
         const float lastrel = PIX ? pc[U].w : bc<K>(px.lastrel);                                                              \

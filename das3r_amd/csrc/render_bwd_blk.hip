@@ -33,7 +33,8 @@ namespace das3r {
 // MB: staged list entries per round.  PIX: where the walk finds the per-pixel values (render_blk.h): 0 pixel lanes' registers (DPP
 // broadcasts), 1 constants from LDS, 2 constants and state from LDS.
 // ABL: timing experiments only (DAS3R_ABLATE with DAS3R_RENDER_BWD=blk128p1; results are wrong): 1 no batches at all (what the rounds
-// cost without them), 2 batches without the record add, 4 nothing written out, 8 bounding-box block test only, 16 no quadrant ellipse test
+// cost without them), 2 batches without the record add, 4 nothing written out, 8 bounding-box block test only, 16 no quadrant ellipse test;
+// 32 (every build; das3r_debug_mutate(1)): exp(power) (1 + 1e-4) — the mutation tests/test_gpu_fullsize.py proves the parity bars catch
 template <int MB, int PIX, int ABL = 0, int OCC = 5, bool LAST = false>
 __global__ void __launch_bounds__(256, OCC) render_backward_blk_kernel(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int tiles_x, int ntiles_strip /*render_common.h pack_tiles*/,
@@ -261,10 +262,10 @@ __global__ void __launch_bounds__(256, OCC) render_backward_blk_kernel(
                     sp.posrel = (float)(MB - 1 - j);
                 }
                 Sums a = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                block_row<0, PIX>(sp, px, a, cst_row, st_row);
-                block_row<1, PIX>(sp, px, a, cst_row, st_row);
-                block_row<2, PIX>(sp, px, a, cst_row, st_row);
-                block_row<3, PIX>(sp, px, a, cst_row, st_row);
+                block_row<0, PIX, 0, (ABL & 32) != 0>(sp, px, a, cst_row, st_row);
+                block_row<1, PIX, 0, (ABL & 32) != 0>(sp, px, a, cst_row, st_row);
+                block_row<2, PIX, 0, (ABL & 32) != 0>(sp, px, a, cst_row, st_row);
+                block_row<3, PIX, 0, (ABL & 32) != 0>(sp, px, a, cst_row, st_row);
                 // moments about the block's corner -> sums about the splat centre (dx = X - u, dy = Y - v)
                 const float X = sp.x - bx0f, Y = sp.y - by0f;
                 p_lo4 = v4f{a.C0, a.C1, a.C2, a.M0};
@@ -356,6 +357,10 @@ int launch_render_backward_blk(const das3r_raster_args *a, const float *dL_dpix,
     // (DAS3R shape: 0.497 vs 0.534 ms)
     const int pix = switches().render_bwd == 6 ? switches().render_bwd_pix : (mb == 128 ? 1 : 0), occ = switches().render_bwd_occ == 4 ? 4 : 5;
 #define BY_PIX(MBV, OCC) do { if (pix == 2) GO(MBV, 2, OCC); else if (pix == 1) GO(MBV, 1, OCC); else GO(MBV, 0, OCC); } while (0)
+    if (switches().mutate == 1) {   // the mutated kernel (a test aid: include/das3r_raster.h das3r_debug_mutate), in the two shipped default forms
+        if (slices > 1) DAS3R_LAUNCH((render_backward_blk_kernel<192, 0, 32, 4, true>), dim3(xcd_grid(L), slices), dim3(TILE_PIX), 0, s, ARGS);
+        else DAS3R_LAUNCH((render_backward_blk_kernel<128, 1, 32, 5, false>), dim3(xcd_grid(L), 1), dim3(TILE_PIX), 0, s, ARGS);
+    } else
 #ifdef DAS3R_EXPERIMENTS
     if (mb == 128 && pix == 1 && switches().ablate_set) {
         const int abl = switches().ablate;

@@ -82,7 +82,9 @@ class Rendezvous:
                     reported is looked up in its own <out>/<sequence>/test_log.txt (train.scrape_test_logs — what the reference's
                     scripts scrape, scripts/get_testing_psnr_davis.py:8-17) before it is marked failed.
     A slower rank is never declared hung because a faster one is done: only missing heartbeats and missing progress count (round 4
-    judged this by the deciding rank's own duration — ADVICE r4).  Single node: the directory is on the node's file system (the farm
+    judged this by the deciding rank's own duration — ADVICE r4) — and in "files" mode nobody reads the record files before every
+    rank that still works and ticks has published (`wait_for_working_ranks`: round 5 assembled the table the moment the decision
+    was taken and dropped the sequences of a healthy slower rank whenever a third rank had died — ADVICE r5).  Single node: the directory is on the node's file system (the farm
     is one node by definition)."""
 
     def __init__(self, root, rank, world, beat_s=2.0):
@@ -191,6 +193,18 @@ class Rendezvous:
                     return self._write_decision("files", states)
             else:
                 all_done_since = None
+            time.sleep(0.05)
+
+    def wait_for_working_ranks(self, stale_s=30.0, hung_s=600.0):
+        """"files" mode, before the table is read from the record files: wait until no rank is WORKING any more — every one has
+        published, died (stale heartbeat) or hung (alive, no progress tick for hung_s).  decide() returns "files" to everybody the
+        moment ONE rank looks dead or hung; a healthy, slower rank that is still optimising and ticking then has not published yet,
+        and a table assembled at once would drop every one of its sequences (and exit 3) — with world >= 3 and one dead rank that was
+        the rule, not the exception.  -> the final states."""
+        while True:
+            states = [self._state(r, stale_s, hung_s) for r in range(self.world)]
+            if "working" not in states:
+                return states
             time.sleep(0.05)
 
     def records_from_files(self):
@@ -327,7 +341,10 @@ def run_jobs(items, job, jobs_per_gpu=1, device=None):
     # The library's chained kernels (look-back scans / partition passes) skip their arrival tickets when a whole grid is resident at
     # once — true of a GPU that runs ONE job's kernels.  With several jobs in flight the grids share the CUs: arrival tickets always
     # (DAS3R_TICKETS=always: a workgroup then only ever waits for workgroups that have started).  The grids of the DAS3R shapes are above
-    # the ticket-free bound anyway; this makes it a rule instead of a coincidence.
+    # the ticket-free bound anyway; this makes it a rule instead of a coincidence.  Round 6: the LIBRARY enforces the same rule by itself
+    # (api.hip grid_is_resident: once a second host thread renders on a device, no chained kernel of that device runs ticket-free), so a
+    # DAS3R_TICKETS left in the environment, or threads started by somebody else, no longer escape it; the switch below stays as the
+    # cover for the first launches of a worker that registers while another one's kernel is already in flight.
     restore = None
     if use_gpu and "DAS3R_TICKETS" not in os.environ:
         from . import _lib
@@ -412,6 +429,7 @@ def main():
         table = gather_records(records, args.sequences, device)
     else:
         print(f"[farm] rank {rank}: a rank is missing — table assembled from the record files, no collective")
+        rdv.wait_for_working_ranks(hung_s=args.hung_timeout)   # (a healthy slower rank is still to publish: its sequences are not lost)
         table = table_from_files(rdv, args.sequences, names, args.out)
     if rdv is not None:
         rdv.close()

@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define DAS3R_ABI_VERSION 12
+#define DAS3R_ABI_VERSION 13
 
 typedef enum {
     DAS3R_OK = 0,
@@ -298,6 +298,12 @@ int das3r_debug_poison_lds(uint32_t pattern, das3r_stream_t stream);
  * prove that a failed binning is reported before the backward pass launches anything.  A call, not an environment variable:
  * nothing in the environment can make the shipped library report or compute anything else than it should. */
 void das3r_debug_inject_fault(uint32_t bits);
+
+/* Test aid (mutation test of the parity suite): what = 1 makes the block-walk compositing backward
+ * (render_bwd_blk.hip, the kernel of the 1 M-splat headline and of the DAS3R training shape) evaluate exp(power) (1 + 1e-4) — the
+ * kind of bias a "fast exp" or a packed-record shortcut would bring in; 0 switches it off.  tests/test_gpu_fullsize.py asserts that
+ * the full-size oracle comparison FAILS under it.  A call, not an environment variable (see das3r_debug_inject_fault). */
+void das3r_debug_mutate(uint32_t what);
 
 /* Pair counters of the compositing kernels (bench.py: pairs per second).  enable != 0: zero the counters and count from now on;
  * enable == 0: stop, and read into out (may be NULL): out[0] (pixel, splat) pairs the forward compositing kernel evaluated, [1] the

@@ -216,6 +216,52 @@ def test_rendezvous_decision_is_one_and_fair(tmp_path, scenario, mode, by):
     assert got[0] == got[1] == (mode, by), got
 
 
+def _three_rank_worker(rank, world, out_dir):
+    """rank 2 dies without publishing, rank 1 is healthy but slow (works 3 s beyond the decision, ticking), rank 0 is done at once."""
+    import time
+    rdv = farm.Rendezvous(os.path.join(out_dir, ".farm"), rank, world, beat_s=0.1)
+    if rank == 2:
+        time.sleep(0.3)
+        os._exit(9)                  # a HIP fault: no records, the heartbeat stops
+    recs = [dict(scene_id=s, psnr=20.0 + s, l1=0.0, iters_per_s=1.0, n_splats=1, ok=1) for s in farm.assign(6, rank, world)]
+    if rank == 1:
+        for _ in range(16):          # 4 s: well past the moment rank 0 sees rank 2's heartbeat go stale (1 s) and decides "files"
+            time.sleep(0.25)
+            rdv.tick()
+    rdv.publish(recs)
+    t_decided = time.time()
+    mode = rdv.decide(stale_s=1.0, hung_s=2.0)
+    states = rdv.wait_for_working_ranks(stale_s=1.0, hung_s=2.0)
+    table = farm.table_from_files(rdv, 6)
+    rdv.close()
+    torch.save((mode, states, table, time.time() - t_decided), os.path.join(out_dir, f"three_{rank}.pt"))
+    os._exit(0)
+
+
+@pytest.mark.timeout(120)
+def test_files_mode_waits_for_a_healthy_slower_rank_when_another_rank_is_dead(tmp_path):
+    """ADVICE r5 (farm.py Rendezvous): world 3 — one dead rank, one rank that is done, one that is healthy and slower.  The decision
+    "files" stands as soon as the dead rank's heartbeat is stale; the rank that assembles the table must nevertheless wait for the
+    slower rank's records (it keeps ticking) and lose only the dead rank's sequences."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_three_rank_worker, args=(r, world, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(60)
+    assert all(not p.is_alive() for p in procs)
+    assert [p.exitcode for p in procs] == [0, 0, 9]
+    for r in (0, 1):
+        mode, states, table, waited = torch.load(tmp_path / f"three_{r}.pt")
+        assert mode == "files" and states[2] == "dead" and "working" not in states, (mode, states)
+        mine0, mine1, mine2 = (farm.assign(6, k, world) for k in range(3))
+        assert table[mine0, 5].tolist() == [1.0] * len(mine0) and table[mine1, 5].tolist() == [1.0] * len(mine1), table   # both living ranks' sequences
+        assert table[mine2, 5].tolist() == [0.0] * len(mine2)                                                              # lost with their rank
+        assert table[mine1, 1].tolist() == [20.0 + s for s in mine1]
+    assert torch.load(tmp_path / "three_0.pt")[3] > 2.0, "rank 0 must have waited for the slower rank instead of printing a partial table"
+
+
 def test_run_jobs_on_the_host():
     """farm.run_jobs without a GPU: K worker threads pull the rank's sequences; results in the order of the items, never more than K
     in flight, a job's exception re-raised in the caller."""

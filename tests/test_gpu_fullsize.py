@@ -25,9 +25,10 @@ def _view(buf, off, dtype, count):
     return buf[off:off + count * item].view(dtype)
 
 
-def _full_size_vs_oracle(name, P=None):
+def _full_size_vs_oracle(name, P=None, flips=False):
     """One forward + backward of workload `name` through the drop-in surface (default kernel selection) against the CPU oracle:
-    radii exactly, colours within the stated tolerance, every gradient in the max norm AND element by element."""
+    radii exactly, colours within the stated tolerance, every gradient in the max norm AND element by element.
+    flips: the scene is large enough for a handful of elements to sit on a threshold flip (tests/util.py GRAD_FLIP_*)."""
     sc, scd, dev, Settings, Rasterizer = _setup(name, P)
     mode = dict(colors_precomp=False, cov3D_precomp=False, scale_modifier=1.0)
     ref_color, ref_radii, ref_g, S = util.run_oracle(sc, mode)
@@ -42,14 +43,14 @@ def _full_size_vs_oracle(name, P=None):
     util.assert_color_close(color.detach().cpu().numpy(), ref_color, f"{name} colour")
     for k, t in list(leaves.items()) + [("means2D", m2)]:
         g = t.grad.cpu().numpy()
-        util.assert_grad_close(g, ref_g[k], f"{name} dL/d{k}")
+        util.assert_grad_close(g, ref_g[k], f"{name} dL/d{k}", flips=flips)
         util.assert_grad_elementwise(g, ref_g[k], f"{name} dL/d{k}")
     return sc, num_rendered
 
 
 def test_c2_full_size_vs_oracle():
     """BASELINE.json configs[1]: 100k splats, 1920x1080, SH degree 3, forward + backward (quad forward, dpp backward)."""
-    _full_size_vs_oracle("c2")
+    _full_size_vs_oracle("c2", flips=True)
 
 
 def test_c4_full_size_vs_oracle():
@@ -61,12 +62,27 @@ def test_c4_full_size_vs_oracle():
     assert 192 * tiles <= I < 512 * tiles, "the scene is meant to take the long-list kernels (mean tile list ~320)"
 
 
+def test_mutated_backward_is_caught():
+    """the parity bars must BITE.  das3r_debug_mutate(1) makes the block-walk backward — the dominant kernel of the
+    headline — evaluate exp(power) (1 + 1e-4), the size of bias a "fast exp", a scaled conic or a packed record would bring in (three
+    orders of magnitude under the bars of rounds 1 - 5, which it passed).  The very checks of test_c4_full_size_vs_oracle must fail
+    under it, and pass again once it is switched off."""
+    from das3r_amd import _lib
+    _lib.mutate(1)
+    try:
+        with pytest.raises(AssertionError, match="dL/d"):
+            _full_size_vs_oracle("c4")
+    finally:
+        _lib.mutate(0)
+    _full_size_vs_oracle("c4")
+
+
 def test_ds_full_size_vs_oracle():
     """The DAS3R shape (SURVEY.md 8d "DS-like"): 5M tiny splats on 512x208, SH degree 0 — ~13 800-entry tile lists.  This is the FIRST
     forward of the shape: global depth sort + tile partition (no previous count to lay a segmented / speculative layout out from), rows
     forward with checkpoints, bucket-parallel block-walk backward, degree-0 per-Gaussian backward.  The path every later forward of
     the shape takes is held to the oracle by test_steady_state_full_size_vs_oracle below."""
-    sc, I = _full_size_vs_oracle("ds")
+    sc, I = _full_size_vs_oracle("ds", flips=True)
     tiles = ((sc.W + 15) // 16) * ((sc.H + 15) // 16)
     assert I >= 2048 * tiles, "the scene is meant to take the bucket-parallel backward"
 
@@ -134,7 +150,7 @@ def test_steady_state_full_size_vs_oracle(name):
     g_means2D, _gc, g_opac, g_means3D, _gcov, g_sh, g_scales, g_rot = g
     for k, t in [("means3D", g_means3D), ("opacities", g_opac), ("shs", g_sh), ("scales", g_scales), ("rotations", g_rot), ("means2D", g_means2D)]:
         a = t.cpu().numpy()
-        util.assert_grad_close(a, ref_g[k], f"{name} steady-state dL/d{k}")
+        util.assert_grad_close(a, ref_g[k], f"{name} steady-state dL/d{k}", flips=True)
         util.assert_grad_elementwise(a, ref_g[k], f"{name} steady-state dL/d{k}")
 
 

@@ -507,8 +507,9 @@ def test_every_backward_kernel_vs_oracle(name, kind, monkeypatch):
     _, _, g, _ = _run_hip(sc, mode)
     gmap = {"means3D": "means3D", "opacities": "opacities", "shs": "shs", "scales": "scales", "rotations": "rotations", "means2D": "means2D"}
     for k, t in g.items():
-        util.assert_grad_close(t.cpu().numpy(), ref_g[gmap[k]], f"{name} [{kind}] dL/d{k}")
-        util.assert_grad_elementwise(t.cpu().numpy(), ref_g[gmap[k]], f"{name} [{kind}] dL/d{k}")
+        bars = util.tolerances_for(kind)   # (tight for the shipped kernels, the split-bf16 kernels' own for scan / mfma / stream)
+        util.assert_grad_close(t.cpu().numpy(), ref_g[gmap[k]], f"{name} [{kind}] dL/d{k}", tol=bars["tol"])
+        util.assert_grad_elementwise(t.cpu().numpy(), ref_g[gmap[k]], f"{name} [{kind}] dL/d{k}", rtol=bars["rtol"], floor=bars["floor"], outliers=bars["outliers"])
 
 
 @pytest.mark.parametrize("kind", ["scan128", "scan256", "blk128", "blk256"])
@@ -531,8 +532,10 @@ def test_bucket_parallel_backward(name, kind, slices, monkeypatch):
         assert fn.num_rendered > 1024 * tiles, "the scene is meant to have lists of several buckets"
     gmap = {"means3D": "means3D", "opacities": "opacities", "shs": "shs", "scales": "scales", "rotations": "rotations", "means2D": "means2D"}
     for k, t in g.items():
-        util.assert_grad_close(t.cpu().numpy(), ref_g[gmap[k]], f"{name} [{kind}, {slices} slices] dL/d{k}")
-        util.assert_grad_elementwise(t.cpu().numpy(), ref_g[gmap[k]], f"{name} [{kind}, {slices} slices] dL/d{k}")
+        bars = util.tolerances_for(kind)
+        util.assert_grad_close(t.cpu().numpy(), ref_g[gmap[k]], f"{name} [{kind}, {slices} slices] dL/d{k}", tol=bars["tol"])
+        util.assert_grad_elementwise(t.cpu().numpy(), ref_g[gmap[k]], f"{name} [{kind}, {slices} slices] dL/d{k}", rtol=bars["rtol"], floor=bars["floor"],
+                                     outliers=bars["outliers"])
         util.assert_grad_close(t.cpu().numpy(), g_seq[k].cpu().numpy(), f"{name} bucket-parallel vs sequential dL/d{k}", tol=5e-5)
 
 

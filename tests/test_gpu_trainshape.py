@@ -99,8 +99,9 @@ FLIP_ELEMENTS = 1e-5   # fraction of a gradient tensor's elements that may miss 
 FLIP_REL = 5e-2        # ... each of them still within this much of the tensor's largest element
 
 
-def _compare_grads(pairs, what):
-    """Max-norm 2e-3 of the largest element and the element-wise bound of the module docstring.  The max-norm bound may be missed by
+def _compare_grads(pairs, what, strict=False):
+    """strict (the noise-depth first iteration, which held the plain bound before the allowance existed — ADVICE r5): max-norm 2e-3 of
+    the largest element for EVERY element, no flips.  Otherwise: max-norm 2e-3 of the largest element and the element-wise bound of the module docstring.  The max-norm bound may be missed by
     single elements (at most FLIP_ELEMENTS of the tensor, >= 3, each within FLIP_REL): one (pixel, Gaussian) pair whose alpha sits on
     1/255 or whose T sits on 1e-4 decides differently on the two sides, and at this shape — Gaussians of one or two pixels — that
     pair can be half of a Gaussian's gradient; when the Gaussian is one of the tensor's largest, the flip shows in the max norm.
@@ -121,7 +122,10 @@ def _compare_grads(pairs, what):
         flips = int((d > 2e-3 * scale).sum())
         bad = float((d > 1e-2 * r.abs() + 1e-4 * scale).double().mean())
         report[k] = (rel, bad)
-        assert flips <= max(3, int(FLIP_ELEMENTS * d.numel())) and rel <= FLIP_REL, (what, k, rel, flips)
+        if strict:
+            assert rel <= 2e-3, (what, k, rel)
+        else:
+            assert flips <= max(3, int(FLIP_ELEMENTS * d.numel())) and rel <= FLIP_REL, (what, k, rel, flips)
         assert bad <= 1e-3, (what, k, bad)
     return report
 
@@ -159,7 +163,7 @@ def test_sintel_shaped_step_vs_float64_host_and_c_oracle(degree, monkeypatch):
         assert model._features_rest.grad is None and compact is not None and tuple(compact.shape) == (P, K1, 3)
         assert float(host.p["f_rest"].grad[:, K1:].abs().max()) == 0.0
         pairs.append(("f_rest", compact, host.p["f_rest"].grad[:, :K1]))
-    report = _compare_grads(pairs, f"degree {degree}")
+    report = _compare_grads(pairs, f"degree {degree}", strict=True)   # (noise depth, first iteration)
     print("degree", degree, "P", P, "loss", float(loss), "max-norm / outlier fraction per gradient:",
           {k: (f"{a:.1e}", f"{b:.1e}") for k, (a, b) in report.items()})
 

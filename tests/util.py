@@ -1,6 +1,8 @@
 """Shared helpers for the parity tests: scene variants that hit every branch of SURVEY.md A.9, oracle runners and the
 stated tolerances."""
+import json
 import math
+import os
 
 import numpy as np
 import torch
@@ -12,7 +14,20 @@ from das3r_amd.synth import Scene, make_scene
 COLOR_TOL = 1e-4          # max |delta| on colours in [0,1] ...
 FLIP_FRACTION = 1e-3      # ... except at most this fraction of pixels, explained by a threshold flip
 FLIP_MAX = 2.5e-2         # (alpha<1/255 or T<1e-4 decided differently by a 1-ulp exp difference), each bounded by this
-GRAD_REL_TOL = 2e-3       # gradients: max |delta| relative to the tensor's max |grad| (atomics reorder + exp ulp)
+# Gradients, max |delta| relative to the tensor's max |grad|.  Round 6: the bars are set to what the kernels
+# measure (DAS3R_TOL_REPORT, tools/tol_report.py; profiles/r06_tol_report.txt), not to the ceiling SURVEY.md section 8(a) gave a
+# kernel with float atomics (1e-3): the shipped kernels have none, and measure <= 1.2e-5 on every fixture and 1.5e-6 at C4.
+# A biased kernel — exp scaled by 1 + 1e-4 — fails them (tests/test_gpu_fullsize.py::test_mutated_backward_is_caught).
+GRAD_REL_TOL = 5e-5       # default kernel selection (dpp / blk backward, every forward kernel)
+GRAD_REL_TOL_SPLIT = 1e-4  # the superseded split-bf16 kernels (scan, mfma: 16 mantissa bits per factor, measured 2.4e-5) and stream
+# Threshold flips.  A pair whose alpha sits within an ulp of 1/255 (or a pixel whose T reaches 1e-4 within an ulp) is decided one way
+# by v_exp_f32 and the other by the oracle's libm expf.  On the small fixtures that happens to no element; at full size (c2: 100 k
+# splats over 2 M pixels, ds: 5 M splats) a handful of ELEMENTS carry such a pair with a weight that shows: measured 6.6e-4 of the
+# tensor maximum on one element of c2, 6.4e-4 on ds, none at C4 (1.5e-6).  Tests at those sizes name the allowance explicitly
+# (`flips=`): at most max(GRAD_FLIP_MIN, GRAD_FLIP_FRACTION * elements) elements may exceed the bar, none by more than GRAD_FLIP_MAX.
+GRAD_FLIP_FRACTION = 2e-6
+GRAD_FLIP_MIN = 3
+GRAD_FLIP_MAX = 2e-3      # (the old max-norm bar)
 
 
 def look_at_view(eye, target, up=(0.0, 1.0, 0.0)):
@@ -136,7 +151,18 @@ def assert_color_close(a, b, what=""):
     assert frac <= FLIP_FRACTION and d.max() <= FLIP_MAX, f"{what}: {frac:.2e} of values differ by > {COLOR_TOL}, max {d.max():.3e}"
 
 
-def assert_grad_close(a, b, what="", tol=GRAD_REL_TOL):
+def _report(kind, what, value, tol):
+    """DAS3R_TOL_REPORT=<file>: every measured error beside its bar (how far under the bar the kernels are: tools/tol_report.py)."""
+    path = os.environ.get("DAS3R_TOL_REPORT")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps({"kind": kind, "what": what, "value": float(value), "tol": float(tol),
+                                "test": os.environ.get("PYTEST_CURRENT_TEST", "")}) + "\n")
+
+
+def assert_grad_close(a, b, what="", tol=None, flips=False):
+    """Max-norm gradient check.  flips=True (full-size scenes only): a few elements may sit on a threshold flip — see GRAD_FLIP_*."""
+    tol = GRAD_REL_TOL if tol is None else tol
     a, b = np.asarray(a, np.float64).reshape(-1), np.asarray(b, np.float64).reshape(-1)
     assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
     assert np.isfinite(a).all(), f"{what}: non-finite gradient"
@@ -144,17 +170,40 @@ def assert_grad_close(a, b, what="", tol=GRAD_REL_TOL):
     if scale == 0:
         assert np.abs(a).max() == 0, f"{what}: expected all-zero gradient"
         return
-    rel = np.abs(a - b).max() / scale
+    d = np.abs(a - b) / scale
+    rel = d.max()
+    over = int((d > tol).sum())
+    _report("max_norm", what, rel, tol)
+    _report("over_bar", what, over, a.size)
+    if flips:
+        allowed = max(GRAD_FLIP_MIN, int(GRAD_FLIP_FRACTION * a.size))
+        assert over <= allowed and rel <= GRAD_FLIP_MAX, (f"{what}: {over} elements (allowed: {allowed} threshold flips) beyond {tol} of max|ref|, "
+                                                           f"the largest at {rel:.3e} (flip bound {GRAD_FLIP_MAX})")
+        return
     assert rel <= tol, f"{what}: max |delta| / max|ref| = {rel:.3e} > {tol}"
 
 
-GRAD_ELEM_RTOL = 1e-3     # element-wise: |delta| <= 1e-3 |ref| + floor * max|ref| ...
-GRAD_ELEM_FLOOR = 2e-5    # ... the floor covers fp32 summation-order noise on elements that are sums of cancelling terms
-GRAD_ELEM_OUTLIERS = 1e-3  # ... for all but this fraction of the elements (threshold flips: a pair with alpha within 1 ulp of 1/255)
+def tolerances_for(kind):
+    """Named bars per backward kernel selection (DAS3R_RENDER_BWD value or None): the shipped kernels get the tight ones, the superseded
+    split-bf16 / stream kernels (selectable for A-B runs, experiments builds) their own."""
+    split = kind is not None and (kind.startswith("scan") or kind.startswith("mfma") or kind.startswith("stream"))
+    if split:
+        return dict(tol=GRAD_REL_TOL_SPLIT, rtol=GRAD_ELEM_RTOL_SPLIT, floor=GRAD_ELEM_FLOOR_SPLIT, outliers=GRAD_ELEM_OUTLIERS_SPLIT)
+    return dict(tol=GRAD_REL_TOL, rtol=GRAD_ELEM_RTOL, floor=GRAD_ELEM_FLOOR, outliers=GRAD_ELEM_OUTLIERS)
 
 
-def assert_grad_elementwise(a, b, what="", rtol=GRAD_ELEM_RTOL, floor=GRAD_ELEM_FLOOR, outliers=GRAD_ELEM_OUTLIERS):
+GRAD_ELEM_RTOL = 1e-4     # element-wise: |delta| <= 1e-4 |ref| + floor * max|ref| ...
+GRAD_ELEM_FLOOR = 2e-6    # ... the floor covers fp32 summation-order noise on elements that are sums of cancelling terms
+GRAD_ELEM_OUTLIERS = 1e-4  # ... for all but this fraction of the elements (threshold flips: a pair with alpha within 1 ulp of 1/255);
+                           # measured with these bars: <= 3.1e-5 of the elements at full size, 0 at C4
+GRAD_ELEM_RTOL_SPLIT, GRAD_ELEM_FLOOR_SPLIT, GRAD_ELEM_OUTLIERS_SPLIT = 1e-3, 2e-5, 1e-3   # (round 1 - 5's bars, for the split-bf16 kernels)
+
+
+def assert_grad_elementwise(a, b, what="", rtol=None, floor=None, outliers=None):
     """Element-wise gradient check (the max-norm check leaves splats with small gradients unchecked)."""
+    rtol = GRAD_ELEM_RTOL if rtol is None else rtol
+    floor = GRAD_ELEM_FLOOR if floor is None else floor
+    outliers = GRAD_ELEM_OUTLIERS if outliers is None else outliers
     a, b = np.asarray(a, np.float64).reshape(-1), np.asarray(b, np.float64).reshape(-1)
     assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
     scale = np.abs(b).max()
@@ -163,6 +212,9 @@ def assert_grad_elementwise(a, b, what="", rtol=GRAD_ELEM_RTOL, floor=GRAD_ELEM_
         return
     bad = np.abs(a - b) > rtol * np.abs(b) + floor * scale
     frac = float(bad.mean())
+    if os.environ.get("DAS3R_TOL_REPORT"):   # the fraction that would fail bars ten and a hundred times tighter
+        for div in (1.0, 10.0, 100.0):
+            _report(f"elementwise/{div:g}", what, float((np.abs(a - b) > (rtol * np.abs(b) + floor * scale) / div).mean()), outliers)
     assert frac <= outliers, f"{what}: {frac:.2e} of the elements differ by more than {rtol} |ref| + {floor} max|ref|"
     # an element that the reference has exactly zero (culled / untouched) must be exactly zero
     zero = b == 0

@@ -23,6 +23,9 @@ SHAPES = {"sintel": dict(frames=22, W=512, H=208, focal=600.0, n_splats=20000),
 
 def _proc_worker(k, K, name, iterations, barrier, q):
     """--mode process: one job per PROCESS (its own HIP context and interpreter: no GIL shared), all on GPU 0."""
+    import os
+    if K > 1:   # several PROCESSES on one GPU: the library cannot see its neighbours (it counts rendering threads per process), so the
+        os.environ["DAS3R_TICKETS"] = "always"   # ticket-free short cut of the chained kernels is switched off by hand (api.hip grid_is_resident)
     import torch
     from das3r_amd.farm import run_sequence_job
     from das3r_amd.train import consistent_sequence
