@@ -444,6 +444,9 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         // kernel of this thread had started counting, the last arriver never saw its total, and the forward ended with "the device never
         // delivered the result of this forward to the host mailbox" (one first-forward in a few dozen two-job runs)
         HIP_TRY(hipMemsetAsync(arrive_ring, 0, ARRIVE_SLOTS * ARRIVE_WORDS * sizeof(unsigned long long), s));
+        // ... and COMPLETE before this call goes on: the ring belongs to the thread, not to the stream — the same thread's next forward may
+        // be issued on another non-blocking stream, which does not wait for this one.  Once per thread and device.
+        HIP_TRY(hipStreamSynchronize(s));
     }
     // Depth order: scenes with short tile lists (the 100 k-splat 1080p benchmark averages 32 entries per tile) skip the global
     // depth sort — five of the eleven binning launches, each latency-bound at that size; the instances are emitted in index

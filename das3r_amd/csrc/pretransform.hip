@@ -187,6 +187,9 @@ __global__ void __launch_bounds__(256) pretransform_backward_kernel(
     //  parameters and moments, and 2048 workgroups doing that took the kernel from 0.15 to 0.60 ms.  The 28 words are agent-scope atomic
     //  stores — written through to where the other XCDs see them — and are complete when the store counter says so; the barrier then
     //  orders them in front of thread 0's arrival, itself a relaxed agent-scope atomic)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "the pose-sum hand-off counts its stores in vmcnt (gfx9: one counter for loads and stores); gfx10+ counts stores in vscnt — use a release-ordered arrival atomic there"
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     uint32_t *const arrived = reinterpret_cast<uint32_t *>(det_partials + (size_t)POSE_MAX_BLOCKS * 28);   // (a fixed place: the grid differs from launch to launch)
@@ -284,8 +287,16 @@ static float *pose_sum_scratch(hipStream_t s) {
         if (e.dev == dev && e.stream == s) return e.buf;
     float *buf = nullptr;
     const size_t bytes = ((size_t)POSE_MAX_BLOCKS * 28 + 4) * sizeof(float);
-    if (hipMalloc((void **)&buf, bytes) != hipSuccess) return nullptr;
-    if (hipMemsetAsync(buf, 0, bytes, s) != hipSuccess) { (void)hipFree(buf); return nullptr; }
+    // (a failure here sends the launch down the float-atomic path — correct sums, not bit-reproducible ones: said once, not silently)
+    auto complain = [] {
+        static bool said = false;
+        if (!__atomic_exchange_n(&said, true, __ATOMIC_RELAXED))
+            fprintf(stderr, "[das3r] no scratch for the fixed-order pose sums: this thread's pose gradients are summed with float atomics (not bit-reproducible)\n");
+    };
+    if (hipMalloc((void **)&buf, bytes) != hipSuccess) { complain(); return nullptr; }
+    // the one-time fill is COMPLETE before anybody counts in it: the slot is keyed by stream, but a caller may hand the same scratch's
+    // stream over to another thread's work order later; one synchronise per (thread, device, stream) lifetime costs nothing
+    if (hipMemsetAsync(buf, 0, bytes, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { (void)hipFree(buf); complain(); return nullptr; }
     slots.push_back({dev, s, buf});
     return buf;
 }

@@ -25,7 +25,7 @@ GRAD_REL_TOL_SPLIT = 1e-4  # the superseded split-bf16 kernels (scan, mfma: 16 m
 # splats over 2 M pixels, ds: 5 M splats) a handful of ELEMENTS carry such a pair with a weight that shows: measured 6.6e-4 of the
 # tensor maximum on one element of c2, 6.4e-4 on ds, none at C4 (1.5e-6).  Tests at those sizes name the allowance explicitly
 # (`flips=`): at most max(GRAD_FLIP_MIN, GRAD_FLIP_FRACTION * elements) elements may exceed the bar, none by more than GRAD_FLIP_MAX.
-GRAD_FLIP_FRACTION = 2e-6
+GRAD_FLIP_FRACTION = 5e-6   # (measured: 9 of the 4.8 M elements of c2's dL/dshs — one splat's row —, 3 of ds's 20 M)
 GRAD_FLIP_MIN = 3
 GRAD_FLIP_MAX = 2e-3      # (the old max-norm bar)
 
