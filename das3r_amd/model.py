@@ -179,6 +179,64 @@ class SplatModel:
         if hasattr(self.optimizer, "set_active_sh_degree"):
             self.optimizer.set_active_sh_degree(self.active_sh_degree)
 
+    # ---- checkpoints (scene/gaussian_model.py:66-101 capture / restore; written by train_gui.py:626-628 as (capture(), iteration))
+    def capture(self):
+        """The reference's fourteen fields in the reference's order — (capture(), iteration) is what its restore() unpacks — so the
+        file loads on either side.  max_radii2D / xyz_gradient_accum / denom are the densification statistics, which DAS3R never
+        updates (the block is commented out: SURVEY.md C1): empty tensors, as the reference's own are before training_setup."""
+        e = torch.empty(0, device=self._xyz.device)
+        return (self.active_sh_degree, self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation, self._opacity,
+                e, e, e, self.optimizer.state_dict(), self.spatial_lr_scale, self.Q, self.T)
+
+    def capture_extras(self):
+        """What the reference's capture() leaves out and a resumed job needs to continue EXACTLY (its checkpoints omit
+        _conf_static, the camera optimizer and the held-out poses — a resumed reference run restarts those from their initial values)."""
+        return dict(conf_static=self._conf_static, aggregated_mask=self.aggregated_mask, optimizer_cam=self.optimizer_cam.state_dict(),
+                    test_Q=self.test_Q, test_T=self.test_T, FoVx=self.FoVx, FoVy=self.FoVy, max_sh_degree=self.max_sh_degree)
+
+    def restore(self, model_args, opt, extras=None, fused=False, device=None):
+        """Counterpart of GaussianModel.restore(model_args, training_args).  Also accepts a capture written by the reference (its
+        optimizer state is torch.optim.Adam's, which FusedAdam reads).  extras: capture_extras() of the same moment, when there is one."""
+        (self.active_sh_degree, xyz, f_dc, f_rest, scaling, rotation, opacity, _mr, _acc, _den, opt_dict, self.spatial_lr_scale, Q, T) = model_args
+        dev = torch.device(device) if device is not None else xyz.device
+        par = lambda t: nn.Parameter(t.detach().to(dev, torch.float32).clone().contiguous())
+        self._xyz, self._features_dc, self._features_rest = par(xyz), par(f_dc), par(f_rest)
+        self._scaling, self._rotation, self._opacity = par(scaling), par(rotation), par(opacity)
+        self.Q, self.T = par(Q), par(T)
+        if extras is not None:
+            self._conf_static = par(extras["conf_static"])
+            self.aggregated_mask = extras["aggregated_mask"].to(dev)
+            self.max_sh_degree = extras.get("max_sh_degree", self.max_sh_degree)
+            if extras.get("test_Q") is not None:
+                self.enable_test = True
+                self.test_Q = extras["test_Q"].detach().to(dev).clone().requires_grad_(True)
+                self.test_T = extras["test_T"].detach().to(dev).clone().requires_grad_(True)
+            if extras.get("FoVx") is not None:
+                self.FoVx = extras["FoVx"].detach().to(dev).clone().requires_grad_(True)
+                self.FoVy = extras["FoVy"].detach().to(dev).clone().requires_grad_(True)
+        elif not hasattr(self, "_conf_static"):
+            raise ValueError("SplatModel.restore: a reference checkpoint does not hold _conf_static / aggregated_mask (SURVEY.md C10): "
+                             "build the model from its sequence first (create_from_frames), then restore into it")
+        self.training_setup(opt, fused=fused)
+        from .fused import remap_state_dict
+
+        def load(optimizer, sd):   # (torch.optim.Adam insists on the same groups: a checkpoint of the other optimizer kind is re-keyed by group name)
+            same = [len(g["params"]) for g in sd["param_groups"]] == [len(g["params"]) for g in optimizer.param_groups]
+            sd = sd if same else remap_state_dict(sd, optimizer)
+            if isinstance(optimizer, torch.optim.Optimizer):   # hyper-parameters torch needs in every group (a FusedAdam checkpoint holds lr / betas / eps)
+                for g, tg in zip(sd["param_groups"], optimizer.param_groups):
+                    for k, v in tg.items():
+                        if k != "params":
+                            g.setdefault(k, v)
+            optimizer.load_state_dict(sd)
+
+        load(self.optimizer, opt_dict)
+        if extras is not None and extras.get("optimizer_cam") is not None:
+            load(self.optimizer_cam, extras["optimizer_cam"])
+        if hasattr(self.optimizer, "set_active_sh_degree"):
+            self.optimizer.set_active_sh_degree(self.active_sh_degree)
+        return self
+
     def update_learning_rate(self, iteration):
         for g in self.optimizer_cam.param_groups:
             if g["name"] in ("pose_Q", "pose_T", "test_pose_Q", "test_pose_T"):   # (the test names never occur in this optimizer:

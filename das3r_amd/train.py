@@ -73,19 +73,66 @@ def train_step(model: SplatModel, cam, opt: OptimParams, iteration, pipe, backgr
     return loss.detach(), psnr_frame.detach(), pkg
 
 
+def save_checkpoint(path, model, iteration, loop_state=None):
+    """<model_path>/chkpnt<iteration>.pth = (model.capture(), iteration): the file train_gui.py:626-628 writes and the reference's
+    restore() reads; beside it chkpnt<iteration>.das3r.pth = what the reference leaves out (SplatModel.capture_extras) and the state
+    of the loop (the camera stack, the generator that draws from it, the running loss), so that a resumed job continues EXACTLY where
+    the killed one was.  Both written to a temporary name first: a job killed while saving leaves the previous checkpoint intact."""
+    import os
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    extras = dict(model=model.capture_extras(), loop=loop_state, iteration=iteration)
+    for target, payload in ((path[:-4] + ".das3r.pth", extras), (path, (model.capture(), iteration))):   # (the main file last: it names a complete pair)
+        torch.save(payload, target + ".tmp")
+        os.replace(target + ".tmp", target)
+
+
+def latest_checkpoint(model_dir):
+    """-> (path, iteration) of the newest complete chkpnt<iteration>.pth pair under model_dir, or (None, 0)."""
+    import os
+    import re
+    best = (None, 0)
+    for f in (os.listdir(model_dir) if model_dir and os.path.isdir(model_dir) else []):
+        m = re.fullmatch(r"chkpnt(\d+)\.pth", f)
+        if m and int(m.group(1)) > best[1] and os.path.exists(os.path.join(model_dir, f[:-4] + ".das3r.pth")):
+            best = (os.path.join(model_dir, f), int(m.group(1)))
+    return best
+
+
+def load_checkpoint(path, model, opt, fused=False, device=None):
+    """Restore `model` from save_checkpoint's pair (or from a reference checkpoint alone, into a model built from its sequence).
+    -> (iteration, loop_state or None)"""
+    import os
+    capture, iteration = torch.load(path, map_location=device, weights_only=False)
+    extras_path = path[:-4] + ".das3r.pth"
+    extras = torch.load(extras_path, map_location=device, weights_only=False) if os.path.exists(extras_path) else None
+    if extras is not None and extras.get("iteration") != iteration:
+        extras = None   # (a pair torn by a kill between the two renames: the extras belong to an older checkpoint of the same name — cannot happen with distinct iterations, kept as a guard)
+    model.restore(capture, opt, extras=extras["model"] if extras else None, fused=fused, device=device)
+    return int(iteration), (extras["loop"] if extras else None)
+
+
 def train(model, cameras, opt: OptimParams, iterations, pipe=None, background=None, seed=0, log_every=0, fused=False,
-          test_cameras=None, gt_dynamic_masks=None, on_progress=None):
+          test_cameras=None, gt_dynamic_masks=None, on_progress=None, start_iteration=1, loop_state=None, checkpoint_every=0,
+          checkpoint_dir=None):
     """Random camera without replacement per epoch (train_gui.py:546-555).  With test_cameras: train_test_psnr.py's loop, which
-    walks the held-out views whenever the training stack has run empty (test_pose_pass).  Returns dict(loss, psnr, iters_per_s)."""
+    walks the held-out views whenever the training stack has run empty (test_pose_pass).  Returns dict(loss, psnr, iters_per_s).
+    checkpoint_every / checkpoint_dir: write chkpnt<iteration>.pth every so many iterations (train_gui.py:626-628 --checkpoint_iterations);
+    start_iteration / loop_state: continue a job from load_checkpoint's result — the iterations that follow are the ones the
+    uninterrupted job would have run (same cameras in the same order, same schedules, same optimizer moments)."""
     pipe = pipe or SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
     dev = model.get_xyz.device
     background = background if background is not None else torch.zeros(3, device=dev)
     rng = random.Random(seed)
     stack, ema, last_psnr = [], torch.zeros((), device=dev), torch.zeros((), device=dev)
+    if loop_state is not None:
+        rng.setstate(loop_state["rng"])
+        by_uid = {c.uid: c for c in cameras}
+        stack = [by_uid[u] for u in loop_state["stack"]]
+        ema, last_psnr = loop_state["ema"].to(dev), loop_state["last_psnr"].to(dev)
     if dev.type == "cuda":
         torch.cuda.current_stream(dev).synchronize()   # (this job's stream only: other jobs may share the GPU — farm.run_jobs)
     t0 = time.perf_counter()
-    for it in range(1, iterations + 1):
+    for it in range(start_iteration, iterations + 1):
         if not stack:
             stack = list(cameras)
         cam = stack.pop(rng.randint(0, len(stack) - 1))
@@ -98,9 +145,14 @@ def train(model, cameras, opt: OptimParams, iterations, pipe=None, background=No
             on_progress()
         if log_every and it % log_every == 0:
             print(f"[ITER {it}] loss {float(ema):.5f} psnr_frame {float(last_psnr):.2f}")
+        if checkpoint_every and checkpoint_dir and it % checkpoint_every == 0 and it < iterations:
+            import os
+            save_checkpoint(os.path.join(checkpoint_dir, f"chkpnt{it}.pth"), model, it,
+                            dict(rng=rng.getstate(), stack=[c.uid for c in stack], ema=ema.detach().clone(), last_psnr=last_psnr.detach().clone()))
     if dev.type == "cuda":
         torch.cuda.current_stream(dev).synchronize()
-    return dict(loss=float(ema), psnr=float(last_psnr), iters_per_s=iterations / (time.perf_counter() - t0))
+    done = max(iterations - start_iteration + 1, 1)
+    return dict(loss=float(ema), psnr=float(last_psnr), iters_per_s=done / (time.perf_counter() - t0))
 
 
 def is_test_index(idx):
