@@ -457,7 +457,7 @@ def cpu_baseline_of(sc_cpu, name, budget_s=30.0):
             "fwd_only": {"value": round(sc_cpu.P / medf / 1e6, 4), "unit": "Msplats/s", "ms_per_step": round(medf * 1e3, 2)}}
 
 
-def train_step_timer(dev, fused, frames=20, W=512, H=208, depth="noise"):
+def train_step_timer(dev, fused, frames=20, W=512, H=208, depth="noise", fused_loss=None):
     """-> (step callable, splats): the DAS3R-shaped optimisation step (render + masked L1/SSIM loss + backward + both Adam steps,
     train_gui.py:542-589) on a synthetic sequence with one Gaussian per pixel of every frame."""
     import torch
@@ -474,8 +474,28 @@ def train_step_timer(dev, fused, frames=20, W=512, H=208, depth="noise"):
 
     def step():
         it[0] += 1
-        train_step(model, cams[it[0] % len(cams)], opt, it[0], pipe, bg, fused=fused)
+        train_step(model, cams[it[0] % len(cams)], opt, it[0], pipe, bg, fused=fused, fused_loss=fused_loss)
     return step, int(model.get_xyz.shape[0])
+
+
+def eval_forward_figure(dev):
+    """Eval-mode (torch.no_grad) forward of a trained model — what /root/reference/render.py:72-86 and every held-out report run: the
+    Sintel-shaped model of a consistent sequence, rendered from its 20 training poses with render_test (das3r_amd/offline.py).  The
+    no-grad path examines the binning self-check inside every call (there is no backward to do it): that wait is in the figure."""
+    from das3r_amd import offline
+    from das3r_amd.train import build_from_sequence, consistent_sequence
+    seq = consistent_sequence(seed=0, device=str(dev), **JOB_SHAPES["sintel"])
+    model, cams = build_from_sequence(seq)
+    loaded = offline.SplatModel(3)   # the state load_ply leaves: per-Gaussian conf_static column, active degree = maximum
+    for n in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+        setattr(loaded, n, getattr(model, n).detach())
+    loaded._conf_static = model._conf_static.detach().reshape(-1, 1)[model.aggregated_mask]
+    loaded.active_sh_degree = 3
+    views = offline.sequence_cameras(seq, dev)[:20]
+    out = offline.forward_throughput(loaded, views, repeats=5)
+    return {"ms_per_view": round(out["ms_per_view"], 4), "views_per_s": round(out["views_per_s"], 1), "Msplats_per_s": round(out["splats"] * out["views_per_s"] / 1e6, 1),
+            "splats": out["splats"], "image": [512, 208], "sh_degree": 3,
+            "what": "torch.no_grad render_test of a loaded model (render.py:72-86), 5 passes over 20 views; includes the per-call wait for the binning self-check"}
 
 
 def extras_main(main_workload):
@@ -490,6 +510,16 @@ def extras_main(main_workload):
     us_step, _ = train_step_timer(dev, fused=False)
     out["train_step_unfused_ms"] = round(rk.timed(us_step, 30, 5) / 30 * 1e3, 4)
     del us_step
+    # what an UNMODIFIED DAS3R checkout gets with `import das3r_amd.integrate; das3r_amd.integrate.patch()`: fused
+    # pre-transform + FusedAdam behind the reference's own loop, its loss in torch ops, its camera gate a host-side `if`
+    pa_step, _ = train_step_timer(dev, fused=True, fused_loss=False)
+    out["train_step_patched_ms"] = round(rk.timed(pa_step, 50, 5) / 50 * 1e3, 4)
+    del pa_step
+    try:
+        out["eval_forward"] = eval_forward_figure(dev)
+    except Exception as ex:  # noqa: BLE001
+        out["eval_forward"] = {"error": repr(ex)}
+    torch.cuda.empty_cache()
     fs_step, fs_splats = train_step_timer(dev, fused=True)
     for _ in range(INIT_STEPS):
         fs_step()
@@ -539,7 +569,11 @@ def extras_main(main_workload):
     mode = os.environ.get("DAS3R_BENCH_JOBS", "1")
     if mode != "0":
         try:
-            out["jobs_in_flight"] = jobs_in_flight(dev) if mode == "full" else jobs_in_flight(dev, shapes=("sintel",), ks=(1, 2))
+            if mode == "full":
+                out["jobs_in_flight"] = jobs_in_flight(dev)
+            else:   # (+ one DAVIS-shaped job, K = 1: its held-out PSNR belongs in the default line — VERDICT r5 item 7; + 20 s)
+                out["jobs_in_flight"] = jobs_in_flight(dev, shapes=("sintel",), ks=(1, 2))
+                out["jobs_in_flight"].update(jobs_in_flight(dev, shapes=("davis",), ks=(1,), warm=False))
         except Exception as ex:  # noqa: BLE001
             out["jobs_in_flight"] = {"error": repr(ex)}
     print("EXTRAS " + json.dumps(out), flush=True)
@@ -549,12 +583,13 @@ JOB_SHAPES = {"sintel": dict(frames=22, W=512, H=208, focal=600.0, n_splats=2000
               "davis": dict(frames=50, W=512, H=288, focal=614.4, n_splats=60000)}      # 45 training frames: 6.64 M Gaussians
 
 
-def jobs_in_flight(dev, shapes=("sintel", "davis"), ks=(1, 2, 3), iterations=ITERS_PER_SCENE):
+def jobs_in_flight(dev, shapes=("sintel", "davis"), ks=(1, 2, 3), iterations=ITERS_PER_SCENE, warm=True):
     """{shape: {K: {wall_s, scenes_per_hour, heldout_psnr, peak_hbm_gb}}} (tools/jobs_per_gpu.py is the same measurement as a tool)."""
     import torch
     from das3r_amd.farm import run_jobs, run_sequence_job
     from das3r_amd.train import consistent_sequence
-    run_sequence_job(0, 60, dev, fused=True, seq=consistent_sequence(frames=12, W=128, H=80, focal=150.0, n_splats=3000, seed=99, device=str(dev)))
+    if warm:
+        run_sequence_job(0, 60, dev, fused=True, seq=consistent_sequence(frames=12, W=128, H=80, focal=150.0, n_splats=3000, seed=99, device=str(dev)))
     res = {}
     for name in shapes:
         seqs = [consistent_sequence(seed=s, device=str(dev), **JOB_SHAPES[name]) for s in range(max(ks))]
@@ -573,6 +608,33 @@ def jobs_in_flight(dev, shapes=("sintel", "davis"), ks=(1, 2, 3), iterations=ITE
         res[name] = rows
         del seqs
     return res
+
+
+def ranked_jobs_in_flight(rk, K, job, what):
+    """N > 1: every rank runs K whole jobs at once (farm.run_jobs: K host threads, each on its own stream and core),
+    all ranks starting behind one barrier; the rate is N x K jobs over the SLOWEST rank's wall time (max over ranks, like `value`).
+    job(s) runs sequence s of this rank.  -> dict on every rank (the gathers are collectives)."""
+    from das3r_amd.farm import run_jobs
+    rk.barrier()
+    t0 = time.perf_counter()
+    failed = None
+    try:
+        recs = run_jobs(range(K), job, K, rk.dev if rk.dev.type == "cuda" else None)
+    except Exception as ex:  # noqa: BLE001 - one rank's failure is reported, not hung on
+        recs, failed = [], repr(ex)
+    rk.sync()
+    local = time.perf_counter() - t0
+    walls = rk.gather_all(local)
+    oks = rk.gather_all(float(sum(1 for r in recs if (r.get("ok", 1) if isinstance(r, dict) else 1))))
+    wall = max(walls)
+    out = {"what": what, "jobs_per_gpu": K, "wall_s": round(wall, 3), "per_rank_wall_s": [round(w, 3) for w in walls], "jobs_ok": int(sum(oks)),
+           "scenes_per_hour": round(sum(oks) * 3600.0 / wall, 1), "per_rank_scenes_per_hour": [round(o * 3600.0 / w, 1) for o, w in zip(oks, walls)]}
+    psnr = [round(r["psnr"], 2) for r in recs if isinstance(r, dict) and r.get("ok") and "psnr" in r]
+    if psnr:
+        out["heldout_psnr_rank0"] = psnr
+    if failed:
+        out["error_this_rank"] = failed
+    return out
 
 
 def run_extras_child(main_workload):
@@ -615,12 +677,15 @@ def main():
         elapsed = rk.timed(step, args.steps, args.warmup)
         ranks_ok = [int(round(v)) for v in rk.gather_all(0.0 if rk.failed else 1.0)]
         per_rank_ms = rk.gather_all(rk.last_local_s / args.steps * 1e3)
+        jobs = None
+        if rk.world > 1:   # the K-jobs-in-flight leg of an N > 1 run, with stand-in jobs (rank r's take 0.05 (r + 1) s)
+            jobs = ranked_jobs_in_flight(rk, 2, lambda s_: (time.sleep(0.05 * (rk.rank + 1)), {"ok": 1})[1], "stub jobs")
         if rk.rank == 0:
             out = {"metric": "stub steps/s (launch-logic dry run, no GPU work)", "value": round(sum(ranks_ok) * args.steps / elapsed, 3),
                    "unit": "steps/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
                    "ms_per_step": round(elapsed / args.steps * 1e3, 6), "higher_is_better": True, "scaling": "weak",
                    "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": "stub"},
-                   "ranks_ok": ranks_ok, "per_rank_ms": per_rank_ms}
+                   "ranks_ok": ranks_ok, "per_rank_ms": per_rank_ms, "jobs_in_flight": jobs}
             print(json.dumps(out), flush=True)
         rk.close()
         return
@@ -665,6 +730,8 @@ def main():
                 train["fused_smooth_depth"] = extras.pop("train_step_fused_smooth_depth_ms")
             if "train_step_unfused_ms" in extras:
                 train["unfused"] = extras.pop("train_step_unfused_ms")
+            if "train_step_patched_ms" in extras:
+                train["patched"] = extras.pop("train_step_patched_ms")   # das3r_amd.integrate.patch() on an unmodified train_gui.py
     if train is None:
         ts_step, ts_splats = train_step_timer(rk.dev, fused=True)
         ts_iters = max(20, min(100, args.steps))
@@ -675,6 +742,20 @@ def main():
     scenes_per_hour = rk.world * 3600e3 / (ITERS_PER_SCENE * train["fused"])
     sph_def = f"N x 3600 s / ({ITERS_PER_SCENE} it x train_step_ms.fused): derived from one step (no whole jobs were run)"
     jobs = extras.pop("jobs_in_flight", None) if extras else None
+    if rk.world > 1 and os.environ.get("DAS3R_BENCH_JOBS", "1") != "0":
+        # N > 1: whole Sintel-shaped jobs, two in flight per rank (the farm's default with --fused), every rank at once
+        from das3r_amd.farm import run_sequence_job
+        from das3r_amd.train import consistent_sequence
+        run_sequence_job(0, 60, rk.dev, fused=True, seq=consistent_sequence(frames=12, W=128, H=80, focal=150.0, n_splats=3000, seed=99, device=str(rk.dev)))
+        seqs = [consistent_sequence(seed=1000 * rk.rank + s_, device=str(rk.dev), **JOB_SHAPES["sintel"]) for s_ in range(2)]
+        ranked = ranked_jobs_in_flight(rk, 2, lambda s_: run_sequence_job(s_, ITERS_PER_SCENE, rk.dev, fused=True, seq=seqs[s_]),
+                                       "whole Sintel-shaped jobs (22 x 512x208, 4000 fused iterations, held-out report), 2 in flight per GPU, all ranks at once")
+        del seqs
+        if ranked["jobs_ok"] == 2 * rk.world:
+            scenes_per_hour = ranked["scenes_per_hour"]
+            sph_def = (f"measured: {2 * rk.world} whole Sintel-shaped jobs, 2 in flight per GPU on {rk.world} GPUs at once, over the slowest rank's wall time "
+                       f"(derived from one step alone: {rk.world * 3600e3 / (ITERS_PER_SCENE * train['fused']):.1f})")
+        jobs = {"ranked": ranked}
     if jobs and "sintel" in jobs:
         jobs["sintel"] = {k: v for k, v in jobs["sintel"].items() if v.get("ok")} or None   # (a job that failed finished early: not a rate)
     if jobs and jobs.get("sintel") and "1" in jobs["sintel"]:
@@ -699,6 +780,7 @@ def main():
                "value": round(msplats, 3), "unit": "Msplats/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
+               "eval_forward": (extras.pop("eval_forward", None) if extras else None),
                "fwd_only": (None if fwd_elapsed is None else
                             {"value": round(rk.world * P_report / (fwd_elapsed / args.steps) / 1e6, 3), "unit": "Msplats/s",
                              "ms_per_step": round(fwd_elapsed / args.steps * 1e3, 4), "what": "forward render alone (training-mode call, no backward), same K / barrier protocol"}),

@@ -308,7 +308,7 @@ def run_sequence_job(scene_id, iterations, device, frames=6, seq_dir=None, out_d
         return dict(scene_id=scene_id, psnr=float("nan"), l1=float("nan"), iters_per_s=0.0, n_splats=0, ok=0)
 
 
-def run_jobs(items, job, jobs_per_gpu=1, device=None):
+def run_jobs(items, job, jobs_per_gpu=1, device=None, pin=None):
     """[job(item) for item in items] with `jobs_per_gpu` of them in flight on this rank's GPU.
 
     One optimisation job leaves the GPU half idle whichever way one looks at it: its compositing kernels are bound by VALU issue at
@@ -318,7 +318,8 @@ def run_jobs(items, job, jobs_per_gpu=1, device=None):
     state (api.hip: thread_local per-device state, host mailbox, allocator callbacks) pull sequences from the rank's list, and the
     hardware interleaves one job's compositing with another's streaming kernels.  ctypes and torch release the GIL inside their calls;
     what the threads share of the interpreter is the glue between calls.  Results come back in the order of `items`; an exception of a
-    job is raised here (run_sequence_job itself never raises: failures are per-sequence records)."""
+    job is raised here (run_sequence_job itself never raises: failures are per-sequence records).
+    pin (default: on a GPU): every worker thread on a core of its own inside the rank's core complex (hostpin.pin_worker_thread)."""
     items = list(items)
     K = max(1, min(int(jobs_per_gpu), len(items)))
     if K == 1:
@@ -329,9 +330,16 @@ def run_jobs(items, job, jobs_per_gpu=1, device=None):
         todo.put((k, it))
     out, errors = [None] * len(items), []
     use_gpu = device is not None and torch.device(device).type == "cuda"
+    pin = use_gpu if pin is None else pin
+    base_mask = sorted(os.sched_getaffinity(0)) if (pin and hasattr(os, "sched_getaffinity")) else None   # (threads inherit the creator's mask: taken before any worker narrows its own)
 
-    def worker():
+    def worker(index):
         try:
+            if base_mask is not None:
+                from .hostpin import worker_cpus
+                mine = worker_cpus(index, K, base_mask) if os.environ.get("DAS3R_PIN", "1") != "0" else None
+                if mine:
+                    os.sched_setaffinity(0, mine)   # (the calling thread only)
             if use_gpu:
                 torch.cuda.set_device(device)
                 stream = torch.cuda.Stream(device=device)
@@ -364,7 +372,7 @@ def run_jobs(items, job, jobs_per_gpu=1, device=None):
         os.environ["DAS3R_TICKETS"] = "always"
         _lib.reload_switches()
         restore = _lib
-    threads = [threading.Thread(target=worker, name=f"das3r-job-{i}") for i in range(K)]
+    threads = [threading.Thread(target=worker, args=(i,), name=f"das3r-job-{i}") for i in range(K)]
     try:
         for t in threads:
             t.start()

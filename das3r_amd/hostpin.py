@@ -112,6 +112,32 @@ def pin_to_ccx(local_rank, sysfs_root="/"):
     return allowed, mine
 
 
+def worker_cpus(index, count, allowed):
+    """The CPUs worker thread `index` of `count` (farm.run_jobs: K jobs in flight on one rank) runs on: ONE core of the rank's
+    complex each, distinct — worker i takes allowed[i].  The rank's other threads (the HIP runtime's helpers, which inherit the whole
+    complex) keep the remaining cores.  Two interpreter threads left to the scheduler inside one eight-core mask end up time-slicing
+    one core whenever a runtime helper is busy on theirs; each on a core of its own, a job's launch loop is never descheduled for its
+    neighbour's.  Needs at least two cores per worker (else -> None: no pin)."""
+    allowed = sorted(allowed)
+    if count < 1 or index < 0 or index >= count or len(allowed) < 2 * count:
+        return None
+    return [allowed[index]]
+
+
+def pin_worker_thread(index, count):
+    """Pin the CALLING thread (sched_setaffinity(0, ...) acts on the calling thread on Linux) to worker_cpus() of the process's mask
+    at the time of the call — i.e. inside the complex pin_to_ccx chose for the rank.  DAS3R_PIN=0 switches it off.  -> the CPUs or None."""
+    if os.environ.get("DAS3R_PIN", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        mine = worker_cpus(index, count, os.sched_getaffinity(0))
+        if mine:
+            os.sched_setaffinity(0, mine)
+        return mine
+    except OSError:
+        return None
+
+
 def unpin(pinned):
     """Give the process its previous CPU mask back (e.g. before a multi-threaded CPU baseline)."""
     if pinned:

@@ -26,12 +26,15 @@ def make_camera(uid, image, focal, W, H, device, focal_y=None, camera_center=Non
                            projection_matrix=projection_matrix(0.01, 100.0, fovx, fovy).transpose(0, 1).to(device))
 
 
-def train_step(model: SplatModel, cam, opt: OptimParams, iteration, pipe, background, fused=False):
+def train_step(model: SplatModel, cam, opt: OptimParams, iteration, pipe, background, fused=False, fused_loss=None):
     """One iteration of the reference hot loop (train_gui.py:532-589).  Returns (loss, psnr_frame, render package).
     fused: the opt-in fused kernels of SURVEY.md section 8(f); with fused optimizers on both parameter sets and the default `pipe` the
     iteration runs as a straight sequence of C-ABI calls without autograd (das3r_amd/fast_step.py; `model.fast_step = False` keeps
-    the autograd form of round 3 — same kernels, the reference's Python around them)."""
-    if fused:
+    the autograd form of round 3 — same kernels, the reference's Python around them).
+    fused_loss=False with fused=True: what das3r_amd.integrate.patch() gives an UNMODIFIED train_gui.py — the fused pre-transform and
+    FusedAdam behind render() / the optimizers, the loss in torch ops and the camera gate a host-side `if`, as the loop has them."""
+    fused_loss = bool(fused) if fused_loss is None else bool(fused_loss)
+    if fused and fused_loss:
         from . import fast_step
         if fast_step.available(model, pipe):
             return fast_step.train_step(model, cam, opt, iteration, pipe, background)
@@ -43,7 +46,7 @@ def train_step(model: SplatModel, cam, opt: OptimParams, iteration, pipe, backgr
     image = pkg["render"]
     gt = cam.original_image
     static = model._conf_static[cam.uid]
-    if fused:   # opt-in: the masked L1 + SSIM loss and the frame MSE as one HIP kernel each way
+    if fused and fused_loss:   # opt-in: the masked L1 + SSIM loss and the frame MSE as one HIP kernel each way
         from .fused import masked_photometric_loss
         loss, mse = masked_photometric_loss(image, gt, static, opt.lambda_dssim)
         psnr_frame = (20 * torch.log10(1.0 / torch.sqrt(mse))).mean()

@@ -31,6 +31,19 @@ def test_gpus_flag_spawns_that_many_ranks():
         assert key in out
 
 
+def test_n_ranks_report_jobs_in_flight_over_the_slowest_rank():
+    """`bench.py --gpus N` carries `jobs_in_flight` for N > 1 — every rank runs K = 2 whole jobs at once behind one
+    barrier (farm.run_jobs), the rate is N x K jobs over the slowest rank's wall time.  Stub jobs: rank r's take 0.05 (r + 1) s."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--stub"],
+                       capture_output=True, text=True, timeout=300, env=_env(), cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    j = _json_line(p.stdout)["jobs_in_flight"]
+    assert j["jobs_per_gpu"] == 2 and j["jobs_ok"] == 4 and len(j["per_rank_wall_s"]) == 2 and len(j["per_rank_scenes_per_hour"]) == 2
+    assert j["wall_s"] == max(j["per_rank_wall_s"]) and 0.1 <= j["per_rank_wall_s"][1] < 2.0
+    assert j["per_rank_wall_s"][1] > j["per_rank_wall_s"][0] - 0.02, "rank 1's stand-in jobs are the slower ones"
+    assert abs(j["scenes_per_hour"] - 4 * 3600.0 / j["wall_s"]) < 0.01 * j["scenes_per_hour"] + 1
+
+
 def test_a_failing_rank_still_yields_the_line():
     """a rank whose job dies keeps its appointments (barriers, reductions); the line comes out with ok = 0 for it,
     its units do not count, and per_rank_ms shows every rank's own time."""

@@ -360,3 +360,51 @@ def test_farm_cli_on_sequence_directories_with_two_jobs_in_flight(tmp_path):
         assert solo["ok"] == 1 and abs(table[i] - solo["psnr"]) < 0.006, (n, table[i], solo["psnr"])   # (the table prints two decimals)
         assert abs(float(log.split()[-1]) - solo["psnr"]) < 1e-9
     assert abs(table[3] - sum(table[:3]) / 3) < 0.011
+
+
+NOISY = dict(depth_noise=0.02, pose_noise=0.0065)   # the predictor's errors put back in: 2 % relative depth error per pixel, 6.5e-3 scene units of pose error
+PSNR_BAR_NOISY = 27.8      # dB; measured 28.84 (direct form) and 28.83 (autograd form), seed 0; 28.02 - 28.03 for the three forms at the small size: the regime of the published numbers (29.03 dB Sintel market_2, 25.70 dB DAVIS mean)
+PSNR_CEIL_NOISY = 31.0     # ... and well below the 43.9 dB of the noiseless sequence: the noise, not the optimiser, sets the level
+
+
+def test_noisy_input_job_lands_in_the_published_regime(monkeypatch):
+    """the 43 dB bar above feeds DAS3R perfect depth maps and perfect poses — the regime of the published numbers
+    (29.03 dB on Sintel market_2, 25.70 dB DAVIS mean: /root/reference/index.html:284-286, assets/table2.png) is the one where the
+    predictor's errors are in the input: poses the optimiser has to MOVE (the camera optimizer steps only on frames above 26 dB,
+    /root/reference/train_gui.py:584-586 — at this level the gate opens on some iterations and stays shut on others), depth maps that put
+    every Gaussian a little off its surface, conf_static learning under a loss that never goes to zero.  The same Sintel-shaped job with
+    consistent_sequence(depth_noise=0.02, pose_noise=0.0065): ends in [PSNR_BAR_NOISY, PSNR_CEIL_NOISY], above where it started, the
+    direct iteration and the autograd form of the same kernels within 0.5 dB of each other."""
+    from das3r_amd.farm import run_sequence_job
+    from das3r_amd.train import consistent_sequence
+    dev = torch.device("cuda:0")
+    seq = consistent_sequence(seed=0, **SINTEL_SHAPE, **NOISY)
+    start = run_sequence_job(0, 20, dev, fused=True, seq=seq)
+    direct = run_sequence_job(0, 4000, dev, fused=True, seq=seq)
+    monkeypatch.setenv("DAS3R_FAST_STEP", "0")
+    autograd = run_sequence_job(0, 4000, dev, fused=True, seq=seq)
+    print("noisy inputs, held-out static-region PSNR: after 20 iterations", start["psnr"], "direct", direct["psnr"], "autograd form", autograd["psnr"])
+    assert start["ok"] == direct["ok"] == autograd["ok"] == 1
+    for r in (direct, autograd):
+        assert PSNR_BAR_NOISY <= r["psnr"] <= PSNR_CEIL_NOISY, (start, direct, autograd)
+        assert r["psnr"] > start["psnr"] + 1.5, (start, direct, autograd)
+    assert abs(direct["psnr"] - autograd["psnr"]) <= 0.5, (direct["psnr"], autograd["psnr"])
+
+
+def test_noisy_input_job_three_forms_agree(monkeypatch):
+    """The noisy regime at the size the plain-PyTorch iteration finishes in seconds (12 frames of 256 x 104, 1000 iterations, 2 % depth
+    and 8e-3 pose error): unfused (what unmodified DAS3R runs on the drop-in), the autograd form of the fused kernels and the direct
+    iteration end within 0.3 dB of each other, in the same regime."""
+    from das3r_amd.farm import run_sequence_job
+    from das3r_amd.train import consistent_sequence
+    dev = torch.device("cuda:0")
+    seq = consistent_sequence(frames=12, W=256, H=104, focal=300.0, n_splats=8000, seed=4, depth_noise=0.02, pose_noise=0.008)
+    direct = run_sequence_job(0, 1000, dev, fused=True, seq=seq)
+    unfused = run_sequence_job(0, 1000, dev, fused=False, seq=seq)
+    monkeypatch.setenv("DAS3R_FAST_STEP", "0")
+    autograd = run_sequence_job(0, 1000, dev, fused=True, seq=seq)
+    forms = (direct, autograd, unfused)
+    print("noisy inputs, three forms:", [r["psnr"] for r in forms])
+    assert all(r["ok"] == 1 for r in forms)
+    assert all(26.0 <= r["psnr"] <= 33.0 for r in forms), forms
+    assert max(r["psnr"] for r in forms) - min(r["psnr"] for r in forms) <= 0.3, forms

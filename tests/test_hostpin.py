@@ -69,3 +69,31 @@ def test_pin_to_ccx_applies_a_mask(tmp_path, monkeypatch):
             assert got is None
     finally:
         os.sched_setaffinity(0, before)
+
+
+def test_worker_threads_get_distinct_cores_of_the_ranks_mask():
+    """K jobs in flight on one rank — every worker thread on a core of its own inside the rank's complex."""
+    import os
+    import threading
+    from das3r_amd import farm, hostpin
+    assert hostpin.worker_cpus(0, 2, range(8, 16)) == [8] and hostpin.worker_cpus(1, 2, range(8, 16)) == [9]
+    assert hostpin.worker_cpus(2, 3, [3, 1, 2, 0, 4, 5]) == [2]
+    assert hostpin.worker_cpus(0, 2, [0, 1, 2]) is None and hostpin.worker_cpus(2, 2, range(8)) is None   # too few cores / no such worker
+    mask = sorted(os.sched_getaffinity(0))
+    if len(mask) < 4:
+        return
+    seen, gate = {}, threading.Barrier(2)
+
+    def job(i):
+        gate.wait(10)                       # both workers are alive at once: two distinct threads
+        seen[i] = (threading.get_ident(), sorted(os.sched_getaffinity(0)))
+        return i
+
+    assert farm.run_jobs(range(2), job, 2, None, pin=True) == [0, 1]
+    (t0, c0), (t1, c1) = seen[0], seen[1]
+    assert t0 != t1 and len(c0) == len(c1) == 1 and c0 != c1 and set(c0 + c1) <= set(mask), seen
+    assert sorted(os.sched_getaffinity(0)) == mask, "the caller's own mask is untouched"
+    seen.clear()
+    gate = threading.Barrier(2)
+    farm.run_jobs(range(2), job, 2, None)   # default on the host: no pin
+    assert seen[0][1] == mask and seen[1][1] == mask

@@ -77,6 +77,22 @@ for depth in sys.argv[1].split(","):
         tmax = steps.max(1).values.reshape(nt, nbt).sum(1).float()        # a barrier per batch: the workgroup's slowest block
         tmean = steps.float().mean(1).reshape(nt, nbt).sum(1)
         print(f"   four lanes per pixel, batches of {B}: steps per tile, slowest block per batch: mean {tmax.mean():.0f} max {tmax.max():.0f};  mean block: mean {tmean.mean():.0f} max {tmean.max():.0f}")
+    # backward block walk (render_bwd_blk.hip): rounds of MB staged entries, a wave = four blocks in lockstep = ceil(longest of its four
+    # lists / 16) batches of sixteen pixel steps.  "wide" (round 6 model): all four rows of a wave on ONE block at a time, 64 entries per
+    # batch, at 1.25 x the cost of a batch (two more DPP steps per scan) — chosen per wave and round when cheaper.
+    for MB in (128, 192):
+        nbt = 16384 // MB * 2
+        batch = tile_of * nbt + pos // MB
+        per = torch.zeros(nt * nbt, 16, dtype=torch.long, device="cuda").index_add_(0, batch, hits).float()
+        pw = per[:, wv]                                                    # [rounds, wave, row]
+        normal = torch.ceil(pw.max(2).values / 16)
+        wide = 1.25 * torch.ceil(pw / 64).sum(2)
+        best = torch.minimum(normal, wide)
+        ideal = torch.ceil(pw.sum(2) / 64)                                 # the four rows perfectly packed
+        crit = lambda x: x.max(1).values.reshape(nt, nbt).sum(1)           # per tile: the slowest wave of every round (a barrier per round)
+        print(f"   backward model, rounds of {MB}: batches issued per tile: lockstep {normal.sum().item() / nt:.0f}  with wide mode {best.sum().item() / nt:.0f}  "
+              f"perfect packing {ideal.sum().item() / nt:.0f};  critical path (slowest wave per round) mean / max tile: lockstep {crit(normal).mean():.0f} / {crit(normal).max():.0f}  "
+              f"wide {crit(best).mean():.0f} / {crit(best).max():.0f};  waves x rounds that would go wide: {(wide < normal).float().mean().item():.2f}")
     # run-ahead model: NB staging areas of B entries, a block starts batch i once it is staged; batch i is staged by the time every block has
     # finished batch i - NB + 1 (loaders write one batch ahead of their own walk); cost = steps (+ a fixed cull per batch)
     for B, NBs in ((512, (2,)), (256, (2, 3, 4, 6))):
