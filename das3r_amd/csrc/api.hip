@@ -75,7 +75,7 @@ static void load_switches() {
     if ((e = env("DAS3R_BINNING"))) w.binning = e[0] == 'l' ? 1 : (e[0] == 'r' ? -1 : (e[0] == 's' ? (strchr(e, '3') ? 3 : 2) : 0));
     w.capacity_exact = (e = env("DAS3R_CAPACITY")) && e[0] == 'e';
     w.fused_emit_off = (e = env("DAS3R_FUSED_EMIT")) && e[0] == '0';
-    if ((e = env("DAS3R_RENDER"))) w.render_fwd = e[0] == 'q' ? 1 : (e[0] == 'r' ? 2 : (e[0] == 'l' ? 3 : 0));
+    if ((e = env("DAS3R_RENDER"))) w.render_fwd = e[0] == 'q' ? 1 : (e[0] == 'r' ? 2 : (e[0] == 'l' ? 3 : (e[0] == 's' ? 4 : 0)));
     if ((e = env("DAS3R_RENDER_BWD"))) {   // dpp | mfma | scan[a][64|128|256|512]
         w.render_bwd = e[0] == 'd' ? 1 : (e[0] == 'm' ? 2 : (strncmp(e, "stream", 6) == 0 ? 5 : (e[0] == 's' ? 3 : (e[0] == 'b' ? 6 : 0))));
         if (w.render_bwd == 6) {

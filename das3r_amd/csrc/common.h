@@ -27,7 +27,7 @@ struct Switches {
     bool capacity_exact;   // DAS3R_CAPACITY=exact: never lay the binning buffer out speculatively
     bool fused_emit_off;   // DAS3R_FUSED_EMIT=0
     bool no_sh_stage;      // DAS3R_NO_SH_STAGE
-    int render_fwd;        // DAS3R_RENDER=quad | rows | lanes: 1 | 2 | 3 (0: by list length and tile count)
+    int render_fwd;        // DAS3R_RENDER=quad | rows | lanes | slices: 1 | 2 | 3 | 4 (0: by list length and tile count)
     int render_bwd;        // DAS3R_RENDER_BWD=dpp | mfma | scan... | stream | blk...: 1 | 2 | 3 | 5 | 6 (0: by list length)
     int render_bwd_mb;     // scan64 / scan128 / scan256, blk64 / blk128 / blk256: entries per round; scana256 / scana512: 1000 + entries, atomic flush
     int tile_chunk;        // DAS3R_TILE_CHUNK: tiles per chunk of the XCD round robin (render_common.h); -1 = default, 0 = contiguous eighths
@@ -271,6 +271,8 @@ int launch_onesweep_partition(int64_t cap, char *geom, char *binning, const Layo
                               uint32_t *ghist_override = nullptr, uint32_t *err_override = nullptr);
 bool use_row_private(int64_t instances, int ntiles);  // forward: 4x4-block-per-row kernel for long tile lists (render_rows.hip)
 bool use_quad_lanes(const Layout &L, const LocalBin &lb);   // forward: four lanes per pixel for few tiles with long lists (render_lanes.hip)
+int launch_render_forward_slices(const das3r_raster_args *a, float *out_color, char *geom, char *binning, char *img, const Layout &L, const LocalBin &lb,
+                                 hipStream_t s);   // the same shapes, a block's list cut into chunks any wave takes (render_slices.hip)
 int launch_render_forward_lanes(const das3r_raster_args *a, float *out_color, char *geom, char *binning, char *img, const Layout &L,
                                 const LocalBin &lb, hipStream_t s);
 int launch_render_forward_rows(const das3r_raster_args *a, float *out_color, char *geom, char *binning, char *img, const Layout &L,

@@ -382,6 +382,54 @@ def test_forward_kernels_agree_bit_for_bit(name, binning, monkeypatch):
             util.assert_grad_close(gr[k].cpu().numpy(), gq[k].cpu().numpy(), f"{kind} vs quad forward dL/d{k}", tol=1e-5)
 
 
+@pytest.mark.parametrize("binning", ["radix", "seg"])
+@pytest.mark.parametrize("name", ["basic_deg3", "long_lists", "deep", "culled", "ragged_image", "depth_ties", "deg0"])
+def test_sliced_forward_against_the_four_lanes_kernel_and_the_oracle(name, binning, monkeypatch):
+    """render_slices.hip (round 6): a block's list of a batch cut into chunks that any wave walks from T = 1, the block's owner composing
+    them in list order and walking exactly the chunk in which a pixel may stop.  Every stop is decided by the exact walk, so n_contrib is
+    the four-lanes kernel's except where a pixel's T came within rounding of 1e-4; final_T differs by the rounding of T (prod) against the
+    running product (<= 1e-5 relative measured bar), the colour by the order of its sum; the gradients computed from its saved state
+    agree with the four-lanes kernel's to 1e-5 of the tensor maximum and with the oracle's within the parity bars."""
+    from das3r_amd import GaussianRasterizationSettings, _lib, rasterizer
+    sc, mode = util.scene_variant(name)
+    monkeypatch.setenv("DAS3R_BINNING", binning)
+    dev = _dev()
+    out, state = {}, {}
+    for kind in ("lanes", "slices"):
+        monkeypatch.setenv("DAS3R_RENDER", kind)
+        _lib.profile_report()
+        _lib.profile_enable(True)
+        c, r, g, fn = _run_hip(sc, mode)
+        _lib.profile_enable(False)
+        ran = _lib.profile_report()
+        assert any(k.startswith("render_forward_" + kind) for k in ran), (kind, list(ran))
+        out[kind] = (c, r, g, fn.num_rendered)
+        kw = {k: v.to(dev) for k, v in util.raster_inputs(sc, mode).items()}
+        skw = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in util.settings_kwargs(sc, mode).items()}
+        rs = GaussianRasterizationSettings(**skw)
+        e = torch.empty(0, device=dev)
+        I, _, _, _, _, img, _ = rasterizer._forward_full(rs, kw["means3D"], kw.get("shs", e), kw.get("colors_precomp", e), kw["opacities"],
+                                                         kw.get("scales", e), kw.get("rotations", e), kw.get("cov3D_precomp", e), exact=True)
+        torch.cuda.synchronize()
+        L = _lib.layout(sc.P, I, sc.W, sc.H)
+        npix = sc.W * sc.H
+        state[kind] = (img[L["final_T"]:L["final_T"] + 4 * npix].view(torch.float32).clone(), img[L["n_contrib"]:L["n_contrib"] + 4 * npix].view(torch.int32).clone())
+    (cl, rl, gl, nl), (cs, rs_, gs, ns) = out["lanes"], out["slices"]
+    assert nl == ns and torch.equal(rl, rs_)
+    same = state["lanes"][1] == state["slices"][1]
+    assert float((~same).float().mean()) <= util.FLIP_FRACTION, "n_contrib: the stops are the exact walk's"
+    tl, ts = state["lanes"][0][same], state["slices"][0][same]
+    assert float(((tl - ts).abs() / tl.abs().clamp_min(1e-30)).max()) <= 1e-5, "final_T: the rounding of T x (product), nothing else"
+    util.assert_color_close(cs.cpu().numpy(), cl.cpu().numpy(), f"{name} slices vs lanes colour")
+    for k in gl:
+        util.assert_grad_close(gs[k].cpu().numpy(), gl[k].cpu().numpy(), f"slices vs lanes forward dL/d{k}", tol=1e-5)
+    ref_color, ref_radii, ref_g, S = util.run_oracle(sc, mode)
+    util.assert_color_close(cs.cpu().numpy(), ref_color, f"{name} slices colour vs oracle")
+    for k, t in gs.items():
+        util.assert_grad_close(t.cpu().numpy(), ref_g[k], f"{name} slices dL/d{k}")
+        util.assert_grad_elementwise(t.cpu().numpy(), ref_g[k], f"{name} slices dL/d{k}")
+
+
 def test_scratch_alignment_does_not_matter(monkeypatch):
     """The per-Gaussian backward reads a workgroup's run of partial rows as 16-byte words when the caller's scratch buffer is 16-byte
     aligned and as 4-byte words otherwise (preprocess_bwd.hip): same rows, same order of the sums — the gradients are the same bits
