@@ -50,6 +50,7 @@ class RasterLayout(C.Structure):
 # every symbol include/das3r_raster.h declares
 EXPORTS = ("das3r_raster_forward", "das3r_raster_backward", "das3r_raster_check", "das3r_raster_backward_scratch_bytes", "das3r_mark_visible", "das3r_knn3_workspace_bytes",
            "das3r_knn3_mean_dist2", "das3r_raster_get_layout", "das3r_abi_version", "das3r_last_error", "das3r_reload_switches", "das3r_get_stats",
+           "das3r_raster_forget_shapes", "das3r_raster_learning",
            "das3r_profile_enable", "das3r_profile_report", "das3r_pretransform_forward", "das3r_pretransform_backward", "das3r_pose_matrices", "das3r_pose_chain",
            "das3r_adam_step", "das3r_adam_step_gated", "das3r_photometric_blocks", "das3r_photometric_forward", "das3r_photometric_backward",
            "das3r_has_experiments", "das3r_pair_counters", "das3r_debug_poison_lds", "das3r_debug_inject_fault", "das3r_debug_mutate",
@@ -155,6 +156,26 @@ def inject_fault(bits):
     L.das3r_debug_inject_fault.restype = None
     L.das3r_debug_inject_fault.argtypes = [C.c_uint32]
     L.das3r_debug_inject_fault(int(bits))
+
+
+def forget_shapes():
+    """The calling thread's library state on the current device forgets what it has learnt about shapes (include/das3r_raster.h
+    das3r_raster_forget_shapes): a job that must end bit-identical whatever its thread ran before calls this first."""
+    L = load()
+    L.das3r_raster_forget_shapes.restype = C.c_int
+    L.das3r_raster_forget_shapes.argtypes = []
+    check(L.das3r_raster_forget_shapes(), "das3r_raster_forget_shapes")
+
+
+def learning(state=None):
+    """include/das3r_raster.h das3r_raster_learning: state=None reads (forward kernel, forwards so far) of the calling thread's current shape;
+    a tuple hands it to the next shape the thread meets (a resumed job)."""
+    L = load()
+    L.das3r_raster_learning.restype = C.c_int
+    L.das3r_raster_learning.argtypes = [C.c_int32, C.POINTER(C.c_uint32)]
+    buf = (C.c_uint32 * 2)(*(state if state is not None else (0, 0)))
+    check(L.das3r_raster_learning(0 if state is None else 1, buf), "das3r_raster_learning")
+    return int(buf[0]), int(buf[1])
 
 
 def mutate(what):

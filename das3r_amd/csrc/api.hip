@@ -75,7 +75,7 @@ static void load_switches() {
     if ((e = env("DAS3R_BINNING"))) w.binning = e[0] == 'l' ? 1 : (e[0] == 'r' ? -1 : (e[0] == 's' ? (strchr(e, '3') ? 3 : 2) : 0));
     w.capacity_exact = (e = env("DAS3R_CAPACITY")) && e[0] == 'e';
     w.fused_emit_off = (e = env("DAS3R_FUSED_EMIT")) && e[0] == '0';
-    if ((e = env("DAS3R_RENDER"))) w.render_fwd = e[0] == 'q' ? 1 : (e[0] == 'r' ? 2 : (e[0] == 'l' ? 3 : (e[0] == 's' ? 4 : 0)));
+    if ((e = env("DAS3R_RENDER"))) w.render_fwd = e[0] == 'q' ? 1 : (e[0] == 'r' ? 2 : (e[0] == 'l' ? 3 : (e[0] == 's' ? 4 : (e[0] == 'f' ? 5 : 0))));
     if ((e = env("DAS3R_RENDER_BWD"))) {   // dpp | mfma | scan[a][64|128|256|512]
         w.render_bwd = e[0] == 'd' ? 1 : (e[0] == 'm' ? 2 : (strncmp(e, "stream", 6) == 0 ? 5 : (e[0] == 's' ? 3 : (e[0] == 'b' ? 6 : 0))));
         if (w.render_bwd == 6) {
@@ -297,12 +297,14 @@ struct Mailbox {
 // Everything the library remembers between calls, per host thread and per device (a thread that renders on two GPUs gets two
 // of these; nothing is shared between threads: any number of them may render concurrently, each on its own stream).
 constexpr uint32_t CHECK_SLOTS = 16, CHECK_WORD0 = 16, MAILBOX_BYTES = 4 * (CHECK_WORD0 + 2 * CHECK_SLOTS);
-struct Verdict { int P, W, H; int64_t last_I, peak_I; int radix_left, backoff; uint32_t gen; int seg_extra; bool last_seg; };
+struct Verdict { int P, W, H; int64_t last_I, peak_I; int radix_left, backoff; uint32_t gen; int seg_extra; bool last_seg; bool fine; uint32_t forwards; };
 struct PerDevice {
     Mailbox mb;
     uint32_t pending[CHECK_SLOTS] = {};             // per slot: tag of the forward whose self-check word has not been examined yet
     unsigned long long *arrive_ring = nullptr;      // self re-arming arrival words of the preprocess kernel's count reduction
     Verdict verdict = {0, 0, 0, -1, 0, 0, 64, 0};  // what the last forward of the current shape (P, W, H) taught us
+    bool pending_fine = false, pending_valid = false;   // das3r_raster_learning(set): handed to the next shape this thread meets
+    uint32_t pending_forwards = 0;
     char *emit_ring = nullptr;                      // control words of the emission fused into the preprocess kernel
     bool emit_ring_dirty = false;
     uint32_t emit_last_tag = 0;
@@ -378,6 +380,37 @@ extern "C" int das3r_raster_check(const das3r_raster_saved *saved, das3r_stream_
     if (!saved->check_word || !saved->check_tag) return DAS3R_OK;   // P == 0, nothing rendered, or a caller that dropped the ticket
     const int r = examine_check_slot((volatile uint32_t *)saved->check_word, saved->check_tag, true, (hipStream_t)stream);
     return r < 0 ? r : DAS3R_OK;
+}
+
+// ABI 13: what the calling thread's library state has LEARNT about shapes on the current device is forgotten (counts, binning path, forward
+// kernel choice); the mailbox, rings and tickets stay.  See include/das3r_raster.h.
+extern "C" int das3r_raster_forget_shapes(void) {
+    PerDevice *T = nullptr;
+    int r = per_device(&T);
+    if (r) return r;
+    const uint32_t gen = T->verdict.gen;   // (generation numbers keep counting: a word a forward of the old shape still has on its way names nobody)
+    T->verdict = Verdict{0, 0, 0, -1, 0, 0, 64, gen};
+    return DAS3R_OK;
+}
+
+// ABI 13: the part of the learnt state that shows in the last bit of a result — the forward kernel of the current shape and the position in its
+// re-decision schedule.  set == 0: read into state[0 .. 1]; set != 0: forget the shapes and hand state[] to the next shape this thread meets.
+extern "C" int das3r_raster_learning(int32_t set, uint32_t state[2]) {
+    if (!state) { set_error("das3r_raster_learning: invalid argument"); return DAS3R_ERR_INVALID_ARG; }
+    PerDevice *T = nullptr;
+    int r = per_device(&T);
+    if (r) return r;
+    if (!set) {
+        state[0] = T->verdict.fine ? 1u : 0u;
+        state[1] = T->verdict.forwards;
+        return DAS3R_OK;
+    }
+    const uint32_t gen = T->verdict.gen;
+    T->verdict = Verdict{0, 0, 0, -1, 0, 0, 64, gen};
+    T->pending_fine = state[0] != 0u;
+    T->pending_forwards = state[1];
+    T->pending_valid = true;
+    return DAS3R_OK;
 }
 
 extern "C" void das3r_get_stats(uint64_t out[4]) {
@@ -462,6 +495,19 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     if (verdict.P != P || verdict.W != W || verdict.H != H) {
         const uint32_t gen = verdict.gen + 1u ? verdict.gen + 1u : 1u;
         verdict = Verdict{P, W, H, -1, 0, 0, 64, gen};
+        if (T->pending_valid) {   // a resumed job: the forward-kernel choice and its schedule continue where the checkpoint left them
+            verdict.fine = T->pending_fine;
+            verdict.forwards = T->pending_forwards;
+            T->pending_valid = false;
+        }
+    }
+    // Skewed tile lists -> the forward kernel with four workgroups per tile (render_regions.hip; below, bin_and_render): decided from the
+    // tile ranges of the shape's FIRST forward and of every 512th after it — a one-workgroup kernel behind the binning leaves the longest
+    // list in the mailbox and the host waits for it (the first forward of a shape waits for its count anyway; afterwards one short wait
+    // per 512 forwards).  Which kernel runs in which forward thus depends on the data alone, never on timing: the two kernels round a
+    // pixel's T differently in the last bit, and a job must end bit-identical however it was scheduled.
+    const bool decide_fine = (verdict.forwards++ & 511u) == 0u;
+    if (verdict.last_I < 0) {   // (a shape's first forward: nothing to learn from yet)
     } else if (too_long == verdict.gen && !(verdict.last_seg && verdict.seg_extra == 0 && L.tile_passes < 3 && seg_dbits(L, L.tile_passes + 1) > 0)) {
         verdict.radix_left = verdict.backoff;   // global sort for a while; longer every time it happens again
         if (verdict.backoff < 4096) verdict.backoff *= 2;
@@ -523,6 +569,14 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         if ((r = launch_binning(P, cap, W, H, out->radii, saved->geom, saved->binning, saved->img, L, fused_scan, host_late, late_tag,
                                 a->debug != 0, s, &dead_keys, emit_slot, mb->dev + 10, verdict.gen))) return r;
         LocalBin lb = {(float4 *)(saved->binning + L.b_ckpt), nullptr, nullptr, nullptr, nullptr, verdict.gen, (uint32_t)(P - 1), (uint32_t)cap};
+        if (decide_fine && cap > 0 && use_quad_lanes(L, lb)) {   // (shapes the one-workgroup-per-tile kernel would take: few tiles, long lists)
+            const uint32_t tag = ++mb->seq ? mb->seq : ++mb->seq;
+            if ((r = launch_list_skew(saved->img, L, (uint32_t)cap, mb->dev + 13, tag, a->debug != 0, s))) return r;
+            if ((r = mailbox_wait(mb, 14, tag, s))) return r;
+            const int64_t longest = (int64_t)mb->host[13], mean = (verdict.last_I > 0 ? verdict.last_I : cap) / std::max(L.ntiles, 1);   // (the last forward's count; the capacity on a shape's first)
+            verdict.fine = longest > mean + (mean * 4) / 5 && longest >= 4096;                 // 1.8 x the mean list: measured crossover (ledger (bd))
+        }
+        lb.prefer_regions = verdict.fine;
         if (local_order && cap > 0) {
             lb.point_list = (uint32_t *)(saved->binning + L.pub.point_list);
             lb.slot_list = (uint32_t *)(saved->binning + L.b_slot);

@@ -27,7 +27,7 @@ struct Switches {
     bool capacity_exact;   // DAS3R_CAPACITY=exact: never lay the binning buffer out speculatively
     bool fused_emit_off;   // DAS3R_FUSED_EMIT=0
     bool no_sh_stage;      // DAS3R_NO_SH_STAGE
-    int render_fwd;        // DAS3R_RENDER=quad | rows | lanes | slices: 1 | 2 | 3 | 4 (0: by list length and tile count)
+    int render_fwd;        // DAS3R_RENDER=quad | rows | lanes | slices | fine: 1 | 2 | 3 | 4 | 5 (0: by list length and tile count)
     int render_bwd;        // DAS3R_RENDER_BWD=dpp | mfma | scan... | stream | blk...: 1 | 2 | 3 | 5 | 6 (0: by list length)
     int render_bwd_mb;     // scan64 / scan128 / scan256, blk64 / blk128 / blk256: entries per round; scana256 / scana512: 1000 + entries, atomic flush
     int tile_chunk;        // DAS3R_TILE_CHUNK: tiles per chunk of the XCD round robin (render_common.h); -1 = default, 0 = contiguous eighths
@@ -226,6 +226,9 @@ struct LocalBin {
     uint32_t *host_flag;                // pinned mailbox word that receives flag_value when such a list was met
     uint32_t flag_value;                // names the shape (P, W, H) this forward belongs to, never 0
     uint32_t last_g, cap;               // P - 1 and the instances the lists hold: bounds for safe_index / safe_range (always set)
+    // round 6: the forward kernel with four workgroups per tile (render_regions.hip) instead of one (render_lanes.hip): chosen by the host for
+    // shapes whose tile lists are skewed (api.hip Verdict::fine, decided from the tile ranges themselves: launch_list_skew)
+    bool prefer_regions;
 };
 void compute_layout(int P, int64_t I, int W, int H, Layout *L);
 
@@ -271,6 +274,9 @@ int launch_onesweep_partition(int64_t cap, char *geom, char *binning, const Layo
                               uint32_t *ghist_override = nullptr, uint32_t *err_override = nullptr);
 bool use_row_private(int64_t instances, int ntiles);  // forward: 4x4-block-per-row kernel for long tile lists (render_rows.hip)
 bool use_quad_lanes(const Layout &L, const LocalBin &lb);   // forward: four lanes per pixel for few tiles with long lists (render_lanes.hip)
+int launch_render_forward_regions(const das3r_raster_args *a, float *out_color, char *geom, char *binning, char *img, const Layout &L, const LocalBin &lb,
+                                  hipStream_t s);   // the same shapes: sixteen lanes per pixel, a wave per 2x2 region, four workgroups per tile (render_regions.hip)
+int launch_list_skew(const char *img, const Layout &L, uint32_t cap, uint32_t *mailbox_words /*{longest list, tag}*/, uint32_t tag, bool debug, hipStream_t s);
 int launch_render_forward_slices(const das3r_raster_args *a, float *out_color, char *geom, char *binning, char *img, const Layout &L, const LocalBin &lb,
                                  hipStream_t s);   // the same shapes, a block's list cut into chunks any wave takes (render_slices.hip)
 int launch_render_forward_lanes(const das3r_raster_args *a, float *out_color, char *geom, char *binning, char *img, const Layout &L,

@@ -104,8 +104,12 @@ int launch_render_forward(const das3r_raster_args *a, const float *colors_precom
                           char *img, const Layout &L, const LocalBin &lb, hipStream_t s) {
     (void)colors_precomp;  // precomputed colours were copied into rgbd by the preprocess kernel
     if (use_quad_lanes(L, lb))
-        return switches().render_fwd == 4 ? launch_render_forward_slices(a, out_color, geom, binning, img, L, lb, s)
-                                          : launch_render_forward_lanes(a, out_color, geom, binning, img, L, lb, s);
+    {   // one workgroup per tile (lanes), or four (regions) where the tile lists are skewed: the host has been told by the forwards before this one
+        const int f = switches().render_fwd;
+        if (f == 4) return launch_render_forward_slices(a, out_color, geom, binning, img, L, lb, s);
+        if (f == 5 || (f == 0 && lb.prefer_regions)) return launch_render_forward_regions(a, out_color, geom, binning, img, L, lb, s);
+        return launch_render_forward_lanes(a, out_color, geom, binning, img, L, lb, s);
+    }
     if (use_row_private(L.capacity, L.ntiles)) return launch_render_forward_rows(a, out_color, geom, binning, img, L, lb, s);
     const int pad_lds = switches().fwd_pad_lds;   // occupancy experiments
     DAS3R_LAUNCH(render_forward_kernel, dim3(xcd_grid(L)), dim3(TILE_PIX), pad_lds, s, (const uint2 *)(img + L.pub.ranges),

@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(LN_THREADS) __attribute__((amdgpu_waves_per_eu
 bool use_quad_lanes(const Layout &L, const LocalBin &lb) {
     if (lb.point_list != nullptr) return false;   // (lists in local depth order: render_rows.hip sorts them itself)
     const int forced = switches().render_fwd;
-    if (forced) return forced == 3 || forced == 4;
+    if (forced) return forced >= 3;
     return L.ntiles <= 1024 && L.capacity >= (int64_t)1024 * L.ntiles;
 }
 

@@ -24,7 +24,8 @@
 // 70 - 97 % of the pixels STOP inside the first third of their tile's list, a block's sixteen stops fall into about half of its chunks
 // while it lives, every such chunk is walked twice (once from T = 1 by whoever drew it, once exactly by the owner) and the chain is
 // not shorter — train step forward 0.239 -> 0.323 ms (noise depth), 0.300 -> 0.444 (smooth depth), a whole self-consistent Sintel-shaped job
-// 8.05 -> 8.57 s.  Selected with DAS3R_RENDER=slices only; kept because it is exact where it matters (tests) and is the measured answer to
+// 8.05 -> 8.57 s (on that sequence the LONG tiles — the dense region of the frame, whose chain the kernel lasts for — are exactly the ones whose pixels
+// saturate: phase clocks on the tiles above 20 000 entries put 7 x the chunk walks' cycles into the owners' exact re-walks).  Selected with DAS3R_RENDER=slices only; kept because it is exact where it matters (tests) and is the measured answer to
 // "split a long tile list across waves": the list can be split, the stops cannot.
 // What differs from them: T after a composed chunk is fl(T fl(prod)) instead of the running product (a relative 1e-7 per chunk; the
 // stop decision itself is always taken by the exact walk), and the colour is the same sum in another order.  final_T / n_contrib agree

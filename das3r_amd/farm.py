@@ -257,6 +257,10 @@ def run_sequence_job(scene_id, iterations, device, frames=6, seq_dir=None, out_d
     progress: called at the job's stages and every few hundred iterations (Rendezvous.tick)."""
     progress = progress or (lambda: None)
     progress()
+    if torch.device(device).type == "cuda":   # the job starts from the library state a fresh thread finds (round 6: the forward kernel a shape gets
+        from . import _lib                     # is learnt from its earlier forwards, and the two kernels differ in the last bit of T) — whatever ran here before
+        with torch.cuda.device(device):
+            _lib.forget_shapes()
     from .model import OptimParams
     from .train import build_from_sequence, psnr_report, synthetic_sequence, train
     try:

@@ -132,6 +132,10 @@ def train(model, cameras, opt: OptimParams, iterations, pipe=None, background=No
         by_uid = {c.uid: c for c in cameras}
         stack = [by_uid[u] for u in loop_state["stack"]]
         ema, last_psnr = loop_state["ema"].to(dev), loop_state["last_psnr"].to(dev)
+        if loop_state.get("library") is not None and dev.type == "cuda":
+            from . import _lib
+            with torch.cuda.device(dev):
+                _lib.learning(tuple(loop_state["library"]))
     if dev.type == "cuda":
         torch.cuda.current_stream(dev).synchronize()   # (this job's stream only: other jobs may share the GPU — farm.run_jobs)
     t0 = time.perf_counter()
@@ -150,8 +154,14 @@ def train(model, cameras, opt: OptimParams, iterations, pipe=None, background=No
             print(f"[ITER {it}] loss {float(ema):.5f} psnr_frame {float(last_psnr):.2f}")
         if checkpoint_every and checkpoint_dir and it % checkpoint_every == 0 and it < iterations:
             import os
+            library = None
+            if dev.type == "cuda":   # which forward kernel the shape has, and where its re-decision schedule stands (include/das3r_raster.h)
+                from . import _lib
+                with torch.cuda.device(dev):
+                    library = _lib.learning()
             save_checkpoint(os.path.join(checkpoint_dir, f"chkpnt{it}.pth"), model, it,
-                            dict(rng=rng.getstate(), stack=[c.uid for c in stack], ema=ema.detach().clone(), last_psnr=last_psnr.detach().clone()))
+                            dict(rng=rng.getstate(), stack=[c.uid for c in stack], ema=ema.detach().clone(), last_psnr=last_psnr.detach().clone(),
+                                 library=library))
     if dev.type == "cuda":
         torch.cuda.current_stream(dev).synchronize()
     done = max(iterations - start_iteration + 1, 1)

@@ -324,6 +324,20 @@ void das3r_reload_switches(void);
  * "a stalled look-back poll was rescued by the atomic read path" note (granule.h; informational), [3] failed self-checks. */
 void das3r_get_stats(uint64_t out[4]);
 
+/* ABI 13.  Forget what the calling thread has learnt about shapes on the current device (das3r_raster.h "State between calls": the
+ * instance counts a speculative capacity is laid out from, the binning path, and — round 6 — which forward compositing kernel a shape
+ * gets: one workgroup per tile or four, chosen from the skew of the tile lists the shape's earlier forwards met).  Every learnt path
+ * computes the same lists and the same gradients; the two forward kernels round a pixel's transmittance differently in the last bit, so
+ * a job that must end bit-identical whatever ran on its thread before it calls this first (das3r_amd.farm.run_sequence_job does): its
+ * forwards then see the library in the state a fresh thread finds it in.  Costs the first forwards of the next shape their short cuts. */
+int das3r_raster_forget_shapes(void);
+
+/* ABI 13.  The part of that state which shows in the last bit of a result, for checkpoints: set == 0 reads {forward kernel of the current shape
+ * (0: one workgroup per tile, 1: four), forwards of the shape so far — the kernel is re-decided from the tile lists every 512th} into
+ * state[0 .. 1]; set != 0 forgets the shapes (as above) and hands state[] to the next shape the calling thread meets: a job resumed from a
+ * checkpoint continues with the kernel, and the re-decision schedule, the killed job had (das3r_amd.train save_checkpoint / farm resume). */
+int das3r_raster_learning(int32_t set, uint32_t state[2]);
+
 /* 1 when the library was built with the superseded experiment kernels (make EXPERIMENTS=1: DAS3R_RENDER_BWD=mfma | stream,
  * DAS3R_SORT=classic), 0 for the shipped build; the parity tests of those kernels skip themselves on 0. */
 int das3r_has_experiments(void);

@@ -384,7 +384,8 @@ def test_forward_kernels_agree_bit_for_bit(name, binning, monkeypatch):
 
 @pytest.mark.parametrize("binning", ["radix", "seg"])
 @pytest.mark.parametrize("name", ["basic_deg3", "long_lists", "deep", "culled", "ragged_image", "depth_ties", "deg0"])
-def test_sliced_forward_against_the_four_lanes_kernel_and_the_oracle(name, binning, monkeypatch):
+@pytest.mark.parametrize("kernel", ["slices", "fine"])
+def test_sliced_forward_against_the_four_lanes_kernel_and_the_oracle(name, binning, kernel, monkeypatch):
     """render_slices.hip (round 6): a block's list of a batch cut into chunks that any wave walks from T = 1, the block's owner composing
     them in list order and walking exactly the chunk in which a pixel may stop.  Every stop is decided by the exact walk, so n_contrib is
     the four-lanes kernel's except where a pixel's T came within rounding of 1e-4; final_T differs by the rounding of T (prod) against the
@@ -395,14 +396,14 @@ def test_sliced_forward_against_the_four_lanes_kernel_and_the_oracle(name, binni
     monkeypatch.setenv("DAS3R_BINNING", binning)
     dev = _dev()
     out, state = {}, {}
-    for kind in ("lanes", "slices"):
+    for kind in ("lanes", kernel):
         monkeypatch.setenv("DAS3R_RENDER", kind)
         _lib.profile_report()
         _lib.profile_enable(True)
         c, r, g, fn = _run_hip(sc, mode)
         _lib.profile_enable(False)
         ran = _lib.profile_report()
-        assert any(k.startswith("render_forward_" + kind) for k in ran), (kind, list(ran))
+        assert any(k.startswith("render_forward_" + {"fine": "regions"}.get(kind, kind)) for k in ran), (kind, list(ran))
         out[kind] = (c, r, g, fn.num_rendered)
         kw = {k: v.to(dev) for k, v in util.raster_inputs(sc, mode).items()}
         skw = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in util.settings_kwargs(sc, mode).items()}
@@ -414,11 +415,11 @@ def test_sliced_forward_against_the_four_lanes_kernel_and_the_oracle(name, binni
         L = _lib.layout(sc.P, I, sc.W, sc.H)
         npix = sc.W * sc.H
         state[kind] = (img[L["final_T"]:L["final_T"] + 4 * npix].view(torch.float32).clone(), img[L["n_contrib"]:L["n_contrib"] + 4 * npix].view(torch.int32).clone())
-    (cl, rl, gl, nl), (cs, rs_, gs, ns) = out["lanes"], out["slices"]
+    (cl, rl, gl, nl), (cs, rs_, gs, ns) = out["lanes"], out[kernel]
     assert nl == ns and torch.equal(rl, rs_)
-    same = state["lanes"][1] == state["slices"][1]
+    same = state["lanes"][1] == state[kernel][1]
     assert float((~same).float().mean()) <= util.FLIP_FRACTION, "n_contrib: the stops are the exact walk's"
-    tl, ts = state["lanes"][0][same], state["slices"][0][same]
+    tl, ts = state["lanes"][0][same], state[kernel][0][same]
     assert float(((tl - ts).abs() / tl.abs().clamp_min(1e-30)).max()) <= 1e-5, "final_T: the rounding of T x (product), nothing else"
     util.assert_color_close(cs.cpu().numpy(), cl.cpu().numpy(), f"{name} slices vs lanes colour")
     for k in gl:

@@ -207,7 +207,10 @@ def test_sintel_shaped_steady_state_direct_step_vs_float64_host_and_c_oracle(dep
     kernels = _lib.profile_report(raw=True)
     n = lambda prefix, sub="": sum(c for k, (c, _) in kernels.items() if k.startswith(prefix) and sub in k)
     assert n("segment_sort_kernel") == 1 and n("depth_hist_kernel") == 0, kernels
-    assert n("render_forward_lanes_kernel") == 1 and n("render_forward_rows_kernel") == 0, kernels
+    # (one workgroup per tile, or four where the tile lists are skewed — the smooth-depth maps: api.hip decides from the tile ranges)
+    assert n("render_forward_lanes_kernel") + n("render_forward_regions_kernel") == 1 and n("render_forward_rows_kernel") == 0, kernels
+    if depth == "noise":
+        assert n("render_forward_lanes_kernel") == 1, kernels
     assert n("render_backward_blk_kernel", "true>") == 1 and n("render_backward_") == 1, kernels
     loss, psnr_frame = float(out8[0]), float(out8[4])
 

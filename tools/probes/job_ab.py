@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Whole Sintel-shaped job on the self-consistent sequence under two settings of an environment switch (A-B on one box).
-    python tools/probes/job_ab.py DAS3R_RENDER=slices [iterations]"""
+    python tools/probes/job_ab.py DAS3R_RENDER=slices [iterations]  (the switch may also be one that turns a default OFF: DAS3R_TILE_LPT=0)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch

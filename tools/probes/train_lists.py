@@ -9,12 +9,16 @@ from types import SimpleNamespace
 from das3r_amd import _lib
 from das3r_amd.rasterizer import _forward_full
 from das3r_amd.render import rasterizer_inputs
-from das3r_amd.train import build_from_sequence, synthetic_sequence
+from das3r_amd.train import build_from_sequence, consistent_sequence, synthetic_sequence
 from das3r_amd.model import OptimParams
 
 for depth in sys.argv[1].split(","):
-    seq = synthetic_sequence(frames=20, W=512, H=208, focal=600.0, n_splats=20000, seed=0, depth=depth)
-    model, cams = build_from_sequence(seq)
+    if depth == "consistent":   # the self-consistent sequence a farm job runs on (all frames see ONE surface)
+        seq = consistent_sequence(frames=22, W=512, H=208, focal=600.0, n_splats=20000, seed=0)
+        model, cams, _test = build_from_sequence(seq, heldout=True)
+    else:
+        seq = synthetic_sequence(frames=20, W=512, H=208, focal=600.0, n_splats=20000, seed=0, depth=depth)
+        model, cams = build_from_sequence(seq)
     model.training_setup(OptimParams(iterations=4000), fused=True)
     pipe = SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
     bg = torch.zeros(3, device="cuda")
@@ -77,6 +81,27 @@ for depth in sys.argv[1].split(","):
         tmax = steps.max(1).values.reshape(nt, nbt).sum(1).float()        # a barrier per batch: the workgroup's slowest block
         tmean = steps.float().mean(1).reshape(nt, nbt).sum(1)
         print(f"   four lanes per pixel, batches of {B}: steps per tile, slowest block per batch: mean {tmax.mean():.0f} max {tmax.max():.0f};  mean block: mean {tmean.mean():.0f} max {tmean.max():.0f}")
+    # round 6 model: sixteen lanes per pixel — a wave = one 2x2 pixel region x 16 consecutive entries of the region's own list, a workgroup of
+    # sixteen waves = one 8x8 quadrant (four workgroups per tile), batches of B tile entries
+    h2 = []
+    for r in range(64):
+        cx, cy = bx + (r % 8) * 2 + 0.5, by + (r // 8) * 2 + 0.5
+        h2.append(((xyh[:, 0] - cx).abs() <= xyh[:, 2] + 0.5) & ((xyh[:, 1] - cy).abs() <= xyh[:, 3] + 0.5))
+    h2 = torch.stack(h2, 1)                                               # [I, 64]
+    print(f"   2x2 regions hit per entry: mean {h2.float().sum(1).mean():.2f} (x 4 pixels = {4 * h2.float().sum(1).mean():.1f} pairs listed per entry; 4x4 blocks: {16 * hits.float().sum(1).mean():.1f})")
+    quad_of = torch.tensor([(r % 8) // 4 + 2 * ((r // 8) // 4) for r in range(64)], device="cuda")
+    for B in (256, 512):
+        nbt = 32768 // B * 2
+        batch = tile_of * nbt + pos // B
+        per = torch.zeros(nt * nbt, 64, dtype=torch.long, device="cuda").index_add_(0, batch, h2.long())
+        st16 = (per + 15) // 16                                           # steps of a region per batch
+        for q in range(4):
+            sq = st16[:, quad_of == q]                                    # [batches, 16 regions]
+            slow = sq.max(1).values.reshape(nt, nbt).sum(1).float()
+            mean = sq.float().mean(1).reshape(nt, nbt).sum(1)
+            if q == 0:
+                print(f"   16 lanes per pixel, batches of {B}, quadrant 0: steps per quadrant workgroup, slowest region per batch: mean {slow.mean():.0f} max {slow.max():.0f};  mean region: mean {mean.mean():.0f} max {mean.max():.0f}")
+        print(f"      total region steps (x 64 lanes) {st16.sum().item()}  against four-lanes steps {((torch.zeros(nt * nbt, 16, dtype=torch.long, device='cuda').index_add_(0, batch, hits.long()) + 3) // 4).sum().item()}")
     # backward block walk (render_bwd_blk.hip): rounds of MB staged entries, a wave = four blocks in lockstep = ceil(longest of its four
     # lists / 16) batches of sixteen pixel steps.  "wide" (round 6 model): all four rows of a wave on ONE block at a time, 64 entries per
     # batch, at 1.25 x the cost of a batch (two more DPP steps per scan) — chosen per wave and round when cheaper.
