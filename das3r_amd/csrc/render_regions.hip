@@ -90,6 +90,20 @@ __device__ __forceinline__ uint32_t row_max_u32(uint32_t v) {
     return v;
 }
 
+// Which of a quadrant's sixteen 2x2 regions (bit 4 ry + rx; region centres qcx0 + 2 rx, qcy0 + 2 ry) can the entry reach?  The test of every
+// forward kernel — |centre distance| <= cull half extent + half the region — evaluated ONCE per entry by the thread that stages it
+// (eight compares) instead of once per entry and wave: a wave's cull is then a bit test.  Entries past the list carry extents nobody meets.
+__device__ __forceinline__ uint32_t region_mask(const float4 p, const float qcx0, const float qcy0) {
+    uint32_t xb = 0, yb = 0;
+    const float hx = p.z + 0.5f, hy = p.w + 0.5f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        xb |= (fabsf(p.x - (qcx0 + (float)(2 * k))) <= hx ? 1u : 0u) << k;
+        yb |= (fabsf(p.y - (qcy0 + (float)(2 * k))) <= hy ? 1u : 0u) << k;
+    }
+    return ((yb & 1u) ? xb : 0u) | ((yb & 2u) ? xb << 4 : 0u) | ((yb & 4u) ? xb << 8 : 0u) | ((yb & 8u) ? xb << 12 : 0u);
+}
+
 // state of a row's pixel: T and live are the same in its sixteen lanes; C and the last contributor are per-lane partial results
 struct RowLane {
     float T, live, C0, C1, C2, pxf, pyf, ef;   // ef: my slot in a step, 0 .. 15
@@ -120,27 +134,41 @@ __device__ __forceinline__ float regions_walk(const StagedSplat *__restrict__ st
             const float a1 = fminf(fminf(0.99f, __fmul_rn(co.w, __expf(power))), lenf - (float)(t + 16 * u));
             av[u] = alpha_if_visible(a1, power);   // (a1 is not positive where the list has no such position)
         }
-#pragma unroll
-        for (int u = 0; u < RG_UNROLL; u++) {
-            const float a = av[u] * q.live;
-            const float incl = row_scan_mul(1.0f - a);       // prod (1 - alpha) of the row's lanes 0 .. mine, tree order
-            const float excl = row_shift1(incl, 1.0f);       //                                  0 .. mine - 1
-            const float x = __fmul_rn(q.T, excl);            // T in front of my entry
-            const float tn = __fmul_rn(q.T, incl);           // the reference's test_T of my entry (falls along the row)
-            float s = 1.0f, t_next = row_bcast<15>(tn), l_next = q.live;
-            if (__builtin_expect(__ballot(tn < 0.0001f) != 0ull, 0)) {   // a pixel of this wave stops inside the step: once in a pixel's life
-                s = tn < 0.0001f ? 0.f : 1.f;                            // (test_T only falls: the entries behind the first failure fail too)
-                t_next = row_min(s != 0.f ? tn : q.T);                   // T behind the last entry taken (the pixel's T where none is)
-                l_next = q.live * row_min(s);
-            }
-            const float w = a * s, wT = w * x;
-            q.C0 = __fmaf_rn(c[u].x, wT, q.C0);
-            q.C1 = __fmaf_rn(c[u].y, wT, q.C1);
-            q.C2 = __fmaf_rn(c[u].z, wT, q.C2);
-            lastf = max_raw(lastf, min_raw((float)j[u], __fmaf_rn(w, 1e30f, -1.0f)));
-            q.T = t_next;
-            q.live = l_next;
+        // the two steps' products are scanned side by side (the second chain fills the first one's DPP wait states), both with the pixel's
+        // `live` of the trip's start; a stop inside the first step — once in a pixel's life — makes the second step's scan stale for that
+        // pixel: redone on the spot
+        static_assert(RG_UNROLL == 2, "the walk scans two steps at a time");
+        float a0 = av[0] * q.live, a1 = av[1] * q.live;
+        float incl0 = 1.0f - a0, incl1 = 1.0f - a1;
+        row_scan_mul_x2(incl0, incl1);   // prod (1 - alpha) of the row's lanes 0 .. mine, tree order
+#define RG_STEP(U, A, INCL)                                                                                                        \
+        {                                                                                                                           \
+            const float excl = row_shift1(INCL, 1.0f);       /* lanes 0 .. mine - 1 */                                              \
+            const float x = __fmul_rn(q.T, excl);            /* T in front of my entry */                                           \
+            const float tn = __fmul_rn(q.T, INCL);           /* the reference's test_T of my entry (falls along the row) */         \
+            float s = 1.0f, t_next = row_bcast<15>(tn), l_next = q.live;                                                            \
+            if (__builtin_expect(__ballot(tn < 0.0001f) != 0ull, 0)) {   /* a pixel of this wave stops inside the step */          \
+                s = tn < 0.0001f ? 0.f : 1.f;                            /* (test_T only falls: the entries behind the first failure fail too) */ \
+                t_next = row_min(s != 0.f ? tn : q.T);                   /* T behind the last entry taken (the pixel's T where none is) */ \
+                l_next = q.live * row_min(s);                                                                                       \
+                stopped = true;                                                                                                     \
+            }                                                                                                                       \
+            const float w = A * s, wT = w * x;                                                                                      \
+            q.C0 = __fmaf_rn(c[U].x, wT, q.C0);                                                                                     \
+            q.C1 = __fmaf_rn(c[U].y, wT, q.C1);                                                                                     \
+            q.C2 = __fmaf_rn(c[U].z, wT, q.C2);                                                                                     \
+            lastf = max_raw(lastf, min_raw((float)j[U], __fmaf_rn(w, 1e30f, -1.0f)));                                               \
+            q.T = t_next;                                                                                                           \
+            q.live = l_next;                                                                                                        \
         }
+        bool stopped = false;
+        RG_STEP(0, a0, incl0)
+        if (__builtin_expect(stopped, 0)) {   // (uniform) the second step with the pixels' new `live`
+            a1 = av[1] * q.live;
+            incl1 = row_scan_mul(1.0f - a1);
+        }
+        RG_STEP(1, a1, incl1)
+#undef RG_STEP
     }
     return lastf;
 }
@@ -153,6 +181,7 @@ __global__ void __launch_bounds__(RG_THREADS) __attribute__((amdgpu_waves_per_eu
     __shared__ StagedSplat stage_all[2 * RG_BATCH];
     __shared__ uint16_t lists[16][RG_LIST];     // [wave][position]: staged index
     __shared__ uint32_t s_done[2][16];
+    __shared__ uint16_t s_mask[2][RG_BATCH];   // per staged entry: the regions of this quadrant it can reach (bit = wave), written with the record
     // workgroup -> (tile, quadrant): the four quadrants of a tile are consecutive workgroups of ONE XCD (the dispatcher deals workgroup b to
     // XCD b % 8): b = (4 j' + quadrant) * 8 + xcd with tile slot 8 j' + xcd of render_common.h's XCD-aware tile order
     const int xcd = blockIdx.x & 7, jq = blockIdx.x >> 3, quad = jq & 3;
@@ -163,7 +192,7 @@ __global__ void __launch_bounds__(RG_THREADS) __attribute__((amdgpu_waves_per_eu
     const int rx0 = bx * TILE_X + ((quad & 1) << 3) + ((wave & 3) << 1), ry0 = by * TILE_Y + ((quad >> 1) << 3) + ((wave >> 2) << 1);   // the wave's region
     const int px = rx0 + (row & 1), py = ry0 + (row >> 1);
     const bool inside = px < W && py < H;
-    const float rcx = (float)rx0 + 0.5f, rcy = (float)ry0 + 0.5f;
+    const float qcx0 = (float)(bx * TILE_X + ((quad & 1) << 3)) + 0.5f, qcy0 = (float)(by * TILE_Y + ((quad >> 1) << 3)) + 0.5f;   // centre of the quadrant's region (0, 0)
     const uint2 range = safe_range(ranges[tile], lb.cap);
     const uint32_t n = range.y - range.x;
     const int rounds = (int)((n + RG_BATCH - 1) / RG_BATCH);
@@ -190,6 +219,7 @@ __global__ void __launch_bounds__(RG_THREADS) __attribute__((amdgpu_waves_per_eu
         }
         if ((uint32_t)(RG_BATCH + tid) < n) g_ahead = point_list[range.x + RG_BATCH + tid];
         stage_all[tid] = rec;
+        s_mask[0][tid] = (uint16_t)region_mask(rec.xyh, qcx0, qcy0);
     }
     for (int i = 0; i < rounds; i++) {
         StagedSplat *const stage = stage_all + (i & 1) * RG_BATCH;
@@ -221,19 +251,21 @@ __global__ void __launch_bounds__(RG_THREADS) __attribute__((amdgpu_waves_per_eu
         uint16_t *const mine = lists[wave];
         int len = 0;
         if (!wave_done) {
-            const int nstaged = (int)min(n - first, (uint32_t)RG_BATCH);
+            const uint16_t *const masks = s_mask[i & 1];
 #pragma unroll
             for (int c = 0; c < RG_BATCH / 64; c++) {
                 const int s = c * 64 + lane;
-                const float4 p = stage[s].xyh;   // (entries past the list hold extents no region can meet)
-                const bool hit = s < nstaged && fabsf(p.x - rcx) <= p.z + 0.5f && fabsf(p.y - rcy) <= p.w + 0.5f;
+                const bool hit = (((uint32_t)masks[s] >> wave) & 1u) != 0u;   // (entries past the list hold extents no region can meet: mask 0)
                 const uint64_t m = __ballot(hit);
                 const int at = len + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 if (hit) mine[at] = (uint16_t)s;
                 len += __popcll(m);
             }
         }
-        if (loader && i + 1 < rounds) stage_all[((i + 1) & 1) * RG_BATCH + tid] = rec;
+        if (loader && i + 1 < rounds) {
+            stage_all[((i + 1) & 1) * RG_BATCH + tid] = rec;
+            s_mask[(i + 1) & 1][tid] = (uint16_t)region_mask(rec.xyh, qcx0, qcy0);
+        }
         if (wave_done) continue;   // (uniform; the wave has staged its share and meets the barriers)
         const float lastf = regions_walk(stage, mine, len, e, q, steps);
         if (lastf >= 0.0f) last_contributor = first + (uint32_t)lastf + 1u;
