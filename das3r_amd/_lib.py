@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdas3r_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
@@ -32,7 +32,7 @@ class RasterOut(C.Structure):
 
 class RasterSaved(C.Structure):
     _fields_ = [("geom", C.c_void_p), ("binning", C.c_void_p), ("img", C.c_void_p), ("num_rendered", C.c_int64), ("capacity", C.c_int64),
-                ("check_word", C.c_void_p), ("check_tag", C.c_uint32)]
+                ("check_word", C.c_void_p), ("check_tag", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class RasterGrads(C.Structure):

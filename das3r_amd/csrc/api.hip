@@ -77,7 +77,7 @@ static void load_switches() {
     w.fused_emit_off = (e = env("DAS3R_FUSED_EMIT")) && e[0] == '0';
     if ((e = env("DAS3R_RENDER"))) w.render_fwd = e[0] == 'q' ? 1 : (e[0] == 'r' ? 2 : (e[0] == 'l' ? 3 : (e[0] == 's' ? 4 : (e[0] == 'f' ? 5 : 0))));
     if ((e = env("DAS3R_RENDER_BWD"))) {   // dpp | mfma | scan[a][64|128|256|512]
-        w.render_bwd = e[0] == 'd' ? 1 : (e[0] == 'm' ? 2 : (strncmp(e, "stream", 6) == 0 ? 5 : (e[0] == 's' ? 3 : (e[0] == 'b' ? 6 : 0))));
+        w.render_bwd = e[0] == 'd' ? 1 : (e[0] == 'm' ? 2 : (strncmp(e, "stream", 6) == 0 ? 5 : (e[0] == 's' ? 3 : (e[0] == 'b' ? 6 : (e[0] == 'f' ? 7 : 0)))));
         if (w.render_bwd == 6) {
             const char *d = e;
             while (*d && (*d < '0' || *d > '9')) d++;
@@ -86,6 +86,12 @@ static void load_switches() {
             w.render_bwd_pix = pp ? atoi(pp + 1) : 0;
             const char *po = strchr(e, 'o');
             w.render_bwd_occ = po ? atoi(po + 1) : 5;
+        }
+        if (w.render_bwd == 7) {   // fine[<entries per round>]: render_bwd_rgn.hip
+            const char *d = e;
+            while (*d && (*d < '0' || *d > '9')) d++;
+            w.render_bwd_mb = *d ? atoi(d) : 128;
+            w.render_bwd_pix = strchr(e, 'q') ? 9 : (strchr(e, 's') ? 8 : 0);
         }
         if (w.render_bwd == 3) {
             const char *d = e;
@@ -297,6 +303,7 @@ struct Mailbox {
 // Everything the library remembers between calls, per host thread and per device (a thread that renders on two GPUs gets two
 // of these; nothing is shared between threads: any number of them may render concurrently, each on its own stream).
 constexpr uint32_t CHECK_SLOTS = 16, CHECK_WORD0 = 16, MAILBOX_BYTES = 4 * (CHECK_WORD0 + 2 * CHECK_SLOTS);
+constexpr uint32_t CROWDED16 = 23u * 16u;   // (api.hip bin_and_render)
 struct Verdict { int P, W, H; int64_t last_I, peak_I; int radix_left, backoff; uint32_t gen; int seg_extra; bool last_seg; bool fine; uint32_t forwards; };
 struct PerDevice {
     Mailbox mb;
@@ -438,6 +445,7 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     saved->capacity = 0;
     saved->check_word = nullptr;
     saved->check_tag = 0;
+    saved->flags = 0;
     if (!saved->geom || !saved->img) { set_error("scratch allocation failed (geom %zu B, img %zu B)", L.pub.geom_bytes, L.pub.img_bytes); return DAS3R_ERR_ALLOC; }
     if (P == 0) {
         // upstream:rasterize_points.cu skips the rasterizer when P == 0: the image stays zero (background NOT applied)
@@ -571,12 +579,18 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         LocalBin lb = {(float4 *)(saved->binning + L.b_ckpt), nullptr, nullptr, nullptr, nullptr, verdict.gen, (uint32_t)(P - 1), (uint32_t)cap};
         if (decide_fine && cap > 0 && use_quad_lanes(L, lb)) {   // (shapes the one-workgroup-per-tile kernel would take: few tiles, long lists)
             const uint32_t tag = ++mb->seq ? mb->seq : ++mb->seq;
-            if ((r = launch_list_skew(saved->img, L, (uint32_t)cap, mb->dev + 13, tag, a->debug != 0, s))) return r;
+            if ((r = launch_list_skew(saved->img, saved->binning, saved->geom, L, (uint32_t)cap, (uint32_t)(P - 1), mb->dev + 13, tag, a->debug != 0, s))) return r;
             if ((r = mailbox_wait(mb, 14, tag, s))) return r;
             const int64_t longest = (int64_t)mb->host[13], mean = (verdict.last_I > 0 ? verdict.last_I : cap) / std::max(L.ntiles, 1);   // (the last forward's count; the capacity on a shape's first)
-            verdict.fine = longest > mean + (mean * 4) / 5 && longest >= 4096;                 // 1.8 x the mean list: measured crossover (ledger (bd))
+            const uint32_t crowd16 = mb->host[15];   // of 64 consecutive list entries, those in the tile's fullest quadrant, x 16 (render_regions.hip list_skew_kernel)
+            // skewed: 1.8 x the mean list, the measured crossover of the forward kernels (ledger (bd)); crowded: a stretch of a list sits in part of
+            // its tile (random depths: 20 of 64 in the fullest quadrant) — there the 2x2-region kernels win both ways whatever the skew (ledger (be))
+            verdict.fine = (longest > mean + (mean * 4) / 5 && longest >= 4096) || crowd16 >= CROWDED16;
+            if (switches().verbose) fprintf(stderr, "[das3r] tile lists: longest %lld, mean %lld, %.1f of 64 consecutive entries in one quadrant -> %s kernels\n", (long long)longest,
+                                            (long long)mean, crowd16 / 16.0, verdict.fine ? "2x2-region" : "block");
         }
         lb.prefer_regions = verdict.fine;
+        if (verdict.fine && cap > 0 && use_quad_lanes(L, lb)) saved->flags |= 1u;   // (the backward pass of this forward: render_bwd.hip)
         if (local_order && cap > 0) {
             lb.point_list = (uint32_t *)(saved->binning + L.pub.point_list);
             lb.slot_list = (uint32_t *)(saved->binning + L.b_slot);
@@ -718,7 +732,7 @@ extern "C" int das3r_raster_backward(const das3r_raster_args *a, const das3r_ras
     bool quad_rows = false;
     if (saved->num_rendered > 0) {
         if (!saved->binning) { set_error("das3r_raster_backward: binning buffer missing"); return DAS3R_ERR_INVALID_ARG; }
-        if ((rc = launch_render_backward(a, dL_dpix, saved->geom, saved->binning, saved->img, L, partial, s, &quad_rows, saved->num_rendered))) return rc;
+        if ((rc = launch_render_backward(a, dL_dpix, saved->geom, saved->binning, saved->img, L, partial, s, &quad_rows, saved->num_rendered, saved->flags))) return rc;
     }
     return launch_preprocess_backward(a, in, saved->geom, saved->binning, L, g, partial, s, quad_rows);
 }

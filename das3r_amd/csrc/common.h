@@ -276,7 +276,8 @@ bool use_row_private(int64_t instances, int ntiles);  // forward: 4x4-block-per-
 bool use_quad_lanes(const Layout &L, const LocalBin &lb);   // forward: four lanes per pixel for few tiles with long lists (render_lanes.hip)
 int launch_render_forward_regions(const das3r_raster_args *a, float *out_color, char *geom, char *binning, char *img, const Layout &L, const LocalBin &lb,
                                   hipStream_t s);   // the same shapes: sixteen lanes per pixel, a wave per 2x2 region, four workgroups per tile (render_regions.hip)
-int launch_list_skew(const char *img, const Layout &L, uint32_t cap, uint32_t *mailbox_words /*{longest list, tag}*/, uint32_t tag, bool debug, hipStream_t s);
+int launch_list_skew(const char *img, const char *binning, const char *geom, const Layout &L, uint32_t cap, uint32_t last_g, uint32_t *mailbox_words, uint32_t tag,
+                     bool debug, hipStream_t s);
 int launch_render_forward_slices(const das3r_raster_args *a, float *out_color, char *geom, char *binning, char *img, const Layout &L, const LocalBin &lb,
                                  hipStream_t s);   // the same shapes, a block's list cut into chunks any wave takes (render_slices.hip)
 int launch_render_forward_lanes(const das3r_raster_args *a, float *out_color, char *geom, char *binning, char *img, const Layout &L,
@@ -295,6 +296,8 @@ int launch_render_backward_scan(const das3r_raster_args *a, const float *dL_dpix
 // 4x4 block per DPP row, pixel state in registers, fp32 accumulators (render_bwd_blk.hip)
 int launch_render_backward_blk(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
                                float *partial, int mb, int slices, hipStream_t s);
+int launch_render_backward_regions(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
+                               float *partial, int mb, int slices, hipStream_t s);   // render_bwd_rgn.hip
 constexpr int LOCAL_MAX = 1024;   // longest tile list the forward kernels sort in LDS
 // chained kernels (scan, radix passes) order their workgroups by ticket unless every workgroup of the grid is resident at once
 // (api.hip: grid_is_resident)
@@ -316,7 +319,7 @@ int launch_render_forward(const das3r_raster_args *a, const float *colors_precom
 // partial: [num_rendered, 9] per-instance sums written by the render backward, gathered by the preprocess backward
 // *quad_rows (out): false = partial[I][9], one row per instance; true = the stream kernel's rows[I][4][12] + existence bytes
 int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
-                           float *partial, hipStream_t s, bool *quad_rows, int64_t num_rendered);
+                           float *partial, hipStream_t s, bool *quad_rows, int64_t num_rendered, uint32_t fwd_flags /*das3r_raster_saved.flags*/);
 // pair_count.hip (measurement aid): out[0] += live pairs, out[1] += (pixel, list position) pairs below the pixel's n_contrib
 int launch_count_live_pairs(const das3r_raster_args *a, char *geom, char *binning, char *img, const Layout &L, unsigned long long *out, hipStream_t s);
 int launch_preprocess_backward(const das3r_raster_args *a, const das3r_raster_in *in, char *geom, char *binning, const Layout &L,

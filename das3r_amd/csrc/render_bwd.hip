@@ -163,10 +163,11 @@ __global__ void __launch_bounds__(256) render_backward_kernel(
 }
 
 int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, char *geom, char *binning, char *img, const Layout &L,
-                           float *partial, hipStream_t s, bool *quad_rows, int64_t num_rendered) {
+                           float *partial, hipStream_t s, bool *quad_rows, int64_t num_rendered, uint32_t fwd_flags) {
     *quad_rows = false;
     // Which decomposition (DAS3R_RENDER_BWD=dpp | mfma | scan<N> | scana<N> | stream forces one; measurements: DESIGN.md §4):
     //   dpp     pixel per lane, cross-lane reduction on the vector ALU (this file): lists of a few hundred entries per tile
+    //   fine    every DPP row of a wave on a 2x2 region's list, four pixel steps per batch (render_bwd_rgn.hip): long, spatially coherent lists
     //   blk     every DPP row of a wave on its own 4x4 block: lanes = 16 splats of the block's culled list, time = its 16 pixels,
     //           recurrences as DPP row scans, sums in fp32 registers (render_bwd_blk.hip): everything but short lists
     //   scan    lanes = 4 pixels x 16 splats of the QUADRANT's list, sums as split-bf16 products on the matrix cores
@@ -185,6 +186,13 @@ int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, cha
         const bool long_lists = mean_list >= 96;
         kind = (sw.bwd_reduce_set || sw.ablate_set || !long_lists) ? 1 : 6;
         mb = mean_list >= 1024 ? 192 : 128;
+        // round 6: long lists that the forward found spatially coherent or skewed (das3r_raster_saved.flags bit 0: the depth maps of a real
+        // sequence) take the 2x2-region walk — self-consistent Sintel-shaped job: backward 0.548 -> 0.414 ms, dsc 0.865 -> 0.590; random depths
+        // stay on the block walk (ds 0.50 against 0.55, noise-depth train step 0.344 against 0.369)
+        if (kind == 6 && mean_list >= 1024 && L.ntiles <= 1024 && (fwd_flags & 1u) && !sw.ablate_set) {
+            kind = 7;
+            mb = 128;
+        }
         if (sw.deterministic && kind == 1) {   // short lists too on the block walk: every sum has a fixed order (rows 0..3 of a wave, waves 0..3)
             kind = 6;
             mb = 64;
@@ -202,13 +210,14 @@ int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, cha
         return DAS3R_ERR_INVALID_ARG;
     }
 #endif
-    if (kind == 3 || kind == 6) {
+    if (kind == 3 || kind == 6 || kind == 7) {
         // long lists are replayed bucket by bucket in parallel workgroups (checkpoints from the forward: common.h BUCKET); slices =
         // buckets of an average tile, so that a tile's workgroups take about one bucket each
         int slices = sw.bwd_buckets;
         if (slices < 0) slices = (int)std::min<int64_t>(32, std::max<int64_t>(1, num_rendered / ((int64_t)BUCKET * std::max(L.ntiles, 1))));
         if (slices > 1 && mb > 256) slices = 1;
         if (kind == 6) return launch_render_backward_blk(a, dL_dpix, geom, binning, img, L, partial, mb, slices, s);
+        if (kind == 7) return launch_render_backward_regions(a, dL_dpix, geom, binning, img, L, partial, mb, slices, s);
         return launch_render_backward_scan(a, dL_dpix, geom, binning, img, L, partial, mb, slices, s);
     }
     const bool use_dpp = !sw.bwd_reduce_shfl;   // "shfl" selects the ds_bpermute reference reduction (diagnostics)

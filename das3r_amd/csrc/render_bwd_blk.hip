@@ -309,15 +309,8 @@ __global__ void __launch_bounds__(256, OCC) render_backward_blk_kernel(
                         if (a[0] == 123.456f) rowp[0] = a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7] + a[8];
                         continue;
                     }
-                    rowp[0] = a[0];
-                    rowp[1] = a[1];
-                    rowp[2] = a[2];
-                    rowp[3] = (Sgx * co.x + Sgy * co.y) * (float)W;        // dL/dmean2D in NDC units: 2 * (W / 2)
-                    rowp[4] = (Sgy * co.z + Sgx * co.y) * (float)H;
-                    rowp[5] = kh * a[6];
-                    rowp[6] = kh * a[7];
-                    rowp[7] = kh * a[8];
-                    rowp[8] = a[3];
+                    store_partial_row(rowp, a[0], a[1], a[2], (Sgx * co.x + Sgy * co.y) * (float)W /*dL/dmean2D in NDC units: 2 * (W / 2)*/,
+                                      (Sgy * co.z + Sgx * co.y) * (float)H, kh * a[6], kh * a[7], kh * a[8], a[3]);
                 }
             }
             __syncthreads();   // stage / s_slot / the lists are free for the next round

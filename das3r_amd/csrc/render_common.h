@@ -223,6 +223,21 @@ __device__ __forceinline__ bool block_hit_oct(const float x, const float y, cons
            (fabsf(ddx - ddy) * RS2 <= hd2 + HALF_DIAG);
 }
 
+// ---- 2x2 regions of an 8x8 quadrant (forward: render_regions.hip, backward: render_bwd_rgn.hip) ----------------------------------
+// Which of a quadrant's sixteen 2x2 regions (bit 4 ry + rx; region centres qcx0 + 2 rx, qcy0 + 2 ry) can the entry reach?  The test of every
+// forward kernel — |centre distance| <= cull half extent + half the region — evaluated ONCE per entry by the thread that stages it
+// (eight compares) instead of once per entry and wave: a wave's cull is then a bit test.  Entries past the list carry extents nobody meets.
+__device__ __forceinline__ uint32_t region_mask(const float4 p, const float qcx0, const float qcy0) {
+    uint32_t xb = 0, yb = 0;
+    const float hx = p.z + 0.5f, hy = p.w + 0.5f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        xb |= (fabsf(p.x - (qcx0 + (float)(2 * k))) <= hx ? 1u : 0u) << k;
+        yb |= (fabsf(p.y - (qcy0 + (float)(2 * k))) <= hy ? 1u : 0u) << k;
+    }
+    return ((yb & 1u) ? xb : 0u) | ((yb & 2u) ? xb << 4 : 0u) | ((yb & 4u) ? xb << 8 : 0u) | ((yb & 8u) ? xb << 12 : 0u);
+}
+
 // ---- checkpoints of long tile lists (common.h: BUCKET) -----------------------------------------------------------------------
 // A tile whose list has len > BUCKET entries owns nb = ceil(len / BUCKET) slots of 256 float4 (one per pixel, row-major inside the
 // tile), the first at block  range.x / BUCKET + tile  (distinct tiles never overlap: floor(a + b) >= floor(a) + floor(b)).

@@ -90,20 +90,7 @@ __device__ __forceinline__ uint32_t row_max_u32(uint32_t v) {
     return v;
 }
 
-// Which of a quadrant's sixteen 2x2 regions (bit 4 ry + rx; region centres qcx0 + 2 rx, qcy0 + 2 ry) can the entry reach?  The test of every
-// forward kernel — |centre distance| <= cull half extent + half the region — evaluated ONCE per entry by the thread that stages it
-// (eight compares) instead of once per entry and wave: a wave's cull is then a bit test.  Entries past the list carry extents nobody meets.
-__device__ __forceinline__ uint32_t region_mask(const float4 p, const float qcx0, const float qcy0) {
-    uint32_t xb = 0, yb = 0;
-    const float hx = p.z + 0.5f, hy = p.w + 0.5f;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        xb |= (fabsf(p.x - (qcx0 + (float)(2 * k))) <= hx ? 1u : 0u) << k;
-        yb |= (fabsf(p.y - (qcy0 + (float)(2 * k))) <= hy ? 1u : 0u) << k;
-    }
-    return ((yb & 1u) ? xb : 0u) | ((yb & 2u) ? xb << 4 : 0u) | ((yb & 4u) ? xb << 8 : 0u) | ((yb & 8u) ? xb << 12 : 0u);
-}
-
+// (region_mask: render_common.h — shared with the backward of render_bwd_rgn.hip)
 // state of a row's pixel: T and live are the same in its sixteen lanes; C and the last contributor are per-lane partial results
 struct RowLane {
     float T, live, C0, C1, C2, pxf, pyf, ef;   // ef: my slot in a step, 0 .. 15
@@ -288,27 +275,57 @@ __global__ void __launch_bounds__(RG_THREADS) __attribute__((amdgpu_waves_per_eu
     }
 }
 
-// The longest tile list of a forward, delivered to the host (pinned mailbox: {value, tag}): what the choice between one workgroup per tile
-// and four is made from (api.hip).  One workgroup; the tile ranges are complete (this runs behind tile_ranges_kernel on the stream).
-__global__ void __launch_bounds__(256) list_skew_kernel(const uint2 *__restrict__ ranges, int ntiles, uint32_t cap, uint32_t *__restrict__ out, uint32_t tag) {
-    __shared__ uint32_t s_max[4];
-    uint32_t m = 0;
+// Two numbers about a forward's tile lists, delivered to the host (pinned mailbox: {longest, tag, crowding}) — what the choice between the
+// compositing kernels for long lists is made from (api.hip): the LONGEST list (one workgroup per tile lasts as long as its longest tile), and
+// how CROWDED a stretch of a list is on the screen: of 64 consecutive entries from the middle of every list of >= 256 entries, how many have
+// their centre in the most popular 8x8 quadrant of the tile (mean over the tiles, in 1/64).  A tile's list is in depth order; on random depths
+// the four quadrants share a stretch evenly (the fullest holds ~20 of 64), on the depth maps of a real sequence a depth slab is a band or a
+// corner of the tile — the kernels with a wave per quadrant then leave three waves waiting for one at every barrier.  Integer sums in a fixed
+// order: the same lists give the same numbers.  One workgroup; the lists are complete (this runs behind the last binning kernel on the stream).
+__global__ void __launch_bounds__(256) list_skew_kernel(const uint2 *__restrict__ ranges, int ntiles, int tiles_x, uint32_t cap, const uint32_t *__restrict__ point_list,
+                                                        const float4 *__restrict__ xyh, uint32_t last_g, uint32_t *__restrict__ out, uint32_t tag) {
+    __shared__ uint32_t s_max[4], s_crowd[4], s_cnt[4];
+    uint32_t m = 0, crowd = 0, cnt = 0;
     for (int t = threadIdx.x; t < ntiles; t += 256) {
         const uint2 r = safe_range(ranges[t], cap);
-        m = max(m, r.y - r.x);
+        const uint32_t n = r.y - r.x;
+        m = max(m, n);
+        if (n >= 256u) {
+            const uint32_t at = r.x + n / 2u;
+            const float cx = (float)((t % tiles_x) * TILE_X + 8), cy = (float)((t / tiles_x) * TILE_Y + 8);
+            uint32_t q[4] = {0u, 0u, 0u, 0u};
+            for (int k = 0; k < 64; k++) {
+                const float4 b = xyh[(size_t)min(point_list[at + k], last_g) * SPLAT_REC];
+                const bool right = b.x >= cx, low = b.y >= cy;
+                q[0] += (!right && !low) ? 1u : 0u;
+                q[1] += (right && !low) ? 1u : 0u;
+                q[2] += (!right && low) ? 1u : 0u;
+                q[3] += (right && low) ? 1u : 0u;
+            }
+            crowd += max(max(q[0], q[1]), max(q[2], q[3]));
+            cnt += 1u;
+        }
     }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+    for (int o = 32; o >= 1; o >>= 1) {
+        m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+        crowd += (uint32_t)__shfl_xor((int)crowd, o, 64);
+        cnt += (uint32_t)__shfl_xor((int)cnt, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { s_max[threadIdx.x >> 6] = m; s_crowd[threadIdx.x >> 6] = crowd; s_cnt[threadIdx.x >> 6] = cnt; }
     __syncthreads();
     if (threadIdx.x == 0) {
+        const uint32_t c = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3], d = s_crowd[0] + s_crowd[1] + s_crowd[2] + s_crowd[3];
         __hip_atomic_store(out, max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(out + 1, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // (the value first)
+        __hip_atomic_store(out + 2, c ? (d * 16u) / c : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (entries of 64 in the fullest quadrant, x 16)
+        __hip_atomic_store(out + 1, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // (the values first)
     }
 }
 
-int launch_list_skew(const char *img, const Layout &L, uint32_t cap, uint32_t *mailbox_words, uint32_t tag, bool debug, hipStream_t s) {
-    DAS3R_LAUNCH(list_skew_kernel, dim3(1), dim3(256), 0, s, (const uint2 *)(img + L.pub.ranges), L.ntiles, cap, mailbox_words, tag);
+int launch_list_skew(const char *img, const char *binning, const char *geom, const Layout &L, uint32_t cap, uint32_t last_g, uint32_t *mailbox_words, uint32_t tag,
+                     bool debug, hipStream_t s) {
+    DAS3R_LAUNCH(list_skew_kernel, dim3(1), dim3(256), 0, s, (const uint2 *)(img + L.pub.ranges), L.ntiles, L.tiles_x, cap, (const uint32_t *)(binning + L.pub.point_list),
+                 (const float4 *)(geom + L.pub.xy), last_g, mailbox_words, tag);
     KERNEL_CHECK(s, debug, "list_skew");
     return DAS3R_OK;
 }

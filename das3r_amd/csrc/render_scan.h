@@ -9,6 +9,17 @@ namespace das3r {
 constexpr int NACC = 9;   // C0, C1, C2, M0, Mu, Mv, Muu, Muv, Mvv
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// One row of partial[] (nine floats, 4-byte aligned: the row stride is 36 bytes) leaves as 16 + 16 + 4 bytes instead of nine scattered words:
+// the rows of a tile's entries lie anywhere in the buffer (slots are handed out in splat or depth order), every lane's store is its own
+// request, and a third as many of them go through the memory pipeline.  (global_store_dwordx4 needs dword alignment only.)
+typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void store_partial_row(float *__restrict__ rowp, const float r0, const float r1, const float r2, const float r3, const float r4,
+                                                  const float r5, const float r6, const float r7, const float r8) {
+    *reinterpret_cast<v4f_u *>(rowp) = v4f_u{r0, r1, r2, r3};
+    *reinterpret_cast<v4f_u *>(rowp + 4) = v4f_u{r4, r5, r6, r7};
+    rowp[8] = r8;
+}
+
 struct PixRow {   // one pixel of a wave's quadrant (32 B, two ds_read_b128)
     float dLp0, dLp1, dLp2, tfbg;   // dL/dpixel, T_final * (bg . dL/dpixel)
     float T, R;                     // replay state (render_common.h: ReplayState)

@@ -165,6 +165,7 @@ class _Capacity(int):
     (das3r_raster_saved.check_word / check_tag) to the backward pass and to `check_forward`."""
     check_word = None
     check_tag = 0
+    flags = 0   # das3r_raster_saved.flags of the forward (which compositing kernels its lists call for)
 
 
 def check_forward(capacity, device):
@@ -225,7 +226,7 @@ def _forward_full(rs, means3D, sh, colors_precomp, opacities, scales, rotations,
     empty = torch.empty(0, dtype=torch.uint8, device=device)
     bufs = alloc.take()
     cap = _Capacity(saved.capacity)
-    cap.check_word, cap.check_tag = saved.check_word, int(saved.check_tag)
+    cap.check_word, cap.check_tag, cap.flags = saved.check_word, int(saved.check_tag), int(saved.flags)
     return (int(rc), color, radii, bufs.get("geom", empty), bufs.get("binning", empty), bufs.get("img", empty), cap)
 
 
@@ -259,6 +260,7 @@ def _backward_impl(rs, num_rendered, grad_out_color, means3D, sh, colors_precomp
     saved.capacity = capacity
     if getattr(ticket, "check_tag", 0):   # the forward's binning self-check is examined before the backward launches anything
         saved.check_word, saved.check_tag = ticket.check_word, ticket.check_tag
+    saved.flags = int(getattr(ticket, "flags", 0))
     g = _lib.RasterGrads()
     g.dL_dmeans2D, g.dL_dopacities, g.dL_dmeans3D = g_means2D.data_ptr(), g_opac.data_ptr(), g_means3D.data_ptr()
     g.dL_dshs = _ptr(g_sh)

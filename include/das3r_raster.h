@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define DAS3R_ABI_VERSION 13
+#define DAS3R_ABI_VERSION 14
 
 typedef enum {
     DAS3R_OK = 0,
@@ -117,6 +117,10 @@ typedef struct {
     int64_t capacity;        /* instances the binning buffer was laid out for (>= num_rendered) */
     void *check_word;        /* HOST address of the {flags, tag} word this forward's binning self-check is delivered to ... */
     uint32_t check_tag;      /* ... and the tag that marks it as this forward's (0: nothing to check) */
+    uint32_t flags;          /* ABI 14 (in what was the struct's tail padding: size and offsets unchanged).  Bit 0: this forward's tile lists are
+                              * long and spatially coherent or skewed (a real sequence's depth maps) — it was composited by the 2x2-region kernel
+                              * and its backward pass takes the 2x2-region kernel too (render_regions.hip / render_bwd_rgn.hip).  A caller that
+                              * rebuilds this struct for the backward call hands the forward's value back; 0 is always valid (block walk). */
 } das3r_raster_saved;
 
 /* Gradient outputs of backward.  Every buffer is fully written by the call (no pre-zeroing needed). */

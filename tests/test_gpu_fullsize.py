@@ -132,14 +132,20 @@ def test_steady_state_full_size_vs_oracle(name):
     workload DESIGN.md calls the shape that matters: the only one that takes the third partition pass by itself and where the block-level
     last contributor drops a fifth of the listed pairs).  Third forward + backward of the shape: image, radii, num_rendered, every
     gradient in the max norm and element by element (tests/util.py tolerances), and the kernels that ran are the steady-state ones:
-    segment_sort_kernel (no global depth sort), render_forward_lanes_kernel, the bucket-parallel render_backward_blk_kernel
-    instantiation with the block-level last contributor, 2 partition passes on `ds`, 3 on `dsc`.
+    segment_sort_kernel (no global depth sort), render_forward_lanes_kernel + the bucket-parallel render_backward_blk_kernel instantiation
+    with the block-level last contributor on `ds`, the 2x2-region kernels (render_regions.hip, render_bwd_rgn.hip) on `dsc`, 2 partition
+    passes on `ds`, 3 on `dsc`.
     Replaces upstream:rasterizer_impl.cu forward()/backward() as called at /root/reference/gaussian_renderer/__init__.py:131-140."""
     sc, kernels, (I, color, radii, geom, binning, img, cap, g) = _steady_state(name)
     assert _launches(kernels, "segment_sort_kernel") == 1, kernels
     assert _launches(kernels, "depth_hist_kernel") == 0, kernels
-    assert _launches(kernels, "render_forward_lanes_kernel") == 1 and _launches(kernels, "render_forward_rows_kernel") == 0, kernels
-    assert _launches(kernels, "render_backward_blk_kernel", "true>") == 1 and _launches(kernels, "render_backward_") == 1, kernels
+    # round 6: the compositing kernels follow the lists — random depths (`ds`): one workgroup per tile forward, the block walk backward;
+    # a depth slab that crowds into part of its tile (`dsc`, every real sequence; api.hip CROWDED16): the 2x2-region kernels both ways
+    fwd, bwd = ("render_forward_regions_kernel", "render_backward_regions_kernel") if name == "dsc" else ("render_forward_lanes_kernel", "render_backward_blk_kernel")
+    assert _launches(kernels, fwd) == 1 and _launches(kernels, "render_forward_") == 1, kernels
+    assert _launches(kernels, bwd) == 1 and _launches(kernels, "render_backward_") == 1, kernels
+    if name == "ds":
+        assert _launches(kernels, "render_backward_blk_kernel", "true>") == 1, kernels   # (the instantiation with the block-level last contributor)
     assert _launches(kernels, "onesweep_pass_kernel") == (3 if name == "dsc" else 2), kernels
     assert int(cap) > I, "the steady state lays the binning buffer out speculatively"
     mode = dict(colors_precomp=False, cov3D_precomp=False, scale_modifier=1.0)
@@ -159,12 +165,13 @@ def test_steady_state_full_size_lists_bit_exact(name, monkeypatch):
     """The same third pass with upstream's 3-sigma square as the binning rectangle (DAS3R_RECT=upstream): the instance count, every
     per-tile list in (depth, index) order and every tile range equal the oracle's BIT FOR BIT at full size — the segmented path's key
     (tile id | depth bucket | fraction), its speculative capacity and the in-LDS segment sort against the stable 64-bit sort of
-    upstream:rasterizer_impl.cu — and n_contrib / final_T of the four-lanes forward against the oracle's walk."""
+    upstream:rasterizer_impl.cu — and n_contrib / final_T of the forward that ran (four lanes per pixel on `ds`, sixteen on `dsc`)
+    against the oracle's walk."""
     from das3r_amd import _lib
     monkeypatch.setenv("DAS3R_RECT", "upstream")
     sc, kernels, (I, color, radii, geom, binning, img, cap, g) = _steady_state(name)
     assert _launches(kernels, "segment_sort_kernel") == 1 and _launches(kernels, "depth_hist_kernel") == 0, kernels
-    assert _launches(kernels, "render_forward_lanes_kernel") == 1, kernels
+    assert _launches(kernels, "render_forward_regions_kernel" if name == "dsc" else "render_forward_lanes_kernel") == 1, kernels   # (round 6: `dsc`'s crowded lists)
     mode = dict(colors_precomp=False, cov3D_precomp=False, scale_modifier=1.0)
     ref_color, ref_radii, _, S = util.run_oracle(sc, mode, backward=False)
     assert I == S["num_rendered"]

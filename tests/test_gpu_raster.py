@@ -513,7 +513,8 @@ def test_deterministic_switch_gives_bit_identical_gradients(monkeypatch):
 
 
 SCAN_KINDS = ("scan64", "scan128", "scan256", "scana256",   # render_bwd_scan.hip: entries per round, private / atomic flush
-              "blk64", "blk128", "blk256")                  # render_bwd_blk.hip: 4x4 block per DPP row, entries per round
+              "blk64", "blk128", "blk256",                  # render_bwd_blk.hip: 4x4 block per DPP row, entries per round
+              "fine64", "fine128", "fine192")               # render_bwd_rgn.hip (round 6): 2x2 region per DPP row, entries per round
 EXPERIMENT_KINDS = ("mfma", "stream")                        # superseded kernels: only in `make EXPERIMENTS=1` builds of the library
 
 
@@ -544,7 +545,7 @@ def test_backward_kernels_agree(name, monkeypatch):
             util.assert_grad_close(out[kind][1][k].cpu().numpy(), out["dpp"][1][k].cpu().numpy(), f"{kind} vs dpp backward dL/d{k}", tol=5e-5)
 
 
-@pytest.mark.parametrize("kind", ["dpp", "mfma", "scan64", "scan128", "scan256", "scana256", "stream", "blk64", "blk128", "blk256"])
+@pytest.mark.parametrize("kind", ["dpp", "mfma", "scan64", "scan128", "scan256", "scana256", "stream", "blk64", "blk128", "blk256", "fine64", "fine128", "fine160", "fine192", "fine256"])
 @pytest.mark.parametrize("name", ["basic_deg3", "long_lists", "deep", "ragged_image", "culled"])
 def test_every_backward_kernel_vs_oracle(name, kind, monkeypatch):
     """Each backward compositing kernel on its own against the CPU oracle (the default one is covered on all variants above)."""
@@ -561,7 +562,7 @@ def test_every_backward_kernel_vs_oracle(name, kind, monkeypatch):
         util.assert_grad_elementwise(t.cpu().numpy(), ref_g[gmap[k]], f"{name} [{kind}] dL/d{k}", rtol=bars["rtol"], floor=bars["floor"], outliers=bars["outliers"])
 
 
-@pytest.mark.parametrize("kind", ["scan128", "scan256", "blk128", "blk256"])
+@pytest.mark.parametrize("kind", ["scan128", "scan256", "blk128", "blk256", "fine128", "fine192"])
 @pytest.mark.parametrize("slices", [2, 5])
 @pytest.mark.parametrize("name", ["deep", "long_lists", "basic_deg3"])
 def test_bucket_parallel_backward(name, kind, slices, monkeypatch):

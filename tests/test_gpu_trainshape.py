@@ -176,7 +176,8 @@ def test_sintel_shaped_steady_state_direct_step_vs_float64_host_and_c_oracle(dep
     per-Gaussian gradient: geometry="pose", nothing changes), then the THIRD forward + backward is held to the float64 host
     restatement with oracle/raster_oracle.c as its renderer: loss, frame PSNR, every parameter gradient, the pose gradient, the mask
     gradient — and the kernels that ran are the ones the train-step profiles show: segmented binning without a global depth sort,
-    render_forward_lanes_kernel, the bucket-parallel render_backward_blk_kernel with the block-level last contributor.
+    render_forward_lanes_kernel + the bucket-parallel render_backward_blk_kernel with the block-level last contributor on noise depth maps,
+    the 2x2-region kernels both ways on the smooth ones.
     Reference: /root/reference/train_gui.py:532-589 around gaussian_renderer/__init__.py:83-140."""
     from das3r_amd import _lib, fast_step
     model, cams, opt, P = _sintel_model(degree, depth)
@@ -211,7 +212,9 @@ def test_sintel_shaped_steady_state_direct_step_vs_float64_host_and_c_oracle(dep
     assert n("render_forward_lanes_kernel") + n("render_forward_regions_kernel") == 1 and n("render_forward_rows_kernel") == 0, kernels
     if depth == "noise":
         assert n("render_forward_lanes_kernel") == 1, kernels
-    assert n("render_backward_blk_kernel", "true>") == 1 and n("render_backward_") == 1, kernels
+        assert n("render_backward_blk_kernel", "true>") == 1 and n("render_backward_") == 1, kernels
+    else:   # (round 6: the backward follows the forward — skewed or crowded lists take the 2x2-region walk, render_bwd_rgn.hip)
+        assert n("render_forward_regions_kernel") == 1 and n("render_backward_regions_kernel") == 1 and n("render_backward_") == 1, kernels
     loss, psnr_frame = float(out8[0]), float(out8[4])
 
     host, d_loss, d_psnr, d_m2d = _host_step(model, cams, uid, degree, monkeypatch)

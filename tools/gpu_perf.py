@@ -36,6 +36,7 @@ def main():
                 saved_env[k] = os.environ.get(k)
                 os.environ[k] = v
             _lib.reload_switches()
+            _lib.forget_shapes()   # (what the library learnt about the previous workload of the same size does not apply)
 
             def step():
                 I, color, radii, geom, binning, img, cap = _forward_full(rs, sc.means3D, sc.shs, e, sc.opacities, sc.scales, sc.rotations, e)
@@ -63,6 +64,11 @@ def main():
             print(f"== {w} [{var or 'default'}] P={sc.P} I={I} step(wall, uninstrumented)={wall:.4f} ms  sum(kernels)={tot:.4f} ms")
             for name, (n, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1]):
                 print(f"   {name:32s} {ms / args.steps:9.4f} ms/step  ({n // args.steps} launches)")
+            _lib.pair_counters(True)
+            step()
+            torch.cuda.synchronize()
+            pc = _lib.pair_counters(False)
+            print(f"   pair slots per instance: forward {pc['fwd_pairs'] / max(I, 1):.1f}  backward {pc['bwd_pairs'] / max(I, 1):.1f}")
             for k, v in saved_env.items():
                 if v is None:
                     os.environ.pop(k, None)
