@@ -21,9 +21,15 @@ class RasterArgs(C.Structure):
                 ("prefiltered", C.c_int32), ("debug", C.c_int32), ("capacity_hint", C.c_int64)]
 
 
+class PreTransform(C.Structure):
+    """include/das3r_raster.h das3r_pretransform (ABI 14): raw model parameters + pose, taken by the rasterizer's own kernels."""
+    _fields_ = [("xyz", C.c_void_p), ("rot", C.c_void_p), ("scaling", C.c_void_p), ("opacity_raw", C.c_void_p), ("conf_flat", C.c_void_p),
+                ("mask_index", C.c_void_p), ("R", C.c_void_p), ("t", C.c_void_p), ("Lq", C.c_void_p)]
+
+
 class RasterIn(C.Structure):
     _fields_ = [("means3D", C.c_void_p), ("opacities", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
-                ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p)]
+                ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("pre", C.POINTER(PreTransform))]
 
 
 class RasterOut(C.Structure):

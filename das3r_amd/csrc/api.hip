@@ -251,10 +251,14 @@ static int validate(const das3r_raster_args *a, const das3r_raster_in *in) {
     }
     if (a->P == 0) return DAS3R_OK;
     if (!a->bg || !a->viewmatrix || !a->projmatrix || !a->campos) { set_error("bg/viewmatrix/projmatrix/campos must be device pointers"); return DAS3R_ERR_INVALID_ARG; }
-    if (!in->means3D || !in->opacities) { set_error("means3D/opacities are required"); return DAS3R_ERR_INVALID_ARG; }
+    if (in->pre) {   // ABI 14: raw parameters + pose; the camera-frame tensors are not looked at
+        const das3r_pretransform *p = in->pre;
+        if (!p->xyz || !p->rot || !p->scaling || !p->opacity_raw || !p->conf_flat || !p->R || !p->t || !p->Lq) { set_error("das3r_raster_in.pre: xyz / rot / scaling / opacity_raw / conf_flat / R / t / Lq are required"); return DAS3R_ERR_INVALID_ARG; }
+        if (in->cov3D_precomp) { set_error("das3r_raster_in.pre excludes cov3D_precomp"); return DAS3R_ERR_INVALID_ARG; }
+    } else if (!in->means3D || !in->opacities) { set_error("means3D/opacities are required"); return DAS3R_ERR_INVALID_ARG; }
     if ((in->shs != nullptr) == (in->colors_precomp != nullptr)) { set_error("Please provide excatly one of either SHs or precomputed colors!"); return DAS3R_ERR_INVALID_ARG; }
-    const bool sr = in->scales != nullptr && in->rotations != nullptr;
-    if ((in->scales != nullptr) != (in->rotations != nullptr) || sr == (in->cov3D_precomp != nullptr)) {
+    const bool sr = in->pre != nullptr || (in->scales != nullptr && in->rotations != nullptr);
+    if ((!in->pre && (in->scales != nullptr) != (in->rotations != nullptr)) || sr == (in->cov3D_precomp != nullptr)) {
         set_error("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
         return DAS3R_ERR_INVALID_ARG;
     }

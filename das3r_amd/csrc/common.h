@@ -5,6 +5,7 @@
 #include <stdio.h>
 
 #include "../../include/das3r_raster.h"
+#include "pretransform_math.h"
 
 #define TILE_X 16
 #define TILE_Y 16
@@ -274,6 +275,16 @@ int launch_onesweep_partition(int64_t cap, char *geom, char *binning, const Layo
                               uint32_t *ghist_override = nullptr, uint32_t *err_override = nullptr);
 bool use_row_private(int64_t instances, int ntiles);  // forward: 4x4-block-per-row kernel for long tile lists (render_rows.hip)
 bool use_quad_lanes(const Layout &L, const LocalBin &lb);   // forward: four lanes per pixel for few tiles with long lists (render_lanes.hip)
+// das3r_raster_in.pre -> the device-side view the per-Gaussian kernels take by value (pretransform_math.h); all null when the caller handed
+// over camera-frame tensors
+inline PreXform pre_xform(const das3r_raster_in *in) {
+    PreXform x = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (in && in->pre) {
+        const das3r_pretransform *p = in->pre;
+        x = PreXform{p->xyz, p->rot, p->scaling, p->opacity_raw, p->conf_flat, p->mask_index, p->R, p->t, p->Lq};
+    }
+    return x;
+}
 int launch_render_forward_regions(const das3r_raster_args *a, float *out_color, char *geom, char *binning, char *img, const Layout &L, const LocalBin &lb,
                                   hipStream_t s);   // the same shapes: sixteen lanes per pixel, a wave per 2x2 region, four workgroups per tile (render_regions.hip)
 int launch_list_skew(const char *img, const char *binning, const char *geom, const Layout &L, uint32_t cap, uint32_t last_g, uint32_t *mailbox_words, uint32_t tag,

@@ -11,6 +11,7 @@
 #include "granule.h"
 #include "segkey.h"
 #include "splat_math.h"
+#include "pretransform_math.h"
 
 namespace das3r {
 
@@ -26,7 +27,8 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     uint32_t zero_b_words, uint32_t *__restrict__ zero_c, uint32_t zero_c_words, unsigned long long *__restrict__ arrive,
     uint32_t *__restrict__ host_out, uint32_t tag, const EmitArgs em,
     uint32_t *__restrict__ dhist /*segmented binning path: 256-bin depth histogram of this forward, zeroed by the caller (segkey.h); else null*/,
-    uint32_t dhist_mask /*a pseudo-random 1 / (mask + 1) of the workgroups contribute (`sampled` below): a sample is all the bucket map needs*/) {
+    uint32_t dhist_mask /*a pseudo-random 1 / (mask + 1) of the workgroups contribute (`sampled` below): a sample is all the bucket map needs*/,
+    const PreXform pre /*xyz != null (round 6, das3r_raster_in.pre): the raw parameters + the pose; means3D / scales / rotations / opacities are not read*/) {
     const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
     // Which workgroups sample the depth histogram: a full-avalanche hash of the index (round 5).  "Every (mask + 1)-th workgroup" is a
     // biased sample of a DAS3R model — its Gaussians are the pixels of its frames in row-major order, 256 of them are half an image row, and
@@ -43,17 +45,32 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     // workgroup instead of two back to back (the kernel spent 77 % of its wave cycles parked on s_waitcnt at 1 M splats).
     const bool live = gidx < P;   // lanes past the end stay alive (workgroup-wide reduction below): they redo the last splat and store nothing
     const int idx = live ? gidx : P - 1;
-    const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
-    const float op = opacities[idx];
-    float3 s_in = make_float3(0.f, 0.f, 0.f);
+    float3 p, s_in = make_float3(0.f, 0.f, 0.f);
+    float op;
     float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
     float c3_in[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (HAS_COV) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) c3_in[i] = cov3D_precomp[6 * idx + i];
+    if (!HAS_COV && pre.xyz != nullptr) {   // (uniform) the pose pre-transform on the way in: pretransform_math.h, the bits of pretransform_forward_kernel
+        PoseRegs pose;
+        load_pose(pre.Rm, pre.tv, pre.Lq, pose);
+        const float rx = pre.xyz[3 * idx], ry = pre.xyz[3 * idx + 1], rz = pre.xyz[3 * idx + 2];
+        const float4 rq = reinterpret_cast<const float4 *>(pre.rot)[idx];
+        const float r0 = pre.scaling[3 * idx], r1 = pre.scaling[3 * idx + 1], r2 = pre.scaling[3 * idx + 2];
+        const float ro = pre.opacity_raw[idx];
+        const float rc = pre.conf_flat[pre.mask_index ? pre.mask_index[idx] : (int64_t)idx];
+        p = pre_mean(pose, rx, ry, rz);
+        q_in = pre_rot(pose, rq);
+        s_in = make_float3(pre_scale(r0), pre_scale(r1), pre_scale(r2));
+        op = pre_opacity(ro, rc);
     } else {
-        s_in = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
-        q_in = reinterpret_cast<const float4 *>(rotations)[idx];
+        p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+        op = opacities[idx];
+        if (HAS_COV) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) c3_in[i] = cov3D_precomp[6 * idx + i];
+        } else {
+            s_in = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
+            q_in = reinterpret_cast<const float4 *>(rotations)[idx];
+        }
     }
     __shared__ uint32_t s_tiles;   // this workgroup's sum of tiles_touched (num_rendered is their grand total)
     if (threadIdx.x == 0) s_tiles = 0;
@@ -367,13 +384,14 @@ int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int
     uint32_t dhist_mask = 0u;   // sample the depth histogram from <= 512 workgroups spread pseudo-randomly over the grid
     while ((grid.x >> __builtin_popcount(dhist_mask)) > 512u) dhist_mask = (dhist_mask << 1) | 1u;
     const bool has_sh = in->shs != nullptr, has_cov = in->cov3D_precomp != nullptr;
+    const PreXform pre = pre_xform(in);
 #define ARGS                                                                                                              \
     P, a->sh_degree, a->M, in->means3D, in->scales, a->scale_modifier, in->rotations, in->opacities, in->shs,             \
         in->cov3D_precomp, in->colors_precomp, a->viewmatrix, a->projmatrix, a->campos, a->image_width, a->image_height,  \
         a->tanfovx, a->tanfovy, L.tiles_x, L.tiles_y, radii, (uint32_t *)(geom + L.g_keyA), (float4 *)(geom + L.pub.xy),  \
         (float4 *)(geom + L.pub.conic_opacity), (float4 *)(geom + L.pub.rgbd), (uint8_t *)(geom + L.pub.clamped),         \
         (uint32_t *)(geom + L.pub.tiles_touched), (uint32_t *)(geom + L.g_rect), (use_tight_rect() ? 1 : 0) | (a->prefiltered ? 2 : 0), (uint32_t *)(geom + L.g_ghist), (uint32_t)(L.g_ctrl_bytes / 4),                 \
-        (uint32_t *)(img + L.pub.ranges), (uint32_t)(2 * L.ntiles), (uint32_t *)binning_ctrl, (uint32_t)(binning_ctrl_bytes / 4), arrive, host_out, tag, em, dhist, dhist_mask
+        (uint32_t *)(img + L.pub.ranges), (uint32_t)(2 * L.ntiles), (uint32_t *)binning_ctrl, (uint32_t)(binning_ctrl_bytes / 4), arrive, host_out, tag, em, dhist, dhist_mask, pre
     const bool stage = has_sh && a->M == 16 && a->sh_degree >= 2 && ((uintptr_t)in->shs & 15) == 0 && !switches().no_sh_stage;
     if (has_sh && !has_cov && stage) DAS3R_LAUNCH((preprocess_kernel<true, false, true>), grid, block, 0, s, ARGS);
     else if (has_sh && has_cov && stage) DAS3R_LAUNCH((preprocess_kernel<true, true, true>), grid, block, 0, s, ARGS);

@@ -13,6 +13,7 @@
 //     backward is streamed (basis values -> LDS row) instead of holding two 48-float arrays in registers.
 #include "common.h"
 #include "splat_math.h"
+#include "pretransform_math.h"
 
 namespace das3r {
 
@@ -102,7 +103,8 @@ __global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
     const uint8_t *__restrict__ row_exists /*[I][4] or null*/, const uint32_t *__restrict__ off_by_gid,
     float *__restrict__ dL_dmeans2D /*[P,3] out*/, float *__restrict__ dL_dopacity /*[P] out*/,
     float *__restrict__ dL_dcolors_precomp /*[P,3] out, precomp mode*/, float *__restrict__ dL_dmeans3D,
-    float *__restrict__ dL_dscales, float *__restrict__ dL_drot, float *__restrict__ dL_dsh, float *__restrict__ dL_dcov3D
+    float *__restrict__ dL_dscales, float *__restrict__ dL_drot, float *__restrict__ dL_dsh, float *__restrict__ dL_dcov3D,
+    const PreXform pre /*xyz != null (das3r_raster_in.pre): the raw parameters + the pose, as in preprocess.hip*/
 #ifdef DAS3R_EXPERIMENTS
     , unsigned long long *__restrict__ trace /*common.h BLK_STAMP (tools/wg_trace.py), region 6*/
 #endif
@@ -120,16 +122,27 @@ __global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
     const int ic = idx < P ? idx : P - 1;
     const uint32_t ntiles_g = idx < P ? tiles_touched[ic] : 0u;
     const uint32_t e0_in = off_by_gid[ic];
-    const float3 mean_in = make_float3(means3D[3 * ic], means3D[3 * ic + 1], means3D[3 * ic + 2]);
-    float3 sc_in = make_float3(0.f, 0.f, 0.f);
+    float3 mean_in, sc_in = make_float3(0.f, 0.f, 0.f);
     float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
     float c3_in[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (HAS_COV) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) c3_in[i] = cov3D_precomp[6 * ic + i];
+    if (!HAS_COV && pre.xyz != nullptr) {   // (uniform) the forward's inputs again, from the raw parameters (pretransform_math.h: the same bits)
+        PoseRegs pose;
+        load_pose(pre.Rm, pre.tv, pre.Lq, pose);
+        const float rx = pre.xyz[3 * ic], ry = pre.xyz[3 * ic + 1], rz = pre.xyz[3 * ic + 2];
+        const float4 rq = reinterpret_cast<const float4 *>(pre.rot)[ic];
+        const float r0 = pre.scaling[3 * ic], r1 = pre.scaling[3 * ic + 1], r2 = pre.scaling[3 * ic + 2];
+        mean_in = pre_mean(pose, rx, ry, rz);
+        q_in = pre_rot(pose, rq);
+        sc_in = make_float3(pre_scale(r0), pre_scale(r1), pre_scale(r2));
     } else {
-        sc_in = make_float3(scales[3 * ic], scales[3 * ic + 1], scales[3 * ic + 2]);
-        q_in = reinterpret_cast<const float4 *>(rotations)[ic];
+        mean_in = make_float3(means3D[3 * ic], means3D[3 * ic + 1], means3D[3 * ic + 2]);
+        if (HAS_COV) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) c3_in[i] = cov3D_precomp[6 * ic + i];
+        } else {
+            sc_in = make_float3(scales[3 * ic], scales[3 * ic + 1], scales[3 * ic + 2]);
+            q_in = reinterpret_cast<const float4 *>(rotations)[ic];
+        }
     }
     const size_t blk4 = (size_t)blockIdx.x * 256 * 12;                    // first float4 of this workgroup's rows
     const size_t limit4 = (size_t)P * 12 > blk4 ? (size_t)P * 12 - blk4 : 0;  // float4s this workgroup owns
@@ -567,12 +580,13 @@ int launch_preprocess_backward(const das3r_raster_args *a, const das3r_raster_in
 #else
 #define PB_TRACE_ARG
 #endif
+    const PreXform pre = pre_xform(in);
 #define ARGS                                                                                                                 \
     P, a->sh_degree, a->M, in->means3D, in->scales, a->scale_modifier, in->rotations, in->shs, in->cov3D_precomp,            \
         a->viewmatrix, a->projmatrix, a->campos, a->image_width, a->image_height, a->tanfovx, a->tanfovy,                    \
         (const uint32_t *)(geom + L.pub.tiles_touched), (const uint8_t *)(geom + L.pub.clamped), partial, exists,        \
         (const uint32_t *)(geom + L.g_off_by_gid), g->dL_dmeans2D, g->dL_dopacities, g->dL_dcolors_precomp, g->dL_dmeans3D,  \
-        g->dL_dscales, g->dL_drotations, g->dL_dshs, g->dL_dcov3D PB_TRACE_ARG
+        g->dL_dscales, g->dL_drotations, g->dL_dshs, g->dL_dcov3D, pre PB_TRACE_ARG
 #define LAUNCH(SH, COV, SI, SO) DAS3R_LAUNCH((preprocess_backward_kernel<SH, COV, SI, SO>), grid, block, 0, s, ARGS)
 #define LAUNCH0(SH, COV) DAS3R_LAUNCH((preprocess_backward_kernel<SH, COV, false, false, true>), grid, block, 0, s, ARGS)
     const bool deg0 = a->sh_degree == 0 && !stage_out;

@@ -13,6 +13,7 @@
 
 #include "common.h"
 #include "adam_math.h"
+#include "pretransform_math.h"
 
 namespace das3r {
 
@@ -23,27 +24,17 @@ __global__ void __launch_bounds__(256) pretransform_forward_kernel(int P, const 
                                                                   const float *__restrict__ Lq, float *__restrict__ means3D,
                                                                   float *__restrict__ rotations, float *__restrict__ scales,
                                                                   float *__restrict__ opacities) {
-    float R[9], t[3], L[16];
-#pragma unroll
-    for (int i = 0; i < 9; i++) R[i] = Rm[i];
-#pragma unroll
-    for (int i = 0; i < 3; i++) t[i] = tv[i];
-#pragma unroll
-    for (int i = 0; i < 16; i++) L[i] = Lq[i];
+    PoseRegs pose;   // (pretransform_math.h: the arithmetic the rasterizer's own kernels repeat when they take the raw parameters)
+    load_pose(Rm, tv, Lq, pose);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x) {
-        const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
-        means3D[3 * (size_t)i] = R[0] * x + R[1] * y + R[2] * z + t[0];
-        means3D[3 * (size_t)i + 1] = R[3] * x + R[4] * y + R[5] * z + t[1];
-        means3D[3 * (size_t)i + 2] = R[6] * x + R[7] * y + R[8] * z + t[2];
-        const float4 q = reinterpret_cast<const float4 *>(rot)[i];
-        reinterpret_cast<float4 *>(rotations)[i] =
-            make_float4(L[0] * q.x + L[1] * q.y + L[2] * q.z + L[3] * q.w, L[4] * q.x + L[5] * q.y + L[6] * q.z + L[7] * q.w,
-                        L[8] * q.x + L[9] * q.y + L[10] * q.z + L[11] * q.w, L[12] * q.x + L[13] * q.y + L[14] * q.z + L[15] * q.w);
+        const float3 m = pre_mean(pose, xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]);
+        means3D[3 * (size_t)i] = m.x;
+        means3D[3 * (size_t)i + 1] = m.y;
+        means3D[3 * (size_t)i + 2] = m.z;
+        reinterpret_cast<float4 *>(rotations)[i] = pre_rot(pose, reinterpret_cast<const float4 *>(rot)[i]);
 #pragma unroll
-        for (int k = 0; k < 3; k++) scales[3 * (size_t)i + k] = expf(scaling[3 * (size_t)i + k]);
-        const float s = 1.0f / (1.0f + expf(-opacity_raw[i]));
-        const float c = conf_flat[mask_index ? mask_index[i] : (int64_t)i];
-        opacities[i] = s * c;
+        for (int k = 0; k < 3; k++) scales[3 * (size_t)i + k] = pre_scale(scaling[3 * (size_t)i + k]);
+        opacities[i] = pre_opacity(opacity_raw[i], conf_flat[mask_index ? mask_index[i] : (int64_t)i]);
     }
 }
 

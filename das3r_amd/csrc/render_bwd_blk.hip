@@ -160,17 +160,28 @@ __global__ void __launch_bounds__(256, OCC) render_backward_blk_kernel(
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // (wave-private rows)
             }
         }
+        uint32_t g_ahead = 0u, slot_ahead = 0u;   // my entry of the next round
+        if (tid < min(MB, (int)max_contrib)) {
+            const uint32_t pos = range.x + lo + max_contrib - 1 - tid;
+            g_ahead = point_list[pos];
+            slot_ahead = slot_list[pos];
+        }
         for (int i = 0; i < rounds; i++) {
             const int done_before = i * MB;
             const int n = min(MB, (int)max_contrib - done_before);
             // stage the round in reverse list order; entry j holds list position (lo + max_contrib - 1 - done_before - j)
-            for (int t = tid; t < n; t += TILE_PIX) {
-                const uint32_t pos = range.x + lo + max_contrib - 1 - done_before - t;
-                const uint32_t g = min(point_list[pos], last_g);
-                s_slot[t] = min(slot_list[pos], cap - 1u);
-                stage[t].xyh = xyh[(size_t)g * SPLAT_REC];           // one 64-byte record: a single cache line per splat
-                stage[t].co = conic_opacity[(size_t)g * SPLAT_REC];
-                stage[t].rgbd = rgbd[(size_t)g * SPLAT_REC];
+            // (MB <= 256: a thread stages at most one entry; round 6: its list words were requested a round ahead — staging is ONE trip to memory)
+            if (tid < n) {
+                const uint32_t g = min(g_ahead, last_g);
+                s_slot[tid] = min(slot_ahead, cap - 1u);
+                stage[tid].xyh = xyh[(size_t)g * SPLAT_REC];           // one 64-byte record: a single cache line per splat
+                stage[tid].co = conic_opacity[(size_t)g * SPLAT_REC];
+                stage[tid].rgbd = rgbd[(size_t)g * SPLAT_REC];
+            }
+            if (i + 1 < rounds && tid < min(MB, (int)max_contrib - done_before - MB)) {
+                const uint32_t pos = range.x + lo + max_contrib - 1 - (done_before + MB) - tid;
+                g_ahead = point_list[pos];
+                slot_ahead = slot_list[pos];
             }
             // the pixel's last contributor relative to the round's window: list position of entry j = base + (MB - 1 - j) with
             // base = lo + max_contrib - done_before - MB (may be negative); entry j takes part iff its position < n_contrib

@@ -146,14 +146,25 @@ def _forward_backward(st, model, cam, q_row, t_row, gq_row, gt_row, static_hw, l
     H, W = int(cam.image_height), int(cam.image_width)
     s = _stream(dev)
     # ---- pre-transform
-    means3D, rotations = torch.empty_like(model._xyz), torch.empty_like(model._rotation)
-    scales, opac = torch.empty_like(model._scaling), torch.empty(P, 1, device=dev)
     conf_flat = model._conf_static.view(-1)
     mats = st.mats
     _lib.check(lib.das3r_pose_matrices_qt(_p(q_row), _p(t_row), _p(mats), s), "das3r_pose_matrices_qt")
-    _lib.check(lib.das3r_pretransform_forward(P, _p(model._xyz), _p(model._rotation), _p(model._scaling), _p(model._opacity), _p(conf_flat),
-                                              st.mask_ptr, _p(mats), C.c_void_p(mats.data_ptr() + 36), C.c_void_p(mats.data_ptr() + 48),
-                                              _p(means3D), _p(rotations), _p(scales), _p(opac), s), "das3r_pretransform_forward")
+    pre = None
+    if getattr(model, "fuse_pretransform", True):
+        # round 6 (include/das3r_raster.h das3r_pretransform, ABI 14): the rasterizer's per-Gaussian kernels take the raw parameters and the pose —
+        # the camera-frame means / rotations / scales / opacities never reach memory, and the pre-transform kernel is not launched.  The four
+        # positional tensors below are placeholders of the right shapes (not read).  model.fuse_pretransform = False: the separate pass.
+        pre = _lib.PreTransform()
+        pre.xyz, pre.rot, pre.scaling, pre.opacity_raw = model._xyz.data_ptr(), model._rotation.data_ptr(), model._scaling.data_ptr(), model._opacity.data_ptr()
+        pre.conf_flat, pre.mask_index = conf_flat.data_ptr(), (st.mask_ptr.value if st.mask_ptr is not None else None)
+        pre.R, pre.t, pre.Lq = mats.data_ptr(), mats.data_ptr() + 36, mats.data_ptr() + 48
+        means3D, rotations, scales, opac = model._xyz, model._rotation, model._scaling, model._opacity
+    else:
+        means3D, rotations = torch.empty_like(model._xyz), torch.empty_like(model._rotation)
+        scales, opac = torch.empty_like(model._scaling), torch.empty(P, 1, device=dev)
+        _lib.check(lib.das3r_pretransform_forward(P, _p(model._xyz), _p(model._rotation), _p(model._scaling), _p(model._opacity), _p(conf_flat),
+                                                  st.mask_ptr, _p(mats), C.c_void_p(mats.data_ptr() + 36), C.c_void_p(mats.data_ptr() + 48),
+                                                  _p(means3D), _p(rotations), _p(scales), _p(opac), s), "das3r_pretransform_forward")
     # ---- the SH tensor of the active degree (das3r_amd.render: DC alone at degree 0, the active prefix below the maximum)
     deg = model.active_sh_degree
     K = (deg + 1) ** 2
@@ -165,7 +176,7 @@ def _forward_backward(st, model, cam, q_row, t_row, gq_row, gt_row, static_hw, l
         shs = torch.cat((model._features_dc, model._features_rest), dim=1)
     rs = _settings(st, cam, model, bg)
     e = st.e
-    I, image, radii, geom, binning, img, cap = _forward_full(rs, means3D, shs, e, opac, scales, rotations, e)
+    I, image, radii, geom, binning, img, cap = _forward_full(rs, means3D, shs, e, opac, scales, rotations, e, pre=pre)
     # ---- loss
     gt = _dense_f32(cam, "original_image")
     static_hw = static_hw if (static_hw.is_contiguous() and static_hw.dtype == torch.float32) else static_hw.contiguous().float()
@@ -181,7 +192,7 @@ def _forward_backward(st, model, cam, q_row, t_row, gq_row, gt_row, static_hw, l
                                               _p(d_static), s), "das3r_photometric_backward")
     # ---- rasterizer backward (examines the forward's binning self-check first: include/das3r_raster.h)
     g_means2D, _g_colors, g_opac, g_means3D, _g_cov, g_sh, g_scales, g_rot = _backward_impl(
-        rs, I, d_render, means3D, shs, e, opac, scales, rotations, e, geom, binning, img, cap)
+        rs, I, d_render, means3D, shs, e, opac, scales, rotations, e, geom, binning, img, cap, pre=pre)
     # ---- pre-transform backward, pose chain rule
     conf_grad = None
     if geometry == "pose":

@@ -127,11 +127,13 @@ def _fill_args(rs, P, M, device, keep):
     return a
 
 
-def _fill_in(means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp):
+def _fill_in(means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp, pre=None):
     i = _lib.RasterIn()
     i.means3D, i.opacities = _ptr(means3D), _ptr(opacities)
     i.shs, i.colors_precomp = _ptr(sh), _ptr(colors_precomp)
     i.scales, i.rotations, i.cov3D_precomp = _ptr(scales), _ptr(rotations), _ptr(cov3Ds_precomp)
+    if pre is not None:   # a _lib.PreTransform the caller keeps alive: the kernels take the pose pre-transform on their way in (ABI 14)
+        i.pre = C.pointer(pre)
     return i
 
 
@@ -187,7 +189,7 @@ def _forward_impl(rs, means3D, sh, colors_precomp, opacities, scales, rotations,
     return _forward_full(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, exact=True)[:6]
 
 
-def _forward_full(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, exact=False):
+def _forward_full(rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, exact=False, pre=None):
     """-> (num_rendered, color, radii, geom, binning, img, capacity); capacity >= num_rendered is what the binning buffer
     was laid out for (`_lib.layout(P, capacity, W, H)`), == num_rendered when `exact`."""
     lib = _lib.load()
@@ -215,7 +217,7 @@ def _forward_full(rs, means3D, sh, colors_precomp, opacities, scales, rotations,
     keep = []
     a = _fill_args(rs, P, M, device, keep)
     a.capacity_hint = -1 if exact else 0   # 0: the library may lay the binning buffer out with headroom (include/das3r_raster.h)
-    i = _fill_in(means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp)
+    i = _fill_in(means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp, pre)
     o = _lib.RasterOut()
     o.out_color, o.radii = color.data_ptr(), radii.data_ptr()
     saved = _lib.RasterSaved()
@@ -231,7 +233,7 @@ def _forward_full(rs, means3D, sh, colors_precomp, opacities, scales, rotations,
 
 
 def _backward_impl(rs, num_rendered, grad_out_color, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                   geom, binning, img, capacity=None, _scratch_misalign=0):
+                   geom, binning, img, capacity=None, _scratch_misalign=0, pre=None):
     ticket = capacity
     capacity = int(num_rendered) if capacity is None else int(capacity)
     lib = _lib.load()
@@ -253,7 +255,7 @@ def _backward_impl(rs, num_rendered, grad_out_color, means3D, sh, colors_precomp
     scratch = torch.empty(int(lib.das3r_raster_backward_scratch_bytes(max(capacity, 1))) + int(_scratch_misalign), dtype=torch.uint8, device=device)
     keep = []
     a = _fill_args(rs, P, M, device, keep)
-    i = _fill_in(means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp)
+    i = _fill_in(means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp, pre)
     saved = _lib.RasterSaved()
     saved.geom, saved.binning, saved.img = _ptr(geom), _ptr(binning), _ptr(img)
     saved.num_rendered = int(num_rendered)

@@ -41,7 +41,10 @@ ALIASES = {"render_forward_rows_kernel": "render_forward_kernel",     # several 
            "render_forward_lanes_kernel": "render_forward_kernel",
            "render_backward_mfma_kernel": "render_backward_kernel",    # (render_rows.hip, render_bwd_mfma.hip,
            "render_backward_scan_kernel": "render_backward_kernel",    #  render_bwd_scan.hip, render_bwd_blk.hip)
-           "render_backward_blk_kernel": "render_backward_kernel"}
+           "render_backward_blk_kernel": "render_backward_kernel",
+           "render_forward_regions_kernel": "render_forward_kernel",   # round 6: 2x2 regions (render_regions.hip, render_bwd_rgn.hip)
+           "render_forward_slices_kernel": "render_forward_kernel",
+           "render_backward_regions_kernel": "render_backward_kernel"}
 
 
 def group_kernel_times(report):

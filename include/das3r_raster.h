@@ -91,8 +91,24 @@ typedef struct {
                               * are reserved. */
 } das3r_raster_args;
 
+/* ABI 14, SURVEY.md section 8(f)-1: the raw parameters of a DAS3R model and the pose of the view — what das3r_pretransform_forward (below)
+ * turns into camera-frame tensors in a pass of its own (/root/reference/gaussian_renderer/__init__.py:83-97,107).  Handed to the rasterizer
+ * through das3r_raster_in.pre instead, the per-Gaussian kernels of forward AND backward take the transform on their way in (the same
+ * arithmetic bit for bit: csrc/pretransform_math.h): means3D / rotations / scales / opacities are never written to or read from memory.
+ * The backward still returns dL/d(camera-frame means3D, scales, rotations, opacities): das3r_pretransform_backward[_adam] consumes them. */
+typedef struct {
+    const float *xyz;            /* [P,3] */
+    const float *rot;            /* [P,4] */
+    const float *scaling;        /* [P,3] log scales */
+    const float *opacity_raw;    /* [P,1] logits */
+    const float *conf_flat;      /* confidence map, flattened */
+    const int64_t *mask_index;   /* [P] position of Gaussian i in conf_flat, or NULL = identity */
+    const float *R, *t, *Lq;     /* [3,3], [3], [4,4] row-major (das3r_pose_matrices[_qt]) */
+} das3r_pretransform;
+
 /* Inputs of GaussianRasterizer.forward.  Exactly one of shs/colors_precomp and exactly one of
- * (scales,rotations)/cov3D_precomp is non-NULL. */
+ * (scales,rotations)/cov3D_precomp is non-NULL — unless `pre` is given: then means3D, opacities, scales and rotations are ignored
+ * (may be NULL) and cov3D_precomp must be NULL. */
 typedef struct {
     const float *means3D;        /* [P,3] */
     const float *opacities;      /* [P,1] */
@@ -101,6 +117,7 @@ typedef struct {
     const float *scales;         /* [P,3]   or NULL (already activated) */
     const float *rotations;      /* [P,4]   or NULL (w,x,y,z), NOT normalised */
     const float *cov3D_precomp;  /* [P,6]   or NULL */
+    const das3r_pretransform *pre; /* ABI 14: NULL, or the raw parameters + pose (HOST struct of device pointers) */
 } das3r_raster_in;
 
 typedef struct {

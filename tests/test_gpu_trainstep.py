@@ -228,6 +228,39 @@ def test_direct_and_autograd_forms_stay_locked_through_a_degree_bump_and_gate_fl
         assert float(far.double().mean()) <= 2e-3, (k, float(far.double().mean()))
 
 
+@pytest.mark.parametrize("generic", [True, False])
+def test_pretransform_inside_the_rasterizer_kernels_is_bit_identical_to_the_separate_pass(generic):
+    """Round 6 (include/das3r_raster.h das3r_pretransform): the direct iteration hands the rasterizer the RAW parameters and
+    the pose; preprocess_kernel and preprocess_backward_kernel take the pre-transform of /root/reference/gaussian_renderer/__init__.py:83-97,107
+    on their way in (csrc/pretransform_math.h) and pretransform_forward_kernel is not launched — the camera-frame means / rotations / scales /
+    opacities never reach memory.  Twelve optimisation steps (Adam of every group, pose steps) with and without it end with EQUAL loss values
+    at every step and EQUAL parameters: the three kernels share one spelled-out arithmetic."""
+    from das3r_amd import _lib, fast_step
+    from das3r_amd.train import train_step
+    bg = torch.zeros(3, device="cuda")
+
+    def run(inside):
+        model, cams, _, opt, _dense = _pair(frames=4, W=48, H=32, seed=21, heldout=False, iterations=4000, fused=True, generic=generic)
+        model.fast_step = True
+        model.fuse_pretransform = inside
+        assert fast_step.available(model, PIPE)
+        _lib.profile_report()
+        _lib.profile_enable(True)
+        try:
+            rec = [tuple(float(v) for v in train_step(model, cams[k % len(cams)], opt, 100 + k, PIPE, bg, fused=True)[:2]) for k in range(12)]
+            torch.cuda.synchronize()
+        finally:
+            _lib.profile_enable(False)
+        kernels = _lib.profile_report()
+        return rec, {k: getattr(model, a).detach().clone() for k, a in NAMES.items()}, kernels
+
+    (ra, pa, ka), (rb, pb, kb) = run(True), run(False)
+    assert not any(k.startswith("pretransform_forward_kernel") for k in ka) and any(k.startswith("pretransform_forward_kernel") for k in kb), (list(ka), list(kb))
+    assert ra == rb, (ra, rb)
+    for k in pa:
+        assert torch.equal(pa[k], pb[k]), k
+
+
 def test_heldout_report_semantics(tmp_path):
     """train_test_psnr.py:241-302: the mask is nearest-resized to the render size and applied to both images, only views WITH a
     mask count, the line appended to test_log.txt has the reference's wording."""

@@ -79,7 +79,24 @@ for depth in sys.argv[1].split(","):
     for r in range(64):
         cx, cy = bx + (r % 8) * 2 + 0.5, by + (r // 8) * 2 + 0.5
         h2.append(((xyh[:, 0] - cx).abs() <= xyh[:, 2] + 0.5) & ((xyh[:, 1] - cy).abs() <= xyh[:, 3] + 0.5))
-    h2 = torch.stack(h2, 1) & (pos.unsqueeze(1) < rlast[tile_of])        # [I, 64]: listed and in front of the region's last contributor
+    h2 = torch.stack(h2, 1)
+    if os.environ.get("OCT"):   # the octagon of render_common.h block_hit_oct at the size of a region: two diagonal slabs on top of the box
+        co = _lib.splat_field(geom, L, "conic_opacity", P)[pl]
+        ex, ey = (xyh[:, 2] - 0.02) / 1.0005, (xyh[:, 3] - 0.02) / 1.0005
+        ex2, ey2 = ex * ex, ey * ey
+        txy = -co[:, 1] * ex2 / co[:, 2]
+        half, slack = 0.5 * (ex2 + ey2), 2e-6 * (ex2 + ey2) + 1e-3
+        hd1 = torch.sqrt((half + txy).clamp_min(0) + slack) * 1.0005 + 0.05
+        hd2 = torch.sqrt((half - txy).clamp_min(0) + slack) * 1.0005 + 0.05
+        o2 = []
+        for r in range(64):
+            cx, cy = bx + (r % 8) * 2 + 0.5, by + (r // 8) * 2 + 0.5
+            ddx, ddy = xyh[:, 0] - cx, xyh[:, 1] - cy
+            o2.append(((ddx + ddy).abs() * 0.70710678 <= hd1 + 0.7081) & ((ddx - ddy).abs() * 0.70710678 <= hd2 + 0.7081))
+        before = h2.float().sum(1).mean().item()
+        h2 = h2 & torch.stack(o2, 1)
+        print(f"   octagon: regions listed per entry {before:.2f} -> {h2.float().sum(1).mean().item():.2f}")
+    h2 = h2 & (pos.unsqueeze(1) < rlast[tile_of])        # [I, 64]: listed and in front of the region's last contributor
     walked = pos < tlast[tile_of]                                        # entries the backward stages at all
     nwalk = int(walked.sum())
     print(f"== {depth}: I {I}, staged by the backward {nwalk}; regions listed per staged entry {h2[walked].float().sum(1).mean():.2f} (x 4 = pair slots at perfect fill)")
@@ -87,7 +104,7 @@ for depth in sys.argv[1].split(","):
     bucket = pos // 1024
     bend = torch.minimum(tlast[tile_of], (bucket + 1) * 1024)             # end of the replayed part of the entry's bucket
     back = bend - 1 - pos                                                 # 0 = first staged
-    for MB in (64, 128, 192, 256):
+    for MB in (128,):
         rid = (tile_of * 64 + bucket) * 16 + back // MB                   # round id (<= 16 rounds per bucket at MB >= 64)
         rid = torch.where(walked, rid, torch.full_like(rid, nt * 64 * 16))
         per = torch.zeros(nt * 64 * 16 + 1, 64, dtype=torch.long, device="cuda").index_add_(0, rid, h2.long())[:-1]
