@@ -371,7 +371,9 @@ __global__ void __launch_bounds__(256, OCC) render_backward_regions_kernel(
                                       (Sgy * co.z + Sgx * co.y) * (float)H, kh * a[6], kh * a[7], kh * a[8], a[3]);
                 }
             }
-            __syncthreads();   // stage / s_slot / the lists are free for the next round
+            // (no barrier here, round 6: MB <= 256 — entry t of a round is staged AND written out by thread t alone, so the next round's staging
+            //  overwrites stage[t] / s_slot[t] behind this thread's own reads; the records it cleared are next touched behind the barrier that
+            //  follows that staging; lists and masks are wave-private; nobody is still walking: every wave has passed the barrier above)
         }
     }
     if (pairs != nullptr && lane == 0 && batches_done > 0) {
