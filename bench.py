@@ -181,6 +181,8 @@ class RasterJob:
     def upload(self):
         import torch
         from das3r_amd import GaussianRasterizer
+        from das3r_amd import _lib
+        _lib.forget_shapes()   # a new scene: what the library learnt about another one of the same size (`ds` / `dsc`: one (P, W, H)) does not apply
         self.sc = self.sc_cpu.to(self.dev)
         self.rast = GaussianRasterizer(self._rs_cls(**self.sc.settings_kwargs()))
         self._set_leaves({k: getattr(self.sc, k) for k in ("means3D", "opacities", "shs", "scales", "rotations")})

@@ -545,7 +545,7 @@ def test_backward_kernels_agree(name, monkeypatch):
             util.assert_grad_close(out[kind][1][k].cpu().numpy(), out["dpp"][1][k].cpu().numpy(), f"{kind} vs dpp backward dL/d{k}", tol=5e-5)
 
 
-@pytest.mark.parametrize("kind", ["dpp", "mfma", "scan64", "scan128", "scan256", "scana256", "stream", "blk64", "blk128", "blk256", "fine64", "fine128", "fine160", "fine192", "fine256"])
+@pytest.mark.parametrize("kind", ["dpp", "mfma", "scan64", "scan128", "scan256", "scana256", "stream", "blk64", "blk128", "blk256", "fine64", "fine128", "fine160", "fine192", "fine256", "fine128q", "fine128s"])
 @pytest.mark.parametrize("name", ["basic_deg3", "long_lists", "deep", "ragged_image", "culled"])
 def test_every_backward_kernel_vs_oracle(name, kind, monkeypatch):
     """Each backward compositing kernel on its own against the CPU oracle (the default one is covered on all variants above)."""
