@@ -23,7 +23,7 @@ struct AdamTable {
     float *m[ADAM_MAX_TENSORS];
     float *v[ADAM_MAX_TENSORS];
     long long n_active[ADAM_MAX_TENSORS];     // rows * active_len
-    int row_len[ADAM_MAX_TENSORS], active_len[ADAM_MAX_TENSORS], grad_row_len[ADAM_MAX_TENSORS];
+    int row_len[ADAM_MAX_TENSORS], active_len[ADAM_MAX_TENSORS], grad_row_len[ADAM_MAX_TENSORS], state_row_len[ADAM_MAX_TENSORS];
     int first_chunk[ADAM_MAX_TENSORS + 1];    // prefix of chunk counts
     float step_size[ADAM_MAX_TENSORS], bc2_sqrt[ADAM_MAX_TENSORS], step_size_tail[ADAM_MAX_TENSORS];
     int head_len[ADAM_MAX_TENSORS];
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) adam_kernel(const AdamTable T, float beta
     float *__restrict__ m = T.m[t];
     float *__restrict__ v = T.v[t];
     const long long n = T.n_active[t];
-    const int row_len = T.row_len[t], active_len = T.active_len[t], grad_row_len = T.grad_row_len[t];
+    const int row_len = T.row_len[t], active_len = T.active_len[t], grad_row_len = T.grad_row_len[t], state_row_len = T.state_row_len[t];
     const float step_size = GATED ? T.step_size[t] / gate_bc1 : T.step_size[t], bc2_sqrt = GATED ? gate_bc2_sqrt : T.bc2_sqrt[t];
     const float step_size_tail = GATED ? T.step_size_tail[t] / gate_bc1 : T.step_size_tail[t];
     const int head_len = T.head_len[t];
@@ -65,14 +65,17 @@ __global__ void __launch_bounds__(256) adam_kernel(const AdamTable T, float beta
     for (int k = 0; k < ADAM_CHUNK / 256; k++) {
         const long long e = base + k * 256 + threadIdx.x;
         if (e < n) {
-            const int col = (int)(e % active_len);
-            const long long off = (row_len == active_len) ? e : (e / active_len) * row_len + col;
-            const float gr = g[(grad_row_len == row_len) ? off : (e / active_len) * grad_row_len + col];   // (a compact gradient: its own row stride)
-            float pp = p[off], mm = m[off], vv = v[off];
+            const long long row = e / active_len;
+            const int col = (int)(e - row * active_len);
+            const long long off = (row_len == active_len) ? e : row * row_len + col;
+            const long long goff = (grad_row_len == row_len) ? off : row * grad_row_len + col;      // (a compact gradient: its own row stride)
+            const long long moff = (state_row_len == row_len) ? off : row * state_row_len + col;    // (compact moments: theirs)
+            const float gr = g[goff];
+            float pp = p[off], mm = m[moff], vv = v[moff];
             adam_update(pp, mm, vv, gr, beta1, beta2, eps, col < head_len ? step_size : step_size_tail, bc2_sqrt);
             p[off] = pp;
-            m[off] = mm;
-            v[off] = vv;
+            m[moff] = mm;
+            v[moff] = vv;
         }
     }
 }
@@ -95,15 +98,16 @@ static int adam_launch(int32_t n, const das3r_adam_tensor *tensors, float beta1,
     for (int i = 0; i < n; i++) {
         const das3r_adam_tensor &a = tensors[i];
         const int grl = a.grad_row_len > 0 ? a.grad_row_len : a.row_len;
-        if (a.rows < 0 || a.row_len <= 0 || a.active_len < 0 || a.active_len > a.row_len || a.active_len > grl || !a.param || !a.grad || !a.exp_avg ||
-            !a.exp_avg_sq) {
+        const int srl = a.state_row_len > 0 ? a.state_row_len : a.row_len;
+        if (a.rows < 0 || a.row_len <= 0 || a.active_len < 0 || a.active_len > a.row_len || a.active_len > grl || a.active_len > srl || !a.param || !a.grad ||
+            ((!a.exp_avg || !a.exp_avg_sq) && (long long)a.rows * a.active_len > 0)) {
             set_error("das3r_adam_step: bad tensor %d", i);
             return DAS3R_ERR_INVALID_ARG;
         }
         const long long na = (long long)a.rows * a.active_len;
         if (na == 0) continue;   // nothing active in this tensor (e.g. f_rest while the SH degree is 0)
         T.p[k] = a.param; T.g[k] = a.grad; T.m[k] = a.exp_avg; T.v[k] = a.exp_avg_sq;
-        T.n_active[k] = na; T.row_len[k] = a.row_len; T.active_len[k] = a.active_len; T.grad_row_len[k] = grl;
+        T.n_active[k] = na; T.row_len[k] = a.row_len; T.active_len[k] = a.active_len; T.grad_row_len[k] = grl; T.state_row_len[k] = srl;
         T.step_size[k] = a.step_size; T.bc2_sqrt[k] = a.bc2_sqrt;
         const bool split = a.head_len > 0 && a.head_len < a.active_len;   // otherwise one rate for the whole row
         T.head_len[k] = split ? a.head_len : a.row_len;

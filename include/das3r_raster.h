@@ -232,6 +232,10 @@ typedef struct {
     float step_size_tail;
     int32_t grad_row_len; /* ABI 9: floats per row of `grad` when it is more compact than the parameter (>= active_len: e.g. the
                              gradient of the first 3 of 15 SH coefficients as [P, 3, 3]); 0 = row_len */
+    int32_t state_row_len; /* ABI 14 (in what was tail padding): floats per row of exp_avg / exp_avg_sq when the MOMENTS are kept more
+                              compact than the parameter (>= active_len; 0 = row_len).  The moments of SH coefficients above the active
+                              degree are exactly zero: FusedAdam keeps only the active prefix — at degree 1, [P, 3, 3] beside a [P, 15, 3]
+                              parameter — so that four of the step's six streams are dense (adam_kernel 0.46 -> see docs/ledger.md (bh)) */
 } das3r_adam_tensor;
 int das3r_adam_step(int32_t n, const das3r_adam_tensor *tensors, float beta1, float beta2, float eps, das3r_stream_t stream);
 /* The same step taken iff the DEVICE scalar gate[0] > threshold (DAS3R's camera optimizer steps only when the frame PSNR exceeds

@@ -131,9 +131,12 @@ def test_active_sh_prefix_steps_like_the_full_tensor(degree):
         bg = torch.zeros(3, device="cuda")
         losses = [float(train_step(model, cams[u], opt, it, PIPE, bg, fused=True)[0]) for it, u in enumerate([0, 2, 1], start=1)]
         st = model.optimizer.state[model._features_rest]
-        out.append((losses, {k: getattr(model, a).detach().clone() for k, a in NAMES.items()}, st["exp_avg"].clone(), st["exp_avg_sq"].clone(), st["step"]))
+        assert st["exp_avg"].shape[1] == (degree + 1) ** 2 - 1   # (round 6: FusedAdam keeps the moments of the ACTIVE coefficients only ...)
+        sd = model.optimizer.state_dict()
+        full_st = sd["state"][[g["name"] for g in sd["param_groups"]].index("f_rest")]   # (... and hands them out in the parameter's shape)
+        out.append((losses, {k: getattr(model, a).detach().clone() for k, a in NAMES.items()}, full_st["exp_avg"].clone(), full_st["exp_avg_sq"].clone(), st["step"]))
     (l0, p0, m0, v0, s0), (l1, p1, m1, v1, s1) = out
-    assert s0 == s1 == 3
+    assert s0 == s1 == 3 and tuple(m0.shape) == tuple(p0["f_rest"].shape)
     for a, b in zip(l0, l1):
         assert abs(a - b) <= 1e-6 * abs(b), (l0, l1)
     K = (degree + 1) ** 2 - 1
