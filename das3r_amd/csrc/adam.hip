@@ -22,6 +22,9 @@ struct AdamTable {
     const float *g[ADAM_MAX_TENSORS];
     float *m[ADAM_MAX_TENSORS];
     float *v[ADAM_MAX_TENSORS];
+    float *mirror[ADAM_MAX_TENSORS];
+    int mirror_row_len[ADAM_MAX_TENSORS];
+    int flat[ADAM_MAX_TENSORS];                // no row structure to resolve: offsets = element index
     long long n_active[ADAM_MAX_TENSORS];     // rows * active_len
     int row_len[ADAM_MAX_TENSORS], active_len[ADAM_MAX_TENSORS], grad_row_len[ADAM_MAX_TENSORS], state_row_len[ADAM_MAX_TENSORS];
     int first_chunk[ADAM_MAX_TENSORS + 1];    // prefix of chunk counts
@@ -57,25 +60,37 @@ __global__ void __launch_bounds__(256) adam_kernel(const AdamTable T, float beta
     float *__restrict__ m = T.m[t];
     float *__restrict__ v = T.v[t];
     const long long n = T.n_active[t];
+    float *__restrict__ mirror = T.mirror[t];
+    const int mirror_row_len = T.mirror_row_len[t];
     const int row_len = T.row_len[t], active_len = T.active_len[t], grad_row_len = T.grad_row_len[t], state_row_len = T.state_row_len[t];
     const float step_size = GATED ? T.step_size[t] / gate_bc1 : T.step_size[t], bc2_sqrt = GATED ? gate_bc2_sqrt : T.bc2_sqrt[t];
     const float step_size_tail = GATED ? T.step_size_tail[t] / gate_bc1 : T.step_size_tail[t];
     const int head_len = T.head_len[t];
+    const bool flat = T.flat[t] != 0;
 #pragma unroll
     for (int k = 0; k < ADAM_CHUNK / 256; k++) {
         const long long e = base + k * 256 + threadIdx.x;
         if (e < n) {
-            const long long row = e / active_len;
-            const int col = (int)(e - row * active_len);
-            const long long off = (row_len == active_len) ? e : row * row_len + col;
-            const long long goff = (grad_row_len == row_len) ? off : row * grad_row_len + col;      // (a compact gradient: its own row stride)
-            const long long moff = (state_row_len == row_len) ? off : row * state_row_len + col;    // (compact moments: theirs)
+            // (row, column) of element e of the active prefix.  A flat tensor — one row, or every stride equal to the active length — needs
+            // neither (uniform branch); a row-form tensor has fewer than 2^32 active elements (checked on the host): one 32-bit division
+            // instead of the 64-bit division and remainder this used to cost every element of every tensor
+            long long off = e, goff = e, moff = e;
+            int col = 0;
+            uint32_t row = 0u;
+            if (!flat) {
+                row = (uint32_t)e / (uint32_t)active_len;
+                col = (int)((uint32_t)e - row * (uint32_t)active_len);
+                off = (long long)row * row_len + col;
+                goff = (long long)row * grad_row_len + col;      // (a compact gradient: its own row stride)
+                moff = (long long)row * state_row_len + col;     // (compact moments: theirs)
+            }
             const float gr = g[goff];
             float pp = p[off], mm = m[moff], vv = v[moff];
-            adam_update(pp, mm, vv, gr, beta1, beta2, eps, col < head_len ? step_size : step_size_tail, bc2_sqrt);
+            adam_update(pp, mm, vv, gr, beta1, beta2, eps, (flat || col < head_len) ? step_size : step_size_tail, bc2_sqrt);
             p[off] = pp;
             m[moff] = mm;
             v[moff] = vv;
+            if (mirror != nullptr) mirror[(long long)row * mirror_row_len + col] = pp;   // (uniform per tensor; never with a flat one)
         }
     }
 }
@@ -100,7 +115,7 @@ static int adam_launch(int32_t n, const das3r_adam_tensor *tensors, float beta1,
         const int grl = a.grad_row_len > 0 ? a.grad_row_len : a.row_len;
         const int srl = a.state_row_len > 0 ? a.state_row_len : a.row_len;
         if (a.rows < 0 || a.row_len <= 0 || a.active_len < 0 || a.active_len > a.row_len || a.active_len > grl || a.active_len > srl || !a.param || !a.grad ||
-            ((!a.exp_avg || !a.exp_avg_sq) && (long long)a.rows * a.active_len > 0)) {
+            ((!a.exp_avg || !a.exp_avg_sq) && (long long)a.rows * a.active_len > 0) || (a.mirror && a.mirror_row_len < a.active_len)) {
             set_error("das3r_adam_step: bad tensor %d", i);
             return DAS3R_ERR_INVALID_ARG;
         }
@@ -108,6 +123,10 @@ static int adam_launch(int32_t n, const das3r_adam_tensor *tensors, float beta1,
         if (na == 0) continue;   // nothing active in this tensor (e.g. f_rest while the SH degree is 0)
         T.p[k] = a.param; T.g[k] = a.grad; T.m[k] = a.exp_avg; T.v[k] = a.exp_avg_sq;
         T.n_active[k] = na; T.row_len[k] = a.row_len; T.active_len[k] = a.active_len; T.grad_row_len[k] = grl; T.state_row_len[k] = srl;
+        T.mirror[k] = a.mirror; T.mirror_row_len[k] = a.mirror_row_len;
+        const bool split_rates = a.head_len > 0 && a.head_len < a.active_len;
+        T.flat[k] = (!a.mirror && !split_rates && a.row_len == a.active_len && grl == a.row_len && srl == a.row_len) ? 1 : 0;
+        if (!T.flat[k] && na >= (1ll << 32)) { set_error("das3r_adam_step: tensor %d: a row-form tensor with 2^32 or more active elements", i); return DAS3R_ERR_INVALID_ARG; }
         T.step_size[k] = a.step_size; T.bc2_sqrt[k] = a.bc2_sqrt;
         const bool split = a.head_len > 0 && a.head_len < a.active_len;   // otherwise one rate for the whole row
         T.head_len[k] = split ? a.head_len : a.row_len;

@@ -87,6 +87,23 @@ def _state(model):
     return st
 
 
+def _packed_sh(st, model, K):
+    """The [P, K, 3] tensor the rasterizer reads above degree 0: DC + the first K - 1 rest coefficients of every Gaussian.  Concatenated once,
+    then KEPT CURRENT BY THE OPTIMIZER: FusedAdam writes the updated values of f_dc and f_rest into it as it steps them
+    (das3r_adam_tensor.mirror) — the parameters themselves stay the truth, this is a cache of them.  Rebuilt whenever it cannot be vouched
+    for: another degree, other tensors, an in-place write torch knows of (_version), or a step of either parameter that did not write it."""
+    dc, rest = model._features_dc, model._features_rest
+    c = getattr(st, "sh_cache", None)
+    key = (K, id(dc), id(rest), dc.data_ptr(), rest.data_ptr())
+    if (c is None or c["key"] != key or c["ver"] != (dc._version, rest._version)
+            or getattr(dc, "_das3r_mirror_ok", None) is not c["t"] or getattr(rest, "_das3r_mirror_ok", None) is not c["t"]):
+        t = torch.cat((dc.detach(), rest.detach()[:, :K - 1]), dim=1)
+        c = st.sh_cache = dict(key=key, ver=(dc._version, rest._version), t=t)
+        dc._das3r_mirror, rest._das3r_mirror = (t, 0), (t, 3)
+        dc._das3r_mirror_ok = rest._das3r_mirror_ok = t
+    return c["t"]
+
+
 def _dense_f32(obj, name):
     """obj.<name> as a contiguous fp32 tensor — the C-ABI takes plain pointers (a ground-truth image that came through the on-disk
     formats is a [3, H, W] VIEW of H x W x 3 memory: round 4's first version of this file read it as if it were dense and trained a
@@ -171,9 +188,9 @@ def _forward_backward(st, model, cam, q_row, t_row, gq_row, gt_row, static_hw, l
     if deg == 0:
         shs = model._features_dc
     elif deg < model.max_sh_degree and getattr(model, "sh_prefix", True):
-        shs = torch.cat((model._features_dc, model._features_rest[:, :K - 1]), dim=1)
+        shs = _packed_sh(st, model, K)
     else:
-        shs = torch.cat((model._features_dc, model._features_rest), dim=1)
+        shs = _packed_sh(st, model, 1 + model._features_rest.shape[1])
     rs = _settings(st, cam, model, bg)
     e = st.e
     I, image, radii, geom, binning, img, cap = _forward_full(rs, means3D, shs, e, opac, scales, rotations, e, pre=pre)
@@ -223,8 +240,8 @@ def _forward_backward(st, model, cam, q_row, t_row, gq_row, gt_row, static_hw, l
         if deg == 0:
             model._features_dc.grad = g_sh
         else:
-            model._features_dc.grad = g_sh[:, :1].contiguous()
-            rest = g_sh[:, 1:].contiguous()
+            model._features_dc.grad = g_sh[:, :1]   # (column blocks of dL/dshs, read in place by FusedAdam with the row stride: no copies)
+            rest = g_sh[:, 1:]
             if rest.shape[1] == K - 1 and K - 1 < model._features_rest.shape[1]:
                 old = getattr(model._features_rest, "_das3r_compact_grad", None)
                 model._features_rest._das3r_compact_grad = rest if old is None else old + rest

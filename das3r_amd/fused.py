@@ -16,7 +16,8 @@ from . import _lib
 class AdamTensor(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("rows", C.c_int64),
                 ("row_len", C.c_int32), ("active_len", C.c_int32), ("step_size", C.c_float), ("bc2_sqrt", C.c_float),
-                ("head_len", C.c_int32), ("step_size_tail", C.c_float), ("grad_row_len", C.c_int32), ("state_row_len", C.c_int32)]
+                ("head_len", C.c_int32), ("step_size_tail", C.c_float), ("grad_row_len", C.c_int32), ("state_row_len", C.c_int32),
+                ("mirror", C.c_void_p), ("mirror_row_len", C.c_int32)]
 
 
 def _stream(device):
@@ -322,7 +323,13 @@ class FusedAdam:
                 t = st["step"]
                 if p.grad is None and (self.active_sh_degree is None or p.dim() != 3):
                     raise RuntimeError("FusedAdam: a compact SH gradient needs set_active_sh_degree() and a [P, K, 3] parameter")
-                grad = (p.grad if p.grad is not None else compact).contiguous()
+                grad = p.grad if p.grad is not None else compact
+                # a gradient that is a block of columns of a wider row-major tensor (round 6: the rasterizer's dL/dshs [P, K, 3], of which f_dc
+                # takes column block 0 and f_rest the blocks behind it) is read in place, with its row stride — no copy per tensor and step
+                row_strided = (grad.dim() >= 2 and not grad.is_contiguous() and grad.stride(-1) == 1 and grad.dtype == torch.float32
+                               and all(grad.stride(i) == grad.stride(i + 1) * grad.shape[i + 1] for i in range(1, grad.dim() - 1)) and grad.stride(0) >= grad[0].numel())
+                if not row_strided:
+                    grad = grad.contiguous()
                 keep.append(grad)
                 e = AdamTensor()
                 e.grad_row_len = 0
@@ -346,6 +353,21 @@ class FusedAdam:
                     e.rows, e.row_len, e.active_len = 1, p.numel(), p.numel()
                     if p.numel() >= 2 ** 31:
                         raise RuntimeError("FusedAdam: tensor too large")
+                    if (row_strided or getattr(p, "_das3r_mirror", None) is not None) and p.dim() >= 2:   # rows of p against rows of a wider tensor
+                        e.rows, e.row_len = p.shape[0], p[0].numel()
+                        e.active_len = e.row_len
+                if row_strided:
+                    e.grad_row_len = grad.stride(0)
+                mirror = getattr(p, "_das3r_mirror", None)   # (tensor [P, K, 3], column offset in floats): das3r_amd/fast_step.py
+                if mirror is not None:
+                    p._das3r_mirror_ok = None   # (this step changes p: the mirror stays current only if the step writes it too)
+                    mt, moff = mirror
+                    if (p.dim() == 3 and mt.shape[0] == p.shape[0] and mt.is_contiguous() and mt.device == p.device and mt.dtype == torch.float32
+                            and moff + e.active_len <= mt[0].numel() and gate is None):
+                        e.mirror = mt.data_ptr() + 4 * moff
+                        e.mirror_row_len = mt[0].numel()
+                        keep.append(mt)
+                        p._das3r_mirror_ok = mt
                 if gate is None:
                     e.step_size = g["lr"] / (1.0 - b1 ** t)
                     e.bc2_sqrt = math.sqrt(1.0 - b2 ** t)

@@ -236,6 +236,11 @@ typedef struct {
                               compact than the parameter (>= active_len; 0 = row_len).  The moments of SH coefficients above the active
                               degree are exactly zero: FusedAdam keeps only the active prefix — at degree 1, [P, 3, 3] beside a [P, 15, 3]
                               parameter — so that four of the step's six streams are dense (adam_kernel 0.46 -> see docs/ledger.md (bh)) */
+    float *mirror;          /* ABI 14: NULL, or a second place the UPDATED active values of each row are written to: row r, column c of the active
+                               prefix -> mirror[r * mirror_row_len + c].  das3r_amd/fast_step.py keeps the packed [P, K, 3] SH tensor the rasterizer
+                               reads (DC + the active rest coefficients) current this way — the steps of f_dc and f_rest write into it, at column
+                               offsets 0 and 3 — instead of concatenating the two parameters before every render (0.16 ms at 2.13 M Gaussians) */
+    int32_t mirror_row_len;
 } das3r_adam_tensor;
 int das3r_adam_step(int32_t n, const das3r_adam_tensor *tensors, float beta1, float beta2, float eps, das3r_stream_t stream);
 /* The same step taken iff the DEVICE scalar gate[0] > threshold (DAS3R's camera optimizer steps only when the frame PSNR exceeds

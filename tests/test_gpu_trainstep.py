@@ -264,6 +264,50 @@ def test_pretransform_inside_the_rasterizer_kernels_is_bit_identical_to_the_sepa
         assert torch.equal(pa[k], pb[k]), k
 
 
+def test_packed_sh_tensor_is_kept_current_by_the_optimizer_and_rebuilt_when_it_cannot_be_vouched_for():
+    """Round 6: above degree 0 the direct iteration used to concatenate f_dc and the active prefix of f_rest before every render (0.16 ms at
+    2.13 M Gaussians) and to split dL/dshs into two copies behind it.  Now the packed [P, K, 3] tensor is built once and FusedAdam writes the
+    stepped values of both parameters into it (das3r_adam_tensor.mirror), reading its gradients as column blocks of dL/dshs in place.  The
+    parameters stay the truth: after every step the packed tensor EQUALS their concatenation, it is the same object from step to step, and
+    an in-place write torch knows of, a degree change or a step that bypasses the mirror make the next iteration rebuild it."""
+    from das3r_amd import fast_step
+    from das3r_amd.train import train_step
+    bg = torch.zeros(3, device="cuda")
+    model, cams, _, opt, _dense = _pair(frames=4, W=48, H=32, seed=31, heldout=False, iterations=4000, fused=True, generic=True)
+    model.fast_step = True
+    model.active_sh_degree = 1
+    model.optimizer.set_active_sh_degree(1)
+    with torch.no_grad():
+        g = torch.Generator(device="cpu").manual_seed(5)
+        model._features_rest[:, :3].copy_((torch.randn(model._features_rest[:, :3].shape, generator=g) * 0.05).cuda())
+    assert fast_step.available(model, PIPE)
+    packed = lambda: torch.cat((model._features_dc.detach(), model._features_rest.detach()[:, :3]), dim=1)
+    seen = []
+    for k in range(6):
+        before = packed()
+        train_step(model, cams[k % len(cams)], opt, 100 + k, PIPE, bg, fused=True)
+        t = fast_step._state(model).sh_cache["t"]
+        assert torch.equal(t, packed()) and not torch.equal(t, before), k   # current, and the step did move the coefficients
+        seen.append(t)
+    assert all(t is seen[0] for t in seen), "one packed tensor for the whole run: nothing was concatenated again"
+    with torch.no_grad():
+        model._features_rest.mul_(0.5)                                       # an in-place write behind the optimizer's back
+    train_step(model, cams[0], opt, 106, PIPE, bg, fused=True)
+    t2 = fast_step._state(model).sh_cache["t"]
+    assert t2 is not seen[0] and torch.equal(t2, packed())
+    model._features_dc.grad = torch.zeros_like(model._features_dc)         # a step that does not go through the mirror's row form ...
+    model._features_dc._das3r_mirror = (torch.zeros(3, 3, device="cuda"), 0)   # ... because the mirror it is offered does not fit
+    model.optimizer.step()
+    model.optimizer.zero_grad(set_to_none=True)
+    train_step(model, cams[1], opt, 107, PIPE, bg, fused=True)
+    t3 = fast_step._state(model).sh_cache["t"]
+    assert t3 is not t2 and torch.equal(t3, packed())
+    model.oneupSHdegree()                                                  # degree 2: another K
+    train_step(model, cams[2], opt, 108, PIPE, bg, fused=True)
+    t4 = fast_step._state(model).sh_cache["t"]
+    assert t4.shape[1] == 9 and torch.equal(t4, torch.cat((model._features_dc.detach(), model._features_rest.detach()[:, :8]), dim=1))
+
+
 def test_heldout_report_semantics(tmp_path):
     """train_test_psnr.py:241-302: the mask is nearest-resized to the render size and applied to both images, only views WITH a
     mask count, the line appended to test_log.txt has the reference's wording."""
