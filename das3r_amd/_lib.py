@@ -41,10 +41,21 @@ class RasterSaved(C.Structure):
                 ("check_word", C.c_void_p), ("check_tag", C.c_uint32), ("flags", C.c_uint32)]
 
 
+class AdamSlot(C.Structure):
+    """include/das3r_raster.h das3r_adam_slot (ABI 11)."""
+    _fields_ = [("param", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("step_size", C.c_float), ("bc2_sqrt", C.c_float)]
+
+
+class Chain(C.Structure):
+    """include/das3r_raster.h das3r_chain (ABI 14): the rasterizer's backward goes on through the pose pre-transform and the Adam step."""
+    _fields_ = [("g_conf_flat", C.c_void_p), ("g_small", C.c_void_p), ("slots", C.POINTER(AdamSlot)), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("eps", C.c_float)]
+
+
 class RasterGrads(C.Structure):
     _fields_ = [("dL_dmeans2D", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dmeans3D", C.c_void_p),
                 ("dL_dshs", C.c_void_p), ("dL_dcolors_precomp", C.c_void_p), ("dL_dscales", C.c_void_p),
-                ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p), ("scratch", C.c_void_p)]
+                ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p), ("scratch", C.c_void_p), ("chain", C.POINTER(Chain))]
 
 
 class RasterLayout(C.Structure):
@@ -62,11 +73,6 @@ EXPORTS = ("das3r_raster_forward", "das3r_raster_backward", "das3r_raster_check"
            "das3r_has_experiments", "das3r_pair_counters", "das3r_debug_poison_lds", "das3r_debug_inject_fault", "das3r_debug_mutate",
            "das3r_pose_matrices_qt", "das3r_pose_chain_qt", "das3r_photometric_finish", "das3r_pretransform_backward_adam", "das3r_pretransform_pose_sums",
            "das3r_raster_count_live_pairs")
-
-class AdamSlot(C.Structure):
-    """include/das3r_raster.h das3r_adam_slot (ABI 11)."""
-    _fields_ = [("param", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("step_size", C.c_float), ("bc2_sqrt", C.c_float)]
-
 
 _lib = None
 

@@ -717,13 +717,15 @@ extern "C" int das3r_raster_backward(const das3r_raster_args *a, const das3r_ras
     if (rc) return rc;
     const int P = a->P;
     if (P == 0) return DAS3R_OK;
-    if (!saved || !saved->geom || !saved->img || !dL_dpix || !g || !g->dL_dmeans2D || !g->dL_dopacities || !g->dL_dmeans3D || (saved && saved->num_rendered > 0 && !g->scratch)) {
+    const bool chained = g && g->chain;   // (ABI 14: dL/d(camera-frame means, opacities, scales, rotations) are then not produced — may be NULL)
+    if (!saved || !saved->geom || !saved->img || !dL_dpix || !g || !g->dL_dmeans2D || (!chained && (!g->dL_dopacities || !g->dL_dmeans3D)) ||
+        (saved && saved->num_rendered > 0 && !g->scratch)) {
         set_error("das3r_raster_backward: null saved state / gradient buffer");
         return DAS3R_ERR_INVALID_ARG;
     }
     const bool has_sh = in->shs != nullptr, has_cov = in->cov3D_precomp != nullptr;
     if ((has_sh && !g->dL_dshs) || (!has_sh && !g->dL_dcolors_precomp) || (has_cov && !g->dL_dcov3D) ||
-        (!has_cov && (!g->dL_dscales || !g->dL_drotations))) {
+        (!has_cov && !chained && (!g->dL_dscales || !g->dL_drotations))) {
         set_error("das3r_raster_backward: gradient buffer missing for a provided input");
         return DAS3R_ERR_INVALID_ARG;
     }

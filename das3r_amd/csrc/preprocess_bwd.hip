@@ -11,9 +11,15 @@
 //   * M == 16: the workgroup's 256 dL_dsh rows (192 B each, contiguous) are assembled in LDS and stored with fully
 //     coalesced float4 stores; at degree >= 2 the SH input rows come in the same way (see preprocess.hip).  The SH
 //     backward is streamed (basis values -> LDS row) instead of holding two 48-float arrays in registers.
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
 #include "common.h"
 #include "splat_math.h"
 #include "pretransform_math.h"
+#include "pretransform_chain.h"
 
 namespace das3r {
 
@@ -93,8 +99,18 @@ __device__ __forceinline__ void wave_store_rows(float *__restrict__ dst /*row 0 
 
 // DEG0: the active degree is 0 (DAS3R's own setting, arguments.py sh_degree): no SH row is read and the view-direction terms
 // vanish at compile time, which halves the register count of the unstaged variant (6 waves per SIMD instead of 3)
-template <bool HAS_SH, bool HAS_COV, bool STAGE_IN, bool STAGE_OUT, bool DEG0 = false>
-__global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
+// CHAIN (round 6, das3r_raster_grads.chain): the kernel does not stop at dL/d(camera-frame means, scales, rotations, opacities) — it goes on
+// through the pose pre-transform (pretransform_chain.h: the arithmetic of pretransform_backward_kernel<1>, bit for bit): chain rule to the raw
+// parameters, their Adam step, dL/d(confidence), the camera's 28 sums in a fixed order.  The four gradient tensors are neither written nor
+// read back (88 B per Gaussian) and the raw parameters are read once for the forward's inputs and the chain rule (40 B): the pair
+// preprocess_backward + pretransform_backward<1> 0.221 -> see docs/ledger.md (bi).  Needs the raw parameters (`pre`) and an unstaged SH layout.
+struct ChainArgs {
+    GeometryAdam A;
+    float *g_conf_flat, *g_small, *det_partials;
+    uint32_t *arrived;
+};
+template <bool HAS_SH, bool HAS_COV, bool STAGE_IN, bool STAGE_OUT, bool DEG0 = false, bool CHAIN = false>
+__global__ void __launch_bounds__(256, DEG0 ? (CHAIN ? 5 : 6) : 3) preprocess_backward_kernel(
     int P, int D_in, int M, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
     const float *__restrict__ rotations, const float *__restrict__ shs, const float *__restrict__ cov3D_precomp,
     const float *__restrict__ viewmatrix, const float *__restrict__ projmatrix, const float *__restrict__ campos, int W, int H,
@@ -104,7 +120,8 @@ __global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
     float *__restrict__ dL_dmeans2D /*[P,3] out*/, float *__restrict__ dL_dopacity /*[P] out*/,
     float *__restrict__ dL_dcolors_precomp /*[P,3] out, precomp mode*/, float *__restrict__ dL_dmeans3D,
     float *__restrict__ dL_dscales, float *__restrict__ dL_drot, float *__restrict__ dL_dsh, float *__restrict__ dL_dcov3D,
-    const PreXform pre /*xyz != null (das3r_raster_in.pre): the raw parameters + the pose, as in preprocess.hip*/
+    const PreXform pre /*xyz != null (das3r_raster_in.pre): the raw parameters + the pose, as in preprocess.hip*/,
+    const ChainArgs ch /*CHAIN only*/
 #ifdef DAS3R_EXPERIMENTS
     , unsigned long long *__restrict__ trace /*common.h BLK_STAMP (tools/wg_trace.py), region 6*/
 #endif
@@ -125,12 +142,21 @@ __global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
     float3 mean_in, sc_in = make_float3(0.f, 0.f, 0.f);
     float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
     float c3_in[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (!HAS_COV && pre.xyz != nullptr) {   // (uniform) the forward's inputs again, from the raw parameters (pretransform_math.h: the same bits)
+    float raw_x = 0.f, raw_y = 0.f, raw_z = 0.f, raw_s0 = 0.f, raw_s1 = 0.f, raw_s2 = 0.f, raw_o = 0.f, raw_c = 0.f;   // CHAIN: kept for the chain rule at the end
+    float4 raw_q = make_float4(0.f, 0.f, 0.f, 0.f);
+    long long raw_ci = 0;
+    if (!HAS_COV && (CHAIN || pre.xyz != nullptr)) {   // (uniform) the forward's inputs again, from the raw parameters (pretransform_math.h: the same bits)
         PoseRegs pose;
         load_pose(pre.Rm, pre.tv, pre.Lq, pose);
         const float rx = pre.xyz[3 * ic], ry = pre.xyz[3 * ic + 1], rz = pre.xyz[3 * ic + 2];
         const float4 rq = reinterpret_cast<const float4 *>(pre.rot)[ic];
         const float r0 = pre.scaling[3 * ic], r1 = pre.scaling[3 * ic + 1], r2 = pre.scaling[3 * ic + 2];
+        if constexpr (CHAIN) {
+            raw_x = rx; raw_y = ry; raw_z = rz; raw_q = rq; raw_s0 = r0; raw_s1 = r1; raw_s2 = r2;
+            raw_o = pre.opacity_raw[ic];
+            raw_ci = pre.mask_index ? (long long)pre.mask_index[ic] : (long long)ic;
+            raw_c = pre.conf_flat[raw_ci];
+        }
         mean_in = pre_mean(pose, rx, ry, rz);
         q_in = pre_rot(pose, rq);
         sc_in = make_float3(pre_scale(r0), pre_scale(r1), pre_scale(r2));
@@ -269,6 +295,8 @@ __global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
     const int rows_valid = min(max(P - wave_first, 0), 64);
     float o_m2d[3] = {0.f, 0.f, 0.f}, o_m3d[3] = {0.f, 0.f, 0.f}, o_sc[3] = {0.f, 0.f, 0.f}, o_cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float o_col[3] = {0.f, 0.f, 0.f}, o_sh0[3] = {0.f, 0.f, 0.f};
+    static_assert(!CHAIN || (XPOSE && HAS_SH && !HAS_COV), "the chained backward: unstaged SH layouts, scales + rotations");
+    float o_rot[4] = {0.f, 0.f, 0.f, 0.f}, o_op = 0.f;   // CHAIN: dL/d(camera-frame rotation, opacity) stay in registers like o_m3d / o_sc
 
     if (idx < P) {
         const bool visible = ntiles_g > 0;
@@ -302,7 +330,8 @@ __global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
                 }
             }
         }
-        dL_dopacity[idx] = acc[8];
+        if constexpr (CHAIN) o_op = acc[8];
+        else dL_dopacity[idx] = acc[8];
         if (XPOSE) {
             o_m2d[0] = acc[3]; o_m2d[1] = acc[4];
             o_col[0] = acc[0]; o_col[1] = acc[1]; o_col[2] = acc[2];
@@ -506,7 +535,10 @@ __global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
                 for (int k = 0; k < 3; k++) dL_dscales[3 * (size_t)idx + k] = dscale[k];
             }
         }
-        if (!HAS_COV) reinterpret_cast<float4 *>(dL_drot)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);   // (16-byte rows: unit stride as they are)
+        if constexpr (CHAIN) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) o_rot[k] = drot[k];
+        } else if (!HAS_COV) reinterpret_cast<float4 *>(dL_drot)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);   // (16-byte rows: unit stride as they are)
         // ---- dL_dsh row: basis[k] * g[c] for the active coefficients, zero above; zero row for culled splats
         if (HAS_SH) {
             const int nk = visible ? (D + 1) * (D + 1) : 0;
@@ -539,9 +571,9 @@ __global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
     }
     if (XPOSE) {   // every lane of the wave takes part (rows_valid guards the stores)
         wave_store_rows<3>(dL_dmeans2D + 3 * (size_t)wave_first, rows_valid, o_m2d, xp, lane);
-        wave_store_rows<3>(dL_dmeans3D + 3 * (size_t)wave_first, rows_valid, o_m3d, xp, lane);
+        if (!CHAIN) wave_store_rows<3>(dL_dmeans3D + 3 * (size_t)wave_first, rows_valid, o_m3d, xp, lane);
         if (HAS_COV) wave_store_rows<6>(dL_dcov3D + 6 * (size_t)wave_first, rows_valid, o_cov, xp, lane);
-        else wave_store_rows<3>(dL_dscales + 3 * (size_t)wave_first, rows_valid, o_sc, xp, lane);
+        else if (!CHAIN) wave_store_rows<3>(dL_dscales + 3 * (size_t)wave_first, rows_valid, o_sc, xp, lane);
         if (!HAS_SH) wave_store_rows<3>(dL_dcolors_precomp + 3 * (size_t)wave_first, rows_valid, o_col, xp, lane);
         else if (M == 1) wave_store_rows<3>(dL_dsh + 3 * (size_t)wave_first, rows_valid, o_sh0, xp, lane);
     }
@@ -562,6 +594,60 @@ __global__ void __launch_bounds__(256, DEG0 ? 6 : 3) preprocess_backward_kernel(
         BLK_STAMP(trace, 6, 7)   // acknowledged
     }
 #endif
+    if constexpr (CHAIN) {   // ---- on through the pose pre-transform: pretransform_chain.h, the work of pretransform_backward_kernel<1> ----
+        __shared__ float red[4][28];
+        float Rp[9], Lp[16], pacc[28];
+#pragma unroll
+        for (int i = 0; i < 9; i++) Rp[i] = pre.Rm[i];
+#pragma unroll
+        for (int i = 0; i < 16; i++) Lp[i] = pre.Lq[i];
+#pragma unroll
+        for (int i = 0; i < 28; i++) pacc[i] = 0.f;
+        if (idx < P) {   // (a culled Gaussian: zero gradients — its Adam step still decays its moments, as in the two-kernel form)
+            ChainIn in;
+            in.x = raw_x; in.y = raw_y; in.z = raw_z; in.q = raw_q;
+            in.sc[0] = raw_s0; in.sc[1] = raw_s1; in.sc[2] = raw_s2; in.o = raw_o; in.c = raw_c;
+            in.gx = o_m3d[0]; in.gy = o_m3d[1]; in.gz = o_m3d[2];
+            in.gq = make_float4(o_rot[0], o_rot[1], o_rot[2], o_rot[3]);
+            in.gs[0] = o_sc[0]; in.gs[1] = o_sc[1]; in.gs[2] = o_sc[2]; in.go = o_op;
+            chain_pose_acc(in, pacc);
+            ChainOut o;
+            chain_grads(Rp, Lp, in, o);
+            ch.g_conf_flat[raw_ci] = o.gconf;   // mask positions are unique: plain store
+            chain_adam(ch.A, (size_t)idx, in, o);
+        }
+        pose_sums_finish(pacc, red, ch.det_partials, ch.arrived, ch.g_small);
+    }
+}
+
+// Scratch of the chained form's fixed-order pose sums: one row of 28 floats per workgroup + the arrival word, per (host thread, device,
+// stream) like pretransform.hip's; grown when a larger model comes along.  Zeroed when allocated (the kernel re-arms the word).
+static float *chain_scratch(hipStream_t s, size_t blocks, uint32_t **arrived) {
+    struct Slot { int dev; hipStream_t stream; float *buf; size_t rows; };
+    static thread_local std::vector<Slot> slots;
+    *arrived = nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    Slot *hit = nullptr;
+    for (auto &e : slots)
+        if (e.dev == dev && e.stream == s) hit = &e;
+    if (!hit || hit->rows < blocks) {
+        auto complain = [] {
+            static bool said = false;
+            if (!__atomic_exchange_n(&said, true, __ATOMIC_RELAXED))
+                fprintf(stderr, "[das3r] no scratch for the fixed-order pose sums: this thread's pose gradients are summed with float atomics (not bit-reproducible)\n");
+        };
+        const size_t rows = std::max(blocks, (size_t)4096) * 2;
+        float *buf = nullptr;
+        if (hit) { (void)hipStreamSynchronize(s); (void)hipFree(hit->buf); hit->buf = nullptr; hit->rows = 0; }
+        if (hipMalloc((void **)&buf, (rows * 28 + 4) * sizeof(float)) != hipSuccess) { complain(); return nullptr; }
+        if (hipMemsetAsync(buf, 0, (rows * 28 + 4) * sizeof(float), s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { (void)hipFree(buf); complain(); return nullptr; }
+        if (hit) { hit->buf = buf; hit->rows = rows; }
+        else { slots.push_back({dev, s, buf, rows}); hit = &slots.back(); }
+    }
+    if (!hit->buf) return nullptr;
+    *arrived = reinterpret_cast<uint32_t *>(hit->buf + hit->rows * 28);
+    return hit->buf;
 }
 
 int launch_preprocess_backward(const das3r_raster_args *a, const das3r_raster_in *in, char *geom, char *binning, const Layout &L,
@@ -586,11 +672,40 @@ int launch_preprocess_backward(const das3r_raster_args *a, const das3r_raster_in
         a->viewmatrix, a->projmatrix, a->campos, a->image_width, a->image_height, a->tanfovx, a->tanfovy,                    \
         (const uint32_t *)(geom + L.pub.tiles_touched), (const uint8_t *)(geom + L.pub.clamped), partial, exists,        \
         (const uint32_t *)(geom + L.g_off_by_gid), g->dL_dmeans2D, g->dL_dopacities, g->dL_dcolors_precomp, g->dL_dmeans3D,  \
-        g->dL_dscales, g->dL_drotations, g->dL_dshs, g->dL_dcov3D, pre PB_TRACE_ARG
+        g->dL_dscales, g->dL_drotations, g->dL_dshs, g->dL_dcov3D, pre, ch PB_TRACE_ARG
+    // ---- the chained form (das3r_raster_grads.chain): unstaged SH rows, raw parameters ----
+    ChainArgs ch;
+    memset(&ch, 0, sizeof(ch));
+    if (g->chain) {
+        const das3r_chain *c = g->chain;
+        if (!pre.xyz || !pre.opacity_raw || !pre.conf_flat || !has_sh || has_cov || stage_out || quad_rows || !c->slots || !c->g_conf_flat || !c->g_small) {
+            set_error("das3r_raster_backward: grads->chain needs in->pre, SH coefficients in an unstaged layout (M < 16 or the active degree below 2 ...), "
+                      "scales + rotations, and g_conf_flat / g_small / slots");
+            return DAS3R_ERR_INVALID_ARG;
+        }
+        for (int k = 0; k < 4; k++) {
+            if (!c->slots[k].param || !c->slots[k].exp_avg || !c->slots[k].exp_avg_sq || !(c->slots[k].bc2_sqrt > 0.f)) {
+                set_error("das3r_raster_backward: grads->chain: bad slot %d", k);
+                return DAS3R_ERR_INVALID_ARG;
+            }
+            ch.A.p[k] = c->slots[k].param; ch.A.m[k] = c->slots[k].exp_avg; ch.A.v[k] = c->slots[k].exp_avg_sq;
+            ch.A.step_size[k] = c->slots[k].step_size; ch.A.bc2_sqrt[k] = c->slots[k].bc2_sqrt;
+        }
+        if (ch.A.p[0] != pre.xyz || ch.A.p[1] != pre.rot || ch.A.p[2] != pre.scaling || ch.A.p[3] != pre.opacity_raw) {
+            set_error("das3r_raster_backward: grads->chain: the slots must be the tensors of in->pre (xyz, rot, scaling, opacity_raw)");
+            return DAS3R_ERR_INVALID_ARG;
+        }
+        ch.A.beta1 = c->beta1; ch.A.beta2 = c->beta2; ch.A.eps = c->eps;
+        ch.g_conf_flat = c->g_conf_flat; ch.g_small = c->g_small;
+        ch.det_partials = chain_scratch(s, (size_t)grid.x, &ch.arrived);   // (null: float atomics, said once)
+    }
 #define LAUNCH(SH, COV, SI, SO) DAS3R_LAUNCH((preprocess_backward_kernel<SH, COV, SI, SO>), grid, block, 0, s, ARGS)
 #define LAUNCH0(SH, COV) DAS3R_LAUNCH((preprocess_backward_kernel<SH, COV, false, false, true>), grid, block, 0, s, ARGS)
     const bool deg0 = a->sh_degree == 0 && !stage_out;
-    if (has_sh && !has_cov) {
+    if (g->chain) {
+        if (deg0) DAS3R_LAUNCH((preprocess_backward_kernel<true, false, false, false, true, true>), grid, block, 0, s, ARGS);
+        else DAS3R_LAUNCH((preprocess_backward_kernel<true, false, false, false, false, true>), grid, block, 0, s, ARGS);
+    } else if (has_sh && !has_cov) {
         if (stage_in) LAUNCH(true, false, true, true);
         else if (stage_out) LAUNCH(true, false, false, true);
         else if (deg0) LAUNCH0(true, false);

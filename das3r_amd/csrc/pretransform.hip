@@ -14,6 +14,7 @@
 #include "common.h"
 #include "adam_math.h"
 #include "pretransform_math.h"
+#include "pretransform_chain.h"
 
 namespace das3r {
 
@@ -38,24 +39,8 @@ __global__ void __launch_bounds__(256) pretransform_forward_kernel(int P, const 
     }
 }
 
-// a b as a rounded fp32 number, whatever consumes it: a gradient is the same number in every MODE below — written to memory (MODE 0) or
-// handed to the Adam step in a register (MODE 1), where the compiler would otherwise contract the product into the step's first subtraction
-// (__fmul_rn is a plain multiplication to this compiler, contraction included)
-__device__ __forceinline__ float rounded_product(const float a, const float b) {
-    float r = a * b;
-    asm volatile("" : "+v"(r));
-    return r;
-}
-
-// The four per-Gaussian parameter tensors the pre-transform reads, as Adam sees them (MODE 1 below): parameter, first and second
-// moment, step_size = lr / (1 - beta1^t) and sqrt(1 - beta2^t) of the group it belongs to.
-struct GeometryAdam {
-    float *p[4], *m[4], *v[4];   // xyz [P,3], rotation [P,4], scaling [P,3], opacity [P,1]
-    float step_size[4], bc2_sqrt[4];
-    float beta1, beta2, eps;
-};
-
-constexpr int POSE_MAX_BLOCKS = 2048;   // largest grid of the backward kernels below (rows of the fixed-order pose-sum scratch)
+// (GeometryAdam, the per-Gaussian chain rule + Adam step and the fixed-order pose sums: pretransform_chain.h — shared with the rasterizer's
+//  backward, which can take this whole kernel's work on itself: preprocess_bwd.hip CHAIN)
 
 // MODE 0: the backward as a producer of gradients (g_xyz, g_rotation, g_scaling, g_opacity_raw, g_conf_flat, the 28 pose sums).
 // MODE 1 (round 4): the same gradients never leave the registers — the Adam step of the four tensors is taken on the spot (adam_math.h:
@@ -80,148 +65,39 @@ __global__ void __launch_bounds__(256) pretransform_backward_kernel(
 #pragma unroll
     for (int i = 0; i < 28; i++) acc[i] = 0.f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x) {
-        const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
-        const float gx = g_means3D[3 * (size_t)i], gy = g_means3D[3 * (size_t)i + 1], gz = g_means3D[3 * (size_t)i + 2];
-        const float rx[3] = {R[0] * gx + R[3] * gy + R[6] * gz, R[1] * gx + R[4] * gy + R[7] * gz, R[2] * gx + R[5] * gy + R[8] * gz};   // R^T g
-        acc[0] += gx * x; acc[1] += gx * y; acc[2] += gx * z;
-        acc[3] += gy * x; acc[4] += gy * y; acc[5] += gy * z;
-        acc[6] += gz * x; acc[7] += gz * y; acc[8] += gz * z;
-        acc[9] += gx; acc[10] += gy; acc[11] += gz;
-        const float4 q = reinterpret_cast<const float4 *>(rot)[i];
-        const float4 gq = reinterpret_cast<const float4 *>(g_rot)[i];
-        const float4 rq = make_float4(L[0] * gq.x + L[4] * gq.y + L[8] * gq.z + L[12] * gq.w, L[1] * gq.x + L[5] * gq.y + L[9] * gq.z + L[13] * gq.w,
-                                      L[2] * gq.x + L[6] * gq.y + L[10] * gq.z + L[14] * gq.w, L[3] * gq.x + L[7] * gq.y + L[11] * gq.z + L[15] * gq.w);
-        const float gv[4] = {gq.x, gq.y, gq.z, gq.w}, qv[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = 0; b < 4; b++) acc[12 + 4 * a + b] += gv[a] * qv[b];
+        ChainIn in;
+        in.x = xyz[3 * (size_t)i]; in.y = xyz[3 * (size_t)i + 1]; in.z = xyz[3 * (size_t)i + 2];
+        in.gx = g_means3D[3 * (size_t)i]; in.gy = g_means3D[3 * (size_t)i + 1]; in.gz = g_means3D[3 * (size_t)i + 2];
+        in.q = reinterpret_cast<const float4 *>(rot)[i];
+        in.gq = reinterpret_cast<const float4 *>(g_rot)[i];
+        chain_pose_acc(in, acc);
         if constexpr (MODE == 2) continue;
-        float sc[3], rs[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            sc[k] = scaling[3 * (size_t)i + k];
-            rs[k] = rounded_product(g_scales[3 * (size_t)i + k], expf(sc[k]));
+            in.sc[k] = scaling[3 * (size_t)i + k];
+            in.gs[k] = g_scales[3 * (size_t)i + k];
         }
-        const float o = opacity_raw[i];
-        const float s = 1.0f / (1.0f + expf(-o));
+        in.o = opacity_raw[i];
         const int64_t ci = mask_index ? mask_index[i] : (int64_t)i;
-        const float c = conf_flat[ci], go = g_opac[i];
-        const float ro = rounded_product(go * c * s, 1.0f - s);
-        g_conf_flat[ci] = go * s;   // mask positions are unique: plain store into the pre-zeroed buffer
+        in.c = conf_flat[ci];
+        in.go = g_opac[i];
+        ChainOut o;
+        chain_grads(R, L, in, o);
+        g_conf_flat[ci] = o.gconf;   // mask positions are unique: plain store into the pre-zeroed buffer
         if constexpr (MODE == 0) {
-            g_xyz[3 * (size_t)i] = rx[0];
-            g_xyz[3 * (size_t)i + 1] = rx[1];
-            g_xyz[3 * (size_t)i + 2] = rx[2];
-            reinterpret_cast<float4 *>(g_rotation)[i] = rq;
+            g_xyz[3 * (size_t)i] = o.rx[0];
+            g_xyz[3 * (size_t)i + 1] = o.rx[1];
+            g_xyz[3 * (size_t)i + 2] = o.rx[2];
+            reinterpret_cast<float4 *>(g_rotation)[i] = o.rq;
 #pragma unroll
-            for (int k = 0; k < 3; k++) g_scaling[3 * (size_t)i + k] = rs[k];
-            g_opacity_raw[i] = ro;
+            for (int k = 0; k < 3; k++) g_scaling[3 * (size_t)i + k] = o.rs[k];
+            g_opacity_raw[i] = o.ro;
         } else {
-            float pv[3] = {x, y, z};
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                float m = A.m[0][3 * (size_t)i + k], v = A.v[0][3 * (size_t)i + k];
-                adam_update(pv[k], m, v, rx[k], A.beta1, A.beta2, A.eps, A.step_size[0], A.bc2_sqrt[0]);
-                A.p[0][3 * (size_t)i + k] = pv[k];
-                A.m[0][3 * (size_t)i + k] = m;
-                A.v[0][3 * (size_t)i + k] = v;
-            }
-            float4 qm = reinterpret_cast<const float4 *>(A.m[1])[i], qvv = reinterpret_cast<const float4 *>(A.v[1])[i], qp = q;
-            adam_update(qp.x, qm.x, qvv.x, rq.x, A.beta1, A.beta2, A.eps, A.step_size[1], A.bc2_sqrt[1]);
-            adam_update(qp.y, qm.y, qvv.y, rq.y, A.beta1, A.beta2, A.eps, A.step_size[1], A.bc2_sqrt[1]);
-            adam_update(qp.z, qm.z, qvv.z, rq.z, A.beta1, A.beta2, A.eps, A.step_size[1], A.bc2_sqrt[1]);
-            adam_update(qp.w, qm.w, qvv.w, rq.w, A.beta1, A.beta2, A.eps, A.step_size[1], A.bc2_sqrt[1]);
-            reinterpret_cast<float4 *>(A.p[1])[i] = qp;
-            reinterpret_cast<float4 *>(A.m[1])[i] = qm;
-            reinterpret_cast<float4 *>(A.v[1])[i] = qvv;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                float m = A.m[2][3 * (size_t)i + k], v = A.v[2][3 * (size_t)i + k];
-                adam_update(sc[k], m, v, rs[k], A.beta1, A.beta2, A.eps, A.step_size[2], A.bc2_sqrt[2]);
-                A.p[2][3 * (size_t)i + k] = sc[k];
-                A.m[2][3 * (size_t)i + k] = m;
-                A.v[2][3 * (size_t)i + k] = v;
-            }
-            float op = o, m = A.m[3][i], v = A.v[3][i];
-            adam_update(op, m, v, ro, A.beta1, A.beta2, A.eps, A.step_size[3], A.bc2_sqrt[3]);
-            A.p[3][i] = op;
-            A.m[3][i] = m;
-            A.v[3][i] = v;
+            chain_adam(A, (size_t)i, in, o);
         }
     }
-    // 28 sums over all splats: wave reduction on the DPP network, 4 waves through LDS, one atomic per workgroup
-    const int lane = __lane_id(), wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < 28; i++) {
-        const float r = wave_sum_to_lane63(acc[i]);
-        if (lane == 63) red[wave][i] = r;
-    }
-    __syncthreads();
-    if (det_partials == nullptr) {
-        if (threadIdx.x < 28) {
-            const float r = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-            if (r != 0.f) unsafeAtomicAdd(&g_small[threadIdx.x], r);
-        }
-        return;
-    }
-    // Round 5: the 28 sums in a FIXED order — the workgroups' float atomics met in whatever order the hardware served them, which made
-    // two identical jobs end 0.1 - 0.2 dB apart after 4000 iterations (the only run-to-run difference of the direct iteration).  Every
-    // workgroup stores its 28 partial sums; the last one to arrive (one integer atomic per workgroup) adds the rows in index order:
-    // thread t takes rows t, t + 256, ..., the 256 threads meet in the same fixed tree (DPP, then LDS).  Bit-identical from run to run, and 28 x gridDim.x float
-    // atomics on 28 addresses fewer.
-    __shared__ uint32_t s_last;
-    if (threadIdx.x < 28)
-        __hip_atomic_store(det_partials + (size_t)blockIdx.x * 28 + threadIdx.x,
-                           red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // (no __threadfence here: an agent-scope release fence writes the XCD's whole L2 back — this kernel has just written > 100 MB of
-    //  parameters and moments, and 2048 workgroups doing that took the kernel from 0.15 to 0.60 ms.  The 28 words are agent-scope atomic
-    //  stores — written through to where the other XCDs see them — and are complete when the store counter says so; the barrier then
-    //  orders them in front of thread 0's arrival, itself a relaxed agent-scope atomic)
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
-#error "the pose-sum hand-off counts its stores in vmcnt (gfx9: one counter for loads and stores); gfx10+ counts stores in vscnt — use a release-ordered arrival atomic there"
-#endif
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    uint32_t *const arrived = reinterpret_cast<uint32_t *>(det_partials + (size_t)POSE_MAX_BLOCKS * 28);   // (a fixed place: the grid differs from launch to launch)
-    if (threadIdx.x == 0) s_last = (__hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) ? 1u : 0u;
-    __syncthreads();
-    if (!s_last) return;   // (uniform)
-    // (every wave of the last workgroup acquires at agent scope — the other workgroups' rows came through other XCDs' L2s — and then reads
-    //  its rows with plain 16-byte loads, all in flight at once: read one atomic word at a time the 224 loads of a thread were 0.45 ms)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    float part[28];
-#pragma unroll
-    for (int i = 0; i < 28; i++) part[i] = 0.f;
-    const float4 *const rows4 = reinterpret_cast<const float4 *>(det_partials);   // a row = 28 floats = 7 float4
-    for (uint32_t b0 = threadIdx.x; b0 < gridDim.x; b0 += 1024u) {
-        float4 v[4][7];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t b = b0 + 256u * u;
-            const uint32_t bc = b < gridDim.x ? b : gridDim.x - 1u;   // (clamped, not guarded: the loads stay in one block, all in flight)
-#pragma unroll
-            for (int q = 0; q < 7; q++) v[u][q] = rows4[(size_t)bc * 7 + q];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const bool have = (b0 + 256u * u) < gridDim.x;   // (a select, not a factor: a row may hold an inf)
-#pragma unroll
-            for (int q = 0; q < 7; q++) {
-                part[4 * q] += have ? v[u][q].x : 0.f; part[4 * q + 1] += have ? v[u][q].y : 0.f;
-                part[4 * q + 2] += have ? v[u][q].z : 0.f; part[4 * q + 3] += have ? v[u][q].w : 0.f;
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 28; i++) {   // the same fixed tree as above: DPP within the wave, the four waves through LDS
-        const float r = wave_sum_to_lane63(part[i]);
-        if (lane == 63) red[wave][i] = r;
-    }
-    __syncthreads();
-    if (threadIdx.x < 28)   // (g_small accumulates: zero at rest, das3r_pose_chain_qt re-arms it)
-        g_small[threadIdx.x] += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    if (threadIdx.x == 0) __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
+    // 28 sums over all splats, in a fixed order when the caller has scratch for it (pretransform_chain.h)
+    pose_sums_finish(acc, red, det_partials, det_partials ? reinterpret_cast<uint32_t *>(det_partials + (size_t)POSE_MAX_BLOCKS * 28) : nullptr, g_small);
 }
 
 // pose (qw,qx,qy,qz,tx,ty,tz) -> mats[28] = R (9, row-major; rotation of the NORMALISED quaternion, like get_camera_from_tensor),

@@ -208,11 +208,24 @@ def _forward_backward(st, model, cam, q_row, t_row, gq_row, gt_row, static_hw, l
     _lib.check(lib.das3r_photometric_backward(H, W, _p(image), _p(gt), _p(static_hw), C.c_float(lam), _p(dmaps), _p(st.one), _p(d_render),
                                               _p(d_static), s), "das3r_photometric_backward")
     # ---- rasterizer backward (examines the forward's binning self-check first: include/das3r_raster.h)
+    # round 6 (include/das3r_raster.h das3r_chain): with geometry == "adam" the rasterizer's backward goes on through the pre-transform — chain
+    # rule, the Adam step of xyz / rotation / scaling / opacity, dL/d(confidence), the pose sums — and the four camera-frame gradient tensors
+    # are never written.  SH rows in an unstaged layout only (below 16 coefficients per Gaussian); model.fuse_backward_chain = False: two calls.
+    chain, conf_grad = None, None
+    if geometry == "adam" and pre is not None and getattr(model, "fuse_backward_chain", True) and shs.shape[1] < 16:
+        opt_ = model.optimizer
+        slots, keep = opt_.adam_slots([model._xyz, model._rotation, model._scaling, model._opacity])
+        g_conf = torch.empty_like(conf_flat) if st.mask_is_everything else torch.zeros_like(conf_flat)
+        chain = _lib.Chain()
+        chain.g_conf_flat, chain.g_small, chain.slots = g_conf.data_ptr(), st.g_small.data_ptr(), slots
+        chain.beta1, chain.beta2, chain.eps = opt_.betas[0], opt_.betas[1], opt_.eps
+        conf_grad = g_conf
     g_means2D, _g_colors, g_opac, g_means3D, _g_cov, g_sh, g_scales, g_rot = _backward_impl(
-        rs, I, d_render, means3D, shs, e, opac, scales, rotations, e, geom, binning, img, cap, pre=pre)
+        rs, I, d_render, means3D, shs, e, opac, scales, rotations, e, geom, binning, img, cap, pre=pre, chain=chain)
     # ---- pre-transform backward, pose chain rule
-    conf_grad = None
-    if geometry == "pose":
+    if chain is not None:
+        del keep
+    elif geometry == "pose":
         _lib.check(lib.das3r_pretransform_pose_sums(P, _p(model._xyz), _p(model._rotation), _p(mats), C.c_void_p(mats.data_ptr() + 48), _p(g_means3D),
                                                     _p(g_rot), _p(st.g_small), s), "das3r_pretransform_pose_sums")
     else:

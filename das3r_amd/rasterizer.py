@@ -233,7 +233,7 @@ def _forward_full(rs, means3D, sh, colors_precomp, opacities, scales, rotations,
 
 
 def _backward_impl(rs, num_rendered, grad_out_color, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                   geom, binning, img, capacity=None, _scratch_misalign=0, pre=None):
+                   geom, binning, img, capacity=None, _scratch_misalign=0, pre=None, chain=None):
     ticket = capacity
     capacity = int(num_rendered) if capacity is None else int(capacity)
     lib = _lib.load()
@@ -242,11 +242,14 @@ def _backward_impl(rs, num_rendered, grad_out_color, means3D, sh, colors_precomp
     M = sh.shape[1] if sh.numel() else 0
     z = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)  # fully written by the library
     has_sh, has_cov = sh.numel() > 0, cov3Ds_precomp.numel() > 0
-    g_means2D, g_opac, g_means3D = z(P, 3), z(P, 1), z(P, 3)
+    # chain (a _lib.Chain the caller keeps alive, with `pre`): the library goes on through the pose pre-transform and the Adam step of the four
+    # geometry tensors itself — dL/d(camera-frame means, opacities, scales, rotations) are not produced (returned as None)
+    g_means2D = z(P, 3)
+    g_opac, g_means3D = (None, None) if chain is not None else (z(P, 1), z(P, 3))
     # only the gradients this call's inputs have (the others are returned as None by the autograd function)
     g_sh = z(P, M, 3) if has_sh else None
     g_colors = None if has_sh else z(P, 3)
-    g_scales, g_rot = (None, None) if has_cov else (z(P, 3), z(P, 4))
+    g_scales, g_rot = (None, None) if (has_cov or chain is not None) else (z(P, 3), z(P, 4))
     g_cov = z(P, 6) if has_cov else None
     if P == 0:
         return g_means2D, g_colors, g_opac, g_means3D, g_cov, g_sh, g_scales, g_rot
@@ -264,7 +267,9 @@ def _backward_impl(rs, num_rendered, grad_out_color, means3D, sh, colors_precomp
         saved.check_word, saved.check_tag = ticket.check_word, ticket.check_tag
     saved.flags = int(getattr(ticket, "flags", 0))
     g = _lib.RasterGrads()
-    g.dL_dmeans2D, g.dL_dopacities, g.dL_dmeans3D = g_means2D.data_ptr(), g_opac.data_ptr(), g_means3D.data_ptr()
+    g.dL_dmeans2D, g.dL_dopacities, g.dL_dmeans3D = g_means2D.data_ptr(), _ptr(g_opac), _ptr(g_means3D)
+    if chain is not None:
+        g.chain = C.pointer(chain)
     g.dL_dshs = _ptr(g_sh)
     g.dL_dcolors_precomp = _ptr(g_colors)
     g.dL_dscales, g.dL_drotations = _ptr(g_scales), _ptr(g_rot)

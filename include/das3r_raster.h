@@ -152,6 +152,7 @@ typedef struct {
     float *dL_dcov3D;          /* [P,6]; NULL unless cov3D_precomp was used */
     float *scratch;            /* das3r_raster_backward_scratch_bytes(saved->capacity) bytes of caller-provided scratch: partial
                                 * sums per instance (the compositing kernels use no atomics) */
+    const struct das3r_chain_s *chain; /* ABI 14: NULL, or "go on through the pose pre-transform" (das3r_chain below) */
 } das3r_raster_grads;
 
 /* Returns num_rendered (>= 0) or a negative das3r_status.  Fills *saved. */
@@ -250,6 +251,20 @@ int das3r_adam_step(int32_t n, const das3r_adam_tensor *tensors, float beta1, fl
 int das3r_adam_step_gated(int32_t n, const das3r_adam_tensor *tensors, float beta1, float beta2, float eps, const float *gate,
                           float threshold, int32_t *state, das3r_stream_t stream);
 
+/* ABI 14 — das3r_raster_grads.chain: the rasterizer's backward goes on where it used to stop.  With in->pre (raw parameters + pose) its
+ * per-Gaussian kernel holds dL/d(camera-frame means, scales, rotations, opacities) in registers: instead of writing them for
+ * das3r_pretransform_backward_adam to read back, it applies that function's chain rule and Adam step itself (the same arithmetic, bit for
+ * bit: csrc/pretransform_chain.h) — slots[0..3] = xyz, rotation, scaling, opacity exactly as for das3r_pretransform_backward_adam (they
+ * must be the tensors of in->pre), g_conf_flat written at the mask positions, the 28 pose sums ADDED to g_small (zero at rest) in a fixed
+ * order.  grads->dL_dmeans3D / dL_dscales / dL_drotations / dL_dopacities are then not written (may be NULL).  SH coefficients in an
+ * unstaged layout only (M < 16, or the active degree below 2): otherwise DAS3R_ERR_INVALID_ARG, use the two calls. */
+typedef struct das3r_chain_s {
+    float *g_conf_flat;
+    float *g_small;
+    const struct das3r_adam_slot_s *slots;
+    float beta1, beta2, eps;
+} das3r_chain;
+
 /* ABI 11: the backward of the pre-transform with the Adam step of the four tensors it differentiates — xyz, rotation, scaling, raw
  * opacity: the reference's groups "xyz", "rotation", "scaling", "opacity" (/root/reference/scene/gaussian_model.py:236-261) — taken in the
  * same pass: their gradients are neither written nor read back, the parameters are read once for both.  slots[0 .. 3] (a HOST array)
@@ -257,7 +272,7 @@ int das3r_adam_step_gated(int32_t n, const das3r_adam_tensor *tensors, float bet
  * place) with their moments and step_size = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t) as in das3r_adam_tensor.  g_conf_flat and
  * g_small leave as from das3r_pretransform_backward (zero on entry): the confidence map and the camera pose have their own steps.
  * Same arithmetic as das3r_pretransform_backward followed by das3r_adam_step on the four tensors. */
-typedef struct {
+typedef struct das3r_adam_slot_s {
     float *param, *exp_avg, *exp_avg_sq;
     float step_size, bc2_sqrt;
 } das3r_adam_slot;

@@ -37,7 +37,8 @@ def test_abi_version_and_layout(hip_lib):
     assert L["splat_stride"] == 64 and L["conic_opacity"] == L["xy"] + 16 and L["rgbd"] == L["xy"] + 32
     # struct sizes seen by ctypes must match what the header lays out (plain C ABI: ints, floats, pointers)
     assert ctypes.sizeof(_lib.RasterArgs) == 5 * 4 + 3 * 4 + 4 * 8 + 2 * 4 + 8
-    assert ctypes.sizeof(_lib.RasterIn) == 7 * 8 + 8 and ctypes.sizeof(_lib.RasterGrads) == 9 * 8   # ABI 14: + pre (das3r_pretransform *)
+    assert ctypes.sizeof(_lib.RasterIn) == 7 * 8 + 8 and ctypes.sizeof(_lib.RasterGrads) == 9 * 8 + 8   # ABI 14: + pre (das3r_pretransform *), + chain (das3r_chain *)
+    assert ctypes.sizeof(_lib.Chain) == 3 * 8 + 3 * 4 + 4 and ctypes.sizeof(_lib.AdamSlot) == 3 * 8 + 2 * 4
     assert ctypes.sizeof(_lib.PreTransform) == 9 * 8
     assert ctypes.sizeof(_lib.RasterSaved) == 5 * 8 + 8 + 8   # + check_word, check_tag and (ABI 14, in what was padding) flags
     assert _lib.RasterSaved.flags.offset == 52 and _lib.RasterSaved.check_tag.offset == 48

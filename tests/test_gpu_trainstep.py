@@ -264,6 +264,59 @@ def test_pretransform_inside_the_rasterizer_kernels_is_bit_identical_to_the_sepa
         assert torch.equal(pa[k], pb[k]), k
 
 
+@pytest.mark.parametrize("degree", [0, 1])
+def test_backward_chained_through_the_pretransform_matches_the_two_calls(degree):
+    """Round 6 (include/das3r_raster.h das3r_chain): with the raw parameters in hand the rasterizer's per-Gaussian backward
+    kernel goes on through the pose pre-transform — chain rule, Adam step of xyz / rotation / scaling / opacity, dL/d(confidence), the camera's
+    28 sums — instead of writing dL/d(camera-frame means, scales, rotations, opacities) for das3r_pretransform_backward_adam to read back
+    (/root/reference/gaussian_renderer/__init__.py:83-97,107 backward + scene/gaussian_model.py:236-261).  One shared arithmetic
+    (csrc/pretransform_chain.h): after ONE step the four tensors, their moments, the confidence map and every SH coefficient are EQUAL bit for
+    bit; the pose gradient — 28 sums over all Gaussians, met in another (still fixed) order — agrees to 1e-5 of its size.  Twelve steps on:
+    the same losses to 1e-5 and parameters within the four-step bars of the direct / autograd lock-step (the poses feed back)."""
+    from das3r_amd import _lib, fast_step
+    from das3r_amd.train import train_step
+    bg = torch.zeros(3, device="cuda")
+
+    def run(chained, steps):
+        model, cams, _, opt, _dense = _pair(frames=4, W=48, H=32, seed=23, heldout=False, iterations=4000, fused=True, generic=True)
+        model.fast_step = True
+        model.fuse_backward_chain = chained
+        if degree:
+            model.active_sh_degree = degree
+            model.optimizer.set_active_sh_degree(degree)
+            with torch.no_grad():
+                g = torch.Generator(device="cpu").manual_seed(2)
+                model._features_rest[:, :3].copy_((torch.randn(model._features_rest[:, :3].shape, generator=g) * 0.05).cuda())
+        assert fast_step.available(model, PIPE)
+        _lib.profile_report()
+        _lib.profile_enable(True)
+        try:
+            rec = [tuple(float(v) for v in train_step(model, cams[k % len(cams)], opt, 100 + k, PIPE, bg, fused=True)[:2]) for k in range(steps)]
+            torch.cuda.synchronize()
+        finally:
+            _lib.profile_enable(False)
+        kernels = _lib.profile_report()
+        moments = {k: model.optimizer.state[getattr(model, a)]["exp_avg"].clone() for k, a in NAMES.items() if k in ("xyz", "rotation", "scaling", "opacity")}
+        return rec, {k: getattr(model, a).detach().clone() for k, a in NAMES.items()}, moments, kernels
+
+    (ra, pa, ma, ka), (rb, pb, mb, kb) = run(True, 1), run(False, 1)
+    assert not any(k.startswith("pretransform_backward_kernel") for k in ka) and any(k.startswith("pretransform_backward_kernel") for k in kb), (list(ka), list(kb))
+    assert ra == rb
+    for k in pa:
+        if k in ("Q", "T"):
+            assert float((pa[k] - pb[k]).abs().max()) <= 1e-6 * float(pb[k].abs().max()), k   # (a first Adam step of size lr whatever the gradient's last bits)
+        else:
+            assert torch.equal(pa[k], pb[k]), k
+    for k in ma:
+        assert torch.equal(ma[k], mb[k]), k
+    (ra, pa, _, _), (rb, pb, _, _) = run(True, 12), run(False, 12)
+    for (la, psa), (lb, psb) in zip(ra, rb):
+        assert abs(la - lb) <= 1e-5 * abs(lb) and abs(psa - psb) <= 1e-3, (ra, rb)
+    for k in pa:
+        far = (pa[k] - pb[k]).abs() > 1e-5 + 1e-4 * pb[k].abs()
+        assert float(far.double().mean()) <= 1e-3, (k, float(far.double().mean()))
+
+
 def test_packed_sh_tensor_is_kept_current_by_the_optimizer_and_rebuilt_when_it_cannot_be_vouched_for():
     """Round 6: above degree 0 the direct iteration used to concatenate f_dc and the active prefix of f_rest before every render (0.16 ms at
     2.13 M Gaussians) and to split dL/dshs into two copies behind it.  Now the packed [P, K, 3] tensor is built once and FusedAdam writes the
