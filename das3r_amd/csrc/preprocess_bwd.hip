@@ -110,7 +110,7 @@ struct ChainArgs {
     uint32_t *arrived;
 };
 template <bool HAS_SH, bool HAS_COV, bool STAGE_IN, bool STAGE_OUT, bool DEG0 = false, bool CHAIN = false>
-__global__ void __launch_bounds__(256, DEG0 ? (CHAIN ? 5 : 6) : 3) preprocess_backward_kernel(
+__global__ void __launch_bounds__(256, DEG0 ? (CHAIN ? 4 : 6) : 3) preprocess_backward_kernel(
     int P, int D_in, int M, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
     const float *__restrict__ rotations, const float *__restrict__ shs, const float *__restrict__ cov3D_precomp,
     const float *__restrict__ viewmatrix, const float *__restrict__ projmatrix, const float *__restrict__ campos, int W, int H,
@@ -145,6 +145,7 @@ __global__ void __launch_bounds__(256, DEG0 ? (CHAIN ? 5 : 6) : 3) preprocess_ba
     float raw_x = 0.f, raw_y = 0.f, raw_z = 0.f, raw_s0 = 0.f, raw_s1 = 0.f, raw_s2 = 0.f, raw_o = 0.f, raw_c = 0.f;   // CHAIN: kept for the chain rule at the end
     float4 raw_q = make_float4(0.f, 0.f, 0.f, 0.f);
     long long raw_ci = 0;
+    ChainMoments moments;
     if (!HAS_COV && (CHAIN || pre.xyz != nullptr)) {   // (uniform) the forward's inputs again, from the raw parameters (pretransform_math.h: the same bits)
         PoseRegs pose;
         load_pose(pre.Rm, pre.tv, pre.Lq, pose);
@@ -156,6 +157,7 @@ __global__ void __launch_bounds__(256, DEG0 ? (CHAIN ? 5 : 6) : 3) preprocess_ba
             raw_o = pre.opacity_raw[ic];
             raw_ci = pre.mask_index ? (long long)pre.mask_index[ic] : (long long)ic;
             raw_c = pre.conf_flat[raw_ci];
+            chain_load_moments(ch.A, (size_t)ic, moments);
         }
         mean_in = pre_mean(pose, rx, ry, rz);
         q_in = pre_rot(pose, rq);
@@ -614,7 +616,7 @@ __global__ void __launch_bounds__(256, DEG0 ? (CHAIN ? 5 : 6) : 3) preprocess_ba
             ChainOut o;
             chain_grads(Rp, Lp, in, o);
             ch.g_conf_flat[raw_ci] = o.gconf;   // mask positions are unique: plain store
-            chain_adam(ch.A, (size_t)idx, in, o);
+            chain_adam(ch.A, (size_t)idx, in, o, moments);
         }
         pose_sums_finish(pacc, red, ch.det_partials, ch.arrived, ch.g_small);
     }

@@ -75,18 +75,35 @@ __device__ __forceinline__ void chain_pose_acc(const ChainIn &in, float *acc) {
 #pragma unroll
         for (int b = 0; b < 4; b++) acc[12 + 4 * a + b] = __fmaf_rn(gv[a], qv[b], acc[12 + 4 * a + b]);
 }
-// the Adam step of the four tensors' rows of Gaussian i (adam_math.h), parameters read from `in`
-__device__ __forceinline__ void chain_adam(const GeometryAdam &A, const size_t i, const ChainIn &in, const ChainOut &o) {
+// the moments of Gaussian i's rows, requested ahead of their use (preprocess_bwd.hip CHAIN asks for them with its other inputs: a lane's whole
+// backward lies between the request and the step — read at the step they were one more exposed trip to memory at the end of every wave)
+struct ChainMoments {
+    float m0[3], v0[3], m2[3], v2[3], m3, v3;
+    float4 m1, v1;
+};
+__device__ __forceinline__ void chain_load_moments(const GeometryAdam &A, const size_t i, ChainMoments &mo) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        mo.m0[k] = A.m[0][3 * i + k]; mo.v0[k] = A.v[0][3 * i + k];
+        mo.m2[k] = A.m[2][3 * i + k]; mo.v2[k] = A.v[2][3 * i + k];
+    }
+    mo.m1 = reinterpret_cast<const float4 *>(A.m[1])[i];
+    mo.v1 = reinterpret_cast<const float4 *>(A.v[1])[i];
+    mo.m3 = A.m[3][i];
+    mo.v3 = A.v[3][i];
+}
+// the Adam step of the four tensors' rows of Gaussian i (adam_math.h), parameters read from `in`, moments from `mo`
+__device__ __forceinline__ void chain_adam(const GeometryAdam &A, const size_t i, const ChainIn &in, const ChainOut &o, const ChainMoments &mo) {
     float pv[3] = {in.x, in.y, in.z};
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        float m = A.m[0][3 * i + k], v = A.v[0][3 * i + k];
+        float m = mo.m0[k], v = mo.v0[k];
         adam_update(pv[k], m, v, o.rx[k], A.beta1, A.beta2, A.eps, A.step_size[0], A.bc2_sqrt[0]);
         A.p[0][3 * i + k] = pv[k];
         A.m[0][3 * i + k] = m;
         A.v[0][3 * i + k] = v;
     }
-    float4 qm = reinterpret_cast<const float4 *>(A.m[1])[i], qvv = reinterpret_cast<const float4 *>(A.v[1])[i], qp = in.q;
+    float4 qm = mo.m1, qvv = mo.v1, qp = in.q;
     adam_update(qp.x, qm.x, qvv.x, o.rq.x, A.beta1, A.beta2, A.eps, A.step_size[1], A.bc2_sqrt[1]);
     adam_update(qp.y, qm.y, qvv.y, o.rq.y, A.beta1, A.beta2, A.eps, A.step_size[1], A.bc2_sqrt[1]);
     adam_update(qp.z, qm.z, qvv.z, o.rq.z, A.beta1, A.beta2, A.eps, A.step_size[1], A.bc2_sqrt[1]);
@@ -97,17 +114,22 @@ __device__ __forceinline__ void chain_adam(const GeometryAdam &A, const size_t i
     float sc[3] = {in.sc[0], in.sc[1], in.sc[2]};
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        float m = A.m[2][3 * i + k], v = A.v[2][3 * i + k];
+        float m = mo.m2[k], v = mo.v2[k];
         adam_update(sc[k], m, v, o.rs[k], A.beta1, A.beta2, A.eps, A.step_size[2], A.bc2_sqrt[2]);
         A.p[2][3 * i + k] = sc[k];
         A.m[2][3 * i + k] = m;
         A.v[2][3 * i + k] = v;
     }
-    float op = in.o, m = A.m[3][i], v = A.v[3][i];
+    float op = in.o, m = mo.m3, v = mo.v3;
     adam_update(op, m, v, o.ro, A.beta1, A.beta2, A.eps, A.step_size[3], A.bc2_sqrt[3]);
     A.p[3][i] = op;
     A.m[3][i] = m;
     A.v[3][i] = v;
+}
+__device__ __forceinline__ void chain_adam(const GeometryAdam &A, const size_t i, const ChainIn &in, const ChainOut &o) {
+    ChainMoments mo;
+    chain_load_moments(A, i, mo);
+    chain_adam(A, i, in, o, mo);
 }
 
 // The 28 sums over all Gaussians of a launch, from every lane's acc[28]: wave reduction on the DPP network, the workgroup's four waves through
