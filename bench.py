@@ -568,6 +568,28 @@ def extras_main(main_workload):
     # whose held-out static-region PSNR is printed beside the rate (the stand-in for configs[2] / [4]: DAS3R_BENCH_JOBS=0 skips it)
     # Default: the Sintel shape with K = 1 and 2 (+ 25 s: the line must stay a matter of a minute); DAS3R_BENCH_JOBS=full: both shapes,
     # K = 1, 2, 3 (+ 2.5 min — what tools/refresh_profiles.sh records in profiles/rNN_bench_c4.json)
+    # "also run the new backward at C4 and report it in the line" — the 2x2-region walk (render_bwd_rgn.hip) forced onto
+    # the 1 M-splat 1080p workload, whose Gaussians cover 45 pixels each: not its shape, and never chosen for it
+    try:
+        from das3r_amd import _lib
+        os.environ["DAS3R_RENDER_BWD"] = "fine128"
+        _lib.reload_switches()
+        j = RasterJob("c4", dev)
+        j.upload()
+        j.step()
+        kt, _rf = kernel_table(j, 30)
+        out["c4_region_backward_ms"] = {"ms": kt["render_backward_kernel"]["ms_per_step"],
+                                        "what": "render_backward_regions_kernel<128> forced at C4 (DAS3R_RENDER_BWD=fine128); the default there is the block walk"}
+        del j
+    except Exception as ex:  # noqa: BLE001
+        out["c4_region_backward_ms"] = {"error": repr(ex)}
+    finally:
+        os.environ.pop("DAS3R_RENDER_BWD", None)
+        try:
+            _lib.reload_switches()
+        except Exception:  # noqa: BLE001
+            pass
+    torch.cuda.empty_cache()
     mode = os.environ.get("DAS3R_BENCH_JOBS", "1")
     if mode != "0":
         try:
@@ -793,6 +815,7 @@ def main():
                           "parallelism": f"{rk.world} independent scenes, one per GPU",
                           "host_cpus": (f"pinned to CPUs {pinned[1][0]}-{pinned[1][-1]} (one core complex per rank)" if pinned
                                         else "not pinned")},
+               "c4_region_backward_ms": (extras.pop("c4_region_backward_ms", None) if extras else None),
                "train_step_ms": train, "scenes_per_hour": round(scenes_per_hour, 2),
                "scenes_per_hour_def": sph_def, "jobs_in_flight": jobs,
                "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels, "extras": extras}
