@@ -28,6 +28,8 @@ def main():
     dev = torch.device("cuda:0")
     e = torch.empty(0, device=dev)
     for w in args.workloads.split(","):
+        _lib.forget_shapes()   # (`ds` and `dsc` are one (P, W, H): what the library learnt on one must not choose the other's kernels — the image of a
+        #  workload is compared with ITS first forward, and the compositing kernels differ in the last bit of T)
         sc = make_workload(w).to(dev)
         rs = GaussianRasterizationSettings(**sc.settings_kwargs())
         errs, counts, t0 = [], set(), time.perf_counter()
