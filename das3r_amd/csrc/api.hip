@@ -308,7 +308,7 @@ struct Mailbox {
 // of these; nothing is shared between threads: any number of them may render concurrently, each on its own stream).
 constexpr uint32_t CHECK_SLOTS = 16, CHECK_WORD0 = 16, MAILBOX_BYTES = 4 * (CHECK_WORD0 + 2 * CHECK_SLOTS);
 constexpr uint32_t CROWDED16 = 23u * 16u;   // (api.hip bin_and_render)
-struct Verdict { int P, W, H; int64_t last_I, peak_I; int radix_left, backoff; uint32_t gen; int seg_extra; bool last_seg; bool fine; uint32_t forwards; };
+struct Verdict { int P, W, H; int64_t last_I, peak_I; int radix_left, backoff; uint32_t gen; int seg_extra; bool last_seg; bool fine; uint32_t forwards; uint32_t clean; };
 struct PerDevice {
     Mailbox mb;
     uint32_t pending[CHECK_SLOTS] = {};             // per slot: tag of the forward whose self-check word has not been examined yet
@@ -521,8 +521,14 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     const bool decide_fine = (verdict.forwards++ & 511u) == 0u;
     if (verdict.last_I < 0) {   // (a shape's first forward: nothing to learn from yet)
     } else if (too_long == verdict.gen && !(verdict.last_seg && verdict.seg_extra == 0 && L.tile_passes < 3 && seg_dbits(L, L.tile_passes + 1) > 0)) {
-        verdict.radix_left = verdict.backoff;   // global sort for a while; longer every time it happens again
+        // global sort for a while; longer every time it happens AGAIN SOON.  Round 6: a failure that comes after 256 or more clean forwards
+        // on the fast path is an occasional one — a view of 45 that looks at a wall head-on (DAVIS-shaped job: one forward in ~ 350) — and
+        // starts from the shortest stint again: the doubling never forgot, and by iteration 4000 such a job had spent 2 447 of its
+        // iterations on the global sort (binning 0.64 ms against 0.47), tools/probes/job_binning_paths.py
+        if (verdict.clean >= 256u) verdict.backoff = 64;
+        verdict.radix_left = verdict.backoff;
         if (verdict.backoff < 4096) verdict.backoff *= 2;
+        verdict.clean = 0;
     } else if (too_long == verdict.gen || want_bits == verdict.gen) {
         verdict.seg_extra = 1;                  // the segmented path with one more partition pass of bucket bits from now on (this shape);
                                                 // a segment that is too long even then sends the shape back to the global sort (above)
@@ -552,6 +558,7 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         }
     };
     verdict.last_seg = seg;
+    if (local || seg) verdict.clean++;   // (a failure of this forward is reported to the next one: reset there)
     if (forced == 0 && verdict.radix_left > 0) verdict.radix_left--;
     const uint32_t count_tag = ++mb->seq ? mb->seq : ++mb->seq;
     unsigned long long *arrive = arrive_ring + (size_t)(count_tag % ARRIVE_SLOTS) * ARRIVE_WORDS;
