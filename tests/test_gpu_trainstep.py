@@ -23,7 +23,7 @@ PIPE = SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_pyth
 SCHEDULE_SIGMA_TRAIN_DB, SCHEDULE_SIGMA_HELDOUT_DB = 0.124, 0.101
 
 
-def _pair(frames, W, H, seed, heldout, iterations, fused=False, generic=False):
+def _pair(frames, W, H, seed, heldout, iterations, fused=False, generic=False, mask_some=False):
     """-> (HIP model, train cams, test cams, dense trainer) initialised from the same sequence.  generic: leave DAS3R's initial
     state (every Gaussian isotropic with an identity quaternion, where dL/d(rotation) is rounding noise around an exact zero that
     Adam's sign-like first steps amplify) for anisotropic scales and random rotations."""
@@ -31,6 +31,8 @@ def _pair(frames, W, H, seed, heldout, iterations, fused=False, generic=False):
     from das3r_amd.train import build_from_sequence, synthetic_sequence
     from oracle.dense_trainer import DenseTrainer
     seq = synthetic_sequence(frames=frames, W=W, H=H, focal=0.9 * W, n_splats=1500, seed=seed)
+    if mask_some:   # pixels below the confidence threshold make no Gaussian: the model's mask index is then not the identity (fast_step: mask_ptr)
+        seq["confs"][:, ::3, 1::5] = -1.0
     if heldout:
         model, cams, test = build_from_sequence(copy.deepcopy(seq), heldout=True)
     else:
@@ -231,8 +233,8 @@ def test_direct_and_autograd_forms_stay_locked_through_a_degree_bump_and_gate_fl
         assert float(far.double().mean()) <= 2e-3, (k, float(far.double().mean()))
 
 
-@pytest.mark.parametrize("generic", [True, False])
-def test_pretransform_inside_the_rasterizer_kernels_is_bit_identical_to_the_separate_pass(generic):
+@pytest.mark.parametrize("generic,masked", [(True, False), (False, False), (True, True)])
+def test_pretransform_inside_the_rasterizer_kernels_is_bit_identical_to_the_separate_pass(generic, masked):
     """Round 6 (include/das3r_raster.h das3r_pretransform): the direct iteration hands the rasterizer the RAW parameters and
     the pose; preprocess_kernel and preprocess_backward_kernel take the pre-transform of /root/reference/gaussian_renderer/__init__.py:83-97,107
     on their way in (csrc/pretransform_math.h) and pretransform_forward_kernel is not launched — the camera-frame means / rotations / scales /
@@ -243,9 +245,10 @@ def test_pretransform_inside_the_rasterizer_kernels_is_bit_identical_to_the_sepa
     bg = torch.zeros(3, device="cuda")
 
     def run(inside):
-        model, cams, _, opt, _dense = _pair(frames=4, W=48, H=32, seed=21, heldout=False, iterations=4000, fused=True, generic=generic)
+        model, cams, _, opt, _dense = _pair(frames=4, W=48, H=32, seed=21, heldout=False, iterations=4000, fused=True, generic=generic, mask_some=masked)
         model.fast_step = True
         model.fuse_pretransform = inside
+        assert fast_step._state(model).mask_is_everything == (not masked)
         assert fast_step.available(model, PIPE)
         _lib.profile_report()
         _lib.profile_enable(True)
@@ -264,8 +267,8 @@ def test_pretransform_inside_the_rasterizer_kernels_is_bit_identical_to_the_sepa
         assert torch.equal(pa[k], pb[k]), k
 
 
-@pytest.mark.parametrize("degree", [0, 1])
-def test_backward_chained_through_the_pretransform_matches_the_two_calls(degree):
+@pytest.mark.parametrize("degree,masked", [(0, False), (1, False), (0, True)])
+def test_backward_chained_through_the_pretransform_matches_the_two_calls(degree, masked):
     """Round 6 (include/das3r_raster.h das3r_chain): with the raw parameters in hand the rasterizer's per-Gaussian backward
     kernel goes on through the pose pre-transform — chain rule, Adam step of xyz / rotation / scaling / opacity, dL/d(confidence), the camera's
     28 sums — instead of writing dL/d(camera-frame means, scales, rotations, opacities) for das3r_pretransform_backward_adam to read back
@@ -278,9 +281,10 @@ def test_backward_chained_through_the_pretransform_matches_the_two_calls(degree)
     bg = torch.zeros(3, device="cuda")
 
     def run(chained, steps):
-        model, cams, _, opt, _dense = _pair(frames=4, W=48, H=32, seed=23, heldout=False, iterations=4000, fused=True, generic=True)
+        model, cams, _, opt, _dense = _pair(frames=4, W=48, H=32, seed=23, heldout=False, iterations=4000, fused=True, generic=True, mask_some=masked)
         model.fast_step = True
         model.fuse_backward_chain = chained
+        assert fast_step._state(model).mask_is_everything == (not masked)
         if degree:
             model.active_sh_degree = degree
             model.optimizer.set_active_sh_degree(degree)
