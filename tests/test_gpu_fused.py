@@ -179,6 +179,66 @@ def test_fused_adam_matches_torch_adam(degree):
     assert tuple(full.shape) == tuple(pa["f_rest"].shape) and torch.equal(full[:, :active], st["exp_avg"]) and not bool(full[:, active:].any())
 
 
+def test_compact_sh_moments_round_trip_through_checkpoints():
+    """Round 6: FusedAdam keeps the moments of an "sh_rest" tensor for the ACTIVE coefficients only.  What leaves through state_dict() has the
+    parameter's shape (torch.optim.Adam and the reference's chkpnt*.pth hold full tensors: scene/gaussian_model.py:66-101), loads into
+    torch.optim.Adam as it is, and comes back compact through load_state_dict() — the run continues with the same bits either way; raising
+    the degree grows the moments with zeros."""
+    from das3r_amd.fused import FusedAdam
+    init, lrs = _adam_params()
+    mk = lambda ps: [dict(params=[ps[k]], lr=lrs[k], name=k, **({"sh_rest": True} if k == "f_rest" else {})) for k in ps]
+    g = torch.Generator().manual_seed(9)
+    grads = [{k: torch.randn(v.shape, generator=g).cuda() for k, v in init.items()} for _ in range(6)]
+    for gr in grads:
+        gr["f_rest"][:, 3:, :] = 0           # degree 1: nothing above the first three rest coefficients
+
+    def steps(opt, ps, which):
+        for i in which:
+            for k in ps:
+                ps[k].grad = grads[i][k].clone()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+
+    pa = {k: torch.nn.Parameter(v.clone()) for k, v in init.items()}
+    fa = FusedAdam(mk(pa), lr=0.0, eps=1e-15)
+    fa.set_active_sh_degree(1)
+    steps(fa, pa, range(6))                  # the uninterrupted run
+    pb = {k: torch.nn.Parameter(v.clone()) for k, v in init.items()}
+    fb = FusedAdam(mk(pb), lr=0.0, eps=1e-15)
+    fb.set_active_sh_degree(1)
+    steps(fb, pb, range(3))
+    assert fb.state[pb["f_rest"]]["exp_avg"].shape[1] == 3
+    sd = fb.state_dict()
+    idx = [gr["name"] for gr in sd["param_groups"]].index("f_rest")
+    assert tuple(sd["state"][idx]["exp_avg"].shape) == tuple(pb["f_rest"].shape) and not bool(sd["state"][idx]["exp_avg"][:, 3:].any())
+    # ... into torch.optim.Adam (the reference's optimizer): loads as it is
+    pt = {k: torch.nn.Parameter(pb[k].detach().clone()) for k in pb}
+    gt = mk(pt)
+    for gd in gt:
+        gd.pop("sh_rest", None)
+    ta = torch.optim.Adam(gt, lr=0.0, eps=1e-15)
+    tsd = {"state": {k: dict(step=v["step"], exp_avg=v["exp_avg"].clone(), exp_avg_sq=v["exp_avg_sq"].clone()) for k, v in sd["state"].items()},
+           "param_groups": [{**{k: v for k, v in gr.items() if k not in ("sh_rest",)}, **{k: v for k, v in tg.items() if k not in gr and k != "params"}}
+                            for gr, tg in zip(sd["param_groups"], ta.param_groups)]}
+    ta.load_state_dict(tsd)
+    assert torch.equal(ta.state[pt["f_rest"]]["exp_avg"], sd["state"][idx]["exp_avg"])
+    # ... and back into a fresh FusedAdam: compact again, and the run ends where the uninterrupted one does
+    pc = {k: torch.nn.Parameter(pb[k].detach().clone()) for k in pb}
+    fc = FusedAdam(mk(pc), lr=0.0, eps=1e-15)
+    fc.set_active_sh_degree(1)
+    fc.load_state_dict(sd)
+    assert fc.state[pc["f_rest"]]["exp_avg"].shape[1] == 3
+    steps(fc, pc, range(3, 6))
+    for k in pa:
+        assert torch.equal(pa[k], pc[k]), k
+    assert torch.equal(fa.state[pa["f_rest"]]["exp_avg_sq"], fc.state[pc["f_rest"]]["exp_avg_sq"])
+    fc.set_active_sh_degree(2)               # the degree goes up: eight coefficients, the new ones with zero moments
+    pc["f_rest"].grad = torch.randn(pc["f_rest"].shape, generator=g).cuda()
+    pc["f_rest"].grad[:, 8:, :] = 0
+    fc.step()
+    assert fc.state[pc["f_rest"]]["exp_avg"].shape[1] == 8 and bool(fc.state[pc["f_rest"]]["exp_avg"][:, 3:8].any())
+
+
 @pytest.mark.parametrize("degree", [0, 2, 3])
 def test_fused_adam_single_sh_tensor_matches_two_torch_groups(degree):
     """One [P, 16, 3] SH tensor with two learning rates (DC / rest) against torch.optim.Adam on the reference's two tensors."""
