@@ -75,6 +75,7 @@ static void load_switches() {
     if ((e = env("DAS3R_BINNING"))) w.binning = e[0] == 'l' ? 1 : (e[0] == 'r' ? -1 : (e[0] == 's' ? (strchr(e, '3') ? 3 : 2) : 0));
     w.capacity_exact = (e = env("DAS3R_CAPACITY")) && e[0] == 'e';
     w.fused_emit_off = (e = env("DAS3R_FUSED_EMIT")) && e[0] == '0';
+    w.tile_lpt_off = (e = env("DAS3R_TILE_LPT")) && e[0] == '0';   // (A-B runs: the region forward in the locality order of the other kernels)
     if ((e = env("DAS3R_RENDER"))) w.render_fwd = e[0] == 'q' ? 1 : (e[0] == 'r' ? 2 : (e[0] == 'l' ? 3 : (e[0] == 's' ? 4 : (e[0] == 'f' ? 5 : 0))));
     if ((e = env("DAS3R_RENDER_BWD"))) {   // dpp | mfma | scan[a][64|128|256|512]
         w.render_bwd = e[0] == 'd' ? 1 : (e[0] == 'm' ? 2 : (strncmp(e, "stream", 6) == 0 ? 5 : (e[0] == 's' ? 3 : (e[0] == 'b' ? 6 : (e[0] == 'f' ? 7 : 0)))));
@@ -239,6 +240,7 @@ void compute_layout(int P, int64_t I, int W, int H, Layout *L) {
     L->pub.final_T = take(4 * (npix > 0 ? npix : 1));
     L->pub.n_contrib = take(4 * (npix > 0 ? npix : 1));
     L->pub.ranges = take(8 * (size_t)(L->ntiles > 0 ? L->ntiles : 1));
+    L->i_order = take(4 * (size_t)(L->ntiles > 0 ? L->ntiles : 1));
     L->pub.img_bytes = o;
 }
 
@@ -601,6 +603,13 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
                                             (long long)mean, crowd16 / 16.0, verdict.fine ? "2x2-region" : "block");
         }
         lb.prefer_regions = verdict.fine;
+        lb.tile_order = nullptr;
+        if (verdict.fine && cap > 0 && use_quad_lanes(L, lb) && L.ntiles <= 1024 && !switches().tile_lpt_off && (switches().render_fwd == 0 || switches().render_fwd == 5)) {
+            // four workgroups per tile are 3 - 4 generations of workgroups on the chip, and a tile whose list is four times the mean (every
+            // real sequence has them) that starts in the last generation adds its whole chain to the kernel: longest lists first
+            if ((r = launch_tile_lpt(saved->img, L, (uint32_t)cap, a->debug != 0, s))) return r;
+            lb.tile_order = (const uint32_t *)(saved->img + L.i_order);
+        }
         if (verdict.fine && cap > 0 && use_quad_lanes(L, lb)) saved->flags |= 1u;   // (the backward pass of this forward: render_bwd.hip)
         if (local_order && cap > 0) {
             lb.point_list = (uint32_t *)(saved->binning + L.pub.point_list);

@@ -36,6 +36,7 @@ struct Switches {
     bool deterministic;    // DAS3R_DETERMINISTIC=1: bit-identical gradients run to run (the block-walk backward for every list length:
                            // the pixel-per-lane kernel meets its four waves with LDS float atomics, whose order varies)
     int render_bwd_occ;    // blk...o<4|5>: workgroups per CU the kernel is compiled for (register cap)
+    bool tile_lpt_off;     // DAS3R_TILE_LPT=0
     int render_bwd_pix;    // blk...p<0|1|2>: where render_bwd_blk.hip keeps the per-pixel values (render_blk.h)
     bool bwd_reduce_set, bwd_reduce_shfl;   // DAS3R_BWD_REDUCE=shfl | dpp (reference reduction of the pixel-per-lane kernel)
     bool ablate_set;       // DAS3R_ABLATE (perf experiments on the pixel-per-lane kernel)
@@ -213,6 +214,7 @@ struct Layout {
                                 // partition's digits start above them
     int part_passes;            // passes of the instance partition: tile_passes, or one more when the segmented path wants more bucket bits
     size_t g_dhist;
+    size_t i_order;   // img buffer, u32[ntiles]: the tiles longest list first (render_regions.hip tile_lpt_kernel; round 6)
 };
 // depth-bucket bits `passes` partition passes (at most three) have room for beside the tile ids (<= 0: none)
 static inline int seg_dbits(const Layout &L, int passes) { return 8 * (passes < 3 ? passes : 3) - L.tbits; }
@@ -230,6 +232,7 @@ struct LocalBin {
     // round 6: the forward kernel with four workgroups per tile (render_regions.hip) instead of one (render_lanes.hip): chosen by the host for
     // shapes whose tile lists are skewed (api.hip Verdict::fine, decided from the tile ranges themselves: launch_list_skew)
     bool prefer_regions;
+    const uint32_t *tile_order;         // with prefer_regions: the tiles, longest list first (tile_lpt_kernel); null: the locality order
 };
 void compute_layout(int P, int64_t I, int W, int H, Layout *L);
 
@@ -287,6 +290,7 @@ inline PreXform pre_xform(const das3r_raster_in *in) {
 }
 int launch_render_forward_regions(const das3r_raster_args *a, float *out_color, char *geom, char *binning, char *img, const Layout &L, const LocalBin &lb,
                                   hipStream_t s);   // the same shapes: sixteen lanes per pixel, a wave per 2x2 region, four workgroups per tile (render_regions.hip)
+int launch_tile_lpt(char *img, const Layout &L, uint32_t cap, bool debug, hipStream_t s);   // render_regions.hip
 int launch_list_skew(const char *img, const char *binning, const char *geom, const Layout &L, uint32_t cap, uint32_t last_g, uint32_t *mailbox_words, uint32_t tag,
                      bool debug, hipStream_t s);
 int launch_render_forward_slices(const das3r_raster_args *a, float *out_color, char *geom, char *binning, char *img, const Layout &L, const LocalBin &lb,

@@ -172,8 +172,15 @@ __global__ void __launch_bounds__(RG_THREADS) __attribute__((amdgpu_waves_per_eu
     // workgroup -> (tile, quadrant): the four quadrants of a tile are consecutive workgroups of ONE XCD (the dispatcher deals workgroup b to
     // XCD b % 8): b = (4 j' + quadrant) * 8 + xcd with tile slot 8 j' + xcd of render_common.h's XCD-aware tile order
     const int xcd = blockIdx.x & 7, jq = blockIdx.x >> 3, quad = jq & 3;
-    const int tile = xcd_tile(((jq >> 2) << 3) | xcd, ntiles_strip, tiles_x);
-    if (tile < 0) return;
+    int tile;
+    if (lb.tile_order != nullptr) {   // (uniform) longest lists first: slot 8 j' + xcd of the order tile_lpt_kernel left (below)
+        const int slot = ((jq >> 2) << 3) | xcd;
+        if (slot >= packed_ntiles(ntiles_strip)) return;
+        tile = (int)min(lb.tile_order[slot], (uint32_t)(packed_ntiles(ntiles_strip) - 1));
+    } else {
+        tile = xcd_tile(((jq >> 2) << 3) | xcd, ntiles_strip, tiles_x);
+        if (tile < 0) return;
+    }
     const int tid = threadIdx.x, lane = __lane_id(), wave = __builtin_amdgcn_readfirstlane(tid >> 6), e = lane & 15, row = lane >> 4;
     const int bx = tile % tiles_x, by = tile / tiles_x;
     const int rx0 = bx * TILE_X + ((quad & 1) << 3) + ((wave & 3) << 1), ry0 = by * TILE_Y + ((quad >> 1) << 3) + ((wave >> 2) << 1);   // the wave's region
@@ -322,6 +329,34 @@ __global__ void __launch_bounds__(256) list_skew_kernel(const uint2 *__restrict_
     }
 }
 
+// The tiles in the order the region forward starts them: longest list first (ties: lower tile first — the same lists give the same order).
+// One workgroup of 1024 threads ranks up to 1024 tiles by counting the keys above its own (broadcast LDS reads); it runs behind the last
+// binning kernel of every forward that takes the region kernel (5 us), because the lists change with every view.
+__global__ void __launch_bounds__(1024) tile_lpt_kernel(const uint2 *__restrict__ ranges, int ntiles, uint32_t cap, uint32_t *__restrict__ order) {
+    __shared__ __attribute__((aligned(16))) uint32_t key[1024];
+    const int t = threadIdx.x;
+    uint32_t k = 0u;
+    if (t < ntiles) {
+        const uint2 r = safe_range(ranges[t], cap);
+        k = (min(r.y - r.x, 0x3FFFFFu) << 10) | (uint32_t)(1023 - t);   // (distinct; larger = earlier)
+    }
+    key[t] = k;
+    __syncthreads();
+    if (t >= ntiles) return;
+    uint32_t rank = 0u;
+    for (int j = 0; j < ntiles; j += 4) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(&key[j]);   // (entries past ntiles hold 0: never above a live key)
+        rank += (v.x > k ? 1u : 0u) + (v.y > k ? 1u : 0u) + (v.z > k ? 1u : 0u) + (v.w > k ? 1u : 0u);
+    }
+    order[rank] = (uint32_t)t;
+}
+
+int launch_tile_lpt(char *img, const Layout &L, uint32_t cap, bool debug, hipStream_t s) {
+    DAS3R_LAUNCH(tile_lpt_kernel, dim3(1), dim3(1024), 0, s, (const uint2 *)(img + L.pub.ranges), L.ntiles, cap, (uint32_t *)(img + L.i_order));
+    KERNEL_CHECK(s, debug, "tile_lpt");
+    return DAS3R_OK;
+}
+
 int launch_list_skew(const char *img, const char *binning, const char *geom, const Layout &L, uint32_t cap, uint32_t last_g, uint32_t *mailbox_words, uint32_t tag,
                      bool debug, hipStream_t s) {
     DAS3R_LAUNCH(list_skew_kernel, dim3(1), dim3(256), 0, s, (const uint2 *)(img + L.pub.ranges), L.ntiles, L.tiles_x, cap, (const uint32_t *)(binning + L.pub.point_list),
@@ -336,7 +371,7 @@ int launch_render_forward_regions(const das3r_raster_args *a, float *out_color, 
     (const uint2 *)(img + L.pub.ranges), (const uint32_t *)(binning + L.pub.point_list), a->image_width, a->image_height, L.tiles_x, pack_tiles(L), \
         (const float4 *)(geom + L.pub.xy), (const float4 *)(geom + L.pub.conic_opacity), (const float4 *)(geom + L.pub.rgbd), a->bg,                \
         (float *)(img + L.pub.final_T), (uint32_t *)(img + L.pub.n_contrib), out_color, lb, pair_counters()
-    DAS3R_LAUNCH(render_forward_regions_kernel, dim3(4 * xcd_grid(L)), dim3(RG_THREADS), 0, s, ARGS);
+    DAS3R_LAUNCH(render_forward_regions_kernel, dim3(lb.tile_order ? 32 * div_up(L.ntiles, 8) : 4 * xcd_grid(L)), dim3(RG_THREADS), 0, s, ARGS);
 #undef ARGS
     KERNEL_CHECK(s, a->debug, "render_forward_regions");
     return DAS3R_OK;
