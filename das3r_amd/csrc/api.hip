@@ -310,7 +310,7 @@ struct Mailbox {
 // of these; nothing is shared between threads: any number of them may render concurrently, each on its own stream).
 constexpr uint32_t CHECK_SLOTS = 16, CHECK_WORD0 = 16, MAILBOX_BYTES = 4 * (CHECK_WORD0 + 2 * CHECK_SLOTS);
 constexpr uint32_t CROWDED16 = 23u * 16u;   // (api.hip bin_and_render)
-struct Verdict { int P, W, H; int64_t last_I, peak_I; int radix_left, backoff; uint32_t gen; int seg_extra; bool last_seg; bool fine; uint32_t forwards; uint32_t clean; };
+struct Verdict { int P, W, H; int64_t last_I, peak_I; int radix_left, backoff; uint32_t gen; int seg_extra; bool last_seg; bool fine; uint32_t forwards; uint32_t clean; uint32_t longest; };
 struct PerDevice {
     Mailbox mb;
     uint32_t pending[CHECK_SLOTS] = {};             // per slot: tag of the forward whose self-check word has not been examined yet
@@ -595,6 +595,7 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
             if ((r = launch_list_skew(saved->img, saved->binning, saved->geom, L, (uint32_t)cap, (uint32_t)(P - 1), mb->dev + 13, tag, a->debug != 0, s))) return r;
             if ((r = mailbox_wait(mb, 14, tag, s))) return r;
             const int64_t longest = (int64_t)mb->host[13], mean = (verdict.last_I > 0 ? verdict.last_I : cap) / std::max(L.ntiles, 1);   // (the last forward's count; the capacity on a shape's first)
+            verdict.longest = (uint32_t)longest;   // (what the backward's grid is sized by until the next look: below)
             const uint32_t crowd16 = mb->host[15];   // of 64 consecutive list entries, those in the tile's fullest quadrant, x 16 (render_regions.hip list_skew_kernel)
             // skewed: 1.8 x the mean list, the measured crossover of the forward kernels (ledger (bd)); crowded: a stretch of a list sits in part of
             // its tile (random depths: 20 of 64 in the fullest quadrant) — there the 2x2-region kernels win both ways whatever the skew (ledger (be))
@@ -610,7 +611,13 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
             if ((r = launch_tile_lpt(saved->img, L, (uint32_t)cap, a->debug != 0, s))) return r;
             lb.tile_order = (const uint32_t *)(saved->img + L.i_order);
         }
-        if (verdict.fine && cap > 0 && use_quad_lanes(L, lb)) saved->flags |= 1u;   // (the backward pass of this forward: render_bwd.hip)
+        if (verdict.fine && cap > 0 && use_quad_lanes(L, lb)) {   // (the backward pass of this forward: render_bwd.hip)
+            // bits 8 - 15: buckets (common.h BUCKET = 1024 list positions) of the shape's longest tile list as last measured, + 2 of headroom — the
+            // bucket-parallel backward launches that many workgroups per tile instead of the AVERAGE list's (a tile of four times the mean then
+            // takes four buckets per workgroup, back to back, and the kernel ends with them: self-consistent job 0.409 -> 0.313 ms)
+            const uint32_t hint = std::min<uint32_t>(63u, verdict.longest / (uint32_t)BUCKET + 2u);
+            saved->flags |= 1u | (hint << 8);
+        }
         if (local_order && cap > 0) {
             lb.point_list = (uint32_t *)(saved->binning + L.pub.point_list);
             lb.slot_list = (uint32_t *)(saved->binning + L.b_slot);

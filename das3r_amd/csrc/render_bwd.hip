@@ -216,6 +216,10 @@ int launch_render_backward(const das3r_raster_args *a, const float *dL_dpix, cha
         int slices = sw.bwd_buckets;
         if (slices < 0) slices = (int)std::min<int64_t>(32, std::max<int64_t>(1, num_rendered / ((int64_t)BUCKET * std::max(L.ntiles, 1))));
         if (slices > 1 && mb > 256) slices = 1;
+        // round 6: skewed lists (das3r_raster_saved.flags bits 8 - 15: buckets of the longest list the forward last measured) — a workgroup per
+        // bucket of the LONGEST tile; the workgroups of shorter tiles that have no bucket leave before they load anything
+        const int hint = (int)((fwd_flags >> 8) & 0xFFu);
+        if (sw.bwd_buckets < 0 && kind == 7 && slices > 1 && hint > slices) slices = std::min(hint, 64);
         if (kind == 6) return launch_render_backward_blk(a, dL_dpix, geom, binning, img, L, partial, mb, slices, s);
         if (kind == 7) return launch_render_backward_regions(a, dL_dpix, geom, binning, img, L, partial, mb, slices, s);
         return launch_render_backward_scan(a, dL_dpix, geom, binning, img, L, partial, mb, slices, s);

@@ -81,6 +81,7 @@ __global__ void __launch_bounds__(256, OCC) render_backward_blk_kernel(
     const int qx0 = bx * TILE_X + ((wave & 1) << 3), qy0 = by * TILE_Y + ((wave >> 1) << 3);   // the wave's quadrant
     const float qcx = (float)qx0 + 3.5f, qcy = (float)qy0 + 3.5f;
     const uint2 range = safe_range(ranges[tile], cap);
+    if (gridDim.y > 1 && (int)blockIdx.y >= max(ckpt_buckets(range), 1)) return;   // (uniform) bucket-parallel launch: this tile's list has no bucket for this workgroup
     const int row = lane >> 4, s = lane & 15;
     uint8_t *const mine = reinterpret_cast<uint8_t *>(lds + OFF_LIST) + (wave * 4 + row) * LIST_STRIDE;
     uint8_t *const wave_lists = reinterpret_cast<uint8_t *>(lds + OFF_LIST) + wave * 4 * LIST_STRIDE;

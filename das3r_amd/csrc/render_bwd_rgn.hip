@@ -136,6 +136,7 @@ __global__ void __launch_bounds__(256, OCC) render_backward_regions_kernel(
     auto region_rx8 = [&](const int B, const int r) { return GEO == 2 ? 2 * ((wave - 2 * B) & 3) + (r & 1) : 4 * strip_h(B) + r; };
     auto region_ry8 = [&](const int B, const int r) { return GEO == 2 ? 2 * B + (r >> 1) : strip_y8(B); };
     const uint2 range = safe_range(ranges[tile], cap);
+    if (gridDim.y > 1 && (int)blockIdx.y >= max(ckpt_buckets(range), 1)) return;   // (uniform) bucket-parallel launch: this tile's list has no bucket for this workgroup
     const int row = lane >> 4, s = lane & 15;
     uint8_t *const wave_lists = reinterpret_cast<uint8_t *>(lds + OFF_LIST) + wave * 4 * LIST_STRIDE;
     char *const cst_wave = lds + OFF_CST + wave * 16 * 64;
