@@ -521,6 +521,12 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     // per 512 forwards).  Which kernel runs in which forward thus depends on the data alone, never on timing: the two kernels round a
     // pixel's T differently in the last bit, and a job must end bit-identical however it was scheduled.
     const bool decide_fine = (verdict.forwards++ & 511u) == 0u;
+    // Every decision below starts a new GENERATION of the shape: the words the kernels raise (mailbox 10 / 11) name the generation they were
+    // launched under, and the host runs one or two forwards ahead of the device — the forward enqueued BEFORE a decision was taken raises
+    // the same word again a moment later, and answered a second time it turned "one more partition pass" straight into "global sort for
+    // 64 forwards" (round 6: seen as a smooth-depth train step of 1.29 ms instead of 1.18 on some boxes, its first 64 timed steps on the
+    // global sort; which box depended on how far ahead its host ran).
+    auto next_gen = [&]() { verdict.gen = verdict.gen + 1u ? verdict.gen + 1u : 1u; };
     if (verdict.last_I < 0) {   // (a shape's first forward: nothing to learn from yet)
     } else if (too_long == verdict.gen && !(verdict.last_seg && verdict.seg_extra == 0 && L.tile_passes < 3 && seg_dbits(L, L.tile_passes + 1) > 0)) {
         // global sort for a while; longer every time it happens AGAIN SOON.  Round 6: a failure that comes after 256 or more clean forwards
@@ -531,9 +537,11 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
         verdict.radix_left = verdict.backoff;
         if (verdict.backoff < 4096) verdict.backoff *= 2;
         verdict.clean = 0;
+        next_gen();
     } else if (too_long == verdict.gen || want_bits == verdict.gen) {
         verdict.seg_extra = 1;                  // the segmented path with one more partition pass of bucket bits from now on (this shape);
                                                 // a segment that is too long even then sends the shape back to the global sort (above)
+        next_gen();
     }
     const int forced = switches().binning;   // DAS3R_BINNING=local | radix | seg: force one (diagnostics, tests)
     bool local = use_onesweep() && (forced == 1 || (forced == 0 && verdict.radix_left == 0 && verdict.last_I <= LOCAL_AVG * L.ntiles));

@@ -17,23 +17,34 @@
 
 namespace das3r {
 
-// Sum of the values of `count` published words spaced RADIX_SIZE granules apart (one column of the status matrix).  Loads
-// go out in windows of LB independent requests; a window with an unpublished word is re-polled as a whole.
+// Round 6: PACKED status rows.  A workgroup's count of a digit is at most 4096: four digits share one 8-byte
+// word (bit 15 of each 16-bit field = published, one store publishes all four), a row is 64 words = 512 bytes instead of 2 KB; a group's
+// total (<= 2^19) takes 32 bits (bit 31 = published), two per word, 1 KB a row.  The four (two) threads whose digits share a word poll the
+// same address: a wave's 64 loads are ONE 128-byte line instead of four.  What every workgroup reads in its look-back (~ 55 rows) was
+// 70 MB per pass at 1 M splats, more than the keys; the rows are also zeroed by every forward.
+constexpr int ROW_WORDS = RADIX_SIZE / 4;          // u64 words of a workgroup's status row
+constexpr int GROUP_ROW_WORDS = RADIX_SIZE / 2;    // ... of a group's row
+
+// Sum of digit `field`'s values in `count` published rows, `stride` words apart, starting at `col` (the word of the first row that
+// holds the digit); a value is BITS wide, its top bit the flag.  Loads go out in windows of LB independent requests; a window with an
+// unpublished word is re-polled as a whole.
 // Slots past `count` are NOT loaded.  (Measured on MI355X: padding the window by re-reading the last word — up to LB
 // back-to-back sc1 loads of one address per poll — made published words invisible to some pollers for seconds, i.e.
 // look-back timeouts in ~30 % of 1M-splat forwards; sc1 loads are L2-served, MI355X_MICROARCH.md.)
-template <int LB = 16>
-__device__ __forceinline__ uint32_t sum_published(const u64 *col, const int count, uint32_t *err) {
+template <int BITS, int LB = 16>
+__device__ __forceinline__ uint32_t sum_published(const u64 *col, const int stride, const int field, const int count, uint32_t *err) {
     uint32_t sum = 0;
     unsigned spins = 0;
+    const int sh = field * BITS;
+    const u64 flag = 1ull << (sh + BITS - 1), vmask = (1ull << (BITS - 1)) - 1ull;
     for (int p = 0; p < count; p += LB) {
         u64 x[LB];
         while (true) {
             bool ok = true;
 #pragma unroll
-            for (int j = 0; j < LB; j++) x[j] = (p + j < count) ? granule_poll(col + (size_t)(p + j) * RADIX_SIZE, spins) : TAG_AGG;
+            for (int j = 0; j < LB; j++) x[j] = (p + j < count) ? granule_poll(col + (size_t)(p + j) * stride, spins) : ~0ull;
 #pragma unroll
-            for (int j = 0; j < LB; j++) ok &= (x[j] & TAG_MASK) != 0;
+            for (int j = 0; j < LB; j++) ok &= (x[j] & flag) != 0;
             if (ok) break;
             if (spins == SOFT_SPINS) atomicOr(err, ERR_HARD_POLL);
             if (++spins > SPIN_LIMIT) {  // a predecessor never published: give up loudly instead of hanging
@@ -43,9 +54,21 @@ __device__ __forceinline__ uint32_t sum_published(const u64 *col, const int coun
             __builtin_amdgcn_s_sleep(1);
         }
 #pragma unroll
-        for (int j = 0; j < LB; j++) sum += (p + j < count) ? (uint32_t)(x[j] & 0xFFFFFFFFull) : 0u;
+        for (int j = 0; j < LB; j++) sum += (p + j < count) ? (uint32_t)((x[j] >> sh) & vmask) : 0u;
     }
     return sum;
+}
+
+// thread d holds digit d's value (v < 2^15): the word of digits 4j .. 4j + 3 lands in lane 4j (other lanes: garbage)
+__device__ __forceinline__ u64 pack_row_word(const uint32_t v) {
+    const uint32_t f = v | 0x8000u;
+    const uint32_t pair = f | ((uint32_t)__shfl_down((int)f, 1, 64) << 16);
+    return (u64)pair | ((u64)(uint32_t)__shfl_down((int)pair, 2, 64) << 32);
+}
+// ... digit d's group total (v < 2^31): the word of digits 2j, 2j + 1 lands in lane 2j
+__device__ __forceinline__ u64 pack_group_word(const uint32_t v) {
+    const uint32_t f = v | 0x80000000u;
+    return (u64)f | ((u64)(uint32_t)__shfl_down((int)f, 1, 64) << 32);
 }
 
 // global histograms of all four 8-bit digits of the depth keys (read once, LDS-privatised, few global atomics)
@@ -79,8 +102,8 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
                                                             uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
                                                             uint32_t cap, const uint32_t *__restrict__ n_ptr, int shift, int bits,
                                                             const uint32_t *__restrict__ ghist /*[256] this digit*/,
-                                                            u64 *__restrict__ status /*[nblocks][256]*/,
-                                                            u64 *__restrict__ group_status /*[ngroups][256]*/, int gs_log2,
+                                                            u64 *__restrict__ status /*[nblocks][ROW_WORDS]*/,
+                                                            u64 *__restrict__ group_status /*[ngroups][GROUP_ROW_WORDS]*/, int gs_log2,
                                                             uint32_t *__restrict__ ticket,
                                                             const uint32_t *__restrict__ vals2_in, uint32_t *__restrict__ vals2_out,
                                                             uint32_t *__restrict__ err, uint32_t *__restrict__ zero_ptr, uint32_t zero_words
@@ -168,7 +191,10 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
     // long been published, and only the final write-out needs its result.
     const uint32_t c0 = cnt[0][tid], c1 = cnt[1][tid], c2 = cnt[2][tid], c3 = cnt[3][tid];
     const uint32_t total = c0 + c1 + c2 + c3;
-    granule_store(status + (size_t)b * RADIX_SIZE + tid, TAG_AGG | total);
+    {
+        const u64 w = pack_row_word(total);
+        if ((tid & 3) == 0) granule_store(status + (size_t)b * ROW_WORDS + (tid >> 2), w);
+    }
     const uint32_t g = ghist[tid];
     uint32_t digit_base, lstart;
     {
@@ -222,9 +248,12 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
         //  the look-back: 8.8 vs 8.4 us median at 1 M splats, tools/wg_trace.py.  What a workgroup waits for is the total of the
         //  group just before its own, which that group's last workgroup publishes only after staging and summing its own group;
         //  and the 55 rows of 2 KB every workgroup reads are 70 MB per pass, more than the keys.)
-        const uint32_t in_group = sum_published(status + (size_t)(b - r) * RADIX_SIZE + tid, (int)r, err);
-        if (r == gs_mask) granule_store(group_status + (size_t)grp * RADIX_SIZE + tid, TAG_AGG | (u64)(in_group + total));
-        const uint32_t before_group = sum_published(group_status + tid, (int)grp, err);
+        const uint32_t in_group = sum_published<16>(status + (size_t)(b - r) * ROW_WORDS + (tid >> 2), ROW_WORDS, tid & 3, (int)r, err);
+        if (r == gs_mask) {   // (uniform)
+            const u64 w = pack_group_word(in_group + total);
+            if ((tid & 1) == 0) granule_store(group_status + (size_t)grp * GROUP_ROW_WORDS + (tid >> 1), w);
+        }
+        const uint32_t before_group = sum_published<32>(group_status + (tid >> 1), GROUP_ROW_WORDS, tid & 1, (int)grp, err);
         const uint32_t excl = in_group + before_group;
         if (b == last_block && excl + total != g) atomicOr(err, ERR_COUNTS);   // self-check: all counts add up to the histogram
         gdelta[tid] = digit_base + excl - lstart;   // destination of staged slot i holding digit d: i + gdelta[d]
@@ -276,7 +305,7 @@ static int onesweep_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kou
     const int ipl = sort_items_per_lane(cap);
     const int nblocks = div_up(cap, (int64_t)256 * ipl);
     const int gs_log2 = onesweep_group_log2(nblocks);
-    u64 *group_status = status + (size_t)nblocks * RADIX_SIZE;
+    u64 *group_status = status + (size_t)nblocks * ROW_WORDS;
 #define PASS(IPL, TWO)                                                                                                    \
     DAS3R_LAUNCH((onesweep_pass_kernel<IPL, TWO>), dim3(nblocks), dim3(256), 0, s, kin, vin, kout, vout, (uint32_t)cap, n_ptr,   \
                  shift, bits, ghist, status, group_status, gs_log2, grid_is_resident(nblocks) ? (uint32_t *)nullptr : ticket, v2in, v2out, \
@@ -298,12 +327,12 @@ static int onesweep_group_log2(int nblocks) {
     return l;
 }
 
-// per pass: one row of 256 granules per workgroup + one per group
+// per pass: one packed row per workgroup + one per group
 size_t onesweep_status_bytes(int64_t n, int passes) {
     if (n <= 0) return 256;
     const int nblocks = div_up(n, (int64_t)256 * sort_items_per_lane(n));
     const int ngroups = div_up(nblocks, 1 << onesweep_group_log2(nblocks));
-    return (size_t)passes * (size_t)(nblocks + ngroups) * RADIX_SIZE * sizeof(u64);
+    return (size_t)passes * ((size_t)nblocks * ROW_WORDS + (size_t)ngroups * GROUP_ROW_WORDS) * sizeof(u64);
 }
 
 // Depth sort of the P splats: ctrl = [ghist 4x256 u32][tickets 4 u32 (+pad)][status 4 passes], zeroed by preprocess_kernel.
