@@ -59,21 +59,38 @@ __global__ void __launch_bounds__(256) photometric_forward_kernel(int H, int W, 
     const bool inside = x < W && y < H;
     const size_t plane = (size_t)H * W;
     float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};   // l1, 1 - ssim, squared error per channel
+    // Round 6: the halo tiles of ALL THREE channels are requested before anything is used (21 loads per thread in flight, indices clamped
+    // instead of guarded: a guarded load is a basic block of its own with a wait behind it) — the kernel used to make nine exposed trips
+    // to memory, one per channel and sweep of the halo, for an image that fits the L2 fifty times: 18.6 -> see DESIGN.md
+    constexpr int SWEEPS = (PH * PH + PT * PT - 1) / (PT * PT);
+    float va[3][SWEEPS], vb[3][SWEEPS];
+#pragma unroll
+    for (int u = 0; u < SWEEPS; u++) {
+        const int e = tid + u * PT * PT, r = e / PH, col = e % PH;
+        const int yy = y0 + r - PR, xx = x0 + col - PR;
+        const bool in = e < PH * PH && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const size_t p = (size_t)min(max(yy, 0), H - 1) * W + (size_t)min(max(xx, 0), W - 1);
+        const float sm = in ? stat[p] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float rv = render[c * plane + p], gv = gt[c * plane + p];
+            va[c][u] = in ? rv * sm : 0.f;   // (outside the image: the zero padding of the reference's convolution)
+            vb[c][u] = in ? gv * sm : 0.f;
+        }
+    }
+#pragma unroll
     for (int c = 0; c < 3; c++) {
-        for (int e = tid; e < PH * PH; e += PT * PT) {
-            const int r = e / PH, col = e % PH;
-            const int yy = y0 + r - PR, xx = x0 + col - PR;
-            float a = 0.f, b = 0.f;
-            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-                const float s = stat[(size_t)yy * W + xx];
-                a = render[c * plane + (size_t)yy * W + xx] * s;
-                b = gt[c * plane + (size_t)yy * W + xx] * s;
+#pragma unroll
+        for (int u = 0; u < SWEEPS; u++) {
+            const int e = tid + u * PT * PT, r = e / PH, col = e % PH;
+            if (e < PH * PH) {
+                const float a = va[c][u], b = vb[c][u];
+                halo[0][r][col] = a;
+                halo[1][r][col] = b;
+                halo[2][r][col] = a * a;
+                halo[3][r][col] = b * b;
+                halo[4][r][col] = a * b;
             }
-            halo[0][r][col] = a;
-            halo[1][r][col] = b;
-            halo[2][r][col] = a * a;
-            halo[3][r][col] = b * b;
-            halo[4][r][col] = a * b;
         }
         __syncthreads();
         float o[5];
@@ -112,52 +129,10 @@ __global__ void __launch_bounds__(256) photometric_forward_kernel(int H, int W, 
     if (tid < 5) partials[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
-__global__ void __launch_bounds__(256) photometric_backward_kernel(int H, int W, const float *__restrict__ render, const float *__restrict__ gt,
-                                                                   const float *__restrict__ stat, float lambda, GaussWin g,
-                                                                   const float *__restrict__ dmaps, const float *__restrict__ grad_loss,
-                                                                   float *__restrict__ d_render, float *__restrict__ d_static) {
-    __shared__ float halo[4][PH][PH + 1];
-    __shared__ float tmp[4][PH][PT + 1];
-    const int tid = threadIdx.x, ty = tid / PT, tx = tid % PT;
-    const int x0 = blockIdx.x * PT, y0 = blockIdx.y * PT;
-    const int x = x0 + tx, y = y0 + ty;
-    const bool inside = x < W && y < H;
-    const size_t plane = (size_t)H * W, pix = (size_t)y * W + x;
-    const float scale = grad_loss[0] / (3.f * (float)plane);       // d loss / d (per-element term)
-    const float s = inside ? stat[pix] : 0.f;
-    float ds = 0.f;
-    for (int c = 0; c < 3; c++) {
-        for (int e = tid; e < PH * PH; e += PT * PT) {
-            const int r = e / PH, col = e % PH;
-            const int yy = y0 + r - PR, xx = x0 + col - PR;
-            const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
-            const size_t p = (size_t)yy * W + xx;
-#pragma unroll
-            for (int q = 0; q < 4; q++) halo[q][r][col] = in ? dmaps[(q * 3 + c) * plane + p] : 0.f;
-        }
-        __syncthreads();
-        float o[4];
-        separable<4>(halo, tmp, g, tid, o);
-        if (inside) {
-            const float R = render[c * plane + pix], G = gt[c * plane + pix];
-            const float a = R * s, b = G * s;
-            const float sgn = a > b ? 1.f : (a < b ? -1.f : 0.f);
-            const float l1 = (1.f - lambda) * sgn;
-            const float da = scale * (l1 - lambda * (o[0] + 2.f * a * o[2] + b * o[3]));
-            const float db = scale * (-l1 - lambda * (o[1] + 2.f * b * o[2] + a * o[3]));
-            d_render[c * plane + pix] = da * s;
-            ds += da * R + db * G;
-        }
-        __syncthreads();
-    }
-    if (inside) d_static[pix] = ds;
-}
-
 // the few hundred rows of tile sums -> {loss, mse_r, mse_g, mse_b, psnr_frame} (what the host side of round 3 did with ~12 tiny
 // PyTorch kernels per iteration); one workgroup, rows added in a fixed order: deterministic
-__global__ void __launch_bounds__(256) photometric_finish_kernel(int nblocks, const float *__restrict__ partials, float npix, float lambda,
-                                                                 float *__restrict__ out /*[8]*/) {
-    __shared__ float red[4][5];
+__device__ __forceinline__ void finish_sums(const int nblocks, const float *__restrict__ partials, const float npix, const float lambda,
+                                            float *__restrict__ out /*[8]*/, float (*red)[5] /*[4][5] LDS*/) {
     const int tid = threadIdx.x, lane = __lane_id(), wave = tid >> 6;
     float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     for (int b = tid; b < nblocks; b += 256)
@@ -186,6 +161,81 @@ __global__ void __launch_bounds__(256) photometric_finish_kernel(int nblocks, co
         out[4] = psnr / 3.f;
         out[5] = out[6] = out[7] = 0.f;
     }
+}
+__global__ void __launch_bounds__(256) photometric_finish_kernel(int nblocks, const float *__restrict__ partials, float npix, float lambda,
+                                                                 float *__restrict__ out /*[8]*/) {
+    __shared__ float red[4][5];
+    finish_sums(nblocks, partials, npix, lambda, out, red);
+}
+
+__global__ void __launch_bounds__(256) photometric_backward_kernel(int H, int W, const float *__restrict__ render, const float *__restrict__ gt,
+                                                                   const float *__restrict__ stat, float lambda, GaussWin g,
+                                                                   const float *__restrict__ dmaps, const float *__restrict__ grad_loss,
+                                                                   float *__restrict__ d_render, float *__restrict__ d_static,
+                                                                   const float *__restrict__ partials, int nblocks, float *__restrict__ out8) {
+    __shared__ float halo[4][PH][PH + 1];
+    __shared__ float tmp[4][PH][PT + 1];
+    const int tid = threadIdx.x, ty = tid / PT, tx = tid % PT;
+    // round 6 (das3r_photometric_backward_finish): the loss and the frame's PSNR — the forward's few hundred rows of tile sums added in a
+    // fixed order — are the first workgroup's side duty instead of a launch of their own between the two kernels (4.8 us of every step)
+    if (out8 != nullptr && blockIdx.x == 0 && blockIdx.y == 0) {   // (uniform)
+        __shared__ float red[4][5];
+        finish_sums(nblocks, partials, (float)H * (float)W, lambda, out8, red);
+    }
+    const int x0 = blockIdx.x * PT, y0 = blockIdx.y * PT;
+    const int x = x0 + tx, y = y0 + ty;
+    const bool inside = x < W && y < H;
+    const size_t plane = (size_t)H * W, pix = (size_t)y * W + x;
+    const float scale = grad_loss[0] / (3.f * (float)plane);       // d loss / d (per-element term)
+    const float s = inside ? stat[pix] : 0.f;
+    float ds = 0.f;
+    // (round 6, as in the forward: the four derivative maps of all three channels and the pixel's own values are requested up front)
+    constexpr int SWEEPS = (PH * PH + PT * PT - 1) / (PT * PT);
+    float vm[3][SWEEPS][4];
+#pragma unroll
+    for (int u = 0; u < SWEEPS; u++) {
+        const int e = tid + u * PT * PT, r = e / PH, col = e % PH;
+        const int yy = y0 + r - PR, xx = x0 + col - PR;
+        const bool in = e < PH * PH && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const size_t p = (size_t)min(max(yy, 0), H - 1) * W + (size_t)min(max(xx, 0), W - 1);
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float v = dmaps[(q * 3 + c) * plane + p];
+                vm[c][u][q] = in ? v : 0.f;
+            }
+    }
+    const size_t pixc = (size_t)min(y, H - 1) * W + (size_t)min(x, W - 1);
+    float Rv[3], Gv[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) Rv[c] = render[c * plane + pixc], Gv[c] = gt[c * plane + pixc];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+#pragma unroll
+        for (int u = 0; u < SWEEPS; u++) {
+            const int e = tid + u * PT * PT, r = e / PH, col = e % PH;
+            if (e < PH * PH) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) halo[q][r][col] = vm[c][u][q];
+            }
+        }
+        __syncthreads();
+        float o[4];
+        separable<4>(halo, tmp, g, tid, o);
+        if (inside) {
+            const float R = Rv[c], G = Gv[c];
+            const float a = R * s, b = G * s;
+            const float sgn = a > b ? 1.f : (a < b ? -1.f : 0.f);
+            const float l1 = (1.f - lambda) * sgn;
+            const float da = scale * (l1 - lambda * (o[0] + 2.f * a * o[2] + b * o[3]));
+            const float db = scale * (-l1 - lambda * (o[1] + 2.f * b * o[2] + a * o[3]));
+            d_render[c * plane + pix] = da * s;
+            ds += da * R + db * G;
+        }
+        __syncthreads();
+    }
+    if (inside) d_static[pix] = ds;
 }
 
 static GaussWin make_window() {
@@ -238,7 +288,21 @@ extern "C" int das3r_photometric_backward(int32_t H, int32_t W, const float *ren
     }
     hipStream_t s = (hipStream_t)stream;
     DAS3R_LAUNCH(photometric_backward_kernel, dim3(div_up(W, PT), div_up(H, PT)), dim3(PT * PT), 0, s, H, W, render, gt, static_mask,
-                 lambda, make_window(), dmaps, grad_loss, d_render, d_static);
+                 lambda, make_window(), dmaps, grad_loss, d_render, d_static, (const float *)nullptr, 0, (float *)nullptr);
+    KERNEL_CHECK(s, false, "photometric_backward");
+    return DAS3R_OK;
+}
+
+extern "C" int das3r_photometric_backward_finish(int32_t H, int32_t W, const float *render, const float *gt, const float *static_mask, float lambda,
+                                                 const float *dmaps, const float *grad_loss, float *d_render, float *d_static,
+                                                 const float *partials, float *out8, das3r_stream_t stream) {
+    if (H <= 0 || W <= 0 || !render || !gt || !static_mask || !dmaps || !grad_loss || !d_render || !d_static || !partials || !out8) {
+        set_error("das3r_photometric_backward_finish: invalid argument");
+        return DAS3R_ERR_INVALID_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    DAS3R_LAUNCH(photometric_backward_kernel, dim3(div_up(W, PT), div_up(H, PT)), dim3(PT * PT), 0, s, H, W, render, gt, static_mask,
+                 lambda, make_window(), dmaps, grad_loss, d_render, d_static, partials, (int)das3r_photometric_blocks(H, W), out8);
     KERNEL_CHECK(s, false, "photometric_backward");
     return DAS3R_OK;
 }

@@ -118,8 +118,14 @@ __global__ void pose_matrices_kernel(const float *__restrict__ pose, const float
 // chain rule of pose_matrices: g[28] = dL/d(R, t, Lq) -> g_pose[7].  One lane.
 // g_t: where dL/dt goes (g_pose + 4 for the 7-vector form); rearm: zero g[0 .. 28) afterwards (the sums of the next backward are
 // accumulated into it with atomics: das3r_pose_chain_qt keeps the caller's buffer zero at rest)
-__global__ void pose_chain_kernel(const float *__restrict__ pose, float *__restrict__ g, float *__restrict__ g_pose, float *__restrict__ g_t, int rearm) {
+__global__ void pose_chain_kernel(const float *__restrict__ pose, float *__restrict__ g, float *__restrict__ g_pose, float *__restrict__ g_t, int rearm,
+                                  float *__restrict__ zero_q = nullptr, float *__restrict__ zero_t = nullptr) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // (das3r_pose_chain_qt_rearm: the rows another view left in the dense pose gradients, zeroed BEFORE this view's are written — they may be the same)
+    if (zero_q != nullptr)
+        for (int a = 0; a < 4; a++) zero_q[a] = 0.f;
+    if (zero_t != nullptr)
+        for (int a = 0; a < 3; a++) zero_t[a] = 0.f;
     const float w = pose[0], x = pose[1], y = pose[2], z = pose[3];
     const float n = sqrtf(w * w + x * x + y * y + z * z), inv = 1.0f / n;
     const float r = w * inv, i = x * inv, j = y * inv, k = z * inv;
@@ -192,6 +198,14 @@ extern "C" int das3r_pose_chain_qt(const float *q, float *g_mats, float *g_q, fl
     if (!q || !g_mats || !g_q || !g_t) { set_error("das3r_pose_chain_qt: invalid argument"); return DAS3R_ERR_INVALID_ARG; }
     hipStream_t s = (hipStream_t)stream;
     DAS3R_LAUNCH(pose_chain_kernel, dim3(1), dim3(64), 0, s, q, g_mats, g_q, g_t, 1);
+    KERNEL_CHECK(s, false, "pose_chain");
+    return DAS3R_OK;
+}
+
+extern "C" int das3r_pose_chain_qt_rearm(const float *q, float *g_mats, float *g_q, float *g_t, float *zero_q, float *zero_t, das3r_stream_t stream) {
+    if (!q || !g_mats || !g_q || !g_t) { set_error("das3r_pose_chain_qt_rearm: invalid argument"); return DAS3R_ERR_INVALID_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    DAS3R_LAUNCH(pose_chain_kernel, dim3(1), dim3(64), 0, s, q, g_mats, g_q, g_t, 1, zero_q, zero_t);
     KERNEL_CHECK(s, false, "pose_chain");
     return DAS3R_OK;
 }

@@ -143,7 +143,7 @@ def _settings(st, cam, model, bg):
     return rs
 
 
-def forward_backward(model, cam, q_row, t_row, gq_row, gt_row, static_hw, lambda_dssim, bg, geometry="grads"):
+def forward_backward(model, cam, q_row, t_row, gq_row, gt_row, static_hw, lambda_dssim, bg, geometry="grads", rearm_rows=None):
     """Render `cam` with the pose (q_row, t_row: views of one row of Q / T), masked photometric loss against cam.original_image
     under `static_hw` [H, W], and the complete backward.  Gradients: model parameters' .grad (f_rest: compact or none, as in
     das3r_amd.render), the pose gradient into gq_row / gt_row, d loss / d static_hw returned.
@@ -154,10 +154,10 @@ def forward_backward(model, cam, q_row, t_row, gq_row, gt_row, static_hw, lambda
     -> (out8 = {loss, mse x 3, psnr_frame, ...} device tensor, d_static [H, W], package)"""
     st = _state(model)
     with _on_device(st.dev):   # (the library's per-device state and the raw stream belong to the model's GPU, current or not)
-        return _forward_backward(st, model, cam, q_row, t_row, gq_row, gt_row, static_hw, lambda_dssim, bg, geometry)
+        return _forward_backward(st, model, cam, q_row, t_row, gq_row, gt_row, static_hw, lambda_dssim, bg, geometry, rearm_rows)
 
 
-def _forward_backward(st, model, cam, q_row, t_row, gq_row, gt_row, static_hw, lambda_dssim, bg, geometry):
+def _forward_backward(st, model, cam, q_row, t_row, gq_row, gt_row, static_hw, lambda_dssim, bg, geometry, rearm_rows=None):
     lib = _lib.load()
     dev, P = st.dev, st.P
     H, W = int(cam.image_height), int(cam.image_width)
@@ -203,10 +203,10 @@ def _forward_backward(st, model, cam, q_row, t_row, gq_row, gt_row, static_hw, l
     out8 = torch.empty(8, device=dev)
     lam = float(lambda_dssim)
     _lib.check(lib.das3r_photometric_forward(H, W, _p(image), _p(gt), _p(static_hw), C.c_float(lam), _p(partials), _p(dmaps), s), "das3r_photometric_forward")
-    _lib.check(lib.das3r_photometric_finish(H, W, _p(partials), C.c_float(lam), _p(out8), s), "das3r_photometric_finish")
     d_render, d_static = torch.empty_like(image), torch.empty(H, W, device=dev)
-    _lib.check(lib.das3r_photometric_backward(H, W, _p(image), _p(gt), _p(static_hw), C.c_float(lam), _p(dmaps), _p(st.one), _p(d_render),
-                                              _p(d_static), s), "das3r_photometric_backward")
+    # (ABI 15: the loss / PSNR reduction of das3r_photometric_finish is the backward kernel's first workgroup's side duty — one launch less)
+    _lib.check(lib.das3r_photometric_backward_finish(H, W, _p(image), _p(gt), _p(static_hw), C.c_float(lam), _p(dmaps), _p(st.one), _p(d_render),
+                                                     _p(d_static), _p(partials), _p(out8), s), "das3r_photometric_backward_finish")
     # ---- rasterizer backward (examines the forward's binning self-check first: include/das3r_raster.h)
     # round 6 (include/das3r_raster.h das3r_chain): with geometry == "adam" the rasterizer's backward goes on through the pre-transform — chain
     # rule, the Adam step of xyz / rotation / scaling / opacity, dL/d(confidence), the pose sums — and the four camera-frame gradient tensors
@@ -247,7 +247,11 @@ def _forward_backward(st, model, cam, q_row, t_row, gq_row, gt_row, static_hw, l
                        "das3r_pretransform_backward")
             model._xyz.grad, model._rotation.grad, model._scaling.grad, model._opacity.grad = g_xyz, g_rotation, g_scaling, g_opacity_raw
         conf_grad = g_conf
-    _lib.check(lib.das3r_pose_chain_qt(_p(q_row), _p(st.g_small), _p(gq_row), _p(gt_row), s), "das3r_pose_chain_qt")
+    if rearm_rows is not None:   # (ABI 15: the previous view's rows of the dense pose gradients are zeroed by this launch, not by two fills)
+        _lib.check(lib.das3r_pose_chain_qt_rearm(_p(q_row), _p(st.g_small), _p(gq_row), _p(gt_row), _p(rearm_rows[0]), _p(rearm_rows[1]), s),
+                   "das3r_pose_chain_qt_rearm")
+    else:
+        _lib.check(lib.das3r_pose_chain_qt(_p(q_row), _p(st.g_small), _p(gq_row), _p(gt_row), s), "das3r_pose_chain_qt")
     # ---- hand the gradients over
     if geometry != "pose":
         if deg == 0:
@@ -274,16 +278,18 @@ def train_step(model, cam, opt, iteration, pipe, background):
     st = _state(model)
     uid = cam.uid
     with torch.no_grad(), _on_device(st.dev):   # (FusedAdam's launches too)
+        # the dense pose gradients are zero outside the row of the view that stepped last; that row is zeroed by this step's pose chain launch
+        prev = getattr(st, "dirty_uid", None)
         out8, d_static, pkg = forward_backward(model, cam, model.Q[uid], model.T[uid], st.Qg[uid], st.Tg[uid], model._conf_static[uid],
-                                               opt.lambda_dssim, background, geometry="adam" if getattr(model, "fuse_geometry_adam", True) else "grads")
+                                               opt.lambda_dssim, background, geometry="adam" if getattr(model, "fuse_geometry_adam", True) else "grads",
+                                               rearm_rows=None if prev is None else (st.Qg[prev], st.Tg[prev]))
+        st.dirty_uid = uid
         model._conf_static.grad[uid] += d_static             # the loss sees conf_static twice: as opacity factor and as the frame's mask
         model.optimizer.step()
         model.optimizer.zero_grad(set_to_none=True)
         model.Q.grad, model.T.grad = st.Qg, st.Tg
         model.optimizer_cam.step(gate=out8[4], threshold=opt.psnr_threshold)
         model.optimizer_cam.zero_grad(set_to_none=True)
-        st.Qg[uid].zero_()                                   # dense pose gradients: zero at rest
-        st.Tg[uid].zero_()
     return out8[0], out8[4], pkg
 
 

@@ -210,6 +210,8 @@ class FusedAdam:
                         st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"][:, :cols].contiguous(), st["exp_avg_sq"][:, :cols].contiguous()
         gate = extra.get("gate_state")
         self._gate_state = None if gate is None else gate.detach().to(params[0].device).clone()
+        if self._gate_state is not None:
+            self._gate_state[1] = 0   # (scratch word: the arrival count of the gated kernel's workgroups, zero between launches — whatever an older checkpoint holds)
 
     # ---- compact moments of an "sh_rest" parameter (round 6).  Above the active degree gradient and moments are exactly zero; at degree 1 the
     # step used to stream 9 of every 45 floats of p, exp_avg and exp_avg_sq — six strided streams that cost what the whole tensors would

@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define DAS3R_ABI_VERSION 14
+#define DAS3R_ABI_VERSION 15
 
 typedef enum {
     DAS3R_OK = 0,
@@ -199,6 +199,10 @@ int das3r_pose_chain(const float *pose, const float *g_mats, float *g_pose, das3
  * caller-owned buffer stays zero at rest (ABI 10). */
 int das3r_pose_matrices_qt(const float *q, const float *t, float *mats, das3r_stream_t stream);
 int das3r_pose_chain_qt(const float *q, float *g_mats, float *g_q, float *g_t, das3r_stream_t stream);
+/* ABI 15 — das3r_pose_chain_qt that first ZEROES the rows zero_q[0 .. 4) / zero_t[0 .. 3) (either may be NULL; they may be g_q / g_t
+ * themselves): the rows the previous view left in dense (frames, 4) / (frames, 3) gradient buffers, which the camera optimizer (dense
+ * Adam over every frame, train_gui.py:584-586) must find zero — two fill launches per iteration otherwise. */
+int das3r_pose_chain_qt_rearm(const float *q, float *g_mats, float *g_q, float *g_t, float *zero_q, float *zero_t, das3r_stream_t stream);
 /* §8f-1: the per-Gaussian pre-transform + activations of /root/reference/gaussian_renderer/__init__.py:83-97,107 in one
  * pass: means3D = R xyz + t, rotations = Lq rot (quadmultiply(pose[:4], .) as a 4x4 matrix), scales = exp(scaling),
  * opacities = sigmoid(opacity_raw) * conf_flat[mask_index[i]] (mask_index NULL = identity).  R [3,3], t [3], Lq [4,4]:
@@ -301,6 +305,11 @@ int das3r_photometric_forward(int32_t H, int32_t W, const float *render, const f
 int das3r_photometric_finish(int32_t H, int32_t W, const float *partials, float lambda, float *out8, das3r_stream_t stream);
 int das3r_photometric_backward(int32_t H, int32_t W, const float *render, const float *gt, const float *static_mask, float lambda,
                                const float *dmaps, const float *grad_loss, float *d_render, float *d_static, das3r_stream_t stream);
+/* ABI 15 — das3r_photometric_backward and das3r_photometric_finish as ONE launch: the first workgroup of the backward kernel adds the
+ * forward's tile sums (`partials`) into out8 on its way in.  Same values, bit for bit; one launch less between the two rasterizer passes. */
+int das3r_photometric_backward_finish(int32_t H, int32_t W, const float *render, const float *gt, const float *static_mask, float lambda,
+                                      const float *dmaps, const float *grad_loss, float *d_render, float *d_static, const float *partials,
+                                      float *out8, das3r_stream_t stream);
 
 /* ---- introspection (used by the parity tests and the roofline accounting) ---- */
 
