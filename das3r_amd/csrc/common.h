@@ -327,7 +327,7 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
 // segsort.hip: exact (depth bits, index) order inside every (tile, depth bucket) segment of the partitioned list, in place
 int launch_segment_sort(int64_t cap, const uint32_t *n_ptr, const uint32_t *keys_final, int fbits, uint32_t *point_list, uint32_t *slot_list,
                         const uint32_t *depth_key, uint32_t last_g, uint32_t *scratch_keys, uint32_t *host_flag, uint32_t flag_value, bool debug,
-                        hipStream_t s);
+                        hipStream_t s, int dbits, uint2 *ranges, const uint32_t *err, uint32_t *host_late, uint32_t tag, uint32_t inject);
 // lb.point_list != null: the tile lists are in index order and the kernel sorts them by depth first
 int launch_render_forward(const das3r_raster_args *a, const float *colors_precomp, float *out_color, char *geom, char *binning,
                           char *img, const Layout &L, const LocalBin &lb, hipStream_t s);

@@ -63,9 +63,17 @@ __global__ void __launch_bounds__(SEG_T) segment_sort_kernel(uint32_t cap, const
                                                              int fbits /*fraction bits below (tile, bucket) in a key*/,
                                                            uint32_t *__restrict__ pl, uint32_t *__restrict__ sl, const uint32_t *__restrict__ depth_key /*[P] by splat*/,
                                                            uint32_t last_g, uint32_t *__restrict__ dk /*u32[cap] scratch (the dead key buffer)*/,
-                                                           uint32_t *__restrict__ host_flag, uint32_t flag_value) {
+                                                           uint32_t *__restrict__ host_flag, uint32_t flag_value,
+                                                           // round 6: the tile ranges and the forward's self-check word, which tile_ranges_kernel used to produce in a
+                                                           // launch of its own behind this one, from the keys this kernel holds anyway
+                                                           int dbits, uint2 *__restrict__ ranges, const uint32_t *__restrict__ err, uint32_t *__restrict__ host_late,
+                                                           uint32_t tag, uint32_t inject) {
     const uint32_t n = n_ptr ? min(*n_ptr, cap) : cap;
     const uint32_t w0 = blockIdx.x * (uint32_t)SEG_CH;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && host_late) {   // last binning kernel: hand the self-check word of this forward to the host mailbox (every
+        host_late[0] = *err | inject;                         // kernel that raises bits in it has finished; this one raises none)
+        __hip_atomic_store(host_late + 1, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (w0 >= n) return;
     __shared__ uint32_t s_a[SEG_CAP + 2];       // the partition keys of positions w0 - 1 .. w0 + SEG_CAP; then the sort words by position; then tie depths by rank
     __shared__ uint32_t s_sorted[SEG_CAP];      // the sort words at their ranks
@@ -100,6 +108,22 @@ __global__ void __launch_bounds__(SEG_T) segment_sort_kernel(uint32_t cap, const
         slot[u][0] = sv.x; slot[u][1] = sv.y;
     }
     __syncthreads();
+    // tile ranges (identifyTileRanges): list position w0 + p of the window starts a tile iff its tile id differs from the one before it
+    for (int p = tid; p < SEG_CH; p += SEG_T) {
+        const uint32_t idx = w0 + (uint32_t)p;
+        if (idx < n) {
+            const uint32_t t = s_a[p + 1] >> (fbits + dbits);
+            if (idx == 0u) ranges[t].x = 0u;
+            else {
+                const uint32_t prev = s_a[p] >> (fbits + dbits);
+                if (prev != t) {
+                    ranges[prev].y = idx;
+                    ranges[t].x = idx;
+                }
+            }
+            if (idx == n - 1u) ranges[t].y = n;
+        }
+    }
     // position p (0 .. SEG_CAP) starts a segment iff its (tile, bucket) — the key above the 16 fraction bits — differs from the one
     // before it; the position just behind the list counts as a start (it ends the last segment), nothing beyond it does
     auto flag = [&](const int p) -> bool {
@@ -316,10 +340,10 @@ __global__ void __launch_bounds__(SEG_T) segment_sort_kernel(uint32_t cap, const
 
 int launch_segment_sort(int64_t cap, const uint32_t *n_ptr, const uint32_t *keys_final, int fbits, uint32_t *point_list, uint32_t *slot_list,
                         const uint32_t *depth_key, uint32_t last_g, uint32_t *scratch_keys, uint32_t *host_flag, uint32_t flag_value, bool debug,
-                        hipStream_t s) {
+                        hipStream_t s, int dbits, uint2 *ranges, const uint32_t *err, uint32_t *host_late, uint32_t tag, uint32_t inject) {
     if (cap <= 0) return DAS3R_OK;
     DAS3R_LAUNCH(segment_sort_kernel, dim3(div_up(cap, SEG_CH)), dim3(SEG_T), 0, s, (uint32_t)cap, n_ptr, keys_final, fbits, point_list, slot_list, depth_key, last_g,
-                 scratch_keys, host_flag, flag_value);
+                 scratch_keys, host_flag, flag_value, dbits, ranges, err, host_late, tag, inject);
     KERNEL_CHECK(s, debug, "segment_sort");
     return DAS3R_OK;
 }

@@ -242,6 +242,8 @@ __global__ void __launch_bounds__(256) emit_kernel(int P, int tiles_x, int tiles
 
 #endif   // DAS3R_EXPERIMENTS
 
+// Four consecutive list positions per thread (round 6: one per thread, each with a load of its own and one of its neighbour's key, was
+// 16 700 workgroups at the DAS3R shape: 10.5 us; the keys are 16-byte aligned, whichever ping-pong buffer they end in).
 __global__ void __launch_bounds__(256) tile_ranges_kernel(uint32_t cap, const uint32_t *__restrict__ n_ptr,
                                                           const uint32_t *__restrict__ tile_keys, uint2 *__restrict__ ranges,
                                                           uint32_t *__restrict__ err, uint32_t *__restrict__ host_late, uint32_t tag,
@@ -255,17 +257,31 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(uint32_t cap, const ui
         __hip_atomic_store(host_late + 1, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (i < rearm_words) err[i] = 0u;   // (thread 0 has read err[0] just above) the ring slot is zero at rest again
-    if (i >= I) return;
-    const uint32_t t = tile_keys[i] >> dbits;
-    if (i == 0) ranges[t].x = 0;
-    else {
-        const uint32_t prev = tile_keys[i - 1] >> dbits;
-        if (prev != t) {
-            ranges[prev].y = i;
-            ranges[t].x = i;
+    const uint32_t i0 = 4u * i;
+    if (i0 >= I) return;
+    uint32_t k[4];
+    if (i0 + 4u <= I) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(tile_keys + i0);
+        k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) k[q] = i0 + q < I ? tile_keys[i0 + q] : 0u;
+    }
+    uint32_t prev = i0 ? tile_keys[i0 - 1u] >> dbits : 0u;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t at = i0 + (uint32_t)q;
+        if (at < I) {
+            const uint32_t t = k[q] >> dbits;
+            if (at == 0u) ranges[t].x = 0u;
+            else if (prev != t) {
+                ranges[prev].y = at;
+                ranges[t].x = at;
+            }
+            if (at == I - 1u) ranges[t].y = I;
+            prev = t;
         }
     }
-    if (i == I - 1) ranges[t].y = I;
 }
 
 // ---------------------------------------------------------------- host side
@@ -331,12 +347,14 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
         if (dead_keys) *dead_keys = kfinal;   // the tile keys are dead once tile_ranges_kernel has run
         if (L.dbits > 0) {   // segmented path: exact depth order inside every (tile, bucket) segment, in place (segsort.hip)
             uint32_t *other = kfinal == keyA ? keyB : keyA;   // the previous pass's keys: dead, scratch for a segment too long for LDS
-            rc1 = launch_segment_sort(I, n_ptr, kfinal, L.kshift, (uint32_t *)(binning + L.pub.point_list), (uint32_t *)(binning + L.b_slot),
-                                      (const uint32_t *)(geom + L.pub.depth_key), (uint32_t)(P - 1), other, seg_host_flag, seg_flag_value, debug, s);
-            if (rc1) return rc1;
+            // (round 6: it also writes the tile ranges and hands over the self-check word — no tile_ranges launch behind it; the segmented path
+            //  never runs with the fused emission, whose ring slot that kernel re-arms)
+            return launch_segment_sort(I, n_ptr, kfinal, L.kshift, (uint32_t *)(binning + L.pub.point_list), (uint32_t *)(binning + L.b_slot),
+                                       (const uint32_t *)(geom + L.pub.depth_key), (uint32_t)(P - 1), other, seg_host_flag, seg_flag_value, debug, s,
+                                       L.dbits, ranges, (const uint32_t *)(geom + L.g_ticket) + 8, host_late, tag, (uint32_t)switches().inject_fault);
         }
         const int rearm = emit_slot ? EMIT_SLOT_WORDS : 0;
-        DAS3R_LAUNCH(tile_ranges_kernel, dim3(div_up(std::max<int64_t>(I, rearm), 256)), dim3(256), 0, s, (uint32_t)I, n_ptr, kfinal, ranges,
+        DAS3R_LAUNCH(tile_ranges_kernel, dim3(div_up(std::max<int64_t>(div_up(I, 4), rearm), 256)), dim3(256), 0, s, (uint32_t)I, n_ptr, kfinal, ranges,
                      emit_slot ? emit_slot : (uint32_t *)(geom + L.g_ticket) + 8, host_late, tag, (uint32_t)rearm, (uint32_t)switches().inject_fault, L.dbits + L.kshift);
         KERNEL_CHECK(s, debug, "tile_ranges");
         return DAS3R_OK;
@@ -358,7 +376,7 @@ int launch_binning(int P, int64_t I, int W, int H, const int32_t *radii, char *g
     }
     // kin/vin now hold the partitioned (tile id, gaussian id) lists; vin == binning + pub.point_list by construction
     if (dead_keys) *dead_keys = kin;
-    DAS3R_LAUNCH(tile_ranges_kernel, dim3(div_up(I, 256)), dim3(256), 0, s, (uint32_t)I, n_ptr, kin, ranges,
+    DAS3R_LAUNCH(tile_ranges_kernel, dim3(div_up(div_up(I, 4), 256)), dim3(256), 0, s, (uint32_t)I, n_ptr, kin, ranges,
                  (uint32_t *)(geom + L.g_ticket) + 8, host_late, tag, 0u, (uint32_t)switches().inject_fault, 0);
     KERNEL_CHECK(s, debug, "tile_ranges");
 #else
