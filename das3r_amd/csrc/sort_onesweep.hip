@@ -71,6 +71,65 @@ __device__ __forceinline__ u64 pack_group_word(const uint32_t v) {
     return (u64)f | ((u64)(uint32_t)__shfl_down((int)f, 1, 64) << 32);
 }
 
+// Round 6: the look-back read by a WAVE, not by a thread.  Wave w owns digits 64 w .. 64 w + 63, i.e. WPW = 64 / FPW consecutive words of
+// every row (FPW fields of BITS bits per word); a load instruction of the wave covers 64 / WPW ROWS at once (lane = row phase x word), so
+// the 63 rows the last workgroup of a group of 64 sums are 16 loads per lane — ONE window, one trip to memory — where a thread reading its
+// own digit's word of every row needed four windows of 16, back to back, and that workgroup's group total is what every later group
+// waits for.  Row phases are folded with xor shuffles, then lane l fetches field l % FPW of word l / FPW: digit (64 w + l)'s sum in lane l,
+// exactly what sum_published returns.  Same polling rules (no padding loads of an address already polled, soft / hard spin limits).
+template <int BITS>
+__device__ __forceinline__ uint32_t sum_published_wave(const u64 *rows, const int stride, const int count, uint32_t *err) {
+    constexpr int FPW = 64 / BITS, WPW = 64 / FPW, PH = 64 / WPW, LB = 16;
+    const int lane = __lane_id(), wave = threadIdx.x >> 6;
+    const int wi = lane & (WPW - 1), ph = lane / WPW;
+    const u64 *col = rows + wave * WPW + wi;
+    constexpr u64 flag = 1ull << (BITS - 1), vmask = (1ull << (BITS - 1)) - 1ull;
+    uint32_t acc[FPW];
+#pragma unroll
+    for (int f = 0; f < FPW; f++) acc[f] = 0u;
+    unsigned spins = 0;
+    for (int p = 0; p < count; p += LB * PH) {
+        u64 x[LB];
+        while (true) {
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < LB; j++) {
+                const int row = p + j * PH + ph;
+                x[j] = row < count ? granule_poll(col + (size_t)row * stride, spins) : ~0ull;
+            }
+#pragma unroll
+            for (int j = 0; j < LB; j++) ok &= (x[j] & flag) != 0;
+            if (__all(ok)) break;   // (wave-uniform: every lane's words are what the others' sums need)
+            if (spins == SOFT_SPINS && lane == 0) atomicOr(err, ERR_HARD_POLL);
+            if (++spins > SPIN_LIMIT) {  // a predecessor never published: give up loudly instead of hanging
+                if (lane == 0) atomicOr(err, ERR_TIMEOUT);
+                return 0u;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int j = 0; j < LB; j++) {
+            const int row = p + j * PH + ph;
+            if (row < count) {
+#pragma unroll
+                for (int f = 0; f < FPW; f++) acc[f] += (uint32_t)((x[j] >> (f * BITS)) & vmask);
+            }
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < FPW; f++) {
+#pragma unroll
+        for (int o = WPW; o < 64; o <<= 1) acc[f] += (uint32_t)__shfl_xor((int)acc[f], o, 64);
+    }
+    uint32_t out = 0u;
+#pragma unroll
+    for (int f = 0; f < FPW; f++) {
+        const uint32_t v = (uint32_t)__shfl((int)acc[f], lane / FPW, 64);
+        if (lane % FPW == f) out = v;
+    }
+    return out;
+}
+
 // global histograms of all four 8-bit digits of the depth keys (read once, LDS-privatised, few global atomics)
 __global__ void __launch_bounds__(256) depth_hist_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ ghist) {
     __shared__ uint32_t h[4][RADIX_SIZE];
@@ -248,12 +307,12 @@ __global__ void __launch_bounds__(256) onesweep_pass_kernel(const uint32_t *__re
         //  the look-back: 8.8 vs 8.4 us median at 1 M splats, tools/wg_trace.py.  What a workgroup waits for is the total of the
         //  group just before its own, which that group's last workgroup publishes only after staging and summing its own group;
         //  and the 55 rows of 2 KB every workgroup reads are 70 MB per pass, more than the keys.)
-        const uint32_t in_group = sum_published<16>(status + (size_t)(b - r) * ROW_WORDS + (tid >> 2), ROW_WORDS, tid & 3, (int)r, err);
+        const uint32_t in_group = sum_published_wave<16>(status + (size_t)(b - r) * ROW_WORDS, ROW_WORDS, (int)r, err);
         if (r == gs_mask) {   // (uniform)
             const u64 w = pack_group_word(in_group + total);
             if ((tid & 1) == 0) granule_store(group_status + (size_t)grp * GROUP_ROW_WORDS + (tid >> 1), w);
         }
-        const uint32_t before_group = sum_published<32>(group_status + (tid >> 1), GROUP_ROW_WORDS, tid & 1, (int)grp, err);
+        const uint32_t before_group = sum_published_wave<32>(group_status, GROUP_ROW_WORDS, (int)grp, err);
         const uint32_t excl = in_group + before_group;
         if (b == last_block && excl + total != g) atomicOr(err, ERR_COUNTS);   // self-check: all counts add up to the histogram
         gdelta[tid] = digit_base + excl - lstart;   // destination of staged slot i holding digit d: i + gdelta[d]
