@@ -354,3 +354,41 @@ def test_densification_growth_c4():
     Ps, Is = [h[0] for h in history], [h[1] for h in history]
     assert Ps[0] == 1_000_000 and Ps[-1] == 1_300_000 and len(Ps) == 7, Ps
     assert all(b > a for a, b in zip(Is, Is[1:])), Is
+
+
+@pytest.mark.parametrize("binning", ["radix", "seg"])
+def test_ten_million_keys_lists_are_ordered(binning, monkeypatch):
+    """Sizes past the benchmarks': 9.5 M splats, ~ 12 M instances — the look-back of the radix passes then sums more than 32 group
+    rows (the wave-cooperative read of sort_onesweep.hip takes a second window: round 6) and more than 2 300 workgroups take tickets.
+    Structural check of the binning output, all of it on the device: every tile's list is in (depth bits, index) order, every splat
+    appears once per tile it touches, the ranges tile the list."""
+    from das3r_amd import GaussianRasterizationSettings, _lib
+    from das3r_amd.rasterizer import _forward_full
+    from das3r_amd.synth import make_scene
+    dev = torch.device("cuda:0")
+    monkeypatch.setenv("DAS3R_BINNING", binning)
+    sc = make_scene(P=9_500_000, W=512, H=208, focal=600.0, sh_degree=0, seed=61, s_px=(0.3, 1.2), opacity=0.01, max_sh_degree=0).to(dev)
+    rs = GaussianRasterizationSettings(**sc.settings_kwargs())
+    e = torch.empty(0, device=dev)
+    with torch.no_grad():
+        I, color, radii, geom, binning_buf, img, cap = _forward_full(rs, sc.means3D, sc.shs, e, sc.opacities, sc.scales, sc.rotations, e, exact=True)
+    torch.cuda.synchronize()
+    P = sc.P
+    assert I > 8_400_000, I
+    L = _lib.layout(P, I, sc.W, sc.H)
+    tiles = ((sc.W + 15) // 16) * ((sc.H + 15) // 16)
+    pl = _view(binning_buf, L["point_list"], torch.int32, I).long()
+    rg = _view(img, L["ranges"], torch.int32, 2 * tiles).reshape(tiles, 2).long()
+    tt = _view(geom, L["tiles_touched"], torch.int32, P).long()
+    assert int(pl.min()) >= 0 and int(pl.max()) < P
+    lens = rg[:, 1] - rg[:, 0]
+    assert int(lens.min()) >= 0 and int(lens.sum()) == I
+    order = torch.argsort(rg[:, 0] + (lens == 0).long() * (I + 1), stable=True)   # non-empty tiles by start: they tile [0, I)
+    ne = order[: int((lens > 0).sum())]
+    assert int(rg[ne[0], 0]) == 0 and int(rg[ne[-1], 1]) == I and torch.equal(rg[ne[1:], 0], rg[ne[:-1], 1])
+    assert torch.equal(torch.bincount(pl, minlength=P), torch.where(radii > 0, tt, torch.zeros_like(tt)))
+    depth_bits = _lib.splat_field(geom, L, "rgbd", P)[:, 3].contiguous().view(torch.int32).long()[pl]
+    tile_of = torch.repeat_interleave(torch.arange(tiles, device=dev), lens)
+    same = tile_of[1:] == tile_of[:-1]
+    ordered = (depth_bits[1:] > depth_bits[:-1]) | ((depth_bits[1:] == depth_bits[:-1]) & (pl[1:] > pl[:-1]))
+    assert bool((ordered | ~same).all()), int((~ordered & same).sum())

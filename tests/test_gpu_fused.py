@@ -401,3 +401,76 @@ def test_train_step_fused_matches_default():
         tol = 2e-4 * float(a.abs().max()) + 1e-6
         # Adam's first steps move by ~lr * sign(g): a gradient that is pure rounding noise may flip -> allow a few outliers
         assert float(((a - b).abs() > tol).float().mean()) <= 5e-3, name
+
+
+def test_fused_adam_device_gate_with_many_workgroups():
+    """Round 6: the gate is decided inside the gated kernel by every workgroup for itself; the last one to arrive writes the new step
+    count and re-arms the arrival word.  Tensors of several chunks each (six workgroups), gate flipping: parameters equal torch's
+    stepped on the open iterations, the count is the number of open gates, the scratch word is zero between launches."""
+    from das3r_amd.fused import FusedAdam
+    g = torch.Generator().manual_seed(12)
+    q0, t0 = torch.randn(1500, 4, generator=g).cuda(), torch.randn(1500, 3, generator=g).cuda()
+    qa, ta = torch.nn.Parameter(q0.clone()), torch.nn.Parameter(t0.clone())
+    qb, tb = torch.nn.Parameter(q0.clone()), torch.nn.Parameter(t0.clone())
+    fa = FusedAdam([dict(params=[qa], lr=3e-5, name="pose_Q"), dict(params=[ta], lr=3e-5, name="pose_T")], lr=0.0, eps=1e-15)
+    tb_opt = torch.optim.Adam([dict(params=[qb], lr=3e-5), dict(params=[tb], lr=3e-5)], lr=0.0, eps=1e-15)
+    opened = 0
+    for step, gv in enumerate([30.0, 10.0, 26.5, 26.0, 27.0, 5.0, 5.0, 41.0, 28.0]):
+        gq, gt = torch.randn(1500, 4, generator=g).cuda(), torch.randn(1500, 3, generator=g).cuda()
+        qa.grad, ta.grad, qb.grad, tb.grad = gq.clone(), gt.clone(), gq.clone(), gt.clone()
+        fa.step(gate=torch.tensor(gv, device="cuda"), threshold=26.0)
+        if gv > 26.0:
+            tb_opt.step()
+            opened += 1
+        assert fa._gate_state.tolist() == [opened, 0], (step, fa._gate_state.tolist())
+    assert float((qa - qb).abs().max()) <= 2e-6 * float(qb.abs().max()) and float((ta - tb).abs().max()) <= 2e-6 * float(tb.abs().max())
+
+
+@pytest.mark.parametrize("hw", [(37, 53), (208, 512)])
+def test_photometric_backward_finish_is_the_two_launches(hw):
+    """ABI 15: das3r_photometric_backward_finish = das3r_photometric_finish + das3r_photometric_backward in one launch, bit for bit."""
+    import ctypes as C
+    from das3r_amd import _lib
+    lib = _lib.load()
+    H, W = hw
+    g = torch.Generator().manual_seed(7 * H + W)
+    render, gt = torch.rand(3, H, W, generator=g).cuda(), torch.rand(3, H, W, generator=g).cuda()
+    static = (0.2 + 0.8 * torch.rand(H, W, generator=g)).cuda()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    nb = int(lib.das3r_photometric_blocks(H, W))
+    partials, dmaps, one = torch.empty(nb, 8, device="cuda"), torch.empty(4, 3, H, W, device="cuda"), torch.ones(1, device="cuda")
+    _lib.check(lib.das3r_photometric_forward(H, W, p(render), p(gt), p(static), C.c_float(0.2), p(partials), p(dmaps), s), "forward")
+    out_a, dr_a, ds_a = torch.empty(8, device="cuda"), torch.empty_like(render), torch.empty(H, W, device="cuda")
+    out_b, dr_b, ds_b = torch.full((8,), -1.0, device="cuda"), torch.empty_like(render), torch.empty(H, W, device="cuda")
+    _lib.check(lib.das3r_photometric_finish(H, W, p(partials), C.c_float(0.2), p(out_a), s), "finish")
+    _lib.check(lib.das3r_photometric_backward(H, W, p(render), p(gt), p(static), C.c_float(0.2), p(dmaps), p(one), p(dr_a), p(ds_a), s), "backward")
+    _lib.check(lib.das3r_photometric_backward_finish(H, W, p(render), p(gt), p(static), C.c_float(0.2), p(dmaps), p(one), p(dr_b), p(ds_b), p(partials),
+                                                     p(out_b), s), "backward_finish")
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b) and torch.equal(dr_a, dr_b) and torch.equal(ds_a, ds_b)
+    assert float(out_a[0]) > 0.0 and float(out_a[4]) > 0.0
+
+
+def test_pose_chain_rearm_zeroes_the_previous_rows():
+    """ABI 15: das3r_pose_chain_qt_rearm writes the same rows as das3r_pose_chain_qt and zeroes the rows it is given first (they may be
+    the rows it writes); g_mats is left zero either way."""
+    import ctypes as C
+    from das3r_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    Q = torch.randn(5, 4, generator=g).cuda()
+    gm = torch.randn(28, generator=g).cuda()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    Qa, Ta, ga = torch.zeros(5, 4, device="cuda"), torch.zeros(5, 3, device="cuda"), gm.clone()
+    _lib.check(lib.das3r_pose_chain_qt(p(Q[2]), p(ga), p(Qa[2]), p(Ta[2]), s), "chain")
+    Qb, Tb, gb = torch.full((5, 4), 9.0, device="cuda"), torch.full((5, 3), 9.0, device="cuda"), gm.clone()
+    _lib.check(lib.das3r_pose_chain_qt_rearm(p(Q[2]), p(gb), p(Qb[2]), p(Tb[2]), p(Qb[4]), p(Tb[4]), s), "rearm")
+    torch.cuda.synchronize()
+    assert torch.equal(Qa[2], Qb[2]) and torch.equal(Ta[2], Tb[2]) and float(ga.abs().max()) == 0.0 and float(gb.abs().max()) == 0.0
+    assert float(Qb[4].abs().max()) == 0.0 and float(Tb[4].abs().max()) == 0.0 and float(Qb[3].min()) == 9.0 and float(Tb[0].min()) == 9.0
+    gc = gm.clone()   # the rows to zero are the rows to write
+    _lib.check(lib.das3r_pose_chain_qt_rearm(p(Q[2]), p(gc), p(Qb[2]), p(Tb[2]), p(Qb[2]), p(Tb[2]), s), "rearm, same rows")
+    torch.cuda.synchronize()
+    assert torch.equal(Qa[2], Qb[2]) and torch.equal(Ta[2], Tb[2])
