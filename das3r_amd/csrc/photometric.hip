@@ -50,8 +50,10 @@ __global__ void __launch_bounds__(256) photometric_forward_kernel(int H, int W, 
                                                                   const float *__restrict__ stat, float lambda, GaussWin g,
                                                                   float *__restrict__ partials /*[blocks][8]*/,
                                                                   float *__restrict__ dmaps /*[4][3][H][W]*/) {
-    __shared__ float halo[5][PH][PH + 1];
-    __shared__ float tmp[5][PH][PT + 1];
+    // (round 6) the three channels side by side: fifteen quantities go through ONE separable pass — three barriers per tile instead of nine,
+    // and fifteen independent dot products per thread between them instead of five
+    __shared__ float halo[15][PH][PH + 1];
+    __shared__ float tmp[15][PH][PT + 1];
     __shared__ float red[4][8];
     const int tid = threadIdx.x, ty = tid / PT, tx = tid % PT;
     const int x0 = blockIdx.x * PT, y0 = blockIdx.y * PT;
@@ -61,9 +63,8 @@ __global__ void __launch_bounds__(256) photometric_forward_kernel(int H, int W, 
     float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};   // l1, 1 - ssim, squared error per channel
     // Round 6: the halo tiles of ALL THREE channels are requested before anything is used (21 loads per thread in flight, indices clamped
     // instead of guarded: a guarded load is a basic block of its own with a wait behind it) — the kernel used to make nine exposed trips
-    // to memory, one per channel and sweep of the halo, for an image that fits the L2 fifty times: 18.6 -> see DESIGN.md
+    // to memory, one per channel and sweep of the halo, for an image that fits the L2 fifty times
     constexpr int SWEEPS = (PH * PH + PT * PT - 1) / (PT * PT);
-    float va[3][SWEEPS], vb[3][SWEEPS];
 #pragma unroll
     for (int u = 0; u < SWEEPS; u++) {
         const int e = tid + u * PT * PT, r = e / PH, col = e % PH;
@@ -71,38 +72,38 @@ __global__ void __launch_bounds__(256) photometric_forward_kernel(int H, int W, 
         const bool in = e < PH * PH && yy >= 0 && yy < H && xx >= 0 && xx < W;
         const size_t p = (size_t)min(max(yy, 0), H - 1) * W + (size_t)min(max(xx, 0), W - 1);
         const float sm = in ? stat[p] : 0.f;
+        float va[3], vb[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const float rv = render[c * plane + p], gv = gt[c * plane + p];
-            va[c][u] = in ? rv * sm : 0.f;   // (outside the image: the zero padding of the reference's convolution)
-            vb[c][u] = in ? gv * sm : 0.f;
+            va[c] = in ? rv * sm : 0.f;   // (outside the image: the zero padding of the reference's convolution)
+            vb[c] = in ? gv * sm : 0.f;
         }
-    }
+        if (e < PH * PH) {
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-#pragma unroll
-        for (int u = 0; u < SWEEPS; u++) {
-            const int e = tid + u * PT * PT, r = e / PH, col = e % PH;
-            if (e < PH * PH) {
-                const float a = va[c][u], b = vb[c][u];
-                halo[0][r][col] = a;
-                halo[1][r][col] = b;
-                halo[2][r][col] = a * a;
-                halo[3][r][col] = b * b;
-                halo[4][r][col] = a * b;
+            for (int c = 0; c < 3; c++) {
+                const float a = va[c], b = vb[c];
+                halo[5 * c + 0][r][col] = a;
+                halo[5 * c + 1][r][col] = b;
+                halo[5 * c + 2][r][col] = a * a;
+                halo[5 * c + 3][r][col] = b * b;
+                halo[5 * c + 4][r][col] = a * b;
             }
         }
-        __syncthreads();
-        float o[5];
-        separable<5>(halo, tmp, g, tid, o);
+    }
+    __syncthreads();
+    float o[15];
+    separable<15>(halo, tmp, g, tid, o);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
         if (inside) {
-            const float mu1 = o[0], mu2 = o[1], e1 = o[2], e2 = o[3], e12 = o[4];
+            const float mu1 = o[5 * c + 0], mu2 = o[5 * c + 1], e1 = o[5 * c + 2], e2 = o[5 * c + 3], e12 = o[5 * c + 4];
             const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
             const float s1 = e1 - mu1s, s2 = e2 - mu2s, s12 = e12 - mu12;
             const float A = 2.f * mu12 + SSIM_C1, B = 2.f * s12 + SSIM_C2, C = mu1s + mu2s + SSIM_C1, D = s1 + s2 + SSIM_C2;
             const float rC = 1.f / C, rD = 1.f / D, rCD = rC * rD;
             const float m = A * B * rCD;
-            const float a = halo[0][ty + PR][tx + PR], b = halo[1][ty + PR][tx + PR];
+            const float a = halo[5 * c + 0][ty + PR][tx + PR], b = halo[5 * c + 1][ty + PR][tx + PR];
             const float d = a - b;
             acc[0] += fabsf(d);
             acc[1] += 1.f - m;
@@ -114,7 +115,6 @@ __global__ void __launch_bounds__(256) photometric_forward_kernel(int H, int W, 
             dmaps[(2 * 3 + c) * plane + pix] = -m * rD;                    // d m / d E[a^2] = d m / d E[b^2]
             dmaps[(3 * 3 + c) * plane + pix] = 2.f * A * rCD;              // d m / d E[ab]
         }
-        __syncthreads();
     }
     // deterministic tile sums: DPP-free plain LDS tree is plenty here (5 values, once per tile)
     const int lane = __lane_id(), wave = tid >> 6;
@@ -173,8 +173,8 @@ __global__ void __launch_bounds__(256) photometric_backward_kernel(int H, int W,
                                                                    const float *__restrict__ dmaps, const float *__restrict__ grad_loss,
                                                                    float *__restrict__ d_render, float *__restrict__ d_static,
                                                                    const float *__restrict__ partials, int nblocks, float *__restrict__ out8) {
-    __shared__ float halo[4][PH][PH + 1];
-    __shared__ float tmp[4][PH][PT + 1];
+    __shared__ float halo[12][PH][PH + 1];   // (round 6: the four derivative maps of the three channels through one separable pass)
+    __shared__ float tmp[12][PH][PT + 1];
     const int tid = threadIdx.x, ty = tid / PT, tx = tid % PT;
     // round 6 (das3r_photometric_backward_finish): the loss and the frame's PSNR — the forward's few hundred rows of tile sums added in a
     // fixed order — are the first workgroup's side duty instead of a launch of their own between the two kernels (4.8 us of every step)
@@ -189,51 +189,46 @@ __global__ void __launch_bounds__(256) photometric_backward_kernel(int H, int W,
     const float scale = grad_loss[0] / (3.f * (float)plane);       // d loss / d (per-element term)
     const float s = inside ? stat[pix] : 0.f;
     float ds = 0.f;
-    // (round 6, as in the forward: the four derivative maps of all three channels and the pixel's own values are requested up front)
+    // (as in the forward: everything is requested up front, indices clamped instead of guarded)
     constexpr int SWEEPS = (PH * PH + PT * PT - 1) / (PT * PT);
-    float vm[3][SWEEPS][4];
 #pragma unroll
     for (int u = 0; u < SWEEPS; u++) {
         const int e = tid + u * PT * PT, r = e / PH, col = e % PH;
         const int yy = y0 + r - PR, xx = x0 + col - PR;
         const bool in = e < PH * PH && yy >= 0 && yy < H && xx >= 0 && xx < W;
         const size_t p = (size_t)min(max(yy, 0), H - 1) * W + (size_t)min(max(xx, 0), W - 1);
+        float vm[12];
 #pragma unroll
         for (int c = 0; c < 3; c++)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const float v = dmaps[(q * 3 + c) * plane + p];
-                vm[c][u][q] = in ? v : 0.f;
+                vm[4 * c + q] = in ? v : 0.f;
             }
+        if (e < PH * PH) {
+#pragma unroll
+            for (int k = 0; k < 12; k++) halo[k][r][col] = vm[k];
+        }
     }
     const size_t pixc = (size_t)min(y, H - 1) * W + (size_t)min(x, W - 1);
     float Rv[3], Gv[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) Rv[c] = render[c * plane + pixc], Gv[c] = gt[c * plane + pixc];
+    __syncthreads();
+    float o[12];
+    separable<12>(halo, tmp, g, tid, o);
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-#pragma unroll
-        for (int u = 0; u < SWEEPS; u++) {
-            const int e = tid + u * PT * PT, r = e / PH, col = e % PH;
-            if (e < PH * PH) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) halo[q][r][col] = vm[c][u][q];
-            }
-        }
-        __syncthreads();
-        float o[4];
-        separable<4>(halo, tmp, g, tid, o);
         if (inside) {
             const float R = Rv[c], G = Gv[c];
             const float a = R * s, b = G * s;
             const float sgn = a > b ? 1.f : (a < b ? -1.f : 0.f);
             const float l1 = (1.f - lambda) * sgn;
-            const float da = scale * (l1 - lambda * (o[0] + 2.f * a * o[2] + b * o[3]));
-            const float db = scale * (-l1 - lambda * (o[1] + 2.f * b * o[2] + a * o[3]));
+            const float da = scale * (l1 - lambda * (o[4 * c + 0] + 2.f * a * o[4 * c + 2] + b * o[4 * c + 3]));
+            const float db = scale * (-l1 - lambda * (o[4 * c + 1] + 2.f * b * o[4 * c + 2] + a * o[4 * c + 3]));
             d_render[c * plane + pix] = da * s;
             ds += da * R + db * G;
         }
-        __syncthreads();
     }
     if (inside) d_static[pix] = ds;
 }
