@@ -244,6 +244,33 @@ void compute_layout(int P, int64_t I, int W, int H, Layout *L) {
     L->pub.img_bytes = o;
 }
 
+// Depth histograms of the segmented path (segkey.h), round 6: two 256-word slots per (host thread, device, stream), used in turn.  A forward's
+// preprocess kernel accumulates into one and ZEROES THE OTHER for the next forward of the stream — the memset that used to precede every
+// forward (a launch of its own: 5 us of every DAS3R-shaped iteration) is gone.  Launches of one stream are ordered, so the slot a forward
+// zeroes is read by nobody (the previous forward's emission has finished), and the slot it reads stays as it is until the NEXT forward's
+// preprocess kernel, however often its own emission is redone.  Should a slot ever be dirty — an aborted forward — the buckets come out
+// less even for one forward and exact all the same: any histogram gives a monotone map, the same one in every workgroup.
+static bool dhist_slots(hipStream_t s, uint32_t **use, uint32_t **next) {
+    struct Slot { int dev; hipStream_t stream; uint32_t *buf; uint32_t turn; };
+    static thread_local std::vector<Slot> slots;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    Slot *e = nullptr;
+    for (auto &c : slots)
+        if (c.dev == dev && c.stream == s) e = &c;
+    if (!e) {
+        uint32_t *buf = nullptr;
+        if (hipMalloc((void **)&buf, 2 * 256 * sizeof(uint32_t)) != hipSuccess) return false;
+        if (hipMemsetAsync(buf, 0, 2 * 256 * sizeof(uint32_t), s) != hipSuccess) return false;   // (on the stream whose kernels use it: ordered)
+        slots.push_back(Slot{dev, s, buf, 0u});
+        e = &slots.back();
+    }
+    e->turn++;
+    *use = e->buf + 256 * (e->turn & 1u);
+    *next = e->buf + 256 * ((e->turn + 1u) & 1u);
+    return true;
+}
+
 static int validate(const das3r_raster_args *a, const das3r_raster_in *in) {
     if (!a || !in) { set_error("null args"); return DAS3R_ERR_INVALID_ARG; }
     if (a->P < 0 || a->image_width <= 0 || a->image_height <= 0) { set_error("bad extents P=%d W=%d H=%d", a->P, a->image_width, a->image_height); return DAS3R_ERR_INVALID_ARG; }
@@ -559,7 +586,9 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
     const int seg_bits = (use_onesweep() && seg_passes <= 3) ? seg_dbits(L, seg_passes) : 0;
     bool seg = !local && seg_bits > 0 && (forced >= 2 || (forced == 0 && verdict.radix_left == 0 && verdict.last_I >= 0 &&
                                                            (verdict.last_I >> std::min(seg_bits, 20)) <= SEG_AVG * L.ntiles));
+    const uint32_t *seg_dhist = nullptr;   // where this forward's depth histogram is (set with the preprocess launch, below)
     auto apply_seg = [&]() {   // (compute_layout starts every layout without buckets)
+        L.dhist_ptr = seg_dhist;
         if (seg) {
             L.dbits = seg_bits;
             L.kbits = L.tbits + seg_bits;
@@ -685,13 +714,15 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
             if ((rc = bin_and_render(cap, true, true, nullptr, 0, emit_slot))) return rc;
             emit_ring_dirty = false;
         } else {
-            uint32_t *dhist = nullptr;
-            if (seg) {   // the depth histogram of this forward (segkey.h): zeroed here, filled by the preprocess kernel, read by the emission
-                dhist = (uint32_t *)(saved->geom + L.g_dhist);
+            uint32_t *dhist = nullptr, *dhist_next = nullptr;
+            if (seg && !dhist_slots(s, &dhist, &dhist_next)) {   // the depth histogram of this forward (segkey.h): filled by the preprocess kernel, read by the emission
+                dhist = (uint32_t *)(saved->geom + L.g_dhist);   // (no slot: in the geometry buffer, zeroed by a memset, as before round 6)
                 HIP_TRY(hipMemsetAsync(dhist, 0, 4 * 256, s));
             }
+            seg_dhist = dhist;
+            apply_seg();
             if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, saved->binning + L.b_ghist, L.b_ctrl_bytes, L, nullptr, mb->dev,
-                                        count_tag, s, nullptr, dhist))) return rc;
+                                        count_tag, s, nullptr, dhist, dhist_next))) return rc;
             if ((rc = bin_and_render(cap, local, true, mb->dev, count_tag))) return rc;
         }
         if ((rc = mailbox_wait(mb, 2, count_tag, s))) return rc;
@@ -711,12 +742,13 @@ extern "C" int64_t das3r_raster_forward(const das3r_raster_args *a, const das3r_
             if ((rc = bin_and_render(cap, local, false))) return rc;
         }
     } else {
-        uint32_t *dhist = nullptr;
-        if (seg) {   // the depth histogram of this forward (segkey.h): zeroed here, filled by the preprocess kernel, read by the emission
+        uint32_t *dhist = nullptr, *dhist_next = nullptr;
+        if (seg && !dhist_slots(s, &dhist, &dhist_next)) {   // the depth histogram of this forward (segkey.h): filled by the preprocess kernel, read by the emission
             dhist = (uint32_t *)(saved->geom + L.g_dhist);
             HIP_TRY(hipMemsetAsync(dhist, 0, 4 * 256, s));
         }
-        if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, nullptr, 0, L, arrive, mb->dev, count_tag, s, nullptr, dhist))) return rc;
+        seg_dhist = dhist;
+        if ((rc = launch_preprocess(a, in, out->radii, saved->geom, saved->img, nullptr, 0, L, arrive, mb->dev, count_tag, s, nullptr, dhist, dhist_next))) return rc;
         if (!local && !seg && (rc = launch_depth_sort(P, saved->geom, L, 0, nullptr, 0, a->debug != 0, s))) return rc;
         if ((rc = mailbox_wait(mb, 2, count_tag, s))) return rc;    // usually there already: preprocess finished long ago
         if ((rc = prefiltered_ok())) return rc;

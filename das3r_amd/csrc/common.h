@@ -214,6 +214,7 @@ struct Layout {
                                 // partition's digits start above them
     int part_passes;            // passes of the instance partition: tile_passes, or one more when the segmented path wants more bucket bits
     size_t g_dhist;
+    const uint32_t *dhist_ptr;  // round 6: where this forward's depth histogram really is (a library-owned slot: api.hip dhist_slots); null = geom + g_dhist
     size_t i_order;   // img buffer, u32[ntiles]: the tiles longest list first (render_regions.hip tile_lpt_kernel; round 6)
 };
 // depth-bucket bits `passes` partition passes (at most three) have room for beside the tile ids (<= 0: none)
@@ -258,7 +259,7 @@ constexpr int EMIT_STATUS_GRANULES = 1024;             // >= resident grid + its
 // arrive: a zeroed 64-bit device word (self re-arming); host_out / tag: pinned mailbox that receives num_rendered
 int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int32_t *radii, char *geom, char *img, char *binning_ctrl,
                       size_t binning_ctrl_bytes, const Layout &L, unsigned long long *arrive, uint32_t *host_out, uint32_t tag,
-                      hipStream_t s, const EmitArgs *emit = nullptr, uint32_t *dhist = nullptr);
+                      hipStream_t s, const EmitArgs *emit = nullptr, uint32_t *dhist = nullptr, uint32_t *dhist_next = nullptr);
 int launch_mark_visible(int P, const float *means3D, const float *viewmatrix, uint8_t *present, hipStream_t s);
 // part 0: everything that can be enqueued before num_rendered is known; part 1: the rest, which also zeroes the binning buffer's
 // control words (binning_ctrl may be null)

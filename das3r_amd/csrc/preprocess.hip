@@ -28,6 +28,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     uint32_t *__restrict__ host_out, uint32_t tag, const EmitArgs em,
     uint32_t *__restrict__ dhist /*segmented binning path: 256-bin depth histogram of this forward, zeroed by the caller (segkey.h); else null*/,
     uint32_t dhist_mask /*a pseudo-random 1 / (mask + 1) of the workgroups contribute (`sampled` below): a sample is all the bucket map needs*/,
+    uint32_t *__restrict__ dhist_next /*round 6: the library's OTHER histogram slot, zeroed here for the next forward of this stream (api.hip dhist_slots); else null*/,
     const PreXform pre /*xyz != null (round 6, das3r_raster_in.pre): the raw parameters + the pose; means3D / scales / rotations / opacities are not read*/) {
     const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
     // Which workgroups sample the depth histogram: a full-avalanche hash of the index (round 5).  "Every (mask + 1)-th workgroup" is a
@@ -80,6 +81,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(
     for (uint32_t i = gidx; i < zero_a_words; i += gridDim.x * blockDim.x) zero_a[i] = 0u;
     for (uint32_t i = gidx; i < zero_b_words; i += gridDim.x * blockDim.x) zero_b[i] = 0u;
     for (uint32_t i = gidx; i < zero_c_words; i += gridDim.x * blockDim.x) zero_c[i] = 0u;   // binning control words (hinted path)
+    if (dhist_next != nullptr && gidx < DBINS) dhist_next[gidx] = 0u;
     // STAGE (M == 16, degree >= 2): the workgroup's 256 SH rows (192 B each, contiguous) are fetched with fully coalesced
     // float4 loads — every 128-B line exactly once — and re-read per lane from LDS.  Per-lane strided row loads re-fetch
     // lines evicted from L1/L2 between the 12 loads of a row: measured 2.5x the algorithmic HBM traffic at 1M splats.
@@ -376,7 +378,7 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float *_
 
 int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int32_t *radii, char *geom, char *img, char *binning_ctrl,
                       size_t binning_ctrl_bytes, const Layout &L, unsigned long long *arrive, uint32_t *host_out, uint32_t tag,
-                      hipStream_t s, const EmitArgs *emit, uint32_t *dhist) {
+                      hipStream_t s, const EmitArgs *emit, uint32_t *dhist, uint32_t *dhist_next) {
     const int P = a->P;
     if (P == 0) return DAS3R_OK;
     const EmitArgs em = emit ? *emit : EmitArgs{nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 0, nullptr, nullptr};
@@ -391,7 +393,7 @@ int launch_preprocess(const das3r_raster_args *a, const das3r_raster_in *in, int
         a->tanfovx, a->tanfovy, L.tiles_x, L.tiles_y, radii, (uint32_t *)(geom + L.g_keyA), (float4 *)(geom + L.pub.xy),  \
         (float4 *)(geom + L.pub.conic_opacity), (float4 *)(geom + L.pub.rgbd), (uint8_t *)(geom + L.pub.clamped),         \
         (uint32_t *)(geom + L.pub.tiles_touched), (uint32_t *)(geom + L.g_rect), (use_tight_rect() ? 1 : 0) | (a->prefiltered ? 2 : 0), (uint32_t *)(geom + L.g_ghist), (uint32_t)(L.g_ctrl_bytes / 4),                 \
-        (uint32_t *)(img + L.pub.ranges), (uint32_t)(2 * L.ntiles), (uint32_t *)binning_ctrl, (uint32_t)(binning_ctrl_bytes / 4), arrive, host_out, tag, em, dhist, dhist_mask, pre
+        (uint32_t *)(img + L.pub.ranges), (uint32_t)(2 * L.ntiles), (uint32_t *)binning_ctrl, (uint32_t)(binning_ctrl_bytes / 4), arrive, host_out, tag, em, dhist, dhist_mask, dhist_next, pre
     const bool stage = has_sh && a->M == 16 && a->sh_degree >= 2 && ((uintptr_t)in->shs & 15) == 0 && !switches().no_sh_stage;
     if (has_sh && !has_cov && stage) DAS3R_LAUNCH((preprocess_kernel<true, false, true>), grid, block, 0, s, ARGS);
     else if (has_sh && has_cov && stage) DAS3R_LAUNCH((preprocess_kernel<true, true, true>), grid, block, 0, s, ARGS);

@@ -280,7 +280,7 @@ int launch_scan_emit(int P, int64_t cap, const int32_t *radii, char *geom, char 
     DAS3R_LAUNCH((scan_emit_kernel<true, IT>), dim3(nblocks), dim3(256), 0, s, SCAN_COMMON, L.tiles_x, L.tiles_y,              \
                  (const float4 *)(geom + L.pub.xy), radii, (uint32_t *)(binning + L.b_keyA), (uint32_t *)(binning + L.b_gid_of), \
                  (uint32_t)cap, (uint32_t *)(binning + L.b_ghist), L.kbits, use_tight_rect() ? 1 : 0, RECT32, index_order ? L.dbits : 0, L.kshift, \
-                 (const uint32_t *)(geom + L.pub.depth_key), (const uint32_t *)(geom + L.g_dhist) SCAN_TRACE_ARG)
+                 (const uint32_t *)(geom + L.pub.depth_key), L.dhist_ptr ? L.dhist_ptr : (const uint32_t *)(geom + L.g_dhist) SCAN_TRACE_ARG)
     switch (scan_items(P)) { case 1: GO(1); break; case 2: GO(2); break; case 4: GO(4); break; case 8: GO(8); break; default: GO(16); }
 #undef GO
     KERNEL_CHECK(s, debug, "scan_emit");
