@@ -495,8 +495,11 @@ def eval_forward_figure(dev):
     loaded.active_sh_degree = 3
     views = offline.sequence_cameras(seq, dev)[:20]
     out = offline.forward_throughput(loaded, views, repeats=5)
+    fz = offline.forward_throughput(loaded, views, repeats=5, fused=True)
     return {"ms_per_view": round(out["ms_per_view"], 4), "views_per_s": round(out["views_per_s"], 1), "Msplats_per_s": round(out["splats"] * out["views_per_s"] / 1e6, 1),
             "splats": out["splats"], "image": [512, 208], "sh_degree": 3,
+            "fused": {"ms_per_view": round(fz["ms_per_view"], 4), "views_per_s": round(fz["views_per_s"], 1), "Msplats_per_s": round(fz["splats"] * fz["views_per_s"] / 1e6, 1),
+                      "what": "offline.render_view_fused: the pose pre-transform inside the rasterizer's kernels (das3r_raster_in.pre) instead of the reference's PyTorch glue"},
             "what": "torch.no_grad render_test of a loaded model (render.py:72-86), 5 passes over 20 views; includes the per-call wait for the binning self-check"}
 
 

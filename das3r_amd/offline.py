@@ -97,24 +97,76 @@ def sequence_cameras(seq, device="cuda"):
 PIPE = SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
 
 
+class _EvalState:
+    """What a model's fused no-grad renders share: the pose matrices' buffer and the packed [P, (D + 1)^2, 3] SH tensor the rasterizer reads
+    (get_features is a torch.cat of 190 bytes per Gaussian — rebuilt only when a parameter was written since)."""
+
+    def __init__(self, model):
+        dev = model._xyz.device
+        self.mats = torch.empty(28, device=dev)
+        self.e = torch.empty(0, device=dev)
+        self.shs, self.versions = None, None
+
+    def packed_sh(self, model):
+        v = (model._features_dc._version, model._features_rest._version, model._features_dc.data_ptr(), model._features_rest.data_ptr())
+        if self.shs is None or v != self.versions:
+            self.shs, self.versions = model.get_features.detach().contiguous(), v
+        return self.shs
+
+
 @torch.no_grad()
-def render_set(model_path, name, iteration, views, model, pipe=PIPE, background=None, poses=None, write=True):
+def render_view_fused(model, view, pose7, background, pipe=PIPE):
+    """render_test of one view (gaussian_renderer/__init__.py:152-277) with the pose pre-transform INSIDE the rasterizer's per-Gaussian
+    kernel (include/das3r_raster.h das3r_raster_in.pre, as the direct training iteration uses it): R xyz + t, quaternion product, exp,
+    sigmoid x the per-Gaussian conf_static column — the dozen PyTorch kernels of the reference's glue (a boolean-mask gather of every
+    tensor among them: 190 bytes of SH per Gaussian copied per view) are not launched and the camera-frame tensors never exist.
+    Same arithmetic up to the rounding of the pre-transform (tests: within the parity bars of the glue form).  -> (image, radii)"""
+    import ctypes as C
+    from . import _lib
+    from .rasterizer import _forward_full, _on_device, _stream, check_forward
+    from .render import _settings
+    st = model.__dict__.get("_das3r_eval")
+    if st is None:
+        st = model.__dict__["_das3r_eval"] = _EvalState(model)
+    dev = model._xyz.device
+    lib = _lib.load()
+    pose7 = pose7.detach().to(device=dev, dtype=torch.float32).contiguous()
+    conf = model._conf_static.detach().reshape(-1)
+    if conf.shape[0] != model._xyz.shape[0]:
+        raise RuntimeError("render_view_fused renders a LOADED model (one conf_static value per Gaussian: load_trained_model)")
+    with _on_device(dev):
+        _lib.check(lib.das3r_pose_matrices(C.c_void_p(pose7.data_ptr()), C.c_void_p(st.mats.data_ptr()), _stream(dev)), "das3r_pose_matrices")
+    pre = _lib.PreTransform()
+    xyz, rot, sc, op = model._xyz.detach(), model._rotation.detach(), model._scaling.detach(), model._opacity.detach()
+    pre.xyz, pre.rot, pre.scaling, pre.opacity_raw = xyz.data_ptr(), rot.data_ptr(), sc.data_ptr(), op.data_ptr()
+    pre.conf_flat, pre.mask_index = conf.data_ptr(), None
+    pre.R, pre.t, pre.Lq = st.mats.data_ptr(), st.mats.data_ptr() + 36, st.mats.data_ptr() + 48
+    rs = _settings(view, model, pipe, background, 1.0, dev)
+    I, image, radii, geom, binning, img, cap = _forward_full(rs, xyz, st.packed_sh(model), st.e, op, sc, rot, st.e, pre=pre)
+    check_forward(cap, dev)   # (no backward pass will examine this forward's binning self-check)
+    return image, radii
+
+
+@torch.no_grad()
+def render_set(model_path, name, iteration, views, model, pipe=PIPE, background=None, poses=None, write=True, fused=False):
     """render.py:72-86.  views: cameras carrying .pose7 (qw, qx, qy, qz, tx, ty, tz world-to-camera); poses: optional [N, 4, 4]
-    world-to-camera matrices that override them.  -> list of the rendered [3, H, W] tensors (on the device)."""
+    world-to-camera matrices that override them.  fused: render_view_fused instead of the reference's PyTorch glue in front of the
+    rasterizer (opt-in, like every fused form).  -> list of the rendered [3, H, W] tensors (on the device)."""
     dev = model.get_xyz.device
     background = background if background is not None else torch.zeros(3, device=dev)
     render_path = os.path.join(model_path, name, f"ours_{iteration}", "renders")
     out = []
     for idx, view in enumerate(views):
         pose = view.pose7 if poses is None else tensor_from_camera(poses[idx], dev)
-        img = das3r_render(view, model, pipe, background, camera_pose=pose, variant="test")["render"]
+        img = (render_view_fused(model, view, pose, background, pipe)[0] if fused
+               else das3r_render(view, model, pipe, background, camera_pose=pose, variant="test")["render"])
         out.append(img)
         if write:
             save_image(img, os.path.join(render_path, f"{idx:05d}.png"))
     return out
 
 
-def render_sets(model_path, seq, iteration=-1, sh_degree=3, white_background=False, optimised_poses=False, device="cuda", write=True):
+def render_sets(model_path, seq, iteration=-1, sh_degree=3, white_background=False, optimised_poses=False, device="cuda", write=True, fused=False):
     """render.py:89-123: load the trained model, write pose_interpolated.npy, render the "interp" set.  seq: the sequence the model was
     trained on (its cameras).  -> (iteration, list of rendered images)"""
     model, iteration = load_trained_model(model_path, iteration, sh_degree, device)
@@ -132,17 +184,18 @@ def render_sets(model_path, seq, iteration=-1, sh_degree=3, white_background=Fal
                 raise ValueError(f"pose_{iteration}.npy holds {len(inter)} poses, the sequence {len(views)} frames ({len(tr)} training frames)")
             views = [views[i] for i in tr]
         poses = inter
-    return iteration, render_set(model_path, "interp", iteration, views, model, PIPE, bg, poses=poses, write=write)
+    return iteration, render_set(model_path, "interp", iteration, views, model, PIPE, bg, poses=poses, write=write, fused=fused)
 
 
 @torch.no_grad()
-def forward_throughput(model, views, repeats=3, background=None):
+def forward_throughput(model, views, repeats=3, background=None, fused=False):
     """Eval-mode (torch.no_grad) forward alone: views per second and ms per view over `repeats` passes of all views, after one
     warm-up pass.  In this mode the rasterizer examines every forward's binning self-check before it returns (there is no backward
     to do it), so the figure contains that wait — the path render.py and every held-out report take."""
     dev = model.get_xyz.device
     background = background if background is not None else torch.zeros(3, device=dev)
-    run = lambda: [das3r_render(v, model, PIPE, background, camera_pose=v.pose7, variant="test")["render"] for v in views]
+    run = ((lambda: [render_view_fused(model, v, v.pose7, background)[0] for v in views]) if fused
+           else (lambda: [das3r_render(v, model, PIPE, background, camera_pose=v.pose7, variant="test")["render"] for v in views]))
     run()
     torch.cuda.current_stream(dev).synchronize()
     t0 = time.perf_counter()
@@ -162,11 +215,12 @@ def main(argv=None):
     ap.add_argument("--white-background", "--white_background", dest="white_background", action="store_true")
     ap.add_argument("--optimised-poses", action="store_true", help="render from pose/pose_N.npy instead of the poses the cameras were loaded with")
     ap.add_argument("--dataset", default="sintel", choices=("sintel", "davis"))
+    ap.add_argument("--fused", action="store_true", help="the pose pre-transform inside the rasterizer's kernels instead of the reference's PyTorch glue (render_view_fused)")
     args = ap.parse_args(argv)
     from .io_formats import load_sequence
     print("Rendering " + args.model_path)
     seq = load_sequence(args.source_path, device="cuda", dataset=args.dataset)
-    it, imgs = render_sets(args.model_path, seq, args.iteration, args.sh_degree, args.white_background, args.optimised_poses)
+    it, imgs = render_sets(args.model_path, seq, args.iteration, args.sh_degree, args.white_background, args.optimised_poses, fused=args.fused)
     print(f"wrote {len(imgs)} images to {os.path.join(args.model_path, 'interp', f'ours_{it}', 'renders')}")
 
 

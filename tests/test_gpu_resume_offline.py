@@ -118,3 +118,14 @@ def test_offline_render_writes_what_a_direct_render_gives(tmp_path):
     assert len(imgs2) == 11 and all(tuple(i.shape) == (3, SMALL["H"], SMALL["W"]) for i in imgs2)
     tp = offline.forward_throughput(loaded, views[:4], repeats=1)
     assert tp["views"] == 4 and tp["ms_per_view"] > 0
+    # round 6: the fused form of the same render (the pose pre-transform inside the rasterizer's kernels) — the glue form's image within
+    # the parity bars, the same Gaussians visible (a radius may move by one where the pre-transform's rounding crosses a ceil)
+    from tests import util
+    fused_img, fused_radii = offline.render_view_fused(loaded, views[4], views[4].pose7, torch.zeros(3, device=dev))
+    util.assert_color_close(fused_img.cpu().numpy(), direct.cpu().numpy(), "render_view_fused vs render_test")
+    with torch.no_grad():
+        glue_radii = das3r_render(views[4], loaded, offline.PIPE, torch.zeros(3, device=dev), camera_pose=views[4].pose7, variant="test")["radii"]
+    assert float(((fused_radii > 0) != (glue_radii > 0)).float().mean()) < 1e-4 and float((fused_radii - glue_radii).abs().max()) <= 1
+    it3, imgs3 = offline.render_sets(out, seq, iteration=40, write=False, fused=True)
+    util.assert_color_close(imgs3[4].cpu().numpy(), direct.cpu().numpy(), "render_sets(fused=True)")
+    assert offline.forward_throughput(loaded, views[:4], repeats=1, fused=True)["views"] == 4
