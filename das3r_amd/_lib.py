@@ -72,7 +72,7 @@ EXPORTS = ("das3r_raster_forward", "das3r_raster_backward", "das3r_raster_check"
            "das3r_adam_step", "das3r_adam_step_gated", "das3r_photometric_blocks", "das3r_photometric_forward", "das3r_photometric_backward",
            "das3r_has_experiments", "das3r_pair_counters", "das3r_debug_poison_lds", "das3r_debug_inject_fault", "das3r_debug_mutate",
            "das3r_pose_matrices_qt", "das3r_pose_chain_qt", "das3r_photometric_finish", "das3r_pretransform_backward_adam", "das3r_pretransform_pose_sums",
-           "das3r_raster_count_live_pairs", "das3r_photometric_backward_finish", "das3r_pose_chain_qt_rearm")
+           "das3r_raster_count_live_pairs", "das3r_photometric_backward_finish", "das3r_pose_chain_qt_rearm", "das3r_ssim_map_forward", "das3r_ssim_map_backward")
 
 _lib = None
 
@@ -135,6 +135,10 @@ def load():
     L.das3r_pose_chain_qt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.das3r_pose_chain_qt_rearm.restype = C.c_int
     L.das3r_pose_chain_qt_rearm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.das3r_ssim_map_forward.restype = C.c_int
+    L.das3r_ssim_map_forward.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.das3r_ssim_map_backward.restype = C.c_int
+    L.das3r_ssim_map_backward.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.das3r_photometric_backward_finish.restype = C.c_int
     L.das3r_photometric_backward_finish.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -49,7 +49,8 @@ __device__ __forceinline__ void separable(const float (*halo)[PH][PH + 1], float
 __global__ void __launch_bounds__(256) photometric_forward_kernel(int H, int W, const float *__restrict__ render, const float *__restrict__ gt,
                                                                   const float *__restrict__ stat, float lambda, GaussWin g,
                                                                   float *__restrict__ partials /*[blocks][8]*/,
-                                                                  float *__restrict__ dmaps /*[4][3][H][W]*/) {
+                                                                  float *__restrict__ dmaps /*[4][3][H][W]*/,
+                                                                  float *__restrict__ ssim_map /*[3][H][W] or null (das3r_ssim_map_forward)*/) {
     // (round 6) the three channels side by side: fifteen quantities go through ONE separable pass — three barriers per tile instead of nine,
     // and fifteen independent dot products per thread between them instead of five
     __shared__ float halo[15][PH][PH + 1];
@@ -71,7 +72,7 @@ __global__ void __launch_bounds__(256) photometric_forward_kernel(int H, int W, 
         const int yy = y0 + r - PR, xx = x0 + col - PR;
         const bool in = e < PH * PH && yy >= 0 && yy < H && xx >= 0 && xx < W;
         const size_t p = (size_t)min(max(yy, 0), H - 1) * W + (size_t)min(max(xx, 0), W - 1);
-        const float sm = in ? stat[p] : 0.f;
+        const float sm = in ? (stat != nullptr ? stat[p] : 1.f) : 0.f;
         float va[3], vb[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -114,6 +115,7 @@ __global__ void __launch_bounds__(256) photometric_forward_kernel(int H, int W, 
             dmaps[(1 * 3 + c) * plane + pix] = mu1 * common - 2.f * m * mu2 * (rC - rD);
             dmaps[(2 * 3 + c) * plane + pix] = -m * rD;                    // d m / d E[a^2] = d m / d E[b^2]
             dmaps[(3 * 3 + c) * plane + pix] = 2.f * A * rCD;              // d m / d E[ab]
+            if (ssim_map != nullptr) ssim_map[c * plane + pix] = m;
         }
     }
     // deterministic tile sums: DPP-free plain LDS tree is plenty here (5 values, once per tile)
@@ -172,7 +174,10 @@ __global__ void __launch_bounds__(256) photometric_backward_kernel(int H, int W,
                                                                    const float *__restrict__ stat, float lambda, GaussWin g,
                                                                    const float *__restrict__ dmaps, const float *__restrict__ grad_loss,
                                                                    float *__restrict__ d_render, float *__restrict__ d_static,
-                                                                   const float *__restrict__ partials, int nblocks, float *__restrict__ out8) {
+                                                                   const float *__restrict__ partials, int nblocks, float *__restrict__ out8,
+                                                                   // das3r_ssim_map_backward: gmap = dL/d(SSIM map) [3][H][W] (then stat may be null, lambda and
+                                                                   // grad_loss are not read, and d_b [3][H][W] receives dL/d(second image)); else both null
+                                                                   const float *__restrict__ gmap, float *__restrict__ d_b) {
     __shared__ float halo[12][PH][PH + 1];   // (round 6: the four derivative maps of the three channels through one separable pass)
     __shared__ float tmp[12][PH][PT + 1];
     const int tid = threadIdx.x, ty = tid / PT, tx = tid % PT;
@@ -186,8 +191,8 @@ __global__ void __launch_bounds__(256) photometric_backward_kernel(int H, int W,
     const int x = x0 + tx, y = y0 + ty;
     const bool inside = x < W && y < H;
     const size_t plane = (size_t)H * W, pix = (size_t)y * W + x;
-    const float scale = grad_loss[0] / (3.f * (float)plane);       // d loss / d (per-element term)
-    const float s = inside ? stat[pix] : 0.f;
+    const float scale = gmap != nullptr ? 1.f : grad_loss[0] / (3.f * (float)plane);       // d loss / d (per-element term)
+    const float s = inside ? (stat != nullptr ? stat[pix] : 1.f) : 0.f;
     float ds = 0.f;
     // (as in the forward: everything is requested up front, indices clamped instead of guarded)
     constexpr int SWEEPS = (PH * PH + PT * PT - 1) / (PT * PT);
@@ -202,7 +207,9 @@ __global__ void __launch_bounds__(256) photometric_backward_kernel(int H, int W,
         for (int c = 0; c < 3; c++)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const float v = dmaps[(q * 3 + c) * plane + p];
+                // (with an upstream gradient PER PIXEL the derivative maps are weighted by it before the window sums: dL/da(p) =
+                //  sum over the window centres q of G(q) w(p - q) dm(q) — the same separable convolution, of G x dm)
+                const float v = dmaps[(q * 3 + c) * plane + p] * (gmap != nullptr ? gmap[c * plane + p] : 1.f);
                 vm[4 * c + q] = in ? v : 0.f;
             }
         if (e < PH * PH) {
@@ -224,13 +231,18 @@ __global__ void __launch_bounds__(256) photometric_backward_kernel(int H, int W,
             const float a = R * s, b = G * s;
             const float sgn = a > b ? 1.f : (a < b ? -1.f : 0.f);
             const float l1 = (1.f - lambda) * sgn;
+            if (gmap != nullptr) {   // (uniform) the SSIM map's own backward: both images, no mask, no L1 term
+                d_render[c * plane + pix] = o[4 * c + 0] + 2.f * a * o[4 * c + 2] + b * o[4 * c + 3];
+                d_b[c * plane + pix] = o[4 * c + 1] + 2.f * b * o[4 * c + 2] + a * o[4 * c + 3];
+                continue;
+            }
             const float da = scale * (l1 - lambda * (o[4 * c + 0] + 2.f * a * o[4 * c + 2] + b * o[4 * c + 3]));
             const float db = scale * (-l1 - lambda * (o[4 * c + 1] + 2.f * b * o[4 * c + 2] + a * o[4 * c + 3]));
             d_render[c * plane + pix] = da * s;
             ds += da * R + db * G;
         }
     }
-    if (inside) d_static[pix] = ds;
+    if (inside && d_static != nullptr) d_static[pix] = ds;
 }
 
 static GaussWin make_window() {
@@ -261,7 +273,7 @@ extern "C" int das3r_photometric_forward(int32_t H, int32_t W, const float *rend
     }
     hipStream_t s = (hipStream_t)stream;
     DAS3R_LAUNCH(photometric_forward_kernel, dim3(div_up(W, PT), div_up(H, PT)), dim3(PT * PT), 0, s, H, W, render, gt, static_mask, lambda,
-                 make_window(), partials, dmaps);
+                 make_window(), partials, dmaps, (float *)nullptr);
     KERNEL_CHECK(s, false, "photometric_forward");
     return DAS3R_OK;
 }
@@ -283,7 +295,7 @@ extern "C" int das3r_photometric_backward(int32_t H, int32_t W, const float *ren
     }
     hipStream_t s = (hipStream_t)stream;
     DAS3R_LAUNCH(photometric_backward_kernel, dim3(div_up(W, PT), div_up(H, PT)), dim3(PT * PT), 0, s, H, W, render, gt, static_mask,
-                 lambda, make_window(), dmaps, grad_loss, d_render, d_static, (const float *)nullptr, 0, (float *)nullptr);
+                 lambda, make_window(), dmaps, grad_loss, d_render, d_static, (const float *)nullptr, 0, (float *)nullptr, (const float *)nullptr, (float *)nullptr);
     KERNEL_CHECK(s, false, "photometric_backward");
     return DAS3R_OK;
 }
@@ -297,7 +309,29 @@ extern "C" int das3r_photometric_backward_finish(int32_t H, int32_t W, const flo
     }
     hipStream_t s = (hipStream_t)stream;
     DAS3R_LAUNCH(photometric_backward_kernel, dim3(div_up(W, PT), div_up(H, PT)), dim3(PT * PT), 0, s, H, W, render, gt, static_mask,
-                 lambda, make_window(), dmaps, grad_loss, d_render, d_static, partials, (int)das3r_photometric_blocks(H, W), out8);
+                 lambda, make_window(), dmaps, grad_loss, d_render, d_static, partials, (int)das3r_photometric_blocks(H, W), out8, (const float *)nullptr, (float *)nullptr);
     KERNEL_CHECK(s, false, "photometric_backward");
+    return DAS3R_OK;
+}
+
+// ABI 15 — the SSIM MAP of two images (utils/loss_utils.py:39-66 with size_average = False: what train_gui.py:568 combines with its L1 map)
+// and its backward for an arbitrary upstream gradient, on the photometric kernels: two launches each way instead of the reference's
+// twelve depthwise convolutions and their elementwise chains (0.75 ms of MIOpen kernels per iteration at 512 x 208).
+extern "C" int das3r_ssim_map_forward(int32_t H, int32_t W, const float *img1, const float *img2, float *ssim_map, float *dmaps, float *partials,
+                                      das3r_stream_t stream) {
+    if (H <= 0 || W <= 0 || !img1 || !img2 || !ssim_map || !dmaps || !partials) { set_error("das3r_ssim_map_forward: invalid argument"); return DAS3R_ERR_INVALID_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    DAS3R_LAUNCH(photometric_forward_kernel, dim3(div_up(W, PT), div_up(H, PT)), dim3(PT * PT), 0, s, H, W, img1, img2, (const float *)nullptr, 1.0f,
+                 make_window(), partials, dmaps, ssim_map);
+    KERNEL_CHECK(s, false, "ssim_map_forward");
+    return DAS3R_OK;
+}
+extern "C" int das3r_ssim_map_backward(int32_t H, int32_t W, const float *img1, const float *img2, const float *dmaps, const float *grad_map,
+                                       float *d_img1, float *d_img2, das3r_stream_t stream) {
+    if (H <= 0 || W <= 0 || !img1 || !img2 || !dmaps || !grad_map || !d_img1 || !d_img2) { set_error("das3r_ssim_map_backward: invalid argument"); return DAS3R_ERR_INVALID_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    DAS3R_LAUNCH(photometric_backward_kernel, dim3(div_up(W, PT), div_up(H, PT)), dim3(PT * PT), 0, s, H, W, img1, img2, (const float *)nullptr, 1.0f,
+                 make_window(), dmaps, (const float *)nullptr, d_img1, (float *)nullptr, (const float *)nullptr, 0, (float *)nullptr, grad_map, d_img2);
+    KERNEL_CHECK(s, false, "ssim_map_backward");
     return DAS3R_OK;
 }

@@ -437,6 +437,47 @@ class _Photometric(torch.autograd.Function):
         return d_render, None, d_static, None
 
 
+class _SsimMap(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img1, img2):
+        lib = _lib.load()
+        dev = img1.device
+        if dev.type != "cuda":
+            raise RuntimeError("das3r_amd.fused.ssim_map: tensors must live on a HIP device; there is no CPU path")
+        if img1.dim() != 3 or img1.shape[0] != 3 or img2.shape != img1.shape:
+            raise ValueError("img1 / img2 must be [3, H, W]")
+        a, b = img1.detach().contiguous().float(), img2.detach().contiguous().float()
+        H, W = int(a.shape[1]), int(a.shape[2])
+        m, dmaps = torch.empty_like(a), torch.empty(4, 3, H, W, device=dev)
+        partials = torch.empty(int(lib.das3r_photometric_blocks(H, W)), 8, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.das3r_ssim_map_forward(H, W, _p(a), _p(b), _p(m), _p(dmaps), _p(partials), _stream(dev))
+        _lib.check(rc, "das3r_ssim_map_forward")
+        ctx.save_for_backward(a, b, dmaps)
+        return m
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        a, b, dmaps = ctx.saved_tensors
+        dev = a.device
+        H, W = int(a.shape[1]), int(a.shape[2])
+        g = g.contiguous().float()
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        with torch.cuda.device(dev):
+            rc = lib.das3r_ssim_map_backward(H, W, _p(a), _p(b), _p(dmaps), _p(g), _p(da), _p(db), _stream(dev))
+        _lib.check(rc, "das3r_ssim_map_backward")
+        return da, db
+
+
+def ssim_map(img1, img2):
+    """The SSIM map of two [3, H, W] images (utils/loss_utils.py:39-66 `ssim(..., size_average=False)`: 11 x 11 Gaussian window, sigma 1.5,
+    zero padding, per channel), differentiable in both — two HIP launches each way instead of twelve depthwise convolutions and their
+    elementwise chains.  For loops that compose the loss themselves (train_gui.py:566-571); das3r_amd.integrate.patch() puts it behind
+    the reference's own `ssim`."""
+    return _SsimMap.apply(img1, img2)
+
+
 def masked_photometric_loss(render, gt, static, lambda_dssim):
     """-> (loss, mse[3]): DAS3R's iteration loss mean[(1 - lambda) |image - gt'| + lambda (1 - SSIM_map(image, gt'))] with
     image = render * static, gt' = gt * static, and the per-channel mean squared error of the same pair (for psnr_frame).

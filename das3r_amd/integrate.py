@@ -18,9 +18,14 @@ needed edits to render() and the optimizer).  What is swapped, and when:
       surface the reference's loop, its update_learning_rate and its capture() use.  Precondition: dense fp32 device parameters.
   GaussianModel.oneupSHdegree -> also tells the fused optimizer the new active degree.
 
-What is NOT swapped, because it is code inside train_gui.py's loop and not a function: the masked L1 + SSIM loss (torch ops) and the
-`if psnr_frame > threshold` gate (one host sync per iteration).  The direct iteration without either is das3r_amd.fast_step.
-`unpatch()` restores everything."""
+  utils.loss_utils.ssim        -> das3r_amd.fused.ssim_map behind the same signature (round 6): the SSIM map of two [3, H, W] fp32 device images
+      with the 11 x 11 window, and its backward, as two HIP launches each way — the reference's twelve depthwise convolutions and their
+      elementwise chains were 0.75 ms of MIOpen kernels of the 2.7 ms patched iteration.  Anything else (another window, a batch, CPU
+      tensors) goes to the original.  Modules that had already imported the name are re-bound.
+
+What is NOT swapped, because it is code inside train_gui.py's loop and not a function: how the loop combines its L1 and SSIM maps into the
+loss (a few elementwise torch kernels) and the `if psnr_frame > threshold` gate (one host sync per iteration).  The direct iteration
+without either is das3r_amd.fast_step.  `unpatch()` restores everything."""
 import sys
 import types
 
@@ -69,6 +74,22 @@ def make_render(original):
     return render
 
 
+def make_ssim(original):
+    """The replacement for utils.loss_utils.ssim (same signature: utils/loss_utils.py:39)."""
+    from .fused import ssim_map
+
+    def ssim(img1, img2, window_size=11, size_average=True):
+        ok = (window_size == 11 and torch.is_tensor(img1) and torch.is_tensor(img2) and img1.dim() == 3 and img1.shape[0] == 3 and img1.shape == img2.shape
+              and img1.device.type == "cuda" and img2.device == img1.device and img1.dtype == torch.float32 and img2.dtype == torch.float32)
+        if not ok:
+            return original(img1, img2, window_size, size_average)
+        m = ssim_map(img1, img2)
+        return m.mean() if size_average else m   # (size_average = False: the reference returns the map, train_gui.py:568)
+
+    ssim._das3r_original = original
+    return ssim
+
+
 def patch_model_class(cls):
     """GaussianModel (or anything with its training_setup / oneupSHdegree): fused optimizers behind the same attributes."""
     if getattr(cls.training_setup, "_das3r_original", None) is not None:
@@ -102,10 +123,26 @@ def patch_model_class(cls):
     return cls
 
 
-def patch(renderer_module=None, model_class=None):
-    """Default: the reference's own modules (`gaussian_renderer`, `scene.gaussian_model.GaussianModel`), imported here.  Tests pass
-    stand-ins.  Idempotent.  -> dict of what was patched."""
+def patch(renderer_module=None, model_class=None, loss_module=None):
+    """Default: the reference's own modules (`gaussian_renderer`, `scene.gaussian_model.GaussianModel`, `utils.loss_utils`), imported here.
+    Tests pass stand-ins.  Idempotent.  -> dict of what was patched."""
     done = {}
+    if loss_module is None:
+        import importlib
+        try:
+            loss_module = importlib.import_module("utils.loss_utils")
+        except ImportError:
+            loss_module = None   # (a checkout without it keeps its loss)
+    if loss_module is not None and getattr(loss_module.ssim, "_das3r_original", None) is None:
+        original_ssim = loss_module.ssim
+        new_ssim = make_ssim(original_ssim)
+        loss_module.ssim = new_ssim
+        _saved.setdefault("ssims", []).append((loss_module, original_ssim))
+        for mod in list(sys.modules.values()):   # `from utils.loss_utils import ssim` happened before us
+            if isinstance(mod, types.ModuleType) and mod is not loss_module and getattr(mod, "ssim", None) is original_ssim:
+                mod.ssim = new_ssim
+                _saved.setdefault("ssims", []).append((mod, original_ssim))
+        done["ssim"] = loss_module.__name__
     if renderer_module is None:
         import importlib
         renderer_module = importlib.import_module("gaussian_renderer")
@@ -130,6 +167,8 @@ def patch(renderer_module=None, model_class=None):
 def unpatch():
     for mod, original in _saved.pop("renderers", []) + _saved.pop("rebound", []):
         mod.render = original
+    for mod, original in _saved.pop("ssims", []):
+        mod.ssim = original
     for cls in _saved.pop("classes", []):
         cls.training_setup = cls.training_setup._das3r_original
         cls.oneupSHdegree = cls.oneupSHdegree._das3r_original

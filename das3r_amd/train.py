@@ -31,8 +31,13 @@ def train_step(model: SplatModel, cam, opt: OptimParams, iteration, pipe, backgr
     fused: the opt-in fused kernels of SURVEY.md section 8(f); with fused optimizers on both parameter sets and the default `pipe` the
     iteration runs as a straight sequence of C-ABI calls without autograd (das3r_amd/fast_step.py; `model.fast_step = False` keeps
     the autograd form of round 3 — same kernels, the reference's Python around them).
-    fused_loss=False with fused=True: what das3r_amd.integrate.patch() gives an UNMODIFIED train_gui.py — the fused pre-transform and
-    FusedAdam behind render() / the optimizers, the loss in torch ops and the camera gate a host-side `if`, as the loop has them."""
+    fused_loss=False with fused=True: the fused pre-transform and FusedAdam behind render() / the optimizers, the loss in torch ops and the
+    camera gate a host-side `if`, as the reference's loop has them; fused_loss="ssim": what das3r_amd.integrate.patch() gives an UNMODIFIED
+    train_gui.py since round 6 — the same, with the loop's `ssim` call answered by the fused SSIM map (fused.ssim_map)."""
+    ssim_fn = ssim
+    if fused_loss == "ssim":
+        from .fused import ssim_map
+        ssim_fn, fused_loss = (lambda a, b, size_average=False: ssim_map(a, b)), False
     fused_loss = bool(fused) if fused_loss is None else bool(fused_loss)
     if fused and fused_loss:
         from . import fast_step
@@ -63,7 +68,7 @@ def train_step(model: SplatModel, cam, opt: OptimParams, iteration, pipe, backgr
     image = image * static
     gt = gt * static
     Ll1 = l1_loss(image, gt, reduce=False)
-    Lssim = ssim(image, gt, size_average=False)
+    Lssim = ssim_fn(image, gt, size_average=False)
     psnr_frame = psnr(image, gt).mean()
     loss = ((1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * (1.0 - Lssim)).mean()
     loss.backward(retain_graph=True)

@@ -307,6 +307,14 @@ int das3r_photometric_backward(int32_t H, int32_t W, const float *render, const 
                                const float *dmaps, const float *grad_loss, float *d_render, float *d_static, das3r_stream_t stream);
 /* ABI 15 — das3r_photometric_backward and das3r_photometric_finish as ONE launch: the first workgroup of the backward kernel adds the
  * forward's tile sums (`partials`) into out8 on its way in.  Same values, bit for bit; one launch less between the two rasterizer passes. */
+/* ABI 15 — the SSIM map itself (utils/loss_utils.py:39-66, size_average = False: 11 x 11 Gaussian window, sigma 1.5, zero padding, per channel)
+ * of two [3, H, W] images, and its backward for an arbitrary upstream gradient [3, H, W] — for callers that compose the loss themselves
+ * (train_gui.py:566-571 combines the map with its L1 map).  dmaps [4][3][H][W] and partials [das3r_photometric_blocks][8] are scratch the
+ * forward fills (the backward reads dmaps). */
+int das3r_ssim_map_forward(int32_t H, int32_t W, const float *img1, const float *img2, float *ssim_map, float *dmaps, float *partials,
+                           das3r_stream_t stream);
+int das3r_ssim_map_backward(int32_t H, int32_t W, const float *img1, const float *img2, const float *dmaps, const float *grad_map,
+                            float *d_img1, float *d_img2, das3r_stream_t stream);
 int das3r_photometric_backward_finish(int32_t H, int32_t W, const float *render, const float *gt, const float *static_mask, float lambda,
                                       const float *dmaps, const float *grad_loss, float *d_render, float *d_static, const float *partials,
                                       float *out8, das3r_stream_t stream);

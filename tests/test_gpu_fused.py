@@ -474,3 +474,25 @@ def test_pose_chain_rearm_zeroes_the_previous_rows():
     _lib.check(lib.das3r_pose_chain_qt_rearm(p(Q[2]), p(gc), p(Qb[2]), p(Tb[2]), p(Qb[2]), p(Tb[2]), s), "rearm, same rows")
     torch.cuda.synchronize()
     assert torch.equal(Qa[2], Qb[2]) and torch.equal(Ta[2], Tb[2])
+
+
+@pytest.mark.parametrize("hw", [(16, 16), (37, 53), (208, 512)])
+def test_ssim_map_matches_torch_ops_both_ways(hw):
+    """ABI 15 fused.ssim_map: the SSIM MAP of two images (utils/loss_utils.py:39-66, size_average=False — what train_gui.py:568 takes) and its
+    gradients w.r.t. BOTH images for an arbitrary upstream gradient, against the torch ops of das3r_amd.losses (pinned to the reference's
+    helper by tests/golden)."""
+    from das3r_amd.fused import ssim_map
+    from das3r_amd.losses import ssim
+    H, W = hw
+    g = torch.Generator().manual_seed(H * 977 + W)
+    a0, b0 = torch.rand(3, H, W, generator=g).cuda(), torch.rand(3, H, W, generator=g).cuda()
+    up = torch.randn(3, H, W, generator=g).cuda()
+    out = {}
+    for name, fn in (("fused", ssim_map), ("torch", lambda x, y: ssim(x, y, size_average=False))):
+        a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        m = fn(a, b)
+        (m * up).sum().backward()
+        out[name] = (m.detach(), a.grad, b.grad)
+    for k, what in enumerate(("map", "d img1", "d img2")):
+        f, t = out["fused"][k], out["torch"][k]
+        assert float((f - t).abs().max()) <= 2e-5 * float(t.abs().max()), (what, float((f - t).abs().max()), float(t.abs().max()))

@@ -25,6 +25,11 @@ def _stand_ins():
     consumer = types.ModuleType("train_gui_standin")      # did `from gaussian_renderer import render` before the patch
     consumer.render = render
     sys.modules[consumer.__name__] = consumer
+    from das3r_amd import losses as repo_losses
+    loss_utils = types.ModuleType("loss_utils_standin")   # utils/loss_utils.py: the repo's counterpart of its ssim (pinned by tests/golden)
+    loss_utils.ssim = lambda img1, img2, window_size=11, size_average=True: (calls.append("original ssim"), repo_losses.ssim(img1, img2, window_size, size_average))[1]
+    consumer.ssim = loss_utils.ssim                        # ... and `from utils.loss_utils import l1_loss, ssim`
+    renderer.loss_utils = loss_utils
 
     class GaussianModel(SplatModel):                       # the reference's training_setup(training_args): plain torch.optim.Adam
         def training_setup(self, training_args):
@@ -37,10 +42,18 @@ def test_patch_swaps_rebinds_and_restores():
     renderer, consumer, Model, calls = _stand_ins()
     original = renderer.render
     try:
-        done = integrate.patch(renderer, Model)
-        assert done == {"render": "gaussian_renderer_standin", "model": "GaussianModel"}
+        original_ssim = renderer.loss_utils.ssim
+        done = integrate.patch(renderer, Model, renderer.loss_utils)
+        assert done == {"ssim": "loss_utils_standin", "render": "gaussian_renderer_standin", "model": "GaussianModel"}
         assert renderer.render is not original and consumer.render is renderer.render and renderer.render._das3r_original is original
-        assert integrate.patch(renderer, Model)["model"] == "GaussianModel" and renderer.render._das3r_original is original   # idempotent
+        assert renderer.loss_utils.ssim is not original_ssim and consumer.ssim is renderer.loss_utils.ssim and consumer.ssim._das3r_original is original_ssim
+        assert integrate.patch(renderer, Model, renderer.loss_utils)["model"] == "GaussianModel" and renderer.render._das3r_original is original   # idempotent
+        assert consumer.ssim._das3r_original is original_ssim
+        # host images: the call goes to the original ssim, same value
+        a, b = torch.rand(3, 20, 24), torch.rand(3, 20, 24)
+        from das3r_amd import losses as repo_losses
+        assert torch.equal(consumer.ssim(a, b, size_average=False), repo_losses.ssim(a, b, size_average=False)) and calls == ["original ssim"]
+        calls.clear()
         # preconditions fail (host tensors): the call goes to the original function, arguments untouched
         pc = types.SimpleNamespace(**{n: torch.zeros(4, 3) for n in ("_xyz", "_rotation", "_scaling", "_opacity", "_conf_static", "_features_dc", "_features_rest")},
                                    aggregated_mask=torch.ones(4, dtype=torch.bool))
@@ -59,6 +72,7 @@ def test_patch_swaps_rebinds_and_restores():
         integrate.unpatch()
         sys.modules.pop(consumer.__name__, None)
     assert renderer.render is original and consumer.render is original and not hasattr(Model.training_setup, "_das3r_original")
+    assert renderer.loss_utils.ssim is original_ssim and consumer.ssim is original_ssim
 
 
 NAMES = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity", "scaling": "_scaling", "rotation": "_rotation",
@@ -66,10 +80,12 @@ NAMES = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opa
 PIPE = types.SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
 
 
-def _reference_loop(render, gaussians, cams, opt, iterations, bg, psnr_threshold):
+def _reference_loop(render, gaussians, cams, opt, iterations, bg, psnr_threshold, ssim=None):
     """train_gui.py:532-589, statement by statement, on the names it uses (the loss helpers are the repo's counterparts of
-    utils/loss_utils.py, pinned by tests/golden/ref_helpers.npz)."""
-    from das3r_amd.losses import l1_loss, psnr, ssim
+    utils/loss_utils.py, pinned by tests/golden/ref_helpers.npz; `ssim`: the name the loop's module holds — patched or not)."""
+    from das3r_amd.losses import l1_loss, psnr
+    if ssim is None:
+        from das3r_amd.losses import ssim
     for iteration, uid in iterations:
         gaussians.update_learning_rate(iteration)
         if iteration % 3000 == 0:
@@ -120,12 +136,12 @@ def test_mocked_train_gui_iteration_through_the_patch_matches_the_direct_iterati
     # (a) the unpatched loop: torch.optim.Adam and the reference's PyTorch glue around the HIP rasterizer
     plain, cams = fresh(Model)
     plain.training_setup(opt)
-    _reference_loop(consumer.render, plain, cams, opt, schedule, bg, opt.psnr_threshold)
+    _reference_loop(consumer.render, plain, cams, opt, schedule, bg, opt.psnr_threshold, consumer.ssim)
     n_plain = len(calls)
-    assert n_plain == len(schedule)
+    assert calls.count("original") == len(schedule) and calls.count("original ssim") == len(schedule)
     # (b) the same loop, same objects' classes, after the one-liner
     try:
-        integrate.patch(renderer, Model)
+        integrate.patch(renderer, Model, renderer.loss_utils)
         patched, cams_b = fresh(Model)
         patched.training_setup(opt)
         assert isinstance(patched.optimizer, FusedAdam) and isinstance(patched.optimizer_cam, FusedAdam)
@@ -133,15 +149,16 @@ def test_mocked_train_gui_iteration_through_the_patch_matches_the_direct_iterati
         assert [g["name"] for g in patched.optimizer_cam.param_groups] == ["pose_Q", "pose_T", "fovX", "fovY"]
         _lib.profile_enable(True)
         try:
-            _reference_loop(consumer.render, patched, cams_b, opt, schedule, bg, opt.psnr_threshold)
+            _reference_loop(consumer.render, patched, cams_b, opt, schedule, bg, opt.psnr_threshold, consumer.ssim)
             torch.cuda.synchronize()
         finally:
             _lib.profile_enable(False)
         kernels = _lib.profile_report(raw=True)
-        assert len(calls) == n_plain, "every render of the patched loop took the fused path"
+        assert len(calls) == n_plain, "every render and every ssim call of the patched loop took the fused path"
         launched = lambda prefix: sum(n for k, (n, _) in kernels.items() if k.startswith(prefix))
         assert launched("pretransform_forward_kernel") == len(schedule) and launched("pretransform_backward_kernel") == len(schedule), kernels
         assert launched("adam_kernel") >= len(schedule), kernels
+        assert launched("photometric_forward_kernel") == len(schedule) and launched("photometric_backward_kernel") == len(schedule), kernels   # (round 6: the loop's ssim)
         assert patched.active_sh_degree == 1 and patched.optimizer.active_sh_degree == 1
     finally:
         integrate.unpatch()
